@@ -1,0 +1,140 @@
+"""
+ctypes binding of ``libbeat_amd.so`` (C ABI declared in ``include/beat_amd.h``).
+
+There is no CPU fallback: if the HIP library is missing, or no GPU is present when a
+context is created, the error is raised to the caller.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbeat_amd.so")
+
+NEAREST_NEIGHBOR, MULTILINEAR = 0, 1
+W_SCALAR, W_DENSE = 0, 1
+INTERPOLATIONS = {"nearest_neighbor": NEAREST_NEIGHBOR, "multilinear": MULTILINEAR}
+
+OK, EINVAL, EHIP, EINDEX, ENOMEM, ENAN = 0, -1, -2, -3, -4, -5
+
+
+class BeatAmdError(RuntimeError):
+    pass
+
+
+class FfiLayout(C.Structure):
+    """mirror of ``beatamd_ffi_layout``"""
+    _fields_ = [
+        ("nparams", C.c_int64),
+        ("nvar", C.c_int32),
+        ("slip_off", C.c_int64 * 4),
+        ("durations_off", C.c_int64),
+        ("velocities_off", C.c_int64),
+        ("nuc_strike_off", C.c_int64),
+        ("nuc_dip_off", C.c_int64),
+        ("time_off", C.c_int64),
+        ("h_laplacian_off", C.c_int64),
+    ]
+
+
+_vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+_pi32, _pi64 = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+
+# name -> argtypes.  Array arguments are void* so that both numpy (host) and device
+# pointers (ints) can be passed.
+_PROTOS = {
+    "beatamd_ctx_create": [C.c_int, C.POINTER(_vp)],
+    "beatamd_ctx_destroy": [_vp],
+    "beatamd_ctx_set_stream": [_vp, _vp],
+    "beatamd_ctx_synchronize": [_vp],
+    "beatamd_ctx_enable_timing": [_vp, C.c_int],
+    "beatamd_ctx_kernel_time": [_vp, C.c_char_p, C.POINTER(_f64), _pi64],
+    "beatamd_ctx_reset_timing": [_vp],
+    "beatamd_fast_sweep_batch": [_vp, _vp, _f64, _vp, _vp, _i32, _i32, _i64, _vp],
+    "beatamd_seis_gflib_create": [_vp, _i64, _i64, _i64, _i64, _i64, _f64, _f64, _f64, _f64, _pi32],
+    "beatamd_seis_gflib_upload": [_vp, _i32, _vp, _i64, _i64],
+    "beatamd_seis_gflib_adopt": [_vp, _i32, _vp],
+    "beatamd_seis_gflib_device_ptr": [_vp, _i32, C.POINTER(_vp)],
+    "beatamd_seis_gflib_destroy": [_vp, _i32],
+    "beatamd_seis_stack_all_batch": [_vp, _i32, _i64, _vp, _vp, _vp, _i32, _vp],
+    "beatamd_geo_gflib_create": [_vp, _i64, _i64, _vp, _pi32],
+    "beatamd_geo_gflib_destroy": [_vp, _i32],
+    "beatamd_geo_stack_all_batch": [_vp, _i32, _i64, _vp, _i32, _vp],
+    "beatamd_weights_create": [_vp, _i32, _i64, _i64, _vp, _vp, _pi32],
+    "beatamd_weights_update": [_vp, _i32, _vp, _vp],
+    "beatamd_weights_destroy": [_vp, _i32],
+    "beatamd_mvn_chol_logp_batch": [_vp, _i32, _i64, _vp, _vp, _vp],
+    "beatamd_laplacian_create": [_vp, _i64, _vp, _f64, _pi32],
+    "beatamd_laplacian_destroy": [_vp, _i32],
+    "beatamd_laplacian_logp_batch": [_vp, _i32, _i64, _i64, _vp, _vp, _vp],
+    "beatamd_ffi_model_create": [_vp, C.POINTER(FfiLayout), _i32, _vp, _vp, _vp, _pi32],
+    "beatamd_ffi_model_add_wavemap": [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32],
+    "beatamd_ffi_model_add_geodetic": [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
+    "beatamd_ffi_model_set_laplacian": [_vp, _i32, _i32],
+    "beatamd_ffi_model_nllk": [_vp, _i32, _pi64],
+    "beatamd_ffi_model_destroy": [_vp, _i32],
+    "beatamd_ffi_logp_batch": [_vp, _i32, _i64, _vp, _vp],
+    "beatamd_ffi_astep_batch": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp],
+}
+
+EXPORTS = sorted(list(_PROTOS) + ["beatamd_last_error", "beatamd_version"])
+
+_lib = None
+
+
+def load():
+    """Load libbeat_amd.so (needs only the HIP runtime, not a GPU)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BeatAmdError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C beat_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, args in _PROTOS.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        lib.beatamd_last_error.restype = C.c_char_p
+        lib.beatamd_last_error.argtypes = []
+        lib.beatamd_version.restype = C.c_int
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    """Map a status code to the exception the reference raises in that situation."""
+    if rc == OK:
+        return
+    msg = load().beatamd_last_error().decode("utf-8", "replace")
+    if rc == EINVAL:
+        raise ValueError(msg)
+    if rc == EINDEX:
+        raise IndexError(msg)
+    if rc == ENOMEM:
+        raise MemoryError(msg)
+    raise BeatAmdError(msg)
+
+
+def ptr(a):
+    """void* of a numpy array (host), a torch tensor (host or device) or a raw int."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    if isinstance(a, int):
+        return a
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
+    raise TypeError("cannot take a pointer of %r" % type(a))
+
+
+def f64(a):
+    """C-contiguous float64 view/copy of a host array; device tensors pass through."""
+    if hasattr(a, "data_ptr") and not isinstance(a, np.ndarray):
+        import torch
+        if a.dtype != torch.float64 or not a.is_contiguous():
+            raise ValueError("device tensors must be contiguous float64")
+        return a
+    return np.ascontiguousarray(a, dtype=np.float64)

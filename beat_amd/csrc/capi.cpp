@@ -1,0 +1,749 @@
+// capi.cpp -- the extern "C" entry points of include/beat_amd.h (host side of the engine).
+#include "kernels.hpp"
+
+using namespace beatamd;
+
+namespace {
+
+int dev_alloc_copy(beatamd_ctx *ctx, const void *src, size_t bytes, void **dst)
+{
+    void *d = nullptr;
+    hipError_t e = hipMalloc(&d, bytes ? bytes : 8);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return BEATAMD_ENOMEM;
+    }
+    if (src && bytes) {
+        e = hipMemcpyAsync(d, src, bytes, hipMemcpyDefault, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(d);
+            set_error("hipMemcpy(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+            return BEATAMD_EHIP;
+        }
+    }
+    *dst = d;
+    return BEATAMD_OK;
+}
+
+template <class T>
+T *get_obj(std::vector<std::unique_ptr<T>> &v, int32_t id)
+{
+    if (id < 0 || (size_t)id >= v.size()) return nullptr;
+    return v[id].get();
+}
+
+template <class T>
+int32_t add_obj(std::vector<std::unique_ptr<T>> &v, std::unique_ptr<T> o)
+{
+    for (size_t i = 0; i < v.size(); i++)
+        if (!v[i]) {
+            v[i] = std::move(o);
+            return (int32_t)i;
+        }
+    v.push_back(std::move(o));
+    return (int32_t)v.size() - 1;
+}
+
+#define ENTER(ctx)                                                    \
+    BA_CHECK((ctx) != nullptr, BEATAMD_EINVAL, "ctx is NULL");        \
+    BA_HIP(hipSetDevice((ctx)->device))
+
+// quad[c,d] = ||W_d x||^2 for one weight set, x(c,d,k) = X[c*xs_c + d*xs_d + k]
+int wset_quad(beatamd_ctx *ctx, const WeightSet &w, int64_t C, const double *X, int64_t xs_c,
+              int64_t xs_d, double *quad)
+{
+    if (w.kind == BEATAMD_W_SCALAR)
+        return launch_scalar_quad(ctx, C, w.nd, w.M, X, xs_c, xs_d, w.w, quad);
+    QuadformCall q;
+    q.A = w.w;
+    q.a_stride = w.M * w.M;
+    q.M = w.M;
+    q.nd = w.nd;
+    q.C = C;
+    q.X = X;
+    q.xs_c = xs_c;
+    q.xs_d = xs_d;
+    q.upper_tri = w.upper_tri;
+    q.quad = quad;
+    q.q_stride = w.nd;
+    return launch_quadform(ctx, q);
+}
+
+// logp_forw_func on device pointers
+int ffi_logp_device(beatamd_ctx *ctx, FfiModel &m, int64_t C, const double *Q, double *LL)
+{
+    const int64_t nllk = m.nllk();
+    const int64_t np = m.layout.nparams;
+    void *p = nullptr;
+    LikeGroups grp;
+    int64_t col = 0;
+
+    ChainVec slips[4];
+    for (int v = 0; v < m.layout.nvar; v++) slips[v] = ChainVec{Q, np, m.layout.slip_off[v]};
+
+    if (!m.wavemaps.empty()) {
+        BA_TRY(ctx->get_scratch(SL_ST0, (size_t)C * m.P * sizeof(double), &p));
+        double *st0 = (double *)p;
+        BA_TRY(launch_sweep_model(ctx, m, Q, C, st0));
+        for (auto &wm : m.wavemaps) {
+            WeightSet *ws = get_obj(ctx->wsets, wm.wset);
+            BA_CHECK(ws, BEATAMD_EINVAL, "wavemap refers to a destroyed weight set");
+            GfStackCall k;
+            k.nvar = m.layout.nvar;
+            for (int v = 0; v < k.nvar; v++) {
+                k.libs[v] = get_obj(ctx->seislibs, wm.libs[v]);
+                BA_CHECK(k.libs[v] && k.libs[v]->g, BEATAMD_EINVAL,
+                         "wavemap refers to a destroyed / empty GF library");
+                k.slips[v] = slips[v];
+            }
+            k.durations = ChainVec{Q, np, m.layout.durations_off};
+            k.st.starttimes0 = st0;
+            k.st.Q = Q;
+            k.st.nparams = np;
+            k.st.shift_off = wm.shift_off;
+            k.interp = wm.interp;
+            k.C = C;
+            k.data = wm.data;
+            BA_TRY(ctx->get_scratch(SL_QUAD, (size_t)C * wm.T * sizeof(double), &p));
+            double *quad = (double *)p;
+            if (ws->kind == BEATAMD_W_SCALAR) {
+                k.mode = GF_RESID_SCALAR;
+                k.wscalar = ws->w;
+                k.quad = quad;
+                BA_TRY(launch_gfstack(ctx, k));
+            } else {
+                k.mode = GF_RESID_STORE;
+                BA_TRY(ctx->get_scratch(SL_RESID, (size_t)C * wm.T * wm.N * sizeof(double), &p));
+                k.out = (double *)p;
+                BA_TRY(launch_gfstack(ctx, k));
+                BA_TRY(wset_quad(ctx, *ws, C, k.out, wm.T * wm.N, wm.N, quad));
+            }
+            BA_TRY(launch_mvn_finish(ctx, C, wm.T, wm.N, quad, ws->slog, HpSrc{Q, np, wm.hp_off},
+                                     LL + col, nllk));
+            col += wm.T;
+        }
+        grp.end[grp.n++] = (int32_t)col;
+    }
+    if (m.has_geo) {
+        Geodetic &g = m.geo;
+        BA_TRY(ctx->get_scratch(SL_MU, (size_t)C * g.Nobs * 2 * sizeof(double), &p));
+        double *mu = (double *)p, *res = mu + C * g.Nobs;
+        for (int v = 0; v < m.layout.nvar; v++) {
+            GeoLib *gl = get_obj(ctx->geolibs, g.libs[v]);
+            BA_CHECK(gl, BEATAMD_EINVAL, "geodetic composite refers to a destroyed GF library");
+            BA_TRY(launch_geo_stack(ctx, *gl, C, slips[v], v > 0, mu));
+        }
+        BA_TRY(launch_geo_residual(ctx, C, g.Nobs, g.data, g.odws, mu, res));
+        BA_TRY(ctx->get_scratch(SL_QUAD, (size_t)C * sizeof(double), &p));
+        double *quad = (double *)p;
+        int64_t o = 0;
+        for (size_t d = 0; d < g.sizes.size(); d++) {
+            WeightSet *ws = get_obj(ctx->wsets, g.wsets[d]);
+            BA_CHECK(ws && ws->nd == 1 && ws->M == g.sizes[d], BEATAMD_EINVAL,
+                     "geodetic dataset %zu: weight set missing or of the wrong size", d);
+            BA_TRY(wset_quad(ctx, *ws, C, res + o, g.Nobs, 0, quad));
+            BA_TRY(launch_mvn_finish(ctx, C, 1, ws->M, quad, ws->slog,
+                                     HpSrc{Q, np, g.hp_off + d}, LL + col + (int64_t)d, nllk));
+            o += g.sizes[d];
+        }
+        col += (int64_t)g.sizes.size();
+        grp.end[grp.n++] = (int32_t)col;
+    }
+    if (m.lap >= 0) {
+        Laplacian *lp = get_obj(ctx->laps, m.lap);
+        BA_CHECK(lp, BEATAMD_EINVAL, "model refers to a destroyed laplacian");
+        const int nvar = m.layout.nvar;
+        BA_TRY(ctx->get_scratch(SL_SLIPS, (size_t)C * nvar * lp->P * sizeof(double), &p));
+        double *sl = (double *)p;
+        BA_TRY(launch_gather_slips(ctx, C, nvar, lp->P, slips, sl));
+        BA_TRY(ctx->get_scratch(SL_QUAD, (size_t)C * nvar * sizeof(double), &p));
+        double *quad = (double *)p;
+        QuadformCall q;
+        q.A = lp->L; q.a_stride = 0; q.M = lp->P; q.nd = nvar; q.C = C;
+        q.X = sl; q.xs_c = nvar * lp->P; q.xs_d = lp->P;
+        q.quad = quad; q.q_stride = nvar;
+        BA_TRY(launch_quadform(ctx, q));
+        static const int64_t zero_off = 0;
+        (void)zero_off;
+        BA_TRY(launch_laplacian_finish(ctx, C, nvar, lp->P, lp->logdet, quad,
+                                       HpSrc{Q + m.layout.h_laplacian_off, np, nullptr}, LL + col,
+                                       nllk));
+        col += 1;
+        grp.end[grp.n++] = (int32_t)col;
+    }
+    BA_CHECK(col == nllk - 1, BEATAMD_EINVAL, "internal: llk layout mismatch");
+    return launch_like_sum(ctx, C, nllk, grp, LL);
+}
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------ fast sweep
+int beatamd_fast_sweep_batch(beatamd_ctx *ctx, const double *slowness, double patch_size,
+                             const int32_t *h_strk, const int32_t *h_dip, int32_t num_strk,
+                             int32_t num_dip, int64_t C, double *out)
+{
+    ENTER(ctx);
+    BA_CHECK(slowness && h_strk && h_dip && out, BEATAMD_EINVAL, "fast_sweep: NULL array");
+    BA_CHECK(num_strk > 0 && num_dip > 0 && C >= 0, BEATAMD_EINVAL, "fast_sweep: bad dimensions");
+    if (C == 0) return BEATAMD_OK;
+    const int64_t n = (int64_t)num_strk * num_dip;
+    const void *d_s, *d_hi, *d_hj;
+    void *d_o;
+    Arg rec;
+    BA_TRY(stage_in(ctx, SL_IN0, slowness, (size_t)C * n * 8, &d_s));
+    BA_TRY(stage_in(ctx, SL_IN1, h_strk, (size_t)C * 4, &d_hi));
+    BA_TRY(stage_in(ctx, SL_IN2, h_dip, (size_t)C * 4, &d_hj));
+    BA_TRY(stage_out(ctx, SL_OUT0, out, (size_t)C * n * 8, &d_o, &rec));
+    BA_TRY(launch_sweep_explicit(ctx, (const double *)d_s, patch_size, (const int32_t *)d_hi,
+                                 (const int32_t *)d_hj, num_strk, num_dip, C, (double *)d_o));
+    return finish_out(ctx, &rec, 1);
+}
+
+// ------------------------------------------------------------------ GF libraries
+int beatamd_seis_gflib_create(beatamd_ctx *ctx, int64_t T, int64_t P, int64_t D, int64_t S,
+                              int64_t N, double st_min, double st_dt, double du_min, double du_dt,
+                              int32_t *lib_id)
+{
+    ENTER(ctx);
+    BA_CHECK(lib_id, BEATAMD_EINVAL, "lib_id is NULL");
+    BA_CHECK(T > 0 && P > 0 && D > 0 && S > 0 && N > 0, BEATAMD_EINVAL,
+             "GF library dimensions must be positive");
+    BA_CHECK(st_dt > 0 && du_dt > 0, BEATAMD_EINVAL, "sampling intervals must be positive");
+    BA_CHECK(D < 32768 && S < 32768, BEATAMD_EINVAL, "int16 index range exceeded");
+    std::unique_ptr<SeisLib> l(new SeisLib());
+    l->T = T; l->P = P; l->D = D; l->S = S; l->N = N;
+    l->st_min = st_min; l->st_dt = st_dt; l->du_min = du_min; l->du_dt = du_dt;
+    *lib_id = add_obj(ctx->seislibs, std::move(l));
+    return BEATAMD_OK;
+}
+
+static int seis_ensure_storage(beatamd_ctx *ctx, SeisLib *l)
+{
+    if (l->g) return BEATAMD_OK;
+    const size_t bytes = (size_t)l->elems() * sizeof(double);
+    hipError_t e = hipMalloc((void **)&l->g, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        l->g = nullptr;
+        set_error("GF library of %.2f GB does not fit in HBM: %s", bytes / 1e9,
+                  hipGetErrorString(e));
+        return BEATAMD_ENOMEM;
+    }
+    l->owned = true;
+    return BEATAMD_OK;
+}
+
+int beatamd_seis_gflib_upload(beatamd_ctx *ctx, int32_t lib_id, const double *src, int64_t offset,
+                              int64_t count)
+{
+    ENTER(ctx);
+    SeisLib *l = get_obj(ctx->seislibs, lib_id);
+    BA_CHECK(l, BEATAMD_EINVAL, "unknown GF library %d", lib_id);
+    BA_CHECK(src && offset >= 0 && count >= 0 && offset + count <= l->elems(), BEATAMD_EINVAL,
+             "gflib_upload: range [%lld, %lld) outside the library (%lld elements)",
+             (long long)offset, (long long)(offset + count), (long long)l->elems());
+    BA_TRY(seis_ensure_storage(ctx, l));
+    BA_HIP(hipMemcpyAsync(l->g + offset, src, (size_t)count * 8, hipMemcpyDefault, ctx->stream));
+    BA_HIP(hipStreamSynchronize(ctx->stream));
+    return BEATAMD_OK;
+}
+
+int beatamd_seis_gflib_adopt(beatamd_ctx *ctx, int32_t lib_id, double *device_ptr)
+{
+    ENTER(ctx);
+    SeisLib *l = get_obj(ctx->seislibs, lib_id);
+    BA_CHECK(l, BEATAMD_EINVAL, "unknown GF library %d", lib_id);
+    BA_CHECK(device_ptr && is_device_ptr(device_ptr), BEATAMD_EINVAL,
+             "gflib_adopt needs a device pointer");
+    BA_CHECK(((uintptr_t)device_ptr & 15) == 0, BEATAMD_EINVAL,
+             "gflib_adopt: pointer must be 16-byte aligned");
+    if (l->owned && l->g) BA_HIP(hipFree(l->g));
+    l->g = device_ptr;
+    l->owned = false;
+    return BEATAMD_OK;
+}
+
+int beatamd_seis_gflib_device_ptr(beatamd_ctx *ctx, int32_t lib_id, double **device_ptr)
+{
+    ENTER(ctx);
+    SeisLib *l = get_obj(ctx->seislibs, lib_id);
+    BA_CHECK(l && device_ptr, BEATAMD_EINVAL, "unknown GF library %d", lib_id);
+    BA_TRY(seis_ensure_storage(ctx, l));
+    *device_ptr = l->g;
+    return BEATAMD_OK;
+}
+
+int beatamd_seis_gflib_destroy(beatamd_ctx *ctx, int32_t lib_id)
+{
+    ENTER(ctx);
+    SeisLib *l = get_obj(ctx->seislibs, lib_id);
+    BA_CHECK(l, BEATAMD_EINVAL, "unknown GF library %d", lib_id);
+    BA_HIP(hipStreamSynchronize(ctx->stream));
+    if (l->owned && l->g) BA_HIP(hipFree(l->g));
+    ctx->seislibs[lib_id].reset();
+    return BEATAMD_OK;
+}
+
+int beatamd_seis_stack_all_batch(beatamd_ctx *ctx, int32_t lib_id, int64_t C,
+                                 const double *durations, const double *starttimes,
+                                 const double *slips, int32_t interpolation, double *out)
+{
+    ENTER(ctx);
+    SeisLib *l = get_obj(ctx->seislibs, lib_id);
+    BA_CHECK(l, BEATAMD_EINVAL, "unknown GF library %d", lib_id);
+    BA_CHECK(l->g, BEATAMD_EINVAL, "GF library %d holds no data (upload or adopt first)", lib_id);
+    BA_CHECK(durations && starttimes && slips && out, BEATAMD_EINVAL, "stack_all: NULL array");
+    BA_CHECK(interpolation == BEATAMD_NEAREST_NEIGHBOR || interpolation == BEATAMD_MULTILINEAR,
+             BEATAMD_EINVAL, "Interpolation scheme %d not implemented!", interpolation);
+    BA_CHECK(C >= 0, BEATAMD_EINVAL, "negative batch size");
+    if (C == 0) return BEATAMD_OK;
+    const void *d_du, *d_st, *d_sl;
+    void *d_o;
+    Arg rec;
+    BA_TRY(stage_in(ctx, SL_IN0, durations, (size_t)C * l->P * 8, &d_du));
+    BA_TRY(stage_in(ctx, SL_IN1, starttimes, (size_t)C * l->T * l->P * 8, &d_st));
+    BA_TRY(stage_in(ctx, SL_IN2, slips, (size_t)C * l->P * 8, &d_sl));
+    BA_TRY(stage_out(ctx, SL_OUT0, out, (size_t)C * l->T * l->N * 8, &d_o, &rec));
+    GfStackCall k;
+    k.libs[0] = l;
+    k.nvar = 1;
+    k.slips[0] = ChainVec{(const double *)d_sl, l->P, 0};
+    k.durations = ChainVec{(const double *)d_du, l->P, 0};
+    k.st.explicit_st = (const double *)d_st;
+    k.interp = interpolation;
+    k.C = C;
+    k.mode = GF_STORE_SYN;
+    k.out = (double *)d_o;
+    BA_TRY(launch_gfstack(ctx, k));
+    return finish_out(ctx, &rec, 1);
+}
+
+int beatamd_geo_gflib_create(beatamd_ctx *ctx, int64_t P, int64_t Nobs, const double *G,
+                             int32_t *lib_id)
+{
+    ENTER(ctx);
+    BA_CHECK(lib_id && G && P > 0 && Nobs > 0, BEATAMD_EINVAL, "geo_gflib_create: bad argument");
+    std::unique_ptr<GeoLib> l(new GeoLib());
+    l->P = P;
+    l->Nobs = Nobs;
+    BA_TRY(dev_alloc_copy(ctx, G, (size_t)P * Nobs * 8, (void **)&l->g));
+    *lib_id = add_obj(ctx->geolibs, std::move(l));
+    return BEATAMD_OK;
+}
+
+int beatamd_geo_gflib_destroy(beatamd_ctx *ctx, int32_t lib_id)
+{
+    ENTER(ctx);
+    GeoLib *l = get_obj(ctx->geolibs, lib_id);
+    BA_CHECK(l, BEATAMD_EINVAL, "unknown geodetic GF library %d", lib_id);
+    BA_HIP(hipStreamSynchronize(ctx->stream));
+    if (l->g) BA_HIP(hipFree(l->g));
+    ctx->geolibs[lib_id].reset();
+    return BEATAMD_OK;
+}
+
+int beatamd_geo_stack_all_batch(beatamd_ctx *ctx, int32_t lib_id, int64_t C, const double *slips,
+                                int32_t accumulate, double *out)
+{
+    ENTER(ctx);
+    GeoLib *l = get_obj(ctx->geolibs, lib_id);
+    BA_CHECK(l, BEATAMD_EINVAL, "unknown geodetic GF library %d", lib_id);
+    BA_CHECK(slips && out && C >= 0, BEATAMD_EINVAL, "geo_stack_all: bad argument");
+    if (C == 0) return BEATAMD_OK;
+    const void *d_sl;
+    void *d_o;
+    Arg rec;
+    BA_TRY(stage_in(ctx, SL_IN0, slips, (size_t)C * l->P * 8, &d_sl));
+    BA_TRY(stage_out(ctx, SL_OUT0, out, (size_t)C * l->Nobs * 8, &d_o, &rec, accumulate != 0));
+    BA_TRY(launch_geo_stack(ctx, *l, C, ChainVec{(const double *)d_sl, l->P, 0}, accumulate,
+                            (double *)d_o));
+    return finish_out(ctx, &rec, 1);
+}
+
+// ------------------------------------------------------------------ likelihood
+static int wset_fill(beatamd_ctx *ctx, WeightSet *w, const double *weights, const double *slog)
+{
+    const size_t wbytes =
+        (size_t)(w->kind == BEATAMD_W_SCALAR ? w->nd : w->nd * w->M * w->M) * sizeof(double);
+    BA_HIP(hipMemcpyAsync(w->w, weights, wbytes, hipMemcpyDefault, ctx->stream));
+    BA_HIP(hipMemcpyAsync(w->slog, slog, (size_t)w->nd * 8, hipMemcpyDefault, ctx->stream));
+    BA_HIP(hipStreamSynchronize(ctx->stream));
+    w->upper_tri = 0;
+    if (w->kind == BEATAMD_W_DENSE) {
+        void *p = nullptr;
+        BA_TRY(ctx->get_scratch(SL_MISC, 64, &p));
+        BA_TRY(launch_check_upper_tri(ctx, w->w, w->nd, w->M, (int *)p));
+        int flag = 0;
+        BA_HIP(hipMemcpyAsync(&flag, p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        BA_HIP(hipStreamSynchronize(ctx->stream));
+        w->upper_tri = flag;
+    }
+    return BEATAMD_OK;
+}
+
+int beatamd_weights_create(beatamd_ctx *ctx, int32_t kind, int64_t nd, int64_t M,
+                           const double *weights, const double *slog_pdet, int32_t *wset_id)
+{
+    ENTER(ctx);
+    BA_CHECK(kind == BEATAMD_W_SCALAR || kind == BEATAMD_W_DENSE, BEATAMD_EINVAL,
+             "unknown weight kind %d", kind);
+    BA_CHECK(nd > 0 && M > 0 && weights && slog_pdet && wset_id, BEATAMD_EINVAL,
+             "weights_create: bad argument");
+    std::unique_ptr<WeightSet> w(new WeightSet());
+    w->kind = kind;
+    w->nd = nd;
+    w->M = M;
+    const size_t wbytes = (size_t)(kind == BEATAMD_W_SCALAR ? nd : nd * M * M) * sizeof(double);
+    BA_TRY(dev_alloc_copy(ctx, nullptr, wbytes, (void **)&w->w));
+    BA_TRY(dev_alloc_copy(ctx, nullptr, (size_t)nd * 8, (void **)&w->slog));
+    BA_TRY(wset_fill(ctx, w.get(), weights, slog_pdet));
+    *wset_id = add_obj(ctx->wsets, std::move(w));
+    return BEATAMD_OK;
+}
+
+int beatamd_weights_update(beatamd_ctx *ctx, int32_t wset_id, const double *weights,
+                           const double *slog_pdet)
+{
+    ENTER(ctx);
+    WeightSet *w = get_obj(ctx->wsets, wset_id);
+    BA_CHECK(w && weights && slog_pdet, BEATAMD_EINVAL, "weights_update: bad argument");
+    BA_HIP(hipStreamSynchronize(ctx->stream));
+    return wset_fill(ctx, w, weights, slog_pdet);
+}
+
+int beatamd_weights_destroy(beatamd_ctx *ctx, int32_t wset_id)
+{
+    ENTER(ctx);
+    WeightSet *w = get_obj(ctx->wsets, wset_id);
+    BA_CHECK(w, BEATAMD_EINVAL, "unknown weight set %d", wset_id);
+    BA_HIP(hipStreamSynchronize(ctx->stream));
+    if (w->w) BA_HIP(hipFree(w->w));
+    if (w->slog) BA_HIP(hipFree(w->slog));
+    ctx->wsets[wset_id].reset();
+    return BEATAMD_OK;
+}
+
+int beatamd_mvn_chol_logp_batch(beatamd_ctx *ctx, int32_t wset_id, int64_t C,
+                                const double *residuals, const double *hp, double *logpts)
+{
+    ENTER(ctx);
+    WeightSet *w = get_obj(ctx->wsets, wset_id);
+    BA_CHECK(w, BEATAMD_EINVAL, "unknown weight set %d", wset_id);
+    BA_CHECK(residuals && hp && logpts && C >= 0, BEATAMD_EINVAL, "mvn_chol_logp: bad argument");
+    if (C == 0) return BEATAMD_OK;
+    const void *d_r, *d_h;
+    void *d_o, *p;
+    Arg rec;
+    BA_TRY(stage_in(ctx, SL_IN0, residuals, (size_t)C * w->nd * w->M * 8, &d_r));
+    BA_TRY(stage_in(ctx, SL_IN1, hp, (size_t)C * w->nd * 8, &d_h));
+    BA_TRY(stage_out(ctx, SL_OUT0, logpts, (size_t)C * w->nd * 8, &d_o, &rec));
+    BA_TRY(ctx->get_scratch(SL_QUAD, (size_t)C * w->nd * 8, &p));
+    BA_TRY(wset_quad(ctx, *w, C, (const double *)d_r, w->nd * w->M, w->M, (double *)p));
+    BA_TRY(launch_mvn_finish(ctx, C, w->nd, w->M, (const double *)p, w->slog,
+                             HpSrc{(const double *)d_h, w->nd, nullptr}, (double *)d_o, w->nd));
+    return finish_out(ctx, &rec, 1);
+}
+
+int beatamd_laplacian_create(beatamd_ctx *ctx, int64_t P, const double *L, double logdet,
+                             int32_t *lap_id)
+{
+    ENTER(ctx);
+    BA_CHECK(P > 0 && L && lap_id, BEATAMD_EINVAL, "laplacian_create: bad argument");
+    std::unique_ptr<Laplacian> l(new Laplacian());
+    l->P = P;
+    l->logdet = logdet;
+    BA_TRY(dev_alloc_copy(ctx, L, (size_t)P * P * 8, (void **)&l->L));
+    *lap_id = add_obj(ctx->laps, std::move(l));
+    return BEATAMD_OK;
+}
+
+int beatamd_laplacian_destroy(beatamd_ctx *ctx, int32_t lap_id)
+{
+    ENTER(ctx);
+    Laplacian *l = get_obj(ctx->laps, lap_id);
+    BA_CHECK(l, BEATAMD_EINVAL, "unknown laplacian %d", lap_id);
+    BA_HIP(hipStreamSynchronize(ctx->stream));
+    if (l->L) BA_HIP(hipFree(l->L));
+    ctx->laps[lap_id].reset();
+    return BEATAMD_OK;
+}
+
+int beatamd_laplacian_logp_batch(beatamd_ctx *ctx, int32_t lap_id, int64_t C, int64_t nvar,
+                                 const double *slips, const double *hp, double *out)
+{
+    ENTER(ctx);
+    Laplacian *l = get_obj(ctx->laps, lap_id);
+    BA_CHECK(l, BEATAMD_EINVAL, "unknown laplacian %d", lap_id);
+    BA_CHECK(slips && hp && out && C >= 0 && nvar > 0, BEATAMD_EINVAL, "laplacian_logp: bad argument");
+    if (C == 0) return BEATAMD_OK;
+    const void *d_s, *d_h;
+    void *d_o, *p;
+    Arg rec;
+    BA_TRY(stage_in(ctx, SL_IN0, slips, (size_t)C * nvar * l->P * 8, &d_s));
+    BA_TRY(stage_in(ctx, SL_IN1, hp, (size_t)C * 8, &d_h));
+    BA_TRY(stage_out(ctx, SL_OUT0, out, (size_t)C * 8, &d_o, &rec));
+    BA_TRY(ctx->get_scratch(SL_QUAD, (size_t)C * nvar * 8, &p));
+    QuadformCall q;
+    q.A = l->L; q.a_stride = 0; q.M = l->P; q.nd = nvar; q.C = C;
+    q.X = (const double *)d_s; q.xs_c = nvar * l->P; q.xs_d = l->P;
+    q.quad = (double *)p; q.q_stride = nvar;
+    BA_TRY(launch_quadform(ctx, q));
+    BA_TRY(launch_laplacian_finish(ctx, C, nvar, l->P, l->logdet, (const double *)p,
+                                   HpSrc{(const double *)d_h, 1, nullptr}, (double *)d_o, 1));
+    return finish_out(ctx, &rec, 1);
+}
+
+// ------------------------------------------------------------------ fused FFI model
+int beatamd_ffi_model_create(beatamd_ctx *ctx, const beatamd_ffi_layout *layout, int32_t nsub,
+                             const int32_t *ndip, const int32_t *nstrike, const double *patch_size,
+                             int32_t *model_id)
+{
+    ENTER(ctx);
+    BA_CHECK(layout && model_id, BEATAMD_EINVAL, "ffi_model_create: bad argument");
+    BA_CHECK(layout->nvar >= 1 && layout->nvar <= 3, BEATAMD_EINVAL,
+             "1..3 slip variables supported, got %d", layout->nvar);
+    BA_CHECK(nsub >= 0 && (nsub == 0 || (ndip && nstrike && patch_size)), BEATAMD_EINVAL,
+             "ffi_model_create: subfault description missing");
+    std::unique_ptr<FfiModel> m(new FfiModel());
+    m->layout = *layout;
+    m->nsub = nsub;
+    int64_t P = 0;
+    for (int s = 0; s < nsub; s++) {
+        BA_CHECK(ndip[s] > 0 && nstrike[s] > 0 && patch_size[s] > 0, BEATAMD_EINVAL,
+                 "subfault %d: bad discretisation", s);
+        m->ndip.push_back(ndip[s]);
+        m->nstrike.push_back(nstrike[s]);
+        m->patch_size.push_back(patch_size[s]);
+        m->patch_off.push_back((int32_t)P);
+        P += (int64_t)ndip[s] * nstrike[s];
+    }
+    m->P = P;
+    if (nsub > 0) {
+        BA_TRY(dev_alloc_copy(ctx, m->ndip.data(), nsub * 4, (void **)&m->d_ndip));
+        BA_TRY(dev_alloc_copy(ctx, m->nstrike.data(), nsub * 4, (void **)&m->d_nstrike));
+        BA_TRY(dev_alloc_copy(ctx, m->patch_off.data(), nsub * 4, (void **)&m->d_patch_off));
+        BA_TRY(dev_alloc_copy(ctx, m->patch_size.data(), nsub * 8, (void **)&m->d_patch_size));
+    }
+    *model_id = add_obj(ctx->models, std::move(m));
+    return BEATAMD_OK;
+}
+
+int beatamd_ffi_model_add_wavemap(beatamd_ctx *ctx, int32_t model_id, const int32_t *lib_ids,
+                                  const double *data, int32_t wset_id, const int64_t *hp_off,
+                                  const int64_t *shift_off, int32_t interpolation)
+{
+    ENTER(ctx);
+    FfiModel *m = get_obj(ctx->models, model_id);
+    BA_CHECK(m, BEATAMD_EINVAL, "unknown model %d", model_id);
+    BA_CHECK(lib_ids && data && hp_off, BEATAMD_EINVAL, "add_wavemap: NULL argument");
+    BA_CHECK(m->nsub > 0, BEATAMD_EINVAL, "add_wavemap: model has no subfaults");
+    BA_CHECK(interpolation == BEATAMD_NEAREST_NEIGHBOR || interpolation == BEATAMD_MULTILINEAR,
+             BEATAMD_EINVAL, "Interpolation scheme %d not implemented!", interpolation);
+    Wavemap w;
+    SeisLib *l0 = nullptr;
+    for (int v = 0; v < m->layout.nvar; v++) {
+        SeisLib *l = get_obj(ctx->seislibs, lib_ids[v]);
+        BA_CHECK(l, BEATAMD_EINVAL, "add_wavemap: unknown GF library %d", lib_ids[v]);
+        if (!l0) l0 = l;
+        w.libs.push_back(lib_ids[v]);
+    }
+    BA_CHECK(l0->P == m->P, BEATAMD_EINVAL,
+             "add_wavemap: library has %lld patches, fault has %lld", (long long)l0->P,
+             (long long)m->P);
+    WeightSet *ws = get_obj(ctx->wsets, wset_id);
+    BA_CHECK(ws && ws->nd == l0->T && ws->M == l0->N, BEATAMD_EINVAL,
+             "add_wavemap: weight set must hold %lld datasets of %lld samples", (long long)l0->T,
+             (long long)l0->N);
+    w.T = l0->T;
+    w.N = l0->N;
+    w.wset = wset_id;
+    w.interp = interpolation;
+    const int64_t np = m->layout.nparams;
+    for (int64_t t = 0; t < w.T; t++) {
+        BA_CHECK(hp_off[t] >= 0 && hp_off[t] < np, BEATAMD_EINVAL, "add_wavemap: hp_off[%lld] outside q",
+                 (long long)t);
+        if (shift_off)
+            BA_CHECK(shift_off[t] >= 0 && shift_off[t] < np, BEATAMD_EINVAL,
+                     "add_wavemap: shift_off[%lld] outside q", (long long)t);
+    }
+    BA_TRY(dev_alloc_copy(ctx, data, (size_t)w.T * w.N * 8, (void **)&w.data));
+    BA_TRY(dev_alloc_copy(ctx, hp_off, (size_t)w.T * 8, (void **)&w.hp_off));
+    if (shift_off) BA_TRY(dev_alloc_copy(ctx, shift_off, (size_t)w.T * 8, (void **)&w.shift_off));
+    m->wavemaps.push_back(std::move(w));
+    return BEATAMD_OK;
+}
+
+int beatamd_ffi_model_add_geodetic(beatamd_ctx *ctx, int32_t model_id, const int32_t *geo_lib_ids,
+                                   const double *data, const double *odws, int32_t nd,
+                                   const int64_t *sizes, const int32_t *wset_ids,
+                                   const int64_t *hp_off)
+{
+    ENTER(ctx);
+    FfiModel *m = get_obj(ctx->models, model_id);
+    BA_CHECK(m, BEATAMD_EINVAL, "unknown model %d", model_id);
+    BA_CHECK(!m->has_geo, BEATAMD_EINVAL, "model already has a geodetic composite");
+    BA_CHECK(geo_lib_ids && data && odws && sizes && wset_ids && hp_off && nd > 0, BEATAMD_EINVAL,
+             "add_geodetic: bad argument");
+    Geodetic g;
+    int64_t nobs = 0;
+    for (int d = 0; d < nd; d++) {
+        BA_CHECK(sizes[d] > 0, BEATAMD_EINVAL, "add_geodetic: empty dataset %d", d);
+        BA_CHECK(hp_off[d] >= 0 && hp_off[d] < m->layout.nparams, BEATAMD_EINVAL,
+                 "add_geodetic: hp_off[%d] outside q", d);
+        WeightSet *ws = get_obj(ctx->wsets, wset_ids[d]);
+        BA_CHECK(ws && ws->nd == 1 && ws->M == sizes[d], BEATAMD_EINVAL,
+                 "add_geodetic: weight set of dataset %d must be 1 x %lld", d, (long long)sizes[d]);
+        g.sizes.push_back(sizes[d]);
+        g.wsets.push_back(wset_ids[d]);
+        g.hp_off_host.push_back(hp_off[d]);
+        nobs += sizes[d];
+    }
+    for (int v = 0; v < m->layout.nvar; v++) {
+        GeoLib *l = get_obj(ctx->geolibs, geo_lib_ids[v]);
+        BA_CHECK(l && l->Nobs == nobs, BEATAMD_EINVAL,
+                 "add_geodetic: library %d missing or observation count mismatch", geo_lib_ids[v]);
+        if (m->nsub > 0)
+            BA_CHECK(l->P == m->P, BEATAMD_EINVAL, "add_geodetic: patch count mismatch");
+        else
+            m->P = l->P;
+        g.libs.push_back(geo_lib_ids[v]);
+    }
+    g.Nobs = nobs;
+    BA_TRY(dev_alloc_copy(ctx, data, (size_t)nobs * 8, (void **)&g.data));
+    BA_TRY(dev_alloc_copy(ctx, odws, (size_t)nobs * 8, (void **)&g.odws));
+    BA_TRY(dev_alloc_copy(ctx, hp_off, (size_t)nd * 8, (void **)&g.hp_off));
+    m->geo = std::move(g);
+    m->has_geo = true;
+    return BEATAMD_OK;
+}
+
+int beatamd_ffi_model_set_laplacian(beatamd_ctx *ctx, int32_t model_id, int32_t lap_id)
+{
+    ENTER(ctx);
+    FfiModel *m = get_obj(ctx->models, model_id);
+    BA_CHECK(m, BEATAMD_EINVAL, "unknown model %d", model_id);
+    Laplacian *l = get_obj(ctx->laps, lap_id);
+    BA_CHECK(l, BEATAMD_EINVAL, "unknown laplacian %d", lap_id);
+    BA_CHECK(m->layout.h_laplacian_off >= 0 && m->layout.h_laplacian_off < m->layout.nparams,
+             BEATAMD_EINVAL, "set_laplacian: layout has no h_laplacian offset");
+    BA_CHECK(m->P == 0 || l->P == m->P, BEATAMD_EINVAL, "set_laplacian: patch count mismatch");
+    if (m->P == 0) m->P = l->P;
+    m->lap = lap_id;
+    return BEATAMD_OK;
+}
+
+int beatamd_ffi_model_nllk(beatamd_ctx *ctx, int32_t model_id, int64_t *nllk)
+{
+    BA_CHECK(ctx && nllk, BEATAMD_EINVAL, "bad argument");
+    FfiModel *m = get_obj(ctx->models, model_id);
+    BA_CHECK(m, BEATAMD_EINVAL, "unknown model %d", model_id);
+    *nllk = m->nllk();
+    return BEATAMD_OK;
+}
+
+int beatamd_ffi_model_destroy(beatamd_ctx *ctx, int32_t model_id)
+{
+    ENTER(ctx);
+    FfiModel *m = get_obj(ctx->models, model_id);
+    BA_CHECK(m, BEATAMD_EINVAL, "unknown model %d", model_id);
+    BA_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &w : m->wavemaps) {
+        if (w.data) (void)hipFree(w.data);
+        if (w.hp_off) (void)hipFree(w.hp_off);
+        if (w.shift_off) (void)hipFree(w.shift_off);
+    }
+    if (m->geo.data) (void)hipFree(m->geo.data);
+    if (m->geo.odws) (void)hipFree(m->geo.odws);
+    if (m->geo.hp_off) (void)hipFree(m->geo.hp_off);
+    if (m->d_ndip) (void)hipFree(m->d_ndip);
+    if (m->d_nstrike) (void)hipFree(m->d_nstrike);
+    if (m->d_patch_off) (void)hipFree(m->d_patch_off);
+    if (m->d_patch_size) (void)hipFree(m->d_patch_size);
+    ctx->models[model_id].reset();
+    return BEATAMD_OK;
+}
+
+static int model_check_layout(const FfiModel &m)
+{
+    const beatamd_ffi_layout &L = m.layout;
+    const int64_t np = L.nparams;
+    BA_CHECK(np > 0, BEATAMD_EINVAL, "layout: nparams must be positive");
+    for (int v = 0; v < L.nvar; v++)
+        BA_CHECK(L.slip_off[v] >= 0 && L.slip_off[v] + m.P <= np, BEATAMD_EINVAL,
+                 "layout: slip variable %d outside q", v);
+    if (!m.wavemaps.empty()) {
+        BA_CHECK(L.durations_off >= 0 && L.durations_off + m.P <= np, BEATAMD_EINVAL,
+                 "layout: durations outside q");
+        BA_CHECK(L.velocities_off >= 0 && L.velocities_off + m.P <= np, BEATAMD_EINVAL,
+                 "layout: velocities outside q");
+        BA_CHECK(L.nuc_strike_off >= 0 && L.nuc_strike_off + m.nsub <= np && L.nuc_dip_off >= 0 &&
+                     L.nuc_dip_off + m.nsub <= np && L.time_off >= 0 && L.time_off + m.nsub <= np,
+                 BEATAMD_EINVAL, "layout: hypocentre variables outside q");
+    }
+    BA_CHECK(!m.wavemaps.empty() || m.has_geo || m.lap >= 0, BEATAMD_EINVAL,
+             "model has no composite");
+    return BEATAMD_OK;
+}
+
+int beatamd_ffi_logp_batch(beatamd_ctx *ctx, int32_t model_id, int64_t C, const double *Q,
+                           double *LL)
+{
+    ENTER(ctx);
+    FfiModel *m = get_obj(ctx->models, model_id);
+    BA_CHECK(m, BEATAMD_EINVAL, "unknown model %d", model_id);
+    BA_CHECK(Q && LL && C >= 0, BEATAMD_EINVAL, "ffi_logp: bad argument");
+    BA_TRY(model_check_layout(*m));
+    if (C == 0) return BEATAMD_OK;
+    const void *d_q;
+    void *d_l;
+    Arg rec;
+    BA_TRY(stage_in(ctx, SL_IN0, Q, (size_t)C * m->layout.nparams * 8, &d_q));
+    BA_TRY(stage_out(ctx, SL_OUT0, LL, (size_t)C * m->nllk() * 8, &d_l, &rec));
+    BA_TRY(ffi_logp_device(ctx, *m, C, (const double *)d_q, (double *)d_l));
+    return finish_out(ctx, &rec, 1);
+}
+
+int beatamd_ffi_astep_batch(beatamd_ctx *ctx, int32_t model_id, int64_t C, double *Q0, double *L0,
+                            const double *delta, const double *scaling, const double *lower,
+                            const double *upper, const double *log_u, double beta,
+                            int32_t *accepted)
+{
+    ENTER(ctx);
+    FfiModel *m = get_obj(ctx->models, model_id);
+    BA_CHECK(m, BEATAMD_EINVAL, "unknown model %d", model_id);
+    BA_CHECK(Q0 && L0 && delta && scaling && lower && upper && log_u && accepted && C >= 0,
+             BEATAMD_EINVAL, "ffi_astep: NULL argument");
+    BA_TRY(model_check_layout(*m));
+    if (C == 0) return BEATAMD_OK;
+    const int64_t np = m->layout.nparams, nllk = m->nllk();
+    const void *d_de, *d_sc, *d_lo, *d_up, *d_lu;
+    void *d_q0, *d_l0, *d_acc, *p;
+    Arg recs[3];
+    BA_TRY(stage_out(ctx, SL_OUT0, Q0, (size_t)C * np * 8, &d_q0, &recs[0], true));
+    BA_TRY(stage_out(ctx, SL_OUT1, L0, (size_t)C * nllk * 8, &d_l0, &recs[1], true));
+    BA_TRY(stage_out(ctx, SL_OUT2, accepted, (size_t)C * 4, &d_acc, &recs[2]));
+    BA_TRY(stage_in(ctx, SL_IN1, delta, (size_t)C * np * 8, &d_de));
+    BA_TRY(stage_in(ctx, SL_IN2, scaling, (size_t)C * 8, &d_sc));
+    BA_TRY(stage_in(ctx, SL_IN3, lower, (size_t)np * 8, &d_lo));
+    BA_TRY(stage_in(ctx, SL_IN4, upper, (size_t)np * 8, &d_up));
+    BA_TRY(stage_in(ctx, SL_IN5, log_u, (size_t)C * 8, &d_lu));
+    BA_TRY(ctx->get_scratch(SL_QPROP, (size_t)C * np * 8, &p));
+    double *qprop = (double *)p;
+    BA_TRY(ctx->get_scratch(SL_LPROP, (size_t)C * nllk * 8, &p));
+    double *lprop = (double *)p;
+    BA_TRY(ctx->get_scratch(SL_MISC, (size_t)C * 4 + 64, &p));
+    int32_t *inb = (int32_t *)p;
+    BA_TRY(launch_propose(ctx, C, np, (const double *)d_q0, (const double *)d_de,
+                          (const double *)d_sc, (const double *)d_lo, (const double *)d_up, qprop,
+                          inb));
+    BA_TRY(ffi_logp_device(ctx, *m, C, qprop, lprop));
+    BA_TRY(launch_accept(ctx, C, np, nllk, (double *)d_q0, (double *)d_l0, qprop, lprop, inb,
+                         (const double *)d_lu, beta, (int32_t *)d_acc));
+    return finish_out(ctx, recs, 3);
+}
+
+}  // extern "C"

@@ -1,0 +1,183 @@
+// ctx.hpp -- context, error handling, host/device argument staging, kernel timing.
+// Internal to libbeat_amd.so (gfx950 only; no CUDA/portability layer).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/beat_amd.h"
+
+namespace beatamd {
+
+void set_error(const char *fmt, ...);
+
+#define BA_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            beatamd::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,                 \
+                               hipGetErrorString(e_));                                       \
+            return BEATAMD_EHIP;                                                             \
+        }                                                                                    \
+    } while (0)
+
+#define BA_CHECK(cond, code, ...)                                                            \
+    do {                                                                                     \
+        if (!(cond)) {                                                                       \
+            beatamd::set_error(__VA_ARGS__);                                                 \
+            return (code);                                                                   \
+        }                                                                                    \
+    } while (0)
+
+#define BA_TRY(expr)                                                                         \
+    do {                                                                                     \
+        int rc_ = (expr);                                                                    \
+        if (rc_ != BEATAMD_OK) return rc_;                                                   \
+    } while (0)
+
+// device status bits set by kernels (checked at synchronisation points)
+enum : int { ST_INDEX_OOB = 1, ST_BAD_HYPO = 2 };
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+};
+
+struct SeisLib {
+    int64_t T = 0, P = 0, D = 0, S = 0, N = 0;
+    double st_min = 0, st_dt = 1, du_min = 0, du_dt = 1;
+    double *g = nullptr;  // HBM, (T,P,D,S,N) C-order, N fastest
+    bool owned = false;
+    int64_t elems() const { return T * P * D * S * N; }
+};
+
+struct GeoLib {
+    int64_t P = 0, Nobs = 0;
+    double *g = nullptr;  // (P, Nobs)
+};
+
+struct WeightSet {
+    int kind = BEATAMD_W_SCALAR;
+    int64_t nd = 0, M = 0;
+    double *w = nullptr;     // [nd] or [nd,M,M]
+    double *slog = nullptr;  // [nd]
+    int upper_tri = 0;       // dense only: exact zeros below the diagonal in every W
+};
+
+struct Laplacian {
+    int64_t P = 0;
+    double *L = nullptr;
+    double logdet = 0;
+};
+
+struct Wavemap {
+    std::vector<int32_t> libs;
+    double *data = nullptr;  // [T,N]
+    int32_t wset = -1;
+    int64_t *hp_off = nullptr;     // device [T]
+    int64_t *shift_off = nullptr;  // device [T] or nullptr
+    int interp = 0;
+    int64_t T = 0, N = 0;
+};
+
+struct Geodetic {
+    std::vector<int32_t> libs;
+    double *data = nullptr, *odws = nullptr;  // [Nobs]
+    int64_t Nobs = 0;
+    std::vector<int64_t> sizes;
+    std::vector<int32_t> wsets;
+    int64_t *hp_off = nullptr;  // device [nd]
+    std::vector<int64_t> hp_off_host;
+};
+
+struct FfiModel {
+    beatamd_ffi_layout layout;
+    int32_t nsub = 0;
+    std::vector<int32_t> ndip, nstrike, patch_off;
+    std::vector<double> patch_size;
+    int64_t P = 0;
+    int32_t *d_ndip = nullptr, *d_nstrike = nullptr, *d_patch_off = nullptr;
+    double *d_patch_size = nullptr;
+    std::vector<Wavemap> wavemaps;
+    bool has_geo = false;
+    Geodetic geo;
+    int32_t lap = -1;
+    int64_t nllk() const;
+};
+
+struct KTimer {
+    double total_ms = 0;
+    int64_t n = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+}  // namespace beatamd
+
+struct beatamd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr, own_stream = nullptr;
+    bool timing = false;
+    std::map<std::string, beatamd::KTimer> timers;
+    std::vector<hipEvent_t> event_pool;
+    int *d_status = nullptr;  // device status word
+    std::vector<beatamd::DevBuf> scratch;
+    std::vector<std::unique_ptr<beatamd::SeisLib>> seislibs;
+    std::vector<std::unique_ptr<beatamd::GeoLib>> geolibs;
+    std::vector<std::unique_ptr<beatamd::WeightSet>> wsets;
+    std::vector<std::unique_ptr<beatamd::Laplacian>> laps;
+    std::vector<std::unique_ptr<beatamd::FfiModel>> models;
+    int num_cu = 256;
+
+    // grow-only scratch slot
+    int get_scratch(int slot, size_t bytes, void **out);
+    hipEvent_t get_event();
+    void time_begin(const char *name);
+    void time_end(const char *name);
+    int check_status();  // sync + read status word; maps to BEATAMD_E*
+};
+
+namespace beatamd {
+
+bool is_device_ptr(const void *p);
+
+// RAII-ish staging of one array argument.  Host pointers are mirrored in a scratch slot.
+struct Arg {
+    beatamd_ctx *ctx;
+    void *host = nullptr;  // non-null => needs copy back (if out) after the launch
+    void *dev = nullptr;
+    size_t bytes = 0;
+    bool out = false;
+};
+
+// in: returns device pointer holding the data (copy if host)
+int stage_in(beatamd_ctx *ctx, int slot, const void *p, size_t bytes, const void **dev);
+// out: returns device pointer to write into; if host, remember for copy_back
+int stage_out(beatamd_ctx *ctx, int slot, void *p, size_t bytes, void **dev, Arg *rec,
+              bool preload = false);
+int finish_out(beatamd_ctx *ctx, Arg *recs, int n);  // D2H copies + sync if any host outs
+
+struct ScopedTimer {
+    beatamd_ctx *c;
+    const char *n;
+    ScopedTimer(beatamd_ctx *ctx, const char *name) : c(ctx), n(name) { c->time_begin(n); }
+    ~ScopedTimer() { c->time_end(n); }
+};
+
+// scratch slot map (one per logical temporary so slots never alias within a call)
+enum Slot : int {
+    SL_IN0 = 0, SL_IN1, SL_IN2, SL_IN3, SL_IN4, SL_IN5, SL_IN6, SL_IN7,
+    SL_OUT0, SL_OUT1, SL_OUT2,
+    SL_ROWOFF, SL_WEIGHTS, SL_ST0, SL_RESID, SL_PARTIAL, SL_QUAD, SL_MU, SL_HP, SL_SLIPS,
+    SL_QPROP, SL_LPROP, SL_MISC, SL_COUNT
+};
+
+}  // namespace beatamd

@@ -1,0 +1,365 @@
+// gfstack.hip -- Green's-function stacking (SeismicGFLibrary.stack_all) for gfx950,
+// batched over chains, with the residual / scalar-covariance misfit fused in the epilogue.
+//
+// Reference arithmetic: beat/ffi/base.py:486-568 (time -> index maps), :607-709
+// (stack_all: gather by (duration, starttime) index + slip-weighted sum over patches).
+//
+// Roofline: HBM.  Per chain-step the kernel must read T*P rows of N doubles (x4 for
+// multilinear) exactly once: 0.25 flop/byte.  Design:
+//   k_gf_tables  one thread per (chain, target, patch): time -> int16 grid index with
+//                numpy semantics (rint = round-half-even, ceil, negative-index wrap),
+//                emits a uint32 row id (and the 4 bilinear factors for multilinear).
+//   k_gfstack    one 256-thread workgroup per (chain, target, 4 KB-wide sample tile).
+//                The row id and the slip are wave-uniform -> fetched with scalar loads
+//                (s_load), the row base lives in SGPRs, and every lane streams 16 B
+//                (global_load_dwordx4) per row: 1 KB per wave-instruction, 4 KB contiguous
+//                per workgroup per row, 8 rows in flight per lane.  fp64 FMA accumulate in
+//                registers, no atomics, no LDS traffic on the streaming path (the stream is
+//                read exactly once, staging it in LDS would only add latency); LDS is used
+//                for the block reduction of the fused misfit.
+#include "kernels.hpp"
+
+namespace beatamd {
+
+// ------------------------------------------------------------------------ tables
+struct TabArgs {
+    int interp;
+    int64_t C, T, P, D, S;
+    double st_min, st_dt, du_min, du_dt;
+    ChainVec durations;
+    StartTimeSrc st;
+    uint32_t *rowoff;  // nn: [C,T,P]   ml: [C,T,P,4] (cc, fc, cf, ff)
+    double *fac;       // ml: [C,T,P,4]
+    int *status;
+};
+
+// numpy: float64 -> int16 astype (wraps modulo 2^16 for in-range int64 values)
+__device__ __forceinline__ int to_int16(double x) { return (int)(int16_t)(long long)x; }
+
+// python negative-index wrap; returns false if outside [-n, n)
+__device__ __forceinline__ bool wrap_index(int &i, int n)
+{
+    if (i < 0) i += n;
+    return i >= 0 && i < n;
+}
+
+__global__ void __launch_bounds__(256) k_gf_tables(TabArgs a)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = a.C * a.T * a.P;
+    if (idx >= total) return;
+    const int64_t p = idx % a.P;
+    const int64_t ct = idx / a.P;
+    const int64_t t = ct % a.T;
+    const int64_t c = ct / a.T;
+
+    double st;
+    if (a.st.explicit_st) {
+        st = a.st.explicit_st[idx];
+    } else {
+        // seismic.py:1283-1296: tile(starttimes0, T) - repeat(time_shifts[station_idx], P)
+        st = a.st.starttimes0[c * a.P + p];
+        if (a.st.shift_off) st = st - a.st.Q[c * a.st.nparams + a.st.shift_off[t]];
+    }
+    const double du = a.durations.base[c * a.durations.stride + a.durations.off + p];
+    const int D = (int)a.D, S = (int)a.S;
+    const int64_t row0 = (t * a.P + p) * a.D;  // row id = (row0 + di) * S + si
+    bool ok = true;
+    if (a.interp == BEATAMD_NEAREST_NEIGHBOR) {
+        // base.py:506-511 / :553-558: round((x - min) / sampling).astype(int16)
+        int si = to_int16(rint((st - a.st_min) / a.st_dt));
+        int di = to_int16(rint((du - a.du_min) / a.du_dt));
+        const bool ok_s = wrap_index(si, S), ok_d = wrap_index(di, D);
+        ok = ok_s && ok_d;
+        if (!ok) { si = 0; di = 0; }
+        a.rowoff[idx] = (uint32_t)((row0 + di) * a.S + si);
+    } else {
+        // base.py:512-517 / :559-564: ceil -> int16, factor = ceil - x (weight of the FLOOR node)
+        const double ds = (st - a.st_min) / a.st_dt;
+        const double dd = (du - a.du_min) / a.du_dt;
+        int sc = to_int16(ceil(ds)), dc = to_int16(ceil(dd));
+        const double stf = (double)sc - ds, rtf = (double)dc - dd;
+        int sf = sc - 1, df = dc - 1;
+        const bool o1 = wrap_index(sc, S), o2 = wrap_index(dc, D), o3 = wrap_index(sf, S),
+                   o4 = wrap_index(df, D);
+        ok = o1 && o2 && o3 && o4;
+        if (!ok) { sc = dc = sf = df = 0; }
+        uint32_t *ro = a.rowoff + idx * 4;
+        double *fa = a.fac + idx * 4;
+        ro[0] = (uint32_t)((row0 + dc) * a.S + sc);  // st ceil , rt ceil
+        ro[1] = (uint32_t)((row0 + dc) * a.S + sf);  // st floor, rt ceil
+        ro[2] = (uint32_t)((row0 + df) * a.S + sc);  // st ceil , rt floor
+        ro[3] = (uint32_t)((row0 + df) * a.S + sf);  // st floor, rt floor
+        // base.py:676-679 (the slip factor is applied in k_gfstack)
+        fa[0] = (1 - stf) * (1 - rtf);
+        fa[1] = stf * (1.0 - rtf);
+        fa[2] = (1 - stf) * rtf;
+        fa[3] = stf * rtf;
+    }
+    if (!ok) atomicOr(a.status, ST_INDEX_OOB);
+}
+
+// ------------------------------------------------------------------------ stacking
+struct GfArgs {
+    const double *G[4];
+    ChainVec slips[4];
+    int64_t T, P, N;
+    const uint32_t *rowoff;
+    const double *fac;
+    const double *data;
+    const double *wscalar;
+    double *out;
+    double *partial;  // [C*T, ntile]
+    int ntile;
+};
+
+template <int W> struct VecT;
+template <> struct VecT<2> { using type = double2; };
+template <> struct VecT<1> { using type = double; };
+
+template <int W>
+__device__ __forceinline__ typename VecT<W>::type ldg(const double *p)
+{
+    return *reinterpret_cast<const typename VecT<W>::type *>(p);
+}
+__device__ __forceinline__ void fma_acc(double2 &acc, double2 x, double w)
+{
+    acc.x = fma(x.x, w, acc.x);
+    acc.y = fma(x.y, w, acc.y);
+}
+__device__ __forceinline__ void fma_acc(double &acc, double x, double w) { acc = fma(x, w, acc); }
+
+// INTERP 0 nn / 1 ml ; NVAR slip variables ; VEC chunks of 256*W samples per thread ;
+// W doubles per lane per load (2 when N is even -> 16-byte loads) ; MODE GfMode
+template <int INTERP, int NVAR, int VEC, int W, int MODE>
+__global__ void __launch_bounds__(256) k_gfstack(GfArgs a)
+{
+    using V = typename VecT<W>::type;
+    constexpr int NROW = INTERP ? 4 : 1;
+    constexpr int CH = 256 * W;  // samples per chunk
+    // rows of V in flight per lane ~ 8
+    constexpr int U = (8 / (NROW * NVAR * VEC)) > 0 ? (8 / (NROW * NVAR * VEC)) : 1;
+
+    const int tile = blockIdx.x % a.ntile;
+    const int64_t ct = blockIdx.x / a.ntile;  // = c*T + t
+    const int64_t c = ct / a.T;
+    const int64_t t = ct - c * a.T;
+    const int64_t N = a.N;
+    const int P = (int)a.P;
+
+    int64_t n[VEC];
+    bool inb[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) {
+        const int64_t nn = ((int64_t)tile * VEC + v) * CH + (int64_t)threadIdx.x * W;
+        inb[v] = nn < N;  // N even when W == 2 -> a pair is never split
+        n[v] = inb[v] ? nn : 0;  // out-of-range lanes re-read sample 0 (discarded)
+    }
+    const uint32_t *ro = a.rowoff + ct * a.P * NROW;
+    const double *fa = INTERP ? (a.fac + ct * a.P * NROW) : nullptr;
+    const double *sl[NVAR];
+#pragma unroll
+    for (int iv = 0; iv < NVAR; iv++)
+        sl[iv] = a.slips[iv].base + c * a.slips[iv].stride + a.slips[iv].off;
+
+    V acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) acc[v] = V{};
+
+    int p = 0;
+    for (; p + U <= P; p += U) {
+        V x[U][NROW][NVAR][VEC];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int k = 0; k < NROW; k++) {
+                const int64_t roff = (int64_t)ro[(p + u) * NROW + k] * N;  // wave-uniform (SGPR)
+#pragma unroll
+                for (int iv = 0; iv < NVAR; iv++) {
+                    const double *row = a.G[iv] + roff;
+#pragma unroll
+                    for (int v = 0; v < VEC; v++) x[u][k][iv][v] = ldg<W>(row + n[v]);
+                }
+            }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int k = 0; k < NROW; k++)
+#pragma unroll
+                for (int iv = 0; iv < NVAR; iv++) {
+                    double w = sl[iv][p + u];
+                    if (INTERP) w = fa[(p + u) * NROW + k] * w;
+#pragma unroll
+                    for (int v = 0; v < VEC; v++) fma_acc(acc[v], x[u][k][iv][v], w);
+                }
+    }
+    for (; p < P; p++) {
+#pragma unroll
+        for (int k = 0; k < NROW; k++) {
+            const int64_t roff = (int64_t)ro[p * NROW + k] * N;
+#pragma unroll
+            for (int iv = 0; iv < NVAR; iv++) {
+                double w = sl[iv][p];
+                if (INTERP) w = fa[p * NROW + k] * w;
+                const double *row = a.G[iv] + roff;
+#pragma unroll
+                for (int v = 0; v < VEC; v++) fma_acc(acc[v], ldg<W>(row + n[v]), w);
+            }
+        }
+    }
+
+    // ---- epilogue
+    if (MODE == GF_STORE_SYN) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++)
+            if (inb[v]) *reinterpret_cast<V *>(a.out + ct * N + n[v]) = acc[v];
+    } else if (MODE == GF_RESID_STORE) {
+        // seismic.py:1332: residuals = data - synthetics
+#pragma unroll
+        for (int v = 0; v < VEC; v++)
+            if (inb[v]) {
+                V d = ldg<W>(a.data + t * N + n[v]);
+                V r;
+                if constexpr (W == 2) { r.x = d.x - acc[v].x; r.y = d.y - acc[v].y; }
+                else { r = d - acc[v]; }
+                *reinterpret_cast<V *>(a.out + ct * N + n[v]) = r;
+            }
+    } else {
+        // distributions.py:128-136 with W = w I: tmp = w * r ; tmp . tmp
+        const double w = a.wscalar[t];
+        double q = 0.0;
+#pragma unroll
+        for (int v = 0; v < VEC; v++)
+            if (inb[v]) {
+                V d = ldg<W>(a.data + t * N + n[v]);
+                if constexpr (W == 2) {
+                    double t0 = w * (d.x - acc[v].x), t1 = w * (d.y - acc[v].y);
+                    q = fma(t0, t0, q);
+                    q = fma(t1, t1, q);
+                } else {
+                    double t0 = w * (d - acc[v]);
+                    q = fma(t0, t0, q);
+                }
+            }
+        for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
+        __shared__ double red[4];
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            a.partial[ct * a.ntile + tile] = ((red[0] + red[1]) + red[2]) + red[3];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_sum_tiles(const double *partial, int64_t n, int ntile,
+                                                  double *quad)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int k = 0; k < ntile; k++) s += partial[i * ntile + k];  // fixed order: deterministic
+    quad[i] = s;
+}
+
+template <int INTERP, int NVAR, int VEC, int W>
+static void launch_mode(int mode, dim3 grid, hipStream_t s, const GfArgs &a)
+{
+    if (mode == GF_STORE_SYN)
+        hipLaunchKernelGGL((k_gfstack<INTERP, NVAR, VEC, W, GF_STORE_SYN>), grid, dim3(256), 0, s, a);
+    else if (mode == GF_RESID_SCALAR)
+        hipLaunchKernelGGL((k_gfstack<INTERP, NVAR, VEC, W, GF_RESID_SCALAR>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((k_gfstack<INTERP, NVAR, VEC, W, GF_RESID_STORE>), grid, dim3(256), 0, s, a);
+}
+
+template <int INTERP, int VEC, int W>
+static void launch_nvar(int nvar, int mode, dim3 grid, hipStream_t s, const GfArgs &a)
+{
+    if (nvar == 1) launch_mode<INTERP, 1, VEC, W>(mode, grid, s, a);
+    else if (nvar == 2) launch_mode<INTERP, 2, VEC, W>(mode, grid, s, a);
+    else launch_mode<INTERP, 3, VEC, W>(mode, grid, s, a);
+}
+
+int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &k)
+{
+    const SeisLib &L = *k.libs[0];
+    BA_CHECK(k.nvar >= 1 && k.nvar <= 3, BEATAMD_EINVAL, "gfstack: 1..3 slip variables supported");
+    for (int v = 1; v < k.nvar; v++) {
+        const SeisLib &M = *k.libs[v];
+        BA_CHECK(M.T == L.T && M.P == L.P && M.D == L.D && M.S == L.S && M.N == L.N &&
+                     M.st_min == L.st_min && M.st_dt == L.st_dt && M.du_min == L.du_min &&
+                     M.du_dt == L.du_dt,
+                 BEATAMD_EINVAL, "gfstack: libraries of the slip variables differ in shape/grid");
+    }
+    BA_CHECK(L.T * L.P * L.D * L.S < (int64_t)0xffffffffLL, BEATAMD_EINVAL,
+             "gfstack: library has more than 2^32 rows");
+    if (k.C == 0) return BEATAMD_OK;
+    const int64_t CTP = k.C * L.T * L.P;
+    const int nrow = k.interp == BEATAMD_MULTILINEAR ? 4 : 1;
+
+    TabArgs ta;
+    ta.interp = k.interp;
+    ta.C = k.C; ta.T = L.T; ta.P = L.P; ta.D = L.D; ta.S = L.S;
+    ta.st_min = L.st_min; ta.st_dt = L.st_dt; ta.du_min = L.du_min; ta.du_dt = L.du_dt;
+    ta.durations = k.durations;
+    ta.st = k.st;
+    ta.status = ctx->d_status;
+    void *p = nullptr;
+    BA_TRY(ctx->get_scratch(SL_ROWOFF, (size_t)CTP * nrow * sizeof(uint32_t), &p));
+    ta.rowoff = (uint32_t *)p;
+    ta.fac = nullptr;
+    if (nrow == 4) {
+        BA_TRY(ctx->get_scratch(SL_WEIGHTS, (size_t)CTP * 4 * sizeof(double), &p));
+        ta.fac = (double *)p;
+    }
+    {
+        ScopedTimer tm(ctx, "tables");
+        hipLaunchKernelGGL(k_gf_tables, dim3((unsigned)((CTP + 255) / 256)), dim3(256), 0,
+                           ctx->stream, ta);
+    }
+    BA_HIP(hipGetLastError());
+
+    GfArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int v = 0; v < k.nvar; v++) {
+        a.G[v] = k.libs[v]->g;
+        a.slips[v] = k.slips[v];
+    }
+    a.T = L.T; a.P = L.P; a.N = L.N;
+    a.rowoff = ta.rowoff;
+    a.fac = ta.fac;
+    a.data = k.data;
+    a.wscalar = k.wscalar;
+    a.out = k.out;
+    const int W = (L.N % 2 == 0) ? 2 : 1;
+    const int VEC = 1;
+    const int64_t tile_w = (int64_t)256 * W * VEC;
+    a.ntile = (int)((L.N + tile_w - 1) / tile_w);
+    if (k.mode == GF_RESID_SCALAR) {
+        BA_TRY(ctx->get_scratch(SL_PARTIAL, (size_t)k.C * L.T * a.ntile * sizeof(double), &p));
+        a.partial = (double *)p;
+    }
+    const int64_t nblocks = k.C * L.T * a.ntile;
+    BA_CHECK(nblocks < (int64_t)0x7fffffff, BEATAMD_EINVAL, "gfstack: batch too large (%lld blocks)",
+             (long long)nblocks);
+    dim3 grid((unsigned)nblocks);
+    {
+        ScopedTimer tm(ctx, "gfstack");
+        if (k.interp == BEATAMD_NEAREST_NEIGHBOR) {
+            if (W == 2) launch_nvar<0, 1, 2>(k.nvar, k.mode, grid, ctx->stream, a);
+            else launch_nvar<0, 1, 1>(k.nvar, k.mode, grid, ctx->stream, a);
+        } else {
+            if (W == 2) launch_nvar<1, 1, 2>(k.nvar, k.mode, grid, ctx->stream, a);
+            else launch_nvar<1, 1, 1>(k.nvar, k.mode, grid, ctx->stream, a);
+        }
+    }
+    BA_HIP(hipGetLastError());
+    if (k.mode == GF_RESID_SCALAR) {
+        const int64_t n = k.C * L.T;
+        hipLaunchKernelGGL(k_sum_tiles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           a.partial, n, a.ntile, k.quad);
+        BA_HIP(hipGetLastError());
+    }
+    return BEATAMD_OK;
+}
+
+}  // namespace beatamd

@@ -1,0 +1,108 @@
+// kernels.hpp -- launch interfaces of the HIP kernels (internal).
+#pragma once
+#include <algorithm>
+
+#include "ctx.hpp"
+
+namespace beatamd {
+
+// ---- sweep.hip -------------------------------------------------------------------
+int launch_sweep_explicit(beatamd_ctx *ctx, const double *slow, double h, const int32_t *hi,
+                          const int32_t *hj, int ni, int nj, int64_t C, double *out);
+int launch_sweep_model(beatamd_ctx *ctx, const FfiModel &m, const double *Q, int64_t C,
+                       double *starttimes0);
+
+// ---- gfstack.hip -----------------------------------------------------------------
+// Where the per-(chain,target,patch) start times come from.
+struct StartTimeSrc {
+    // explicit: st[(c*T + t)*P + p]
+    const double *explicit_st = nullptr;
+    // model: st = starttimes0[c*P + p] - Q[c*nparams + shift_off[t]]   (seismic.py:1283-1296)
+    const double *starttimes0 = nullptr;
+    const double *Q = nullptr;
+    int64_t nparams = 0;
+    const int64_t *shift_off = nullptr;  // device [T] or nullptr (no station corrections)
+};
+
+// a strided view of per-chain vectors: value(c, k) = base[c*stride + off + k]
+struct ChainVec {
+    const double *base = nullptr;
+    int64_t stride = 0, off = 0;
+};
+
+enum GfMode : int {
+    GF_STORE_SYN = 0,     // out[c,t,n] = synthetics                      (stack_all)
+    GF_RESID_SCALAR = 1,  // partial[c,t,tile] = sum (w_t (d - syn))^2     (fused logp, W = w I)
+    GF_RESID_STORE = 2    // out[c,t,n] = d[t,n] - synthetics              (feeds the dense W quadform)
+};
+
+struct GfStackCall {
+    const SeisLib *libs[4] = {nullptr, nullptr, nullptr, nullptr};
+    int nvar = 1;
+    ChainVec slips[4];
+    ChainVec durations;
+    StartTimeSrc st;
+    int interp = 0;
+    int64_t C = 0;
+    int mode = GF_STORE_SYN;
+    const double *data = nullptr;     // [T,N]   (modes 1,2)
+    const double *wscalar = nullptr;  // [T]     (mode 1)
+    double *out = nullptr;            // [C,T,N] (modes 0,2)
+    double *quad = nullptr;           // [C,T]   (mode 1) sum over tiles, fixed order
+};
+int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &call);
+
+// ---- quadform.hip ----------------------------------------------------------------
+// quad[c,d] = || A_d x_{c,d} ||^2 ; A [nd or 1, M, M] row-major ; x(c,d,k) = X[c*xs_c + d*xs_d + k]
+struct QuadformCall {
+    const double *A = nullptr;
+    int64_t a_stride = 0;  // elements between consecutive A_d (0: one shared A)
+    int64_t M = 0, nd = 0, C = 0;
+    const double *X = nullptr;
+    int64_t xs_c = 0, xs_d = 0;
+    int upper_tri = 0;
+    double *quad = nullptr;  // [C, nd] with row stride q_stride
+    int64_t q_stride = 0;
+};
+int launch_quadform(beatamd_ctx *ctx, const QuadformCall &call);
+int launch_check_upper_tri(beatamd_ctx *ctx, const double *A, int64_t nd, int64_t M, int *flag_dev);
+
+// ---- logp.hip (small kernels) ------------------------------------------------------
+struct HpSrc {  // hp(c,d) = base[c*stride + (offs ? offs[d] : d)]
+    const double *base = nullptr;
+    int64_t stride = 0;
+    const int64_t *offs = nullptr;
+};
+// logpts[c*ld + d] = -0.5*(slog[d] + int16(M)*(2hp+log2pi) + (1/exp(2hp))*quad[c*nd+d]*wsq)
+int launch_mvn_finish(beatamd_ctx *ctx, int64_t C, int64_t nd, int64_t M, const double *quad,
+                      const double *slog, HpSrc hp, double *logpts, int64_t ld);
+// scalar-weight quadratic form: quad[c,d] = sum_k (w_d * X[c,d,k])^2
+int launch_scalar_quad(beatamd_ctx *ctx, int64_t C, int64_t nd, int64_t M, const double *X,
+                       int64_t xs_c, int64_t xs_d, const double *w, double *quad);
+// geodetic: mu[c,k] (+)= sum_p slips(c,p) G[p,k]
+int launch_geo_stack(beatamd_ctx *ctx, const GeoLib &lib, int64_t C, ChainVec slips,
+                     int accumulate, double *mu);
+// res[c,k] = (data[k] - mu[c,k]) * odw[k]
+int launch_geo_residual(beatamd_ctx *ctx, int64_t C, int64_t Nobs, const double *data,
+                        const double *odw, const double *mu, double *res);
+// laplacian: out[c*ld] = sum_v -0.5*(-logdet + P*(log2pi+2h) + (1/exp(2h))*quad[c,v])
+int launch_laplacian_finish(beatamd_ctx *ctx, int64_t C, int64_t nvar, int64_t P, double logdet,
+                            const double *quad, HpSrc hp, double *out, int64_t ld);
+// LL[c, nllk-1] = sum of composite sums (problems.py:227-247)
+struct LikeGroups {  // composite boundaries inside the llk vector (exclusive ends)
+    int32_t end[8];
+    int n = 0;
+};
+int launch_like_sum(beatamd_ctx *ctx, int64_t C, int64_t nllk, const LikeGroups &grp, double *LL);
+// gather slips of all variables into a dense [C, nvar, P] buffer
+int launch_gather_slips(beatamd_ctx *ctx, int64_t C, int nvar, int64_t P, const ChainVec *slips,
+                        double *out);
+// metropolis.py:276-422 pieces
+int launch_propose(beatamd_ctx *ctx, int64_t C, int64_t nparams, const double *Q0,
+                   const double *delta, const double *scaling, const double *lower,
+                   const double *upper, double *Qprop, int32_t *inbounds);
+int launch_accept(beatamd_ctx *ctx, int64_t C, int64_t nparams, int64_t nllk, double *Q0,
+                  double *L0, const double *Qprop, const double *Lprop, const int32_t *inbounds,
+                  const double *log_u, double beta, int32_t *accepted);
+
+}  // namespace beatamd

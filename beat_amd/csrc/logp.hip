@@ -1,0 +1,272 @@
+// logp.hip -- the small kernels around the two heavy ones: likelihood epilogues, the
+// geodetic static stacking, the Metropolis propose/accept step.  All O(C * small).
+#include "kernels.hpp"
+
+namespace beatamd {
+
+#define LOG_2PI 1.8378770664093453  // log(2*pi), distributions.py:13
+
+__device__ __forceinline__ double hp_value(const HpSrc &h, int64_t c, int64_t d)
+{
+    return h.base[c * h.stride + (h.offs ? h.offs[d] : d)];
+}
+
+// distributions.py:119-138:
+//   -0.5 * (slog_pdet + M*(2*hp + log_2pi) + (1/exp(hp*2)) * dot(tmp,tmp)),  M cast to int16
+__global__ void __launch_bounds__(256) k_mvn_finish(int64_t C, int64_t nd, int64_t M,
+                                                   const double *quad, const double *slog,
+                                                   HpSrc hp, double *logpts, int64_t ld)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= C * nd) return;
+    const int64_t c = i / nd, d = i - c * nd;
+    const double h = hp_value(hp, c, d);
+    const double norm = (double)(int16_t)M * (2 * h + LOG_2PI);
+    logpts[c * ld + d] = (-0.5) * (slog[d] + norm + (1 / exp(h * 2)) * quad[i]);
+}
+
+int launch_mvn_finish(beatamd_ctx *ctx, int64_t C, int64_t nd, int64_t M, const double *quad,
+                      const double *slog, HpSrc hp, double *logpts, int64_t ld)
+{
+    const int64_t n = C * nd;
+    if (n == 0) return BEATAMD_OK;
+    ScopedTimer tm(ctx, "finish");
+    hipLaunchKernelGGL(k_mvn_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       C, nd, M, quad, slog, hp, logpts, ld);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
+// one wavefront per (c,d): quad = sum_k (w_d x_k)^2
+__global__ void __launch_bounds__(256) k_scalar_quad(int64_t C, int64_t nd, int64_t M,
+                                                    const double *X, int64_t xs_c, int64_t xs_d,
+                                                    const double *w, double *quad)
+{
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= C * nd) return;
+    const int64_t c = i / nd, d = i - c * nd;
+    const double *x = X + c * xs_c + d * xs_d;
+    const double wd = w[d];
+    double q = 0.0;
+    for (int64_t k = lane; k < M; k += 64) {
+        const double t = wd * x[k];
+        q = fma(t, t, q);
+    }
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
+    if (lane == 0) quad[i] = q;
+}
+
+int launch_scalar_quad(beatamd_ctx *ctx, int64_t C, int64_t nd, int64_t M, const double *X,
+                       int64_t xs_c, int64_t xs_d, const double *w, double *quad)
+{
+    const int64_t n = C * nd;
+    if (n == 0) return BEATAMD_OK;
+    hipLaunchKernelGGL(k_scalar_quad, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, C,
+                       nd, M, X, xs_c, xs_d, w, quad);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
+// ffi/base.py:292-305  mu = G.T.dot(slips): block (chain c, 256 observations), slips in LDS
+__global__ void __launch_bounds__(256) k_geo_stack(const double *G, int64_t P, int64_t Nobs,
+                                                  ChainVec slips, int accumulate, double *mu)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_slip[];
+    const int64_t c = blockIdx.y;
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const double *sl = slips.base + c * slips.stride + slips.off;
+    for (int64_t p = threadIdx.x; p < P; p += 256) s_slip[p] = sl[p];
+    __syncthreads();
+    if (k >= Nobs) return;
+    double acc = accumulate ? mu[c * Nobs + k] : 0.0;
+    for (int64_t p = 0; p < P; p++) acc = fma(G[p * Nobs + k], s_slip[p], acc);
+    mu[c * Nobs + k] = acc;
+}
+
+int launch_geo_stack(beatamd_ctx *ctx, const GeoLib &lib, int64_t C, ChainVec slips,
+                     int accumulate, double *mu)
+{
+    if (C == 0) return BEATAMD_OK;
+    BA_CHECK(C <= 65535, BEATAMD_EINVAL, "geo_stack: at most 65535 chains per call");
+    BA_CHECK(lib.P * 8 <= 64 * 1024, BEATAMD_EINVAL, "geo_stack: more than 8192 patches");
+    ScopedTimer tm(ctx, "geostack");
+    hipLaunchKernelGGL(k_geo_stack, dim3((unsigned)((lib.Nobs + 255) / 256), (unsigned)C),
+                       dim3(256), (size_t)lib.P * sizeof(double), ctx->stream, lib.g, lib.P,
+                       lib.Nobs, slips, accumulate, mu);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
+// geodetic.py:1072-1074: (sdata - mu) * sodws
+__global__ void __launch_bounds__(256) k_geo_residual(int64_t C, int64_t Nobs, const double *data,
+                                                     const double *odw, const double *mu,
+                                                     double *res)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= C * Nobs) return;
+    const int64_t k = i % Nobs;
+    res[i] = (data[k] - mu[i]) * odw[k];
+}
+
+int launch_geo_residual(beatamd_ctx *ctx, int64_t C, int64_t Nobs, const double *data,
+                        const double *odw, const double *mu, double *res)
+{
+    const int64_t n = C * Nobs;
+    if (n == 0) return BEATAMD_OK;
+    hipLaunchKernelGGL(k_geo_residual, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       ctx->stream, C, Nobs, data, odw, mu, res);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
+// laplacian.py:88-96 _eval_prior summed over slip variables (:126-139)
+__global__ void __launch_bounds__(256) k_laplacian_finish(int64_t C, int64_t nvar, int64_t P,
+                                                         double logdet, const double *quad,
+                                                         HpSrc hp, double *out, int64_t ld)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double h = hp_value(hp, c, 0);
+    double s = 0.0;
+    for (int64_t v = 0; v < nvar; v++)
+        s += (-0.5) * (-logdet + ((double)P * (LOG_2PI + 2 * h)) +
+                       (1.0 / exp(h * 2) * quad[c * nvar + v]));
+    out[c * ld] = s;
+}
+
+int launch_laplacian_finish(beatamd_ctx *ctx, int64_t C, int64_t nvar, int64_t P, double logdet,
+                            const double *quad, HpSrc hp, double *out, int64_t ld)
+{
+    if (C == 0) return BEATAMD_OK;
+    hipLaunchKernelGGL(k_laplacian_finish, dim3((unsigned)((C + 255) / 256)), dim3(256), 0,
+                       ctx->stream, C, nvar, P, logdet, quad, hp, out, ld);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
+// problems.py:227-247: like = sum over composites of (composite llk vector).sum()
+__global__ void __launch_bounds__(256) k_like_sum(int64_t C, int64_t nllk, LikeGroups grp,
+                                                 double *LL)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double *l = LL + c * nllk;
+    double total = 0.0;
+    int k = 0;
+    for (int g = 0; g < grp.n; g++) {
+        double s = 0.0;
+        for (; k < grp.end[g]; k++) s += l[k];
+        total += s;
+    }
+    l[nllk - 1] = total;
+}
+
+int launch_like_sum(beatamd_ctx *ctx, int64_t C, int64_t nllk, const LikeGroups &grp, double *LL)
+{
+    if (C == 0) return BEATAMD_OK;
+    hipLaunchKernelGGL(k_like_sum, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, ctx->stream, C,
+                       nllk, grp, LL);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
+struct GatherArgs {
+    ChainVec slips[4];
+};
+__global__ void __launch_bounds__(256) k_gather_slips(int64_t C, int nvar, int64_t P, GatherArgs g,
+                                                     double *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= C * nvar * P) return;
+    const int64_t p = i % P;
+    const int64_t cv = i / P;
+    const int v = (int)(cv % nvar);
+    const int64_t c = cv / nvar;
+    out[i] = g.slips[v].base[c * g.slips[v].stride + g.slips[v].off + p];
+}
+
+int launch_gather_slips(beatamd_ctx *ctx, int64_t C, int nvar, int64_t P, const ChainVec *slips,
+                        double *out)
+{
+    GatherArgs g;
+    for (int v = 0; v < nvar; v++) g.slips[v] = slips[v];
+    const int64_t n = C * nvar * P;
+    if (n == 0) return BEATAMD_OK;
+    hipLaunchKernelGGL(k_gather_slips, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       C, nvar, P, g, out);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
+// metropolis.py:313-343: q = q0 + delta * scaling ; prior_logp finite <=> inside the box
+__global__ void __launch_bounds__(256) k_propose(int64_t C, int64_t nparams, const double *Q0,
+                                                const double *delta, const double *scaling,
+                                                const double *lower, const double *upper,
+                                                double *Qprop, int32_t *inbounds)
+{
+    const int64_t c = blockIdx.x;
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) s_ok = 1;
+    __syncthreads();
+    const double sc = scaling[c];
+    int ok = 1;
+    for (int64_t k = threadIdx.x; k < nparams; k += 256) {
+        const double d = delta[c * nparams + k] * sc;
+        const double q = Q0[c * nparams + k] + d;
+        Qprop[c * nparams + k] = q;
+        if (!(q >= lower[k] && q <= upper[k])) ok = 0;
+    }
+    if (!ok) s_ok = 0;
+    __syncthreads();
+    // metropolis.py:341-343,383-385: outside the prior box the forward model is NOT evaluated
+    // and the chain stays.  The batch evaluates every chain, so park the rejected chain on its
+    // current point (keeps durations/start times inside the library grid).
+    if (!s_ok)
+        for (int64_t k = threadIdx.x; k < nparams; k += 256)
+            Qprop[c * nparams + k] = Q0[c * nparams + k];
+    if (threadIdx.x == 0) inbounds[c] = s_ok;
+}
+
+int launch_propose(beatamd_ctx *ctx, int64_t C, int64_t nparams, const double *Q0,
+                   const double *delta, const double *scaling, const double *lower,
+                   const double *upper, double *Qprop, int32_t *inbounds)
+{
+    if (C == 0) return BEATAMD_OK;
+    hipLaunchKernelGGL(k_propose, dim3((unsigned)C), dim3(256), 0, ctx->stream, C, nparams, Q0,
+                       delta, scaling, lower, upper, Qprop, inbounds);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
+// metropolis.py:344-385 + pymc metrop_select: accept iff in bounds, isfinite(mr), log u < mr
+__global__ void __launch_bounds__(256) k_accept(int64_t C, int64_t nparams, int64_t nllk,
+                                               double *Q0, double *L0, const double *Qprop,
+                                               const double *Lprop, const int32_t *inbounds,
+                                               const double *log_u, double beta,
+                                               int32_t *accepted)
+{
+    const int64_t c = blockIdx.x;
+    const double mr = beta * (Lprop[c * nllk + nllk - 1] - L0[c * nllk + nllk - 1]);
+    const bool acc = inbounds[c] && isfinite(mr) && (log_u[c] < mr);
+    if (acc) {
+        for (int64_t k = threadIdx.x; k < nparams; k += 256) Q0[c * nparams + k] = Qprop[c * nparams + k];
+        __syncthreads();  // all lanes have read L0[like] before it is overwritten
+        for (int64_t k = threadIdx.x; k < nllk; k += 256) L0[c * nllk + k] = Lprop[c * nllk + k];
+    }
+    if (threadIdx.x == 0) accepted[c] = acc ? 1 : 0;
+}
+
+int launch_accept(beatamd_ctx *ctx, int64_t C, int64_t nparams, int64_t nllk, double *Q0,
+                  double *L0, const double *Qprop, const double *Lprop, const int32_t *inbounds,
+                  const double *log_u, double beta, int32_t *accepted)
+{
+    if (C == 0) return BEATAMD_OK;
+    ScopedTimer tm(ctx, "astep");
+    hipLaunchKernelGGL(k_accept, dim3((unsigned)C), dim3(256), 0, ctx->stream, C, nparams, nllk,
+                       Q0, L0, Qprop, Lprop, inbounds, log_u, beta, accepted);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
+}  // namespace beatamd

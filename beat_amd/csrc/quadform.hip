@@ -1,0 +1,171 @@
+// quadform.hip -- chain-batched covariance-weighted misfit  quad[c,d] = || A_d x_{c,d} ||^2
+// on the FP64 matrix cores of gfx950 (v_mfma_f64_16x16x4_f64).
+//
+// Reference arithmetic: beat/models/distributions.py:128-136 (tmp = dot(W_i, r_i);
+// dot(tmp, tmp)) with W_i = Covariance.chol_inverse (heart.py:211-237, dense (M,M) with
+// upper-triangular content); beat/models/laplacian.py:126-127 (Ls = L.dot(s); Ls.T.dot(Ls)).
+//
+// One chain is a GEMV (bandwidth bound on W: 134 MB per dataset at M=4096).  Batched over C
+// chains it is a GEMM  Y_d = A_d (MxM) * X_d (MxC)  followed by a column-wise squared norm:
+// A is read once per 64 chains instead of once per chain, and the arithmetic moves to MFMA.
+//
+// Tiling: 256-thread workgroup = 4 wavefronts; block tile 64 rows x 64 chains; each wave owns
+// 16 rows x 64 chains = four 16x16 f64 accumulators (8 VGPRs each).  K is walked in steps of
+// 16 through LDS (row pitch 17 doubles -> conflict-free ds_read_b64 of the MFMA operands).
+// For upper-triangular W the K loop starts at the block's first row (half the flops/bytes).
+// f64 MFMA layouts (cdna_hip_programming.md section 3): A lane l -> A[i=l&15][k=l>>4],
+// B lane l -> B[k=l>>4][j=l&15], C/D reg r of lane l -> row (l>>4)+4r, col l&15.
+#include "kernels.hpp"
+
+namespace beatamd {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+constexpr int QF_BM = 64, QF_BC = 64, QF_KB = 16, QF_PITCH = QF_KB + 1;
+
+struct QfArgs {
+    const double *A;
+    int64_t a_stride, M, nd, C;
+    const double *X;
+    int64_t xs_c, xs_d;
+    int upper_tri;
+    double *partial;  // [nd, nrb, C]
+    int nrb;
+};
+
+__global__ void __launch_bounds__(256) k_quadform(QfArgs a)
+{
+    __shared__ double As[QF_BM * QF_PITCH];
+    __shared__ double Xs[QF_BC * QF_PITCH];
+    __shared__ double red[4][QF_BC];
+
+    const int rb = blockIdx.x, cb = blockIdx.y, d = blockIdx.z;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t M = a.M;
+    const int64_t i0 = (int64_t)rb * QF_BM, c0 = (int64_t)cb * QF_BC;
+    const double *A = a.A + (int64_t)d * a.a_stride;
+
+    const int lr = tid >> 2;        // tile row (A) / tile chain (X) loaded by this thread
+    const int lk = (tid & 3) * 4;   // first of its 4 k entries
+    const int64_t arow = i0 + lr;
+    const int64_t xch = c0 + lr;
+    const double *Ap = A + arow * M;
+    const double *Xp = a.X + xch * a.xs_c + (int64_t)d * a.xs_d;
+    const bool arow_ok = arow < M, xch_ok = xch < a.C;
+
+    v4f64 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[j] = v4f64{0.0, 0.0, 0.0, 0.0};
+
+    const int64_t kstart = a.upper_tri ? i0 : 0;
+    for (int64_t k0 = kstart; k0 < M; k0 += QF_KB) {
+        double av[4], xv[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int64_t k = k0 + lk + e;
+            const bool kok = k < M;
+            av[e] = (arow_ok && kok) ? Ap[k] : 0.0;
+            xv[e] = (xch_ok && kok) ? Xp[k] : 0.0;
+        }
+        __syncthreads();  // previous tile fully consumed
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            As[lr * QF_PITCH + lk + e] = av[e];
+            Xs[lr * QF_PITCH + lk + e] = xv[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < QF_KB / 4; kk++) {
+            const int kcol = kk * 4 + (lane >> 4);
+            const double aop = As[(wave * 16 + (lane & 15)) * QF_PITCH + kcol];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const double bop = Xs[(j * 16 + (lane & 15)) * QF_PITCH + kcol];
+                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    // column-wise squared norm of this wave's 16 rows
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        double s = acc[j][0] * acc[j][0];
+        s = fma(acc[j][1], acc[j][1], s);
+        s = fma(acc[j][2], acc[j][2], s);
+        s = fma(acc[j][3], acc[j][3], s);
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (lane < 16) red[wave][j * 16 + lane] = s;
+    }
+    __syncthreads();
+    if (tid < QF_BC) {
+        const int64_t c = c0 + tid;
+        if (c < a.C) {
+            const double s = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+            a.partial[((int64_t)d * a.nrb + rb) * a.C + c] = s;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_quadform_reduce(const double *partial, int64_t C,
+                                                        int64_t nd, int nrb, double *quad,
+                                                        int64_t q_stride)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= C * nd) return;
+    const int64_t c = i / nd, d = i - c * nd;
+    double s = 0.0;
+    for (int rb = 0; rb < nrb; rb++) s += partial[((int64_t)d * nrb + rb) * C + c];
+    quad[c * q_stride + d] = s;
+}
+
+int launch_quadform(beatamd_ctx *ctx, const QuadformCall &k)
+{
+    if (k.C == 0 || k.nd == 0) return BEATAMD_OK;
+    QfArgs a;
+    a.A = k.A; a.a_stride = k.a_stride; a.M = k.M; a.nd = k.nd; a.C = k.C;
+    a.X = k.X; a.xs_c = k.xs_c; a.xs_d = k.xs_d;
+    a.upper_tri = k.upper_tri;
+    a.nrb = (int)((k.M + QF_BM - 1) / QF_BM);
+    void *p = nullptr;
+    BA_TRY(ctx->get_scratch(SL_PARTIAL, (size_t)k.nd * a.nrb * k.C * sizeof(double), &p));
+    a.partial = (double *)p;
+    const int64_t ncb = (k.C + QF_BC - 1) / QF_BC;
+    BA_CHECK(ncb <= 65535 && k.nd <= 65535, BEATAMD_EINVAL, "quadform: batch too large");
+    {
+        ScopedTimer tm(ctx, "quadform");
+        hipLaunchKernelGGL(k_quadform, dim3((unsigned)a.nrb, (unsigned)ncb, (unsigned)k.nd),
+                           dim3(256), 0, ctx->stream, a);
+    }
+    BA_HIP(hipGetLastError());
+    const int64_t n = k.C * k.nd;
+    hipLaunchKernelGGL(k_quadform_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       ctx->stream, a.partial, k.C, k.nd, a.nrb, k.quad, k.q_stride);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
+// flag_dev[0] is cleared to 0 if any entry strictly below the diagonal is non-zero
+__global__ void __launch_bounds__(256) k_check_upper(const double *A, int64_t nd, int64_t M,
+                                                    int *flag)
+{
+    const int64_t total = nd * M * M;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * 256) {
+        const int64_t r = (i / M) % M, cidx = i % M;
+        if (cidx < r && A[i] != 0.0) *flag = 0;
+    }
+}
+
+int launch_check_upper_tri(beatamd_ctx *ctx, const double *A, int64_t nd, int64_t M, int *flag_dev)
+{
+    int one = 1;
+    BA_HIP(hipMemcpyAsync(flag_dev, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    BA_HIP(hipStreamSynchronize(ctx->stream));  // `one` is a stack temporary
+    const int64_t total = nd * M * M;
+    unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_check_upper, dim3(grid), dim3(256), 0, ctx->stream, A, nd, M, flag_dev);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
+}  // namespace beatamd

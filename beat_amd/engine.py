@@ -1,0 +1,296 @@
+"""
+Thin object layer over the C ABI: one :class:`Context` per (process, GPU).
+
+Arrays may be numpy arrays (host; results come back as numpy) or torch CUDA tensors
+(device; results are torch tensors on the same device, the call is asynchronous on the
+context stream).  PyTorch is only plumbing here (device memory, streams); all arithmetic
+is in ``libbeat_amd.so``.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import INTERPOLATIONS, check, f64, ptr
+
+
+def _is_dev(a):
+    return hasattr(a, "data_ptr") and not isinstance(a, np.ndarray) and a.is_cuda
+
+
+def _empty_like(ref, shape, dtype=np.float64):
+    if _is_dev(ref):
+        import torch
+        tdt = {np.float64: torch.float64, np.int32: torch.int32}[dtype]
+        return torch.empty(shape, dtype=tdt, device=ref.device)
+    return np.empty(shape, dtype=dtype)
+
+
+def _i32(a, ref=None):
+    if _is_dev(a):
+        import torch
+        if a.dtype != torch.int32 or not a.is_contiguous():
+            raise ValueError("device index tensors must be contiguous int32")
+        return a
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _i64arr(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _interp(interpolation):
+    if interpolation not in INTERPOLATIONS:
+        raise NotImplementedError("Interpolation scheme %s not implemented!" % interpolation)
+    return INTERPOLATIONS[interpolation]
+
+
+class Context(object):
+    """Owns the HBM-resident state of one GPU: GF libraries, weights, models, scratch."""
+
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        check(self._lib.beatamd_ctx_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.beatamd_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def use_torch_stream(self):
+        """Launch on torch's current stream of this device (so torch ops interleave in order)."""
+        import torch
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        check(self._lib.beatamd_ctx_set_stream(self._h, C.c_void_p(s)))
+
+    def set_stream(self, stream_ptr):
+        check(self._lib.beatamd_ctx_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def synchronize(self):
+        check(self._lib.beatamd_ctx_synchronize(self._h))
+
+    def enable_timing(self, on=True):
+        check(self._lib.beatamd_ctx_enable_timing(self._h, int(bool(on))))
+
+    def reset_timing(self):
+        check(self._lib.beatamd_ctx_reset_timing(self._h))
+
+    def kernel_time(self, name):
+        """-> (total_ms, launches) measured with HIP events on the launch stream"""
+        ms, n = C.c_double(), C.c_int64()
+        check(self._lib.beatamd_ctx_kernel_time(self._h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # -- fast sweep
+    def fast_sweep_batch(self, slowness, patch_size, h_strk, h_dip, num_strk, num_dip):
+        slowness = f64(slowness)
+        n = int(num_strk) * int(num_dip)
+        Cn = int(slowness.shape[0]) if slowness.ndim == 2 else 1
+        if slowness.ndim == 1:
+            slowness = slowness.reshape(1, -1)
+        if slowness.shape[1] != n:
+            raise ValueError("slowness has %d entries per chain, grid has %d" % (slowness.shape[1], n))
+        hs, hd = _i32(h_strk), _i32(h_dip)
+        out = _empty_like(slowness, (Cn, n))
+        check(self._lib.beatamd_fast_sweep_batch(self._h, ptr(slowness), float(patch_size), ptr(hs),
+                                                 ptr(hd), int(num_strk), int(num_dip), Cn, ptr(out)))
+        return out
+
+    # -- seismic GF library
+    def seis_gflib_create(self, dims, starttime_min, starttime_sampling, duration_min,
+                          duration_sampling):
+        T, P, D, S, N = [int(d) for d in dims]
+        lid = C.c_int32()
+        check(self._lib.beatamd_seis_gflib_create(self._h, T, P, D, S, N, float(starttime_min),
+                                                  float(starttime_sampling), float(duration_min),
+                                                  float(duration_sampling), C.byref(lid)))
+        return lid.value
+
+    def seis_gflib_upload(self, lib_id, array, offset=0):
+        a = f64(array)
+        count = int(a.numel()) if _is_dev(a) else int(a.size)
+        check(self._lib.beatamd_seis_gflib_upload(self._h, lib_id, ptr(a), int(offset), count))
+
+    def seis_gflib_adopt(self, lib_id, device_tensor):
+        check(self._lib.beatamd_seis_gflib_adopt(self._h, lib_id, ptr(device_tensor)))
+
+    def seis_gflib_device_ptr(self, lib_id):
+        p = C.c_void_p()
+        check(self._lib.beatamd_seis_gflib_device_ptr(self._h, lib_id, C.byref(p)))
+        return p.value
+
+    def seis_gflib_destroy(self, lib_id):
+        check(self._lib.beatamd_seis_gflib_destroy(self._h, lib_id))
+
+    def seis_stack_all_batch(self, lib_id, dims, durations, starttimes, slips,
+                             interpolation="nearest_neighbor"):
+        T, P, D, S, N = dims
+        it = _interp(interpolation)
+        du, st, sl = f64(durations), f64(starttimes), f64(slips)
+        Cn = int(du.shape[0])
+        if tuple(du.shape) != (Cn, P) or tuple(sl.shape) != (Cn, P) or tuple(st.shape) != (Cn, T, P):
+            raise ValueError("stack_all_batch: expected durations/slips (C,%d) and starttimes (C,%d,%d)"
+                             % (P, T, P))
+        out = _empty_like(du, (Cn, T, N))
+        check(self._lib.beatamd_seis_stack_all_batch(self._h, lib_id, Cn, ptr(du), ptr(st), ptr(sl), it,
+                                                     ptr(out)))
+        return out
+
+    # -- geodetic GF library
+    def geo_gflib_create(self, G):
+        G = f64(G)
+        lid = C.c_int32()
+        check(self._lib.beatamd_geo_gflib_create(self._h, int(G.shape[0]), int(G.shape[1]), ptr(G),
+                                                 C.byref(lid)))
+        return lid.value
+
+    def geo_gflib_destroy(self, lib_id):
+        check(self._lib.beatamd_geo_gflib_destroy(self._h, lib_id))
+
+    def geo_stack_all_batch(self, lib_id, nobs, slips, out=None):
+        sl = f64(slips)
+        Cn = int(sl.shape[0])
+        acc = out is not None
+        if out is None:
+            out = _empty_like(sl, (Cn, nobs))
+        check(self._lib.beatamd_geo_stack_all_batch(self._h, lib_id, Cn, ptr(sl), int(acc), ptr(out)))
+        return out
+
+    # -- weights / likelihood
+    def weights_create_scalar(self, w, slog_pdet, M):
+        w, sl = f64(w).ravel(), f64(slog_pdet).ravel()
+        wid = C.c_int32()
+        check(self._lib.beatamd_weights_create(self._h, _lib.W_SCALAR, int(w.size), int(M), ptr(w),
+                                               ptr(sl), C.byref(wid)))
+        return wid.value
+
+    def weights_create_dense(self, W, slog_pdet):
+        W, sl = f64(W), f64(slog_pdet).ravel()
+        if W.ndim == 2:
+            W = W.reshape((1,) + W.shape)
+        nd, M, M2 = W.shape
+        if M != M2:
+            raise ValueError("weights must be square")
+        wid = C.c_int32()
+        check(self._lib.beatamd_weights_create(self._h, _lib.W_DENSE, int(nd), int(M), ptr(W), ptr(sl),
+                                               C.byref(wid)))
+        return wid.value
+
+    def weights_update(self, wset_id, weights, slog_pdet):
+        W, sl = f64(weights), f64(slog_pdet).ravel()
+        check(self._lib.beatamd_weights_update(self._h, wset_id, ptr(W), ptr(sl)))
+
+    def weights_destroy(self, wset_id):
+        check(self._lib.beatamd_weights_destroy(self._h, wset_id))
+
+    def mvn_chol_logp_batch(self, wset_id, residuals, hp):
+        r, h = f64(residuals), f64(hp)
+        Cn, nd = int(r.shape[0]), int(r.shape[1])
+        out = _empty_like(r, (Cn, nd))
+        check(self._lib.beatamd_mvn_chol_logp_batch(self._h, wset_id, Cn, ptr(r), ptr(h), ptr(out)))
+        return out
+
+    def laplacian_create(self, L, logdet):
+        L = f64(L)
+        lid = C.c_int32()
+        check(self._lib.beatamd_laplacian_create(self._h, int(L.shape[0]), ptr(L), float(logdet),
+                                                 C.byref(lid)))
+        return lid.value
+
+    def laplacian_destroy(self, lap_id):
+        check(self._lib.beatamd_laplacian_destroy(self._h, lap_id))
+
+    def laplacian_logp_batch(self, lap_id, slips, hp):
+        s, h = f64(slips), f64(hp)
+        Cn, nvar = int(s.shape[0]), int(s.shape[1])
+        out = _empty_like(s, (Cn,))
+        check(self._lib.beatamd_laplacian_logp_batch(self._h, lap_id, Cn, nvar, ptr(s), ptr(h), ptr(out)))
+        return out
+
+    # -- fused FFI model
+    def ffi_model_create(self, layout, n_patch_dip, n_patch_strike, patch_size):
+        nd = np.ascontiguousarray(n_patch_dip, dtype=np.int32)
+        ns = np.ascontiguousarray(n_patch_strike, dtype=np.int32)
+        ps = np.ascontiguousarray(patch_size, dtype=np.float64)
+        mid = C.c_int32()
+        check(self._lib.beatamd_ffi_model_create(self._h, C.byref(layout), int(nd.size), ptr(nd) if nd.size else None,
+                                                 ptr(ns) if ns.size else None, ptr(ps) if ps.size else None,
+                                                 C.byref(mid)))
+        return mid.value
+
+    def ffi_model_add_wavemap(self, model_id, lib_ids, data, wset_id, hp_off, shift_off=None,
+                              interpolation="nearest_neighbor"):
+        libs = np.ascontiguousarray(lib_ids, dtype=np.int32)
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        hp = _i64arr(hp_off)
+        sh = _i64arr(shift_off)
+        check(self._lib.beatamd_ffi_model_add_wavemap(self._h, model_id, ptr(libs), ptr(data), wset_id,
+                                                      ptr(hp), ptr(sh), _interp(interpolation)))
+
+    def ffi_model_add_geodetic(self, model_id, geo_lib_ids, data, odws, sizes, wset_ids, hp_off):
+        libs = np.ascontiguousarray(geo_lib_ids, dtype=np.int32)
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        odws = np.ascontiguousarray(odws, dtype=np.float64)
+        sizes = _i64arr(sizes)
+        ws = np.ascontiguousarray(wset_ids, dtype=np.int32)
+        hp = _i64arr(hp_off)
+        check(self._lib.beatamd_ffi_model_add_geodetic(self._h, model_id, ptr(libs), ptr(data), ptr(odws),
+                                                       int(sizes.size), ptr(sizes), ptr(ws), ptr(hp)))
+
+    def ffi_model_set_laplacian(self, model_id, lap_id):
+        check(self._lib.beatamd_ffi_model_set_laplacian(self._h, model_id, lap_id))
+
+    def ffi_model_nllk(self, model_id):
+        n = C.c_int64()
+        check(self._lib.beatamd_ffi_model_nllk(self._h, model_id, C.byref(n)))
+        return n.value
+
+    def ffi_model_destroy(self, model_id):
+        check(self._lib.beatamd_ffi_model_destroy(self._h, model_id))
+
+    def ffi_logp_batch(self, model_id, Q, nllk, out=None):
+        Q = f64(Q)
+        Cn = int(Q.shape[0])
+        if out is None:
+            out = _empty_like(Q, (Cn, nllk))
+        check(self._lib.beatamd_ffi_logp_batch(self._h, model_id, Cn, ptr(Q), ptr(out)))
+        return out
+
+    def ffi_astep_batch(self, model_id, Q0, L0, delta, scaling, lower, upper, log_u, beta,
+                        accepted=None):
+        """In-place update of Q0 / L0 (must be contiguous float64); returns accepted (int32)."""
+        Cn = int(Q0.shape[0])
+        if accepted is None:
+            accepted = _empty_like(Q0, (Cn,), np.int32)
+        for a in (Q0, L0):
+            if isinstance(a, np.ndarray) and not (a.flags.c_contiguous and a.dtype == np.float64):
+                raise ValueError("Q0 / L0 must be C-contiguous float64 (updated in place)")
+        check(self._lib.beatamd_ffi_astep_batch(self._h, model_id, Cn, ptr(Q0), ptr(L0), ptr(f64(delta)),
+                                                ptr(f64(scaling)), ptr(f64(lower)), ptr(f64(upper)),
+                                                ptr(f64(log_u)), float(beta), ptr(accepted)))
+        return accepted
+
+
+_contexts = {}
+
+
+def get_context(device=None):
+    """Process-wide context of a device (default: LOCAL_RANK or 0)."""
+    import os
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    ctx = _contexts.get(device)
+    if ctx is None or ctx._h is None:
+        ctx = Context(device)
+        _contexts[device] = ctx
+    return ctx

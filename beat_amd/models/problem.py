@@ -1,0 +1,307 @@
+"""
+Host-side description of a distributed-slip (FFI) problem and its compilation to the
+fused GPU model -- the counterpart of what the reference assembles in
+
+  beat/models/problems.py:212-248        Problem.built_model  (like = sum of composites)
+  beat/models/seismic.py:1210-1349       SeismicDistributerComposite.get_formula
+  beat/models/geodetic.py:1030-1084      GeodeticDistributerComposite.get_formula
+  beat/models/laplacian.py:98-139        LaplacianDistributerComposite.get_formula
+  beat/sampler/base.py:598-615           logp_forw  (the compiled function seam, "B1")
+
+The reference builds a pytensor graph and compiles it to a one-chain function
+``f(q) -> [unobserved RVs..., seis_like, geo_like, laplacian_like, like]``.  Here the
+same description is uploaded once to HBM and evaluated for a whole batch of chains per
+call; ``LogpForwFunc`` keeps the one-chain call signature on top of the batched one.
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+from .. import _lib
+from ..engine import get_context
+
+hyper_name_laplacian = "h_laplacian"  # beat/config.py:126
+hypo_vars = ["nucleation_strike", "nucleation_dip", "time"]  # beat/config.py:86
+static_dist_vars = ["uparr", "uperp", "utens"]  # beat/config.py:83
+
+
+class ParameterLayout(object):
+    """Flat parameter vector q: concatenation of the raveled value variables in model
+    order (pymc DictToArrayBijection; reference backend.py:147,165)."""
+
+    def __init__(self, varsizes):
+        self.varsizes = OrderedDict((k, int(v)) for k, v in varsizes.items())
+        self.offsets = OrderedDict()
+        o = 0
+        for k, v in self.varsizes.items():
+            self.offsets[k] = o
+            o += v
+        self.size = o
+
+    def offset(self, name, index=0):
+        if name not in self.offsets:
+            raise KeyError("variable %s is not part of the parameter vector" % name)
+        if not (0 <= index < self.varsizes[name]):
+            raise IndexError("index %d outside variable %s" % (index, name))
+        return self.offsets[name] + index
+
+    def map(self, point):
+        """dict -> flat array (bij.map)"""
+        q = np.empty(self.size)
+        for k, o in self.offsets.items():
+            q[o:o + self.varsizes[k]] = np.ravel(point[k])
+        return q
+
+    def rmap(self, q):
+        """flat array -> dict (bij.rmap)"""
+        q = np.asarray(q)
+        return OrderedDict((k, q[..., o:o + self.varsizes[k]]) for k, o in self.offsets.items())
+
+    def bounds(self, lower, upper):
+        lo, up = np.empty(self.size), np.empty(self.size)
+        for k, o in self.offsets.items():
+            lo[o:o + self.varsizes[k]] = lower[k]
+            up[o:o + self.varsizes[k]] = upper[k]
+        return lo, up
+
+
+class SeismicWavemap(object):
+    """One wavemap of the seismic composite (seismic.py:1274-1341).
+
+    gfs            dict slip-varname -> beat_amd.ffi.SeismicGFLibrary (HBM resident)
+    data           (T, N) observed, tapered/filtered traces (wmap.shared_data_array)
+    weights        (T,) scalars [W = w I] or (T, N, N) dense chol_inverse matrices
+    slog_pdet      (T,)
+    hypers         list of (hyper-parameter name, index) per dataset
+                   (distributions.py:117-126: index 0 unless hp_specific)
+    time_shifts    None or (name of the hierarchical variable, station_correction_idxs (T,))
+    """
+
+    def __init__(self, gfs, data, weights, slog_pdet, hypers, time_shifts=None,
+                 interpolation="nearest_neighbor", name="any_P_0"):
+        self.gfs = gfs
+        self.data = np.ascontiguousarray(data, dtype=np.float64)
+        self.weights = weights
+        self.slog_pdet = np.ascontiguousarray(slog_pdet, dtype=np.float64)
+        self.hypers = list(hypers)
+        self.time_shifts = time_shifts
+        self.interpolation = interpolation
+        self.name = name
+        self._wset = None
+
+    @property
+    def n_t(self):
+        return self.data.shape[0]
+
+
+class GeodeticData(object):
+    """The geodetic composite (geodetic.py:1030-1084).
+
+    gfs        dict slip-varname -> beat_amd.ffi.GeodeticGFLibrary
+    data/odws  (Nobs,) concatenated over datasets (heart.concatenate_datasets :3356-3384)
+    sizes      samples per dataset (Bij.srmap split)
+    weights    list of (n_k, n_k) chol_inverse matrices or scalars
+    """
+
+    def __init__(self, gfs, data, odws, sizes, weights, slog_pdets, hypers):
+        self.gfs = gfs
+        self.data = np.ascontiguousarray(data, dtype=np.float64)
+        self.odws = np.ascontiguousarray(odws, dtype=np.float64)
+        self.sizes = [int(s) for s in sizes]
+        self.weights = weights
+        self.slog_pdets = [float(s) for s in slog_pdets]
+        self.hypers = list(hypers)
+        self._wsets = []
+
+
+class FFIProblem(object):
+    """Distributed-slip problem: which variables are sampled and which composites make up
+    ``like``.  Output vector order: seis_like (per wavemap, per dataset), geo_like (per
+    dataset), laplacian_like, like  (SURVEY Appendix C)."""
+
+    def __init__(self, layout, n_patch_dip, n_patch_strike, patch_sizes, slip_varnames,
+                 wavemaps=(), geodetic=None, laplacian=None, lower=None, upper=None):
+        self.layout = layout
+        self.n_patch_dip = [int(v) for v in np.atleast_1d(n_patch_dip)]
+        self.n_patch_strike = [int(v) for v in np.atleast_1d(n_patch_strike)]
+        self.patch_sizes = [float(v) for v in np.atleast_1d(patch_sizes)]
+        self.slip_varnames = list(slip_varnames)
+        self.wavemaps = list(wavemaps)
+        self.geodetic = geodetic
+        self.laplacian = laplacian  # (L (P,P), logdet) or None
+        self.lower, self.upper = lower, upper
+        if not (1 <= len(self.slip_varnames) <= 3):
+            raise ValueError("1..3 slip variables supported")
+        for v in self.slip_varnames:
+            if v not in static_dist_vars:
+                raise ValueError("%s is not a slip variable %s" % (v, static_dist_vars))
+
+    @property
+    def npatches(self):
+        return int(sum(d * s for d, s in zip(self.n_patch_dip, self.n_patch_strike)))
+
+    @property
+    def out_names(self):
+        names = []
+        for wm in self.wavemaps:
+            names += ["seis_like_%s_%d" % (wm.name, i) for i in range(wm.n_t)]
+        if self.geodetic is not None:
+            names += ["geo_like_%d" % i for i in range(len(self.geodetic.sizes))]
+        if self.laplacian is not None:
+            names.append("laplacian_like")
+        names.append("like")
+        return names
+
+    def c_layout(self):
+        L = _lib.FfiLayout()
+        lay = self.layout
+        L.nparams = lay.size
+        L.nvar = len(self.slip_varnames)
+        for i in range(4):
+            L.slip_off[i] = lay.offsets[self.slip_varnames[i]] if i < L.nvar else -1
+        L.durations_off = lay.offsets.get("durations", -1)
+        L.velocities_off = lay.offsets.get("velocities", -1)
+        L.nuc_strike_off = lay.offsets.get("nucleation_strike", -1)
+        L.nuc_dip_off = lay.offsets.get("nucleation_dip", -1)
+        L.time_off = lay.offsets.get("time", -1)
+        L.h_laplacian_off = lay.offsets.get(hyper_name_laplacian, -1)
+        return L
+
+    def compile(self, ctx=None):
+        """Upload to HBM and return the batched log-likelihood function (``logp_forw``)."""
+        ctx = ctx or get_context()
+        lay = self.layout
+        seismic = len(self.wavemaps) > 0
+        mid = ctx.ffi_model_create(self.c_layout(),
+                                   self.n_patch_dip if seismic else [],
+                                   self.n_patch_strike if seismic else [],
+                                   self.patch_sizes if seismic else [])
+        for wm in self.wavemaps:
+            libs = []
+            for v in self.slip_varnames:
+                gf = wm.gfs[v]
+                gf.init_optimization(ctx)
+                libs.append(gf.lib_id)
+            T, N = wm.data.shape
+            w = np.asarray(wm.weights, dtype=np.float64)
+            if w.ndim == 1:
+                wm._wset = ctx.weights_create_scalar(w, wm.slog_pdet, N)
+            else:
+                wm._wset = ctx.weights_create_dense(w, wm.slog_pdet)
+            hp_off = [lay.offset(n, i) for n, i in wm.hypers]
+            shift_off = None
+            if wm.time_shifts is not None:
+                name, sidx = wm.time_shifts
+                shift_off = [lay.offset(name, int(i)) for i in sidx]
+            ctx.ffi_model_add_wavemap(mid, libs, wm.data, wm._wset, hp_off, shift_off,
+                                      wm.interpolation)
+        if self.geodetic is not None:
+            g = self.geodetic
+            libs = []
+            for v in self.slip_varnames:
+                gf = g.gfs[v]
+                gf.init_optimization(ctx)
+                libs.append(gf.lib_id)
+            g._wsets = []
+            for n, W, sl in zip(g.sizes, g.weights, g.slog_pdets):
+                if np.ndim(W) == 0:
+                    g._wsets.append(ctx.weights_create_scalar([float(W)], [sl], n))
+                else:
+                    g._wsets.append(ctx.weights_create_dense(np.asarray(W), [sl]))
+            hp_off = [lay.offset(n, i) for n, i in g.hypers]
+            ctx.ffi_model_add_geodetic(mid, libs, g.data, g.odws, g.sizes, g._wsets, hp_off)
+        if self.laplacian is not None:
+            L, logdet = self.laplacian
+            self._lap = ctx.laplacian_create(L, logdet)
+            ctx.ffi_model_set_laplacian(mid, self._lap)
+        return LogpForwFunc(ctx, mid, self)
+
+
+class _SharedView(object):
+    """Stand-in for the pytensor shared variables the reference exposes through
+    ``f.get_shared()`` (sampler/base.py:274-282, 541-555): name/get_value/set_value."""
+
+    def __init__(self, name, getter, setter=None):
+        self.name = name
+        self._get, self._set = getter, setter
+
+    def get_value(self, borrow=False):
+        return self._get()
+
+    def set_value(self, value, borrow=False):
+        if self._set is None:
+            raise AttributeError("%s is resident in HBM and read-only" % self.name)
+        self._set(value)
+
+
+class LogpForwFunc(object):
+    """Duck-type of the compiled ``logp_forw_func`` (sampler/base.py:598-615):
+    ``f(q) -> list of arrays`` ordered like the likelihood deterministics, with
+    ``f.trust_input`` and ``f.get_shared()``; plus the batched form ``f.batch(Q)``.
+
+    The reference returns every unobserved RV followed by the deterministics; the
+    parameters themselves are the input, so this function returns the deterministics
+    block only: [seis_like..., geo_like..., laplacian_like, like]
+    (``astep`` reads ``out[_llk_index]``, metropolis.py:160-162, here index -1)."""
+
+    def __init__(self, ctx, model_id, problem):
+        self.ctx, self.model_id, self.problem = ctx, model_id, problem
+        self.nllk = ctx.ffi_model_nllk(model_id)
+        self.nparams = problem.layout.size
+        self.trust_input = True
+        self._llk_index = self.nllk - 1
+
+    def batch(self, Q, out=None):
+        """Q (C, nparams) numpy or torch-cuda -> LL (C, nllk)"""
+        if Q.shape[-1] != self.nparams:
+            raise ValueError("expected %d parameters, got %d" % (self.nparams, Q.shape[-1]))
+        return self.ctx.ffi_logp_batch(self.model_id, Q, self.nllk, out)
+
+    def __call__(self, q):
+        q = np.ascontiguousarray(q, dtype=np.float64).reshape(1, -1)
+        ll = self.batch(q)[0]
+        out = []
+        o = 0
+        for wm in self.problem.wavemaps:
+            out.append(ll[o:o + wm.n_t].copy())
+            o += wm.n_t
+        if self.problem.geodetic is not None:
+            n = len(self.problem.geodetic.sizes)
+            out.append(ll[o:o + n].copy())
+            o += n
+        if self.problem.laplacian is not None:
+            out.append(np.array(ll[o]))
+            o += 1
+        out.append(np.array(ll[o]))
+        return out
+
+    def astep_batch(self, Q0, L0, delta, scaling, lower, upper, log_u, beta, accepted=None):
+        return self.ctx.ffi_astep_batch(self.model_id, Q0, L0, delta, scaling, lower, upper, log_u,
+                                        beta, accepted)
+
+    def get_shared(self):
+        sh = []
+        for wm in self.problem.wavemaps:
+            for v, gf in wm.gfs.items():
+                sh.append(_SharedView(gf.filename, gf.get_all))
+        return sh
+
+    def update_weights(self, wavemap_index, weights, slog_pdet):
+        """seismic.py:1509-1534 update_weights: new chol_inverse + slog_pdet per dataset"""
+        wm = self.problem.wavemaps[wavemap_index]
+        self.ctx.weights_update(wm._wset, weights, slog_pdet)
+        wm.weights, wm.slog_pdet = weights, np.asarray(slog_pdet, dtype=np.float64)
+
+
+def prior_logp_func(lower, upper):
+    """metropolis.py:176-181: with Uniform priors and no transform the prior logp is a
+    constant inside the box and -inf outside."""
+    lower, upper = np.asarray(lower), np.asarray(upper)
+    const = -np.sum(np.log(np.where(upper > lower, upper - lower, 1.0)))
+
+    def f(q):
+        q = np.asarray(q)
+        inside = np.all((q >= lower) & (q <= upper))
+        return np.array(const if inside else -np.inf)
+
+    return f

@@ -1,0 +1,228 @@
+"""
+Seeded synthetic distributed-slip problems: the shapes of
+BASELINE.json's configurations with random-normal Green's functions.  Used by the
+tests, ``__graft_entry__.smoke()`` and ``bench.py``; no reference data is needed.
+
+Everything here is input construction -- no forward-model arithmetic.
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+from .ffi import (GeodeticGFLibrary, GeodeticGFLibraryConfig, SeismicGFLibrary,
+                  SeismicGFLibraryConfig)
+from .models.problem import (FFIProblem, GeodeticData, ParameterLayout, SeismicWavemap,
+                             hyper_name_laplacian)
+
+
+def exponential_data_covariance(n, dt, tzero):
+    """reference beat/covariance.py:24-51 (structure only)"""
+    i = np.arange(n)
+    return np.exp(-np.abs(i[:, None] - i[None, :]) * (dt / tzero))
+
+
+def smoothing_operator_nearest_neighbor(n_patch_strike, n_patch_dip, ps_strike, ps_dip):
+    """reference beat/models/laplacian.py:209-258 (5-point Laplacian, one-sided at the edges)"""
+    n = n_patch_dip * n_patch_strike
+    op = np.zeros((n, n))
+    dd, ds = 1.0 / ps_dip ** 2, 1.0 / ps_strike ** 2
+    for i in range(n):
+        r, c = divmod(i, n_patch_strike)
+        nb = [(r > 0, -n_patch_strike, dd), (r < n_patch_dip - 1, n_patch_strike, dd),
+              (c > 0, -1, ds), (c < n_patch_strike - 1, 1, ds)]
+        op[i, i] = -sum(w for ok, _, w in nb if ok)
+        for ok, off, w in nb:
+            if ok:
+                op[i, i + off] = w
+    return op
+
+
+class SyntheticSpec(object):
+    """Sizes and grids of a synthetic FFI problem.
+
+    Defaults = BASELINE config 3: one 20x20 subfault of 1 km patches, 64 targets, 4096
+    samples, D=3 durations from 0.5 s every 0.5 s, S=25 start times from 0 s every 0.5 s."""
+
+    def __init__(self, n_patch_dip=(20,), n_patch_strike=(20,), patch_size=(1.0,), T=64, N=4096,
+                 D=3, S=25, st_min=0.0, st_dt=0.5, du_min=0.5, du_dt=0.5,
+                 slip_varnames=("uparr",), covariance="scalar", sigma=0.5, station_shifts=False,
+                 geodetic_nobs=None, laplacian=False, interpolation="nearest_neighbor",
+                 hp_specific=False, seed=20250711, vel_bounds=(2.5, 4.0)):
+        self.n_patch_dip = tuple(n_patch_dip)
+        self.n_patch_strike = tuple(n_patch_strike)
+        self.patch_size = tuple(patch_size)
+        self.T, self.N, self.D, self.S = T, N, D, S
+        self.st_min, self.st_dt, self.du_min, self.du_dt = st_min, st_dt, du_min, du_dt
+        self.slip_varnames = tuple(slip_varnames)
+        self.covariance = covariance  # "scalar" | "toeplitz"
+        self.sigma = sigma
+        self.station_shifts = station_shifts
+        self.geodetic_nobs = geodetic_nobs  # None or tuple of dataset sizes
+        self.laplacian = laplacian
+        self.interpolation = interpolation
+        self.hp_specific = hp_specific
+        self.seed = seed
+        self.vel_bounds = vel_bounds
+
+    @property
+    def nsub(self):
+        return len(self.n_patch_dip)
+
+    @property
+    def P(self):
+        return int(sum(d * s for d, s in zip(self.n_patch_dip, self.n_patch_strike)))
+
+    @property
+    def lib_bytes(self):
+        return self.T * self.P * self.D * self.S * self.N * 8
+
+
+def _layout_and_bounds(spec):
+    P, nsub = spec.P, spec.nsub
+    sizes, lower, upper = OrderedDict(), {}, {}
+
+    def add(name, size, lo, up):
+        sizes[name] = size
+        lower[name], upper[name] = lo, up
+
+    seismic = spec.T > 0
+    for v in spec.slip_varnames:
+        add(v, P, 0.0 if v == "uparr" else -1.0, 5.0 if v == "uparr" else 1.0)
+    if seismic:
+        add("durations", P, spec.du_min, spec.du_min + (spec.D - 1) * spec.du_dt)
+        add("velocities", P, spec.vel_bounds[0], spec.vel_bounds[1])
+        ext_s = max(s * h for s, h in zip(spec.n_patch_strike, spec.patch_size))
+        ext_d = max(d * h for d, h in zip(spec.n_patch_dip, spec.patch_size))
+        # keep the rounded nucleation index inside the grid
+        add("nucleation_strike", nsub, 0.0, ext_s - 0.51 * max(spec.patch_size))
+        add("nucleation_dip", nsub, 0.0, ext_d - 0.51 * max(spec.patch_size))
+        add("time", nsub, 0.0, 1.0)
+        if spec.station_shifts:
+            add("time_shifts_any_P_0", max(spec.T // 2, 1), -1.0, 1.0)
+        add("h_any_P_0_Z", spec.T if spec.hp_specific else 1, -2.0, 2.0)
+    if spec.geodetic_nobs:
+        add("h_SAR", len(spec.geodetic_nobs) if spec.hp_specific else 1, -2.0, 2.0)
+    if spec.laplacian:
+        add(hyper_name_laplacian, 1, -2.0, 2.0)
+    return ParameterLayout(sizes), lower, upper
+
+
+def max_sweep_time(spec):
+    ext = max((d + s) * h for d, s, h in zip(spec.n_patch_dip, spec.n_patch_strike, spec.patch_size))
+    return ext / spec.vel_bounds[0]
+
+
+def draw_population(spec, layout, lower, upper, n_chains, seed_offset=1000):
+    """chain c drawn from default_rng(seed_offset + c) uniformly inside the prior box
+    (initialize_population, metropolis.py:125-152: prior draws)"""
+    lo, up = layout.bounds(lower, upper)
+    Q = np.empty((n_chains, layout.size))
+    for c in range(n_chains):
+        rng = np.random.default_rng(seed_offset + c)
+        Q[c] = lo + (up - lo) * rng.random(layout.size)
+    return Q
+
+
+def build_problem(spec, device_library=False, ctx=None):
+    """-> (FFIProblem, host_arrays dict for the oracle).
+
+    device_library=True generates the seismic libraries directly in HBM with torch
+    (for sizes that should not be materialised on the host, e.g. the 62.9 GB of config 3);
+    host_arrays then holds no G."""
+    rng = np.random.default_rng(spec.seed)
+    layout, lower, upper = _layout_and_bounds(spec)
+    P, T, N = spec.P, spec.T, spec.N
+    host = dict(spec=spec, layout=layout, lower=lower, upper=upper)
+    seismic = T > 0
+    # make sure the library start-time axis covers sweep + time - shifts
+    if seismic:
+        need = max_sweep_time(spec) + 1.0 + (1.0 if spec.station_shifts else 0.0)
+        have = spec.st_min + (spec.S - 1) * spec.st_dt
+        if need > have + 1e-9 and not device_library:
+            raise ValueError("library start-time axis (%.2f s) does not cover the rupture (%.2f s)"
+                             % (have, need))
+
+    wavemaps = []
+    if seismic:
+        gfs, Gs = {}, []
+        for v in spec.slip_varnames:
+            cfg = SeismicGFLibraryConfig(dimensions=(T, P, spec.D, spec.S, N),
+                                         starttime_sampling=spec.st_dt,
+                                         duration_sampling=spec.du_dt, starttime_min=spec.st_min,
+                                         duration_min=spec.du_min, component=v)
+            gf = SeismicGFLibrary(cfg)
+            if device_library:
+                import torch
+                dev = torch.device("cuda", ctx.device if ctx is not None else 0)
+                gen = torch.Generator(device=dev)
+                gen.manual_seed(spec.seed + len(Gs))
+                G = torch.empty((T, P, spec.D, spec.S, N), dtype=torch.float64, device=dev)
+                flat = G.view(-1)
+                step = 1 << 28
+                for o in range(0, flat.numel(), step):
+                    flat[o:o + step].normal_(generator=gen)
+                gf.adopt_device_tensor(G)
+                Gs.append(None)
+            else:
+                gf.setup(T, P, spec.D, spec.S, N, allocate=True)
+                gf._gfmatrix[:] = rng.standard_normal((T, P, spec.D, spec.S, N))
+                Gs.append(gf._gfmatrix)
+            gfs[v] = gf
+        data = spec.sigma * rng.standard_normal((T, N)) + rng.standard_normal((T, N)) * 3.0
+        if spec.covariance == "scalar":
+            sig = spec.sigma * (1.0 + 0.1 * rng.random(T))
+            weights = 1.0 / sig                       # chol_inverse of sigma^2 I = I / sigma
+            slog = N * np.log(sig ** 2)               # log det(sigma^2 I)
+        else:
+            # covariance.py:413-427: C_i = scaling_i * structure(dt, tzero)
+            base = exponential_data_covariance(N, 0.5, 2.0)
+            Lb = np.linalg.cholesky(base)
+            Wb = np.linalg.cholesky(np.linalg.inv(base)).T
+            ldb = 2.0 * np.log(np.diag(Lb)).sum()
+            scal = (spec.sigma * (1.0 + 0.1 * rng.random(T))) ** 2
+            weights = np.stack([Wb / np.sqrt(s) for s in scal])
+            slog = np.array([ldb + N * np.log(s) for s in scal])
+        hypers = [("h_any_P_0_Z", t if spec.hp_specific else 0) for t in range(T)]
+        ts = None
+        if spec.station_shifts:
+            nst = layout.varsizes["time_shifts_any_P_0"]
+            ts = ("time_shifts_any_P_0", np.arange(T) % nst)
+        wavemaps.append(SeismicWavemap(gfs, data, weights, slog, hypers, ts, spec.interpolation))
+        host.update(Gs=Gs, data=data, weights=weights, slog=slog, hypers=hypers, time_shifts=ts)
+
+    geodetic = None
+    if spec.geodetic_nobs:
+        nobs = int(sum(spec.geodetic_nobs))
+        ggfs, gGs = {}, []
+        for v in spec.slip_varnames:
+            gg = GeodeticGFLibrary(GeodeticGFLibraryConfig(dimensions=(P, nobs), component=v))
+            gg.setup(P, nobs, allocate=True)
+            gg._gfmatrix[:] = 1e-1 * rng.standard_normal((P, nobs))
+            ggfs[v] = gg
+            gGs.append(gg._gfmatrix)
+        gdata = rng.standard_normal(nobs)
+        godw = 0.5 + rng.random(nobs)
+        gW, gslog = [], []
+        for n in spec.geodetic_nobs:
+            b = rng.standard_normal((n, n))
+            Cg = b @ b.T / n + np.eye(n)
+            gW.append(np.linalg.cholesky(np.linalg.inv(Cg)).T)
+            gslog.append(2.0 * np.log(np.diag(np.linalg.cholesky(Cg))).sum())
+        ghyp = [("h_SAR", k if spec.hp_specific else 0) for k in range(len(spec.geodetic_nobs))]
+        geodetic = GeodeticData(ggfs, gdata, godw, spec.geodetic_nobs, gW, gslog, ghyp)
+        host.update(gGs=gGs, gdata=gdata, godw=godw, gW=gW, gslog=gslog, ghyp=ghyp)
+
+    lap = None
+    if spec.laplacian:
+        if spec.nsub != 1:
+            raise ValueError("nearest-neighbour smoothing operator is defined for one subfault")
+        L = smoothing_operator_nearest_neighbor(spec.n_patch_strike[0], spec.n_patch_dip[0],
+                                                spec.patch_size[0], spec.patch_size[0])
+        LtL = L.T * L  # elementwise, as in laplacian.py:58
+        logdet = 2.0 * np.log(np.diag(np.linalg.cholesky(LtL))).sum()
+        lap = (L, logdet)
+        host.update(L=L, lap_logdet=logdet)
+
+    prob = FFIProblem(layout, spec.n_patch_dip, spec.n_patch_strike, spec.patch_size,
+                      spec.slip_varnames, wavemaps, geodetic, lap, lower, upper)
+    return prob, host

@@ -1,0 +1,206 @@
+/*
+ * beat_amd.h -- C ABI of libbeat_amd.so: the MI355X (gfx950) forward-model +
+ * likelihood engine for BEAT's SMC/PT inner loop.
+ *
+ * This is the drop-in boundary (DESIGN.md "Boundary"): plain pointers and sizes, no
+ * torch / numpy / Python types.  Each entry point names the reference interface it
+ * replaces (file:line under hvasbath/beat v2.0.5).  INTEGRATION.md shows the ctypes
+ * stubs a BEAT maintainer would add.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative BEATAMD_E* code;
+ *    beatamd_last_error() returns the thread-local message of the last failure.
+ *  - all arrays are C-contiguous IEEE float64 unless stated; indices are int32.
+ *  - array arguments may be HOST pointers (numpy) or DEVICE pointers (HBM, e.g. a torch
+ *    tensor's data_ptr()); the library detects which (hipPointerGetAttributes) and
+ *    stages host buffers through context-owned HBM scratch.  With device pointers no
+ *    copy is made and the call is asynchronous on the context stream; with host
+ *    pointers the call returns after the results are back in host memory.
+ *  - "C" is the number of Markov chains in the batch: chains are the batch dimension
+ *    of every kernel (the reference evaluates one chain per call).
+ *  - one beatamd_ctx per (process, GPU); a context is not thread-safe.
+ */
+#ifndef BEAT_AMD_H
+#define BEAT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BEATAMD_OK 0
+#define BEATAMD_EINVAL (-1)   /* bad argument (reference: AttributeError / ValueError)   */
+#define BEATAMD_EHIP (-2)     /* HIP runtime failure                                       */
+#define BEATAMD_EINDEX (-3)   /* index outside the GF library (reference: numpy IndexError) */
+#define BEATAMD_ENOMEM (-4)
+#define BEATAMD_ENAN (-5)     /* non-finite likelihood at stage 0 (metropolis.py:279-284)  */
+
+#define BEATAMD_NEAREST_NEIGHBOR 0 /* interpolation="nearest_neighbor" */
+#define BEATAMD_MULTILINEAR 1      /* interpolation="multilinear"      */
+
+#define BEATAMD_W_SCALAR 0 /* W_i = w_i * I   (chol_inverse of sigma^2 I)            */
+#define BEATAMD_W_DENSE 1  /* W_i dense (M,M) row-major, upper-triangular content    */
+
+typedef struct beatamd_ctx beatamd_ctx;
+
+const char *beatamd_last_error(void);
+int beatamd_version(void);
+
+/* ---------------------------------------------------------------- context --------- */
+int beatamd_ctx_create(int device, beatamd_ctx **out);
+int beatamd_ctx_destroy(beatamd_ctx *ctx);
+/* launch on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream);
+ * NULL restores the context's own stream */
+int beatamd_ctx_set_stream(beatamd_ctx *ctx, void *hip_stream);
+int beatamd_ctx_synchronize(beatamd_ctx *ctx);
+/* per-kernel HIP-event timing on the launch stream (bench.py roofline leg).
+ * kernel names: "sweep", "tables", "gfstack", "quadform", "geostack", "finish", "astep" */
+int beatamd_ctx_enable_timing(beatamd_ctx *ctx, int on);
+int beatamd_ctx_kernel_time(beatamd_ctx *ctx, const char *kernel, double *total_ms,
+                            int64_t *launches);
+int beatamd_ctx_reset_timing(beatamd_ctx *ctx);
+
+/* ---------------------------------------------------------------- fast sweep -------
+ * replaces: fast_sweep_ext.fast_sweep(slowness, patch_size, h_strk, h_dip, num_strk,
+ *           num_dip)                       beat/fast_sweeping/fast_sweep_ext.c:120-245
+ *           pytensorf.Sweeper.perform      beat/pytensorf.py:443-500
+ * Batched over chains.  Same argument slots as the C extension: rows i in
+ * [0,num_strk), columns j in [0,num_dip), flat index i*num_dip + j (BEAT passes
+ * dip in the "strk" slots, pytensorf.py:473-482).
+ *   slowness [C, num_strk*num_dip]   h_strk/h_dip [C] int32   out [C, num_strk*num_dip]
+ * A hypocentre index outside the grid is BEATAMD_EINVAL (the reference writes out of
+ * bounds). */
+int beatamd_fast_sweep_batch(beatamd_ctx *ctx, const double *slowness, double patch_size,
+                             const int32_t *h_strk, const int32_t *h_dip, int32_t num_strk,
+                             int32_t num_dip, int64_t C, double *out);
+
+/* ---------------------------------------------------------------- GF libraries -----
+ * replaces: SeismicGFLibrary (5-D float64 array (ntargets, npatches, ndurations,
+ *           nstarttimes, nsamples) + index maps)          beat/ffi/base.py:320-709
+ *           init_optimization() / parallel.memshare: one HBM-resident copy per GPU
+ *                                              beat/ffi/base.py:387-404, parallel.py:285-439 */
+int beatamd_seis_gflib_create(beatamd_ctx *ctx, int64_t ntargets, int64_t npatches,
+                              int64_t ndurations, int64_t nstarttimes, int64_t nsamples,
+                              double starttime_min, double starttime_sampling,
+                              double duration_min, double duration_sampling, int32_t *lib_id);
+/* copy `count` doubles (host or device source) to element offset `offset` of the library */
+int beatamd_seis_gflib_upload(beatamd_ctx *ctx, int32_t lib_id, const double *src,
+                              int64_t offset, int64_t count);
+/* use a caller-owned device allocation as the library storage (no copy) */
+int beatamd_seis_gflib_adopt(beatamd_ctx *ctx, int32_t lib_id, double *device_ptr);
+int beatamd_seis_gflib_device_ptr(beatamd_ctx *ctx, int32_t lib_id, double **device_ptr);
+int beatamd_seis_gflib_destroy(beatamd_ctx *ctx, int32_t lib_id);
+
+/* replaces: SeismicGFLibrary.stack_all(durations, starttimes, slips, targetidxs,
+ *           patchidxs, interpolation)                      beat/ffi/base.py:607-709
+ *           (incl. starttimes2idxs :486-521, durations2idxs :535-568)
+ *   durations [C,P]  starttimes [C,T,P]  slips [C,P]  ->  out [C,T,N]
+ * An index outside the library is BEATAMD_EINDEX (numpy IndexError); negative indices
+ * wrap like numpy. */
+int beatamd_seis_stack_all_batch(beatamd_ctx *ctx, int32_t lib_id, int64_t C,
+                                 const double *durations, const double *starttimes,
+                                 const double *slips, int32_t interpolation, double *out);
+
+/* replaces: GeodeticGFLibrary.stack_all(slips) = G.T.dot(slips)  beat/ffi/base.py:292-305
+ *   G [P,Nobs] (uploaded once)   slips [C,P]  ->  out [C,Nobs]; accumulate!=0 adds */
+int beatamd_geo_gflib_create(beatamd_ctx *ctx, int64_t npatches, int64_t nobs, const double *G,
+                             int32_t *lib_id);
+int beatamd_geo_gflib_destroy(beatamd_ctx *ctx, int32_t lib_id);
+int beatamd_geo_stack_all_batch(beatamd_ctx *ctx, int32_t lib_id, int64_t C,
+                                const double *slips, int32_t accumulate, double *out);
+
+/* ---------------------------------------------------------------- likelihood -------
+ * replaces: multivariate_normal_chol(datasets, weights, hyperparams, residuals)
+ *                                              beat/models/distributions.py:72-140
+ * A "weight set" holds what the reference keeps in pytensor shared variables per
+ * dataset: W_i = Covariance.chol_inverse (heart.py:211-237), slog_pdet_i
+ * (heart.py:239-253) and M_i = nsamples.  All datasets of a set share M.
+ *   kind SCALAR: weights [nd]      kind DENSE: weights [nd, M, M]
+ * update = SeismicComposite.update_weights (seismic.py:1509-1534): same call again. */
+int beatamd_weights_create(beatamd_ctx *ctx, int32_t kind, int64_t ndatasets, int64_t M,
+                           const double *weights, const double *slog_pdet, int32_t *wset_id);
+int beatamd_weights_update(beatamd_ctx *ctx, int32_t wset_id, const double *weights,
+                           const double *slog_pdet);
+int beatamd_weights_destroy(beatamd_ctx *ctx, int32_t wset_id);
+/*   residuals [C, nd, M]   hp [C, nd] (hyperparameter already resolved per dataset,
+ *   distributions.py:117-126)   ->   logpts [C, nd]                                  */
+int beatamd_mvn_chol_logp_batch(beatamd_ctx *ctx, int32_t wset_id, int64_t C,
+                                const double *residuals, const double *hp, double *logpts);
+
+/* replaces: LaplacianDistributerComposite.get_formula / _eval_prior
+ *                                              beat/models/laplacian.py:88-139
+ *   L [P,P]  slips [C, nvar, P]  hp [C]  ->  out [C]  (sum over slip variables)      */
+int beatamd_laplacian_create(beatamd_ctx *ctx, int64_t npatches, const double *L,
+                             double logdet, int32_t *lap_id);
+int beatamd_laplacian_destroy(beatamd_ctx *ctx, int32_t lap_id);
+int beatamd_laplacian_logp_batch(beatamd_ctx *ctx, int32_t lap_id, int64_t C, int64_t nvar,
+                                 const double *slips, const double *hp, double *out);
+
+/* ---------------------------------------------------------------- fused FFI model ---
+ * replaces: the compiled logp_forw_func(q) of a DistributionOptimizer (FFI) problem:
+ *           sampler/base.py:598-615 logp_forw; graph built by
+ *           SeismicDistributerComposite.get_formula   beat/models/seismic.py:1210-1349
+ *           GeodeticDistributerComposite.get_formula  beat/models/geodetic.py:1030-1084
+ *           LaplacianDistributerComposite.get_formula beat/models/laplacian.py:98-139
+ *           Problem.built_model (like = sum)          beat/models/problems.py:212-248
+ * Q [C, nparams] -> LL [C, nllk]; nllk = sum(seismic datasets) + sum(geodetic
+ * datasets) + (laplacian ? 1 : 0) + 1, ordered seis_like.., geo_like.., laplacian_like,
+ * like  (SURVEY Appendix C "Outputs").
+ * Offsets are positions in the flat parameter vector q (DictToArrayBijection order,
+ * taken from the host model); -1 = variable absent / fixed. */
+typedef struct beatamd_ffi_layout {
+    int64_t nparams;
+    int32_t nvar;            /* slip variables (uparr, uperp, ...)                        */
+    int64_t slip_off[4];     /* [nvar] offset of each slip variable (size npatches)        */
+    int64_t durations_off;   /* size npatches                                              */
+    int64_t velocities_off;  /* size npatches                                              */
+    int64_t nuc_strike_off;  /* size nsubfaults                                            */
+    int64_t nuc_dip_off;     /* size nsubfaults                                            */
+    int64_t time_off;        /* size nsubfaults                                            */
+    int64_t h_laplacian_off; /* size 1, -1 if no laplacian                                 */
+} beatamd_ffi_layout;
+
+int beatamd_ffi_model_create(beatamd_ctx *ctx, const beatamd_ffi_layout *layout,
+                             int32_t nsubfaults, const int32_t *n_patch_dip,
+                             const int32_t *n_patch_strike, const double *patch_size,
+                             int32_t *model_id);
+/* one seismic wavemap (seismic.py:1274-1341):
+ *   lib_ids [nvar]   data [T,N]   wset_id over the T datasets
+ *   hp_off [T]: offset in q of each dataset's hyperparameter
+ *   shift_off [T]: offset in q of each target's station time-shift, or NULL
+ *                  (hierarchicals[time_shifts_id][station_correction_idxs])           */
+int beatamd_ffi_model_add_wavemap(beatamd_ctx *ctx, int32_t model_id, const int32_t *lib_ids,
+                                  const double *data, int32_t wset_id, const int64_t *hp_off,
+                                  const int64_t *shift_off, int32_t interpolation);
+/* geodetic composite (geodetic.py:1065-1081): geo lib per slip var, data [Nobs],
+ * odws [Nobs], dataset sizes [nd] (srmap), one wset per dataset (sizes differ) */
+int beatamd_ffi_model_add_geodetic(beatamd_ctx *ctx, int32_t model_id, const int32_t *geo_lib_ids,
+                                   const double *data, const double *odws, int32_t ndatasets,
+                                   const int64_t *dataset_sizes, const int32_t *wset_ids,
+                                   const int64_t *hp_off);
+int beatamd_ffi_model_set_laplacian(beatamd_ctx *ctx, int32_t model_id, int32_t lap_id);
+int beatamd_ffi_model_nllk(beatamd_ctx *ctx, int32_t model_id, int64_t *nllk);
+int beatamd_ffi_model_destroy(beatamd_ctx *ctx, int32_t model_id);
+
+/* logp_forw_func batched: Q [C,nparams] -> LL [C,nllk] */
+int beatamd_ffi_logp_batch(beatamd_ctx *ctx, int32_t model_id, int64_t C, const double *Q,
+                           double *LL);
+
+/* replaces: Metropolis.astep for C chains at once   beat/sampler/metropolis.py:276-422
+ *           (stage > 0, check_bound=True, continuous variables)
+ *   Q0 [C,nparams] current points (updated in place)
+ *   L0 [C,nllk]    current likelihood vectors = chain_previous_lpoint (updated in place)
+ *   delta [C,nparams] proposal_samples_array[stage_sample] rows
+ *   scaling [C]    per-chain step scaling;  lower/upper [nparams] Uniform prior boxes
+ *   log_u [C]      log of the MH uniforms (metrop_select)
+ *   beta           tempering parameter;  accepted [C] int32 out (1 = moved)            */
+int beatamd_ffi_astep_batch(beatamd_ctx *ctx, int32_t model_id, int64_t C, double *Q0,
+                            double *L0, const double *delta, const double *scaling,
+                            const double *lower, const double *upper, const double *log_u,
+                            double beta, int32_t *accepted);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEAT_AMD_H */

@@ -1,0 +1,332 @@
+"""GPU parity tests: the HIP path (through the C ABI, via beat_amd.engine) against the CPU
+oracle and the committed golden vectors.  Run on the MI355X box: pytest -m gpu.
+
+Tolerances: indices bit-exact; rupture times <= 1e-12 s abs (sqrt vs glibc pow, SURVEY
+A.8); synthetics and log-likelihoods <= 1e-6 rel as BASELINE.json's north_star states
+(observed ~1e-13)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6  # north_star tolerance for synthetics / logp
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import beat_amd
+    c = beat_amd.get_context(0)
+    yield c
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+# ----------------------------------------------------------------------------- sweep
+def test_sweep_golden_times_and_indices(ctx, orc):
+    g = load_golden("sweep")
+    for name in g["names"]:
+        slow = g[name + "_slow"]
+        psz, hd, hs, nd, ns = g[name + "_meta"]
+        nd, ns = int(nd), int(ns)
+        out = ctx.fast_sweep_batch(slow.reshape(1, -1), psz, [int(hd)], [int(hs)], nd, ns)[0]
+        ref = g[name + "_c"]  # the reference C extension's output
+        np.testing.assert_allclose(out, ref, rtol=0, atol=1e-12, err_msg=name)
+        # bit-exact rupture-time INDEXING (north_star): nn and multilinear grid indices
+        for dt in (0.5, 0.25, 0.1):
+            assert np.array_equal(orc.time2idx(out, 0.0, dt)[0], orc.time2idx(ref, 0.0, dt)[0])
+            assert np.array_equal(orc.time2idx(out, 0.0, dt, "multilinear")[0],
+                                  orc.time2idx(ref, 0.0, dt, "multilinear")[0])
+
+
+def test_sweep_batch_random_vs_oracle(ctx, orc):
+    rng = np.random.default_rng(5)
+    for nd, ns in [(20, 20), (7, 31), (64, 3), (70, 70), (1, 1), (2, 90)]:
+        C = 37
+        slow = 1.0 / rng.uniform(0.5, 6.0, (C, nd * ns))
+        hd = rng.integers(0, nd, C).astype(np.int32)
+        hs = rng.integers(0, ns, C).astype(np.int32)
+        out = ctx.fast_sweep_batch(slow, 1.5, hd, hs, nd, ns)
+        for c in range(C):
+            ref = orc.fast_sweep(slow[c], 1.5, hd[c], hs[c], nd, ns)
+            np.testing.assert_allclose(out[c], ref, rtol=0, atol=1e-12)
+            assert np.array_equal(orc.time2idx(out[c], 0.0, 0.5)[0], orc.time2idx(ref, 0.0, 0.5)[0])
+
+
+def test_sweep_bad_hypocentre_raises(ctx):
+    with pytest.raises(ValueError):
+        ctx.fast_sweep_batch(np.ones((1, 12)), 1.0, [3], [0], 3, 4)
+
+
+def test_sweep_reference_module_signature(ctx):
+    """drop-in for fast_sweep_ext.fast_sweep / get_rupture_times_c / Sweeper.perform"""
+    from beat_amd.fast_sweeping import fast_sweep, fast_sweep_ext
+    from beat_amd.pytensorf import Sweeper
+    g = load_golden("sweep")
+    slow = g["kat_slow"]
+    ref = g["kat_c"]
+    a = fast_sweep_ext.fast_sweep(slow.ravel().copy(), 10.0, 3, 2, 6, 4)
+    b = fast_sweep.get_rupture_times_c(slow.ravel().copy(), 10.0, 4, 6, 2, 3)
+    out = [[None]]
+    Sweeper(10.0, 6, 4, "c").perform(None, (slow.ravel(), 3, 2), out)
+    for x in (a, b, out[0][0]):
+        np.testing.assert_allclose(x, ref, rtol=0, atol=1e-12)
+    with pytest.raises(AttributeError):
+        fast_sweep_ext.fast_sweep(slow.ravel().astype(np.float32), 10.0, 3, 2, 6, 4)
+    with pytest.raises(AttributeError):
+        fast_sweep_ext.fast_sweep([1.0, 2.0], 10.0, 0, 0, 1, 2)
+
+
+# ----------------------------------------------------------------------------- stacking
+def _make_lib(ctx, G, st_min, st_dt, du_min, du_dt):
+    from beat_amd.ffi import SeismicGFLibrary, SeismicGFLibraryConfig
+    T, P, D, S, N = G.shape
+    gf = SeismicGFLibrary(SeismicGFLibraryConfig(dimensions=G.shape, starttime_sampling=st_dt,
+                                                 duration_sampling=du_dt, starttime_min=st_min,
+                                                 duration_min=du_min))
+    gf.setup(T, P, D, S, N, allocate=True)
+    gf._gfmatrix[:] = G
+    gf.init_optimization(ctx)
+    return gf
+
+
+@pytest.mark.parametrize("interp,tag", [("nearest_neighbor", "nn"), ("multilinear", "ml")])
+def test_stack_all_golden(ctx, interp, tag):
+    g = load_golden("stack_all")
+    st_min, st_dt, du_min, du_dt = g["cfg"]
+    gf = _make_lib(ctx, g["G"], st_min, st_dt, du_min, du_dt)
+    T = g["G"].shape[0]
+    for k in range(int(g["ncase"])):
+        out = gf.stack_all(durations=g["c%d_dur" % k], starttimes=g["c%d_st" % k],
+                           slips=g["c%d_sl" % k], targetidxs=np.atleast_2d(np.arange(T)).T,
+                           interpolation=interp)
+        ref = g["c%d_%s_out" % (k, tag)]
+        np.testing.assert_allclose(out, ref, rtol=RTOL, atol=1e-9)
+        assert np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("N", [16, 37, 512, 1000, 1026])
+@pytest.mark.parametrize("interp", ["nearest_neighbor", "multilinear"])
+def test_stack_all_batch_vs_oracle(ctx, orc, N, interp):
+    rng = np.random.default_rng(N)
+    T, P, D, S = 3, 21, 3, 6
+    G = rng.standard_normal((T, P, D, S, N))
+    gf = _make_lib(ctx, G, 0.0, 0.5, 0.5, 0.25)
+    C = 5
+    dur = rng.uniform(0.5, 1.0, (C, P))
+    st = rng.uniform(0.0, 2.5, (C, T, P))
+    sl = rng.uniform(0, 5, (C, P))
+    out = gf.stack_all_batch(dur, st, sl, interpolation=interp)
+    for c in range(C):
+        ref = orc.stack_all(G, dur[c], st[c], sl[c], 0.5, 0.25, 0.0, 0.5, interp)
+        np.testing.assert_allclose(out[c], ref, rtol=RTOL, atol=1e-9)
+        assert np.abs(out[c] - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
+def test_stack_closed_form_and_linearity(ctx):
+    """reference test/test_ffi.py:22-89 recipe: out[t,n] = t*n*sum(slips); plus linearity"""
+    T, P, D, S, N = 30, 40, 11, 31, 10
+    G = np.empty((T, P, D, S, N))
+    G[:] = (np.arange(N)[None, :] * np.arange(T)[:, None])[:, None, None, None, :]
+    gf = _make_lib(ctx, G, 0.0, 0.5, 5.0, 0.5)
+    rng = np.random.default_rng(0)
+    dur = rng.uniform(5.0, 10.0, (2, P))
+    st = rng.uniform(0.0, 15.0, (2, T, P))
+    sl = rng.random((2, P))
+    for interp in ("nearest_neighbor", "multilinear"):
+        out = gf.stack_all_batch(dur, st, sl, interpolation=interp)
+        for c in range(2):
+            expect = np.arange(T)[:, None] * np.arange(N)[None, :] * sl[c].sum()
+            np.testing.assert_allclose(out[c], expect, rtol=1e-12, atol=1e-9)
+        out2 = gf.stack_all_batch(dur, st, 2.5 * sl, interpolation=interp)
+        np.testing.assert_allclose(out2, 2.5 * out, rtol=1e-13, atol=1e-10)
+
+
+def test_stack_index_out_of_bounds_raises(ctx):
+    G = np.zeros((2, 3, 2, 2, 8))
+    gf = _make_lib(ctx, G, 0.0, 0.5, 0.5, 0.5)
+    with pytest.raises(IndexError):
+        gf.stack_all_batch(np.full((1, 3), 5.0), np.zeros((1, 2, 3)), np.ones((1, 3)))
+    # the context stays usable afterwards
+    out = gf.stack_all_batch(np.full((1, 3), 0.5), np.zeros((1, 2, 3)), np.ones((1, 3)))
+    assert out.shape == (1, 2, 8)
+    with pytest.raises(NotImplementedError):
+        gf.stack_all_batch(np.full((1, 3), 0.5), np.zeros((1, 2, 3)), np.ones((1, 3)),
+                           interpolation="cubic")
+    with pytest.raises(ValueError):
+        gf.stack_all(np.full(3, 0.5), np.zeros((2, 3)), np.ones(3))  # targetidxs missing
+
+
+def test_geo_stack_golden(ctx):
+    from beat_amd.ffi import GeodeticGFLibrary, GeodeticGFLibraryConfig
+    g = load_golden("geo_stack")
+    G = g["G"]
+    gg = GeodeticGFLibrary(GeodeticGFLibraryConfig(dimensions=G.shape))
+    gg.setup(*G.shape, allocate=True)
+    gg._gfmatrix[:] = G
+    np.testing.assert_allclose(gg.stack_all(g["slips"]), g["out"], rtol=1e-12, atol=1e-12)
+
+
+# ----------------------------------------------------------------------------- likelihood
+@pytest.mark.parametrize("M", [10, 48, 205, 214, 400, 1000])
+def test_mvn_chol_dense_vs_oracle(ctx, orc, M):
+    rng = np.random.default_rng(M)
+    nd, C = 3, 70
+    Ws, slogs = [], []
+    for d in range(nd):
+        Cd = (0.3 + d) * orc.exponential_data_covariance(M, 0.5, 2.0) + 0.01 * np.eye(M)
+        Ws.append(orc.cov_chol_inverse(Cd))
+        slogs.append(orc.cov_log_pdet(Cd))
+    Ws[1] = Ws[1] + 1e-3 * rng.standard_normal((M, M))  # a non-triangular weight matrix
+    wid = ctx.weights_create_dense(np.stack(Ws), slogs)
+    res = rng.standard_normal((C, nd, M))
+    hp = rng.uniform(-1, 1, (C, nd))
+    out = ctx.mvn_chol_logp_batch(wid, res, hp)
+    for c in range(0, C, 7):
+        ref = orc.multivariate_normal_chol(Ws, slogs, hp[c], res[c])
+        np.testing.assert_allclose(out[c], ref, rtol=RTOL)
+        np.testing.assert_allclose(out[c], ref, rtol=1e-11)
+    ctx.weights_destroy(wid)
+
+
+def test_mvn_chol_scalar_and_scipy(ctx, orc):
+    """reference test/test_models.py:149-222 toy: C = 0.001 I, hyper 0 -> scipy logpdf"""
+    import scipy.stats
+    rng = np.random.default_rng(1)
+    M, nd, C = 10, 2, 4
+    res = 0.03 * rng.standard_normal((C, nd, M))
+    Cov = 0.001 * np.eye(M)
+    slog = [orc.cov_log_pdet(Cov)] * nd
+    wid = ctx.weights_create_scalar([1.0 / np.sqrt(0.001)] * nd, slog, M)
+    out = ctx.mvn_chol_logp_batch(wid, res, np.zeros((C, nd)))
+    wid2 = ctx.weights_create_dense(np.stack([orc.cov_chol_inverse(Cov)] * nd), slog)
+    out2 = ctx.mvn_chol_logp_batch(wid2, res, np.zeros((C, nd)))
+    for c in range(C):
+        for d in range(nd):
+            ref = scipy.stats.multivariate_normal.logpdf(res[c, d], mean=np.zeros(M), cov=Cov)
+            np.testing.assert_allclose(out[c, d], ref, rtol=0, atol=1e-6)
+            np.testing.assert_allclose(out2[c, d], ref, rtol=0, atol=1e-6)
+
+
+def test_laplacian_vs_oracle(ctx, orc):
+    g = load_golden("laplacian")
+    L, logdet = g["20x20_L"], float(g["20x20_logdet"])
+    lid = ctx.laplacian_create(L, logdet)
+    rng = np.random.default_rng(2)
+    C, nvar = 33, 2
+    s = rng.uniform(0, 5, (C, nvar, 400))
+    h = rng.uniform(-1, 1, C)
+    out = ctx.laplacian_logp_batch(lid, s, h)
+    for c in range(C):
+        ref = sum(orc.laplacian_logp(L, s[c, v], logdet, h[c]) for v in range(nvar))
+        np.testing.assert_allclose(out[c], ref, rtol=1e-11)
+
+
+def test_laquila_geodetic_fixture(ctx, orc):
+    """the only real-data fixture: 2 SAR scenes with full covariances"""
+    g = load_golden("laquila_geodetic")
+    rng = np.random.default_rng(3)
+    C = 16
+    for i in range(int(g["n"])):
+        Cd = g["d%d_C" % i]
+        W = orc.cov_chol_inverse(Cd)
+        sl = orc.cov_log_pdet(Cd)
+        np.testing.assert_allclose(sl, g["d%d_logpdet" % i], rtol=1e-12)
+        n = Cd.shape[0]
+        wid = ctx.weights_create_dense(W, [sl])
+        res = (g["d%d_displacement" % i][None, :] + 0.01 * rng.standard_normal((C, n))) * g["d%d_odw" % i]
+        hp = rng.uniform(-0.5, 0.5, (C, 1))
+        out = ctx.mvn_chol_logp_batch(wid, res.reshape(C, 1, n), hp)
+        for c in range(C):
+            ref = orc.mvn_chol_logp(W, res[c], sl, hp[c, 0])
+            np.testing.assert_allclose(out[c, 0], ref, rtol=1e-10)
+
+
+# ----------------------------------------------------------------------------- fused model
+def _specs():
+    from beat_amd.synthetic import SyntheticSpec
+    return {
+        "seis_scalar_nn": SyntheticSpec((6,), (5,), (1.0,), T=4, N=64, D=3, S=25),
+        "seis_dense_ml_shifts": SyntheticSpec((6,), (5,), (1.0,), T=5, N=48, D=3, S=30,
+                                              covariance="toeplitz", station_shifts=True,
+                                              interpolation="multilinear", hp_specific=True),
+        "joint_multifault": SyntheticSpec((4, 3), (5, 6), (2.0, 2.0), T=3, N=100, D=3, S=40,
+                                          slip_varnames=("uparr", "uperp"), covariance="toeplitz",
+                                          station_shifts=True, geodetic_nobs=(21, 17)),
+        "geo_lap_only": SyntheticSpec((5,), (7,), (1.0,), T=0, N=0, slip_varnames=("uparr", "uperp"),
+                                      geodetic_nobs=(30, 12), laplacian=True),
+        "all_nn_odd_N": SyntheticSpec((5,), (4,), (1.0,), T=3, N=33, D=3, S=25,
+                                      geodetic_nobs=(9,), laplacian=True, hp_specific=True),
+    }
+
+
+@pytest.mark.parametrize("name", list(_specs().keys()))
+def test_ffi_logp_batch_vs_oracle(ctx, name):
+    from beat_amd.synthetic import build_problem, draw_population
+    from oracle import problem_oracle
+    spec = _specs()[name]
+    prob, host = build_problem(spec)
+    f = prob.compile(ctx)
+    C = 9
+    Q = draw_population(spec, host["layout"], host["lower"], host["upper"], C)
+    LL = f.batch(Q)
+    assert LL.shape == (C, f.nllk) and len(prob.out_names) == f.nllk
+    for c in range(C):
+        ref, _ = problem_oracle.forward(host, Q[c])
+        np.testing.assert_allclose(LL[c], ref, rtol=RTOL)
+        np.testing.assert_allclose(LL[c], ref, rtol=1e-9, atol=1e-9)
+    # one-chain call signature of logp_forw_func: list of arrays, like last
+    one = f(Q[0])
+    assert float(one[-1]) == LL[0, -1]
+    assert f.trust_input is True
+
+
+def test_astep_batch_vs_oracle(ctx):
+    from beat_amd.synthetic import build_problem, draw_population
+    from oracle import problem_oracle
+    spec = _specs()["all_nn_odd_N"]
+    prob, host = build_problem(spec)
+    f = prob.compile(ctx)
+    lay = host["layout"]
+    lo, up = lay.bounds(host["lower"], host["upper"])
+    C = 24
+    rng = np.random.default_rng(9)
+    Q0 = draw_population(spec, lay, host["lower"], host["upper"], C)
+    L0 = f.batch(Q0)
+    delta = rng.standard_normal((C, lay.size)) * (up - lo) * 0.02
+    delta[3] *= 100.0  # certainly outside the prior box -> rejected without evaluation
+    scaling = rng.uniform(0.5, 1.5, C)
+    log_u = np.log(rng.random(C))
+    beta = 0.3
+    Qn, Ln = Q0.copy(), L0.copy()
+    acc = f.astep_batch(Qn, Ln, delta, scaling, lo, up, log_u, beta)
+    n_acc = 0
+    for c in range(C):
+        q_ref, l_ref, a_ref = problem_oracle.astep(host, Q0[c], L0[c], delta[c], scaling[c], lo, up,
+                                                   log_u[c], beta)
+        assert bool(acc[c]) == a_ref
+        np.testing.assert_array_equal(Qn[c], q_ref)
+        np.testing.assert_allclose(Ln[c], l_ref, rtol=1e-9, atol=1e-9)
+        n_acc += a_ref
+    assert acc[3] == 0 and 0 < n_acc < C
+
+
+def test_device_pointer_path_matches_host_path(ctx):
+    """torch CUDA tensors in -> torch CUDA tensors out, no host staging"""
+    import torch
+    from beat_amd.synthetic import build_problem, draw_population
+    spec = _specs()["seis_scalar_nn"]
+    prob, host = build_problem(spec)
+    f = prob.compile(ctx)
+    Q = draw_population(spec, host["layout"], host["lower"], host["upper"], 6)
+    LLh = f.batch(Q)
+    Qd = torch.from_numpy(Q).cuda()
+    LLd = f.batch(Qd)
+    ctx.synchronize()
+    assert LLd.is_cuda
+    np.testing.assert_array_equal(LLd.cpu().numpy(), LLh)
