@@ -91,6 +91,14 @@ def load():
             raise BeatAmdError(
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C beat_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        # One HIP runtime per process: the torch wheel bundles its own libamdhip64.so.7; if
+        # torch is imported AFTER a library bound to /opt/rocm's copy, torch finds "No HIP
+        # GPUs".  Importing torch first lets the loader resolve our DT_NEEDED libamdhip64.so.7
+        # to the copy torch already mapped.  Without torch the system runtime is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, args in _PROTOS.items():
             fn = getattr(lib, name)

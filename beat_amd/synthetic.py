@@ -91,11 +91,12 @@ def _layout_and_bounds(spec):
     if seismic:
         add("durations", P, spec.du_min, spec.du_min + (spec.D - 1) * spec.du_dt)
         add("velocities", P, spec.vel_bounds[0], spec.vel_bounds[1])
-        ext_s = max(s * h for s, h in zip(spec.n_patch_strike, spec.patch_size))
-        ext_d = max(d * h for d, h in zip(spec.n_patch_dip, spec.patch_size))
-        # keep the rounded nucleation index inside the grid
-        add("nucleation_strike", nsub, 0.0, ext_s - 0.51 * max(spec.patch_size))
-        add("nucleation_dip", nsub, 0.0, ext_d - 0.51 * max(spec.patch_size))
+        # per-subfault bounds (reference apps/beat.py:1577-1589 sets them from the fault
+        # length / width); keep the rounded nucleation index inside the grid
+        ext_s = np.array([s * h - 0.51 * h for s, h in zip(spec.n_patch_strike, spec.patch_size)])
+        ext_d = np.array([d * h - 0.51 * h for d, h in zip(spec.n_patch_dip, spec.patch_size)])
+        add("nucleation_strike", nsub, 0.0, ext_s)
+        add("nucleation_dip", nsub, 0.0, ext_d)
         add("time", nsub, 0.0, 1.0)
         if spec.station_shifts:
             add("time_shifts_any_P_0", max(spec.T // 2, 1), -1.0, 1.0)
