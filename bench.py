@@ -1,0 +1,289 @@
+#!/usr/bin/env python
+"""
+bench.py -- SMC chain-steps/s of the FFI seismic hot path on MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[2], SURVEY.md 8(d) "config 3"): one 20x20-patch subfault
+(P=400, 1 km), T=64 targets, N=4096 samples, library (64,400,3,25,4096) float64 = 62.9 GB
+resident in HBM, N(0,1) values generated on device (synthetic), covariance sigma^2 I
+(``--covariance toeplitz`` for the dense-W variant), nearest-neighbour interpolation
+(``--interp multilinear`` for the 4-row blend).
+
+One "step" = one batched Metropolis.astep (reference beat/sampler/metropolis.py:276-422)
+for ``--chains`` chains per GPU: proposal, prior-box check, forward model
+(fast sweep -> start times -> GF stacking -> residual -> sum logp), tempered MH accept.
+All inputs (library, data, weights, chain states, proposal rows, uniforms) are resident in
+HBM when the timed region starts.
+
+    python bench.py                        # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Chains are sharded over ranks (weak scaling: fixed chains per GPU); there is no collective
+inside a step -- the SMC stage transition (all-gather of end points, once per ~100-400
+steps) is timed separately and reported as ``stage_transition_ms``.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def algorithmic_bytes_per_chain_step(spec, nvar=1):
+    """gathered rows + index/slip tables + the data read of the fused
+    residual (replaces the synthetics write of the unfused form, same size)."""
+    T, P, N = spec.T, spec.P, spec.N
+    rows = 4 if spec.interpolation == "multilinear" else 1
+    gathered = T * P * N * 8 * rows * nvar
+    tables = T * P * (4 * rows + (8 * rows if rows == 4 else 0)) + P * 8 * nvar
+    data = T * N * 8
+    return gathered + tables + data
+
+
+def cpu_baseline(spec, seconds=12.0):
+    """Reference-equivalent CPU path (oracle/beat_oracle.c bo_ffi_seismic_forward, the C
+    restatement pinned to the reference) on the host cores of this box, on a bounded
+    sample: T_sub of the T targets with the full P x N gather per target."""
+    from multiprocessing import get_context
+
+    from oracle import oracle as orc  # noqa: F401  (cpu_baseline leg only)
+
+    T_sub = 4
+    ncores = len(os.sched_getaffinity(0))
+    rng = np.random.default_rng(spec.seed)
+    P, N, S = spec.P, spec.N, spec.S
+    ml = spec.interpolation == "multilinear"
+    D_cpu = 2 if ml else 1  # D reduced: same gathered volume per step, fits host RAM
+    G = rng.standard_normal((T_sub, P, D_cpu, S, N))
+    data = rng.standard_normal((T_sub, N))
+    w = np.full(T_sub, 2.0)
+    slog = np.zeros(T_sub)
+    lib_cfg = dict(dur_min=spec.du_min, dur_dt=spec.du_dt, st_min=spec.st_min, st_dt=spec.st_dt)
+    fault = dict(ndip=spec.n_patch_dip, nstrike=spec.n_patch_strike, patch_size=spec.patch_size)
+
+    def one(seed):
+        r = np.random.default_rng(seed)
+        params = dict(slips=r.uniform(0, 5, (1, P)), durations=r.uniform(0.55, 0.7, P) if not ml else r.uniform(0.55, 0.95, P),
+                      velocities=r.uniform(*spec.vel_bounds, P),
+                      nuc_strike=[r.uniform(6, 13)], nuc_dip=[r.uniform(6, 13)], time=[0.0])
+        orc.ffi_seismic_forward([G], lib_cfg, fault, params, data, w, slog, 0.0,
+                                interpolation=spec.interpolation, return_synthetics=False)
+
+    global _cpu_one
+    _cpu_one = one
+    one(0)
+    t0 = time.perf_counter()
+    n1 = 0
+    while time.perf_counter() - t0 < seconds / 3:
+        one(n1)
+        n1 += 1
+    t1 = (time.perf_counter() - t0) / n1
+    rate1 = (T_sub / spec.T) / t1  # full chain-steps/s on one core
+    # all cores, one chain per forked worker (iter_parallel_chains, sampler/base.py:428-595)
+    rate_all, nsteps = rate1, n1
+    if ncores > 1:
+        per = max(2, int((seconds * 2 / 3) / t1))
+        ctx = get_context("fork")
+        with ctx.Pool(ncores) as pool:
+            pool.map(_cpu_worker, range(ncores))  # warm
+            t0 = time.perf_counter()
+            pool.map(_cpu_worker_n, [(i, per) for i in range(ncores)])
+            dt = time.perf_counter() - t0
+        rate_all = (ncores * per) * (T_sub / spec.T) / dt
+        nsteps = ncores * per
+    return dict(value=rate_all, unit="chain-steps/s", cores=ncores, kind="port",
+                value_1core=rate1,
+                sample="%d of %d targets (full %dx%d gather per target), %d chain-steps, "
+                       "oracle/beat_oracle.c (C restatement of the reference numpy/C path), "
+                       "%d forked workers x 1 thread" % (T_sub, spec.T, P, N, nsteps, ncores))
+
+
+_cpu_one = None
+
+
+def _cpu_worker(i):
+    _cpu_one(i)
+    return 0
+
+
+def _cpu_worker_n(a):
+    i, n = a
+    for k in range(n):
+        _cpu_one(1000 * i + k)
+    return 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--chains", type=int, default=128, help="chains per GPU per step")
+    ap.add_argument("--interp", default="nearest_neighbor",
+                    choices=["nearest_neighbor", "multilinear"])
+    ap.add_argument("--covariance", default="scalar", choices=["scalar", "toeplitz"])
+    ap.add_argument("--targets", type=int, default=64)
+    ap.add_argument("--samples", type=int, default=4096)
+    ap.add_argument("--nstarttimes", type=int, default=25)
+    ap.add_argument("--ndurations", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`"
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    import beat_amd
+    from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
+
+    dev = torch.device("cuda", local_rank)
+    ctx = beat_amd.get_context(local_rank)
+    ctx.use_torch_stream()
+
+    spec = SyntheticSpec((20,), (20,), (1.0,), T=args.targets, N=args.samples, D=args.ndurations,
+                         S=args.nstarttimes, covariance=args.covariance,
+                         interpolation=args.interp, nuc_margin=6.0, time_bounds=(0.0, 0.5))
+    t_build = time.perf_counter()
+    prob, host = build_problem(spec, device_library=True, ctx=ctx)
+    f = prob.compile(ctx)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+
+    B, K, W = args.chains, args.steps, args.warmup
+    lay = host["layout"]
+    lo, up = lay.bounds(host["lower"], host["upper"])
+    # chain c of rank r is global chain r*B + c (seed 1000 + id)
+    Q0 = torch.from_numpy(draw_population(spec, lay, host["lower"], host["upper"], B,
+                                          seed_offset=1000 + rank * B)).to(dev)
+    L0 = f.batch(Q0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4242 + rank)
+    span = torch.from_numpy(up - lo).to(dev)
+    # proposal rows: proposal_samples_array[stage_sample] of every chain (metropolis.py:289-313)
+    delta = torch.randn((K + W, B, lay.size), generator=gen, device=dev, dtype=torch.float64) \
+        * (0.01 * span)
+    log_u = torch.log(torch.rand((K + W, B), generator=gen, device=dev, dtype=torch.float64))
+    scaling = torch.ones(B, device=dev, dtype=torch.float64)
+    lo_d, up_d = torch.from_numpy(lo).to(dev), torch.from_numpy(up).to(dev)
+    accepted = torch.zeros(B, device=dev, dtype=torch.int32)
+    beta = 0.05
+    ctx.synchronize()
+
+    def step(i):
+        f.astep_batch(Q0, L0, delta[i], scaling, lo_d, up_d, log_u[i], beta, accepted)
+
+    for i in range(W):
+        step(i)
+    ctx.synchronize()  # also surfaces an out-of-library index as an exception
+    ctx.enable_timing(True)
+    ctx.reset_timing()
+    n_acc = 0
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ctx.synchronize()
+    n_acc = int(accepted.sum().item())
+
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt_max = float(tmax.item())
+
+    # SMC stage transition exchange (select_end_points, smc.py:188-240): all-gather of the
+    # per-rank end points + likelihoods; outside the timed steps, reported separately
+    stage_ms = None
+    if world > 1:
+        from beat_amd import parallel
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        Qall, Lall = parallel.allgather_population(Q0, L0)
+        torch.cuda.synchronize()
+        stage_ms = (time.perf_counter() - t1) * 1e3
+        assert Qall.shape[0] == world * B
+
+    gf_ms, gf_n = ctx.kernel_time("gfstack")
+    times = {k: ctx.kernel_time(k) for k in ("sweep", "tables", "gfstack", "quadform", "finish",
+                                             "astep")}
+    if rank == 0:
+        alg = algorithmic_bytes_per_chain_step(spec) * B  # per launch
+        avg_ms = gf_ms / max(gf_n, 1)
+        achieved = alg / (avg_ms * 1e-3) / 1e9 if gf_n else 0.0
+        out = {
+            "metric": "SMC chain-steps/s (FFI seismic gfstacking 400 patches x %d targets x %d samples)"
+                      % (spec.T, spec.N),
+            "value": world * B * K / dt_max,
+            "unit": "chain-steps/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": dt_max / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[2]: FFI seismic gfstacking, 400 patches x %d targets x "
+                            "%d samples, library (%d,%d,%d,%d,%d) f64 = %.1f GB in HBM, %s, "
+                            "covariance %s" % (spec.T, spec.N, spec.T, spec.P, spec.D, spec.S, spec.N,
+                                               spec.lib_bytes / 1e9, spec.interpolation,
+                                               spec.covariance),
+                "chains_per_gpu": B,
+                "global_chains": world * B,
+                "parallelism": "chains sharded over %d GPU(s), library replicated" % world,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_gfstack",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg,
+                "avg_launch_ms": avg_ms,
+                "launches": gf_n,
+            },
+            "kernel_ms_per_step": {k: (v[0] / K) for k, v in times.items() if v[1]},
+            "accept_rate_last_step": n_acc / float(B),
+            "setup_s": t_build,
+        }
+        if stage_ms is not None:
+            out["stage_transition_ms"] = stage_ms
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(spec)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
