@@ -17,6 +17,8 @@
 //                registers, no atomics, no LDS traffic on the streaming path (the stream is
 //                read exactly once, staging it in LDS would only add latency); LDS is used
 //                for the block reduction of the fused misfit.
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace beatamd {
@@ -111,6 +113,9 @@ struct GfArgs {
     double *out;
     double *partial;  // [C*T, ntile]
     int ntile;
+    int order;        // 0: blocks ordered (chain, target, tile); 1: (group, target, chain, tile)
+    int64_t C;
+    int cgroup;       // order 1: chains per group
 };
 
 template <int W> struct VecT;
@@ -141,9 +146,25 @@ __global__ void __launch_bounds__(256) k_gfstack(GfArgs a)
     constexpr int U = (8 / (NROW * NVAR * VEC)) > 0 ? (8 / (NROW * NVAR * VEC)) : 1;
 
     const int tile = blockIdx.x % a.ntile;
-    const int64_t ct = blockIdx.x / a.ntile;  // = c*T + t
-    const int64_t c = ct / a.T;
-    const int64_t t = ct - c * a.T;
+    const int64_t bq = blockIdx.x / a.ntile;
+    int64_t c, t;
+    if (a.order == 0) {
+        c = bq / a.T;
+        t = bq - c * a.T;
+    } else {
+        // target-major: the chains of one target run concurrently and walk the patches
+        // roughly in step, so rows shared by several chains are served from L2 / MALL
+        // within a group of `cgroup` chains
+        const int64_t per_group = (int64_t)a.cgroup * a.T;
+        const int64_t g = bq / per_group;
+        const int64_t r = bq - g * per_group;
+        const int64_t c0 = g * a.cgroup;
+        const int64_t gsz = min((int64_t)a.cgroup, a.C - c0);  // last group may be short
+        // groups before the last are full, so r indexes (t, c) with the group's own size
+        t = r / gsz;
+        c = c0 + (r - t * gsz);
+    }
+    const int64_t ct = c * a.T + t;
     const int64_t N = a.N;
     const int P = (int)a.P;
 
@@ -325,6 +346,14 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &k)
         a.slips[v] = k.slips[v];
     }
     a.T = L.T; a.P = L.P; a.N = L.N;
+    a.C = k.C;
+    {
+        const char *e = getenv("BEATAMD_GF_ORDER");
+        a.order = e ? atoi(e) : 1;
+        const char *g = getenv("BEATAMD_GF_CGROUP");
+        a.cgroup = g ? atoi(g) : 128;
+        if (a.cgroup < 1) a.cgroup = 1;
+    }
     a.rowoff = ta.rowoff;
     a.fac = ta.fac;
     a.data = k.data;

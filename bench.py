@@ -90,18 +90,18 @@ def cpu_baseline(spec, seconds=12.0):
     # all cores, one chain per forked worker (iter_parallel_chains, sampler/base.py:428-595)
     rate_all, nsteps = rate1, n1
     if ncores > 1:
-        per = max(2, int((seconds * 2 / 3) / t1))
+        budget = seconds * 2 / 3
         ctx = get_context("fork")
         with ctx.Pool(ncores) as pool:
-            pool.map(_cpu_worker, range(ncores))  # warm
+            pool.map(_cpu_worker, range(ncores))  # warm (page tables of the forked workers)
             t0 = time.perf_counter()
-            pool.map(_cpu_worker_n, [(i, per) for i in range(ncores)])
+            counts = pool.map(_cpu_worker_for, [(i, budget) for i in range(ncores)])
             dt = time.perf_counter() - t0
-        rate_all = (ncores * per) * (T_sub / spec.T) / dt
-        nsteps = ncores * per
+        nsteps = int(sum(counts))
+        rate_all = nsteps * (T_sub / spec.T) / dt
     return dict(value=rate_all, unit="chain-steps/s", cores=ncores, kind="port",
                 value_1core=rate1,
-                sample="%d of %d targets (full %dx%d gather per target), %d chain-steps, "
+                sample="%d of %d targets (full %dx%d gather per target), %d sample evaluations, "
                        "oracle/beat_oracle.c (C restatement of the reference numpy/C path), "
                        "%d forked workers x 1 thread" % (T_sub, spec.T, P, N, nsteps, ncores))
 
@@ -114,11 +114,15 @@ def _cpu_worker(i):
     return 0
 
 
-def _cpu_worker_n(a):
-    i, n = a
-    for k in range(n):
+def _cpu_worker_for(a):
+    """run sample evaluations until the time budget is spent; -> count"""
+    i, budget = a
+    t0 = time.perf_counter()
+    k = 0
+    while time.perf_counter() - t0 < budget:
         _cpu_one(1000 * i + k)
-    return 0
+        k += 1
+    return k
 
 
 def main():
@@ -135,7 +139,12 @@ def main():
     ap.add_argument("--nstarttimes", type=int, default=25)
     ap.add_argument("--ndurations", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gf-order", type=int, default=None,
+                    help="k_gfstack block order: 0 (chain,target,tile) 1 (target,chain,tile)")
     args = ap.parse_args()
+
+    if args.gf_order is not None:
+        os.environ["BEATAMD_GF_ORDER"] = str(args.gf_order)
 
     import torch
     import torch.distributed as dist

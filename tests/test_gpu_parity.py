@@ -128,6 +128,25 @@ def test_stack_all_batch_vs_oracle(ctx, orc, N, interp):
         assert np.abs(out[c] - ref).max() <= 1e-11 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("order,cgroup", [("0", "128"), ("1", "2"), ("1", "3"), ("1", "128")])
+def test_stack_block_orders_identical(ctx, orc, monkeypatch, order, cgroup):
+    """the block -> (chain, target, tile) mapping is a pure scheduling choice"""
+    monkeypatch.setenv("BEATAMD_GF_ORDER", order)
+    monkeypatch.setenv("BEATAMD_GF_CGROUP", cgroup)
+    rng = np.random.default_rng(77)
+    T, P, D, S, N = 4, 9, 2, 5, 1100
+    G = rng.standard_normal((T, P, D, S, N))
+    gf = _make_lib(ctx, G, 0.0, 0.5, 0.5, 0.5)
+    C = 7
+    dur = rng.uniform(0.5, 1.0, (C, P))
+    st = rng.uniform(0.0, 2.0, (C, T, P))
+    sl = rng.uniform(0, 5, (C, P))
+    out = gf.stack_all_batch(dur, st, sl)
+    for c in range(C):
+        ref = orc.stack_all(G, dur[c], st[c], sl[c], 0.5, 0.5, 0.0, 0.5)
+        assert np.abs(out[c] - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
 def test_stack_closed_form_and_linearity(ctx):
     """reference test/test_ffi.py:22-89 recipe: out[t,n] = t*n*sum(slips); plus linearity"""
     T, P, D, S, N = 30, 40, 11, 31, 10
