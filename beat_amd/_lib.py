@@ -76,6 +76,7 @@ _PROTOS = {
     "beatamd_ffi_model_destroy": [_vp, _i32],
     "beatamd_ffi_logp_batch": [_vp, _i32, _i64, _vp, _vp],
     "beatamd_ffi_astep_batch": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp],
+    "beatamd_ffi_astep_batch_betas": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 
 EXPORTS = sorted(list(_PROTOS) + ["beatamd_last_error", "beatamd_version"])

@@ -707,10 +707,10 @@ int beatamd_ffi_logp_batch(beatamd_ctx *ctx, int32_t model_id, int64_t C, const 
     return finish_out(ctx, &rec, 1);
 }
 
-int beatamd_ffi_astep_batch(beatamd_ctx *ctx, int32_t model_id, int64_t C, double *Q0, double *L0,
-                            const double *delta, const double *scaling, const double *lower,
-                            const double *upper, const double *log_u, double beta,
-                            int32_t *accepted)
+static int astep_impl(beatamd_ctx *ctx, int32_t model_id, int64_t C, double *Q0, double *L0,
+                      const double *delta, const double *scaling, const double *lower,
+                      const double *upper, const double *log_u, double beta, const double *betas,
+                      int32_t *accepted)
 {
     ENTER(ctx);
     FfiModel *m = get_obj(ctx->models, model_id);
@@ -720,7 +720,7 @@ int beatamd_ffi_astep_batch(beatamd_ctx *ctx, int32_t model_id, int64_t C, doubl
     BA_TRY(model_check_layout(*m));
     if (C == 0) return BEATAMD_OK;
     const int64_t np = m->layout.nparams, nllk = m->nllk();
-    const void *d_de, *d_sc, *d_lo, *d_up, *d_lu;
+    const void *d_de, *d_sc, *d_lo, *d_up, *d_lu, *d_be = nullptr;
     void *d_q0, *d_l0, *d_acc, *p;
     Arg recs[3];
     BA_TRY(stage_out(ctx, SL_OUT0, Q0, (size_t)C * np * 8, &d_q0, &recs[0], true));
@@ -731,6 +731,7 @@ int beatamd_ffi_astep_batch(beatamd_ctx *ctx, int32_t model_id, int64_t C, doubl
     BA_TRY(stage_in(ctx, SL_IN3, lower, (size_t)np * 8, &d_lo));
     BA_TRY(stage_in(ctx, SL_IN4, upper, (size_t)np * 8, &d_up));
     BA_TRY(stage_in(ctx, SL_IN5, log_u, (size_t)C * 8, &d_lu));
+    if (betas) BA_TRY(stage_in(ctx, SL_IN6, betas, (size_t)C * 8, &d_be));
     BA_TRY(ctx->get_scratch(SL_QPROP, (size_t)C * np * 8, &p));
     double *qprop = (double *)p;
     BA_TRY(ctx->get_scratch(SL_LPROP, (size_t)C * nllk * 8, &p));
@@ -742,8 +743,28 @@ int beatamd_ffi_astep_batch(beatamd_ctx *ctx, int32_t model_id, int64_t C, doubl
                           inb));
     BA_TRY(ffi_logp_device(ctx, *m, C, qprop, lprop));
     BA_TRY(launch_accept(ctx, C, np, nllk, (double *)d_q0, (double *)d_l0, qprop, lprop, inb,
-                         (const double *)d_lu, beta, (int32_t *)d_acc));
+                         (const double *)d_lu, beta, (const double *)d_be, (int32_t *)d_acc));
     return finish_out(ctx, recs, 3);
+}
+
+int beatamd_ffi_astep_batch(beatamd_ctx *ctx, int32_t model_id, int64_t C, double *Q0, double *L0,
+                            const double *delta, const double *scaling, const double *lower,
+                            const double *upper, const double *log_u, double beta,
+                            int32_t *accepted)
+{
+    BA_CHECK(ctx != nullptr, BEATAMD_EINVAL, "ctx is NULL");
+    return astep_impl(ctx, model_id, C, Q0, L0, delta, scaling, lower, upper, log_u, beta, nullptr,
+                      accepted);
+}
+
+int beatamd_ffi_astep_batch_betas(beatamd_ctx *ctx, int32_t model_id, int64_t C, double *Q0,
+                                  double *L0, const double *delta, const double *scaling,
+                                  const double *lower, const double *upper, const double *log_u,
+                                  const double *betas, int32_t *accepted)
+{
+    BA_CHECK(ctx != nullptr && betas != nullptr, BEATAMD_EINVAL, "ffi_astep_betas: NULL argument");
+    return astep_impl(ctx, model_id, C, Q0, L0, delta, scaling, lower, upper, log_u, 1.0, betas,
+                      accepted);
 }
 
 }  // extern "C"

@@ -103,6 +103,6 @@ int launch_propose(beatamd_ctx *ctx, int64_t C, int64_t nparams, const double *Q
                    const double *upper, double *Qprop, int32_t *inbounds);
 int launch_accept(beatamd_ctx *ctx, int64_t C, int64_t nparams, int64_t nllk, double *Q0,
                   double *L0, const double *Qprop, const double *Lprop, const int32_t *inbounds,
-                  const double *log_u, double beta, int32_t *accepted);
+                  const double *log_u, double beta, const double *betas, int32_t *accepted);
 
 }  // namespace beatamd

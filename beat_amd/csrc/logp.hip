@@ -244,10 +244,11 @@ __global__ void __launch_bounds__(256) k_accept(int64_t C, int64_t nparams, int6
                                                double *Q0, double *L0, const double *Qprop,
                                                const double *Lprop, const int32_t *inbounds,
                                                const double *log_u, double beta,
-                                               int32_t *accepted)
+                                               const double *betas, int32_t *accepted)
 {
     const int64_t c = blockIdx.x;
-    const double mr = beta * (Lprop[c * nllk + nllk - 1] - L0[c * nllk + nllk - 1]);
+    const double b = betas ? betas[c] : beta;  // per-replica beta for parallel tempering
+    const double mr = b * (Lprop[c * nllk + nllk - 1] - L0[c * nllk + nllk - 1]);
     const bool acc = inbounds[c] && isfinite(mr) && (log_u[c] < mr);
     if (acc) {
         for (int64_t k = threadIdx.x; k < nparams; k += 256) Q0[c * nparams + k] = Qprop[c * nparams + k];
@@ -259,12 +260,12 @@ __global__ void __launch_bounds__(256) k_accept(int64_t C, int64_t nparams, int6
 
 int launch_accept(beatamd_ctx *ctx, int64_t C, int64_t nparams, int64_t nllk, double *Q0,
                   double *L0, const double *Qprop, const double *Lprop, const int32_t *inbounds,
-                  const double *log_u, double beta, int32_t *accepted)
+                  const double *log_u, double beta, const double *betas, int32_t *accepted)
 {
     if (C == 0) return BEATAMD_OK;
     ScopedTimer tm(ctx, "astep");
     hipLaunchKernelGGL(k_accept, dim3((unsigned)C), dim3(256), 0, ctx->stream, C, nparams, nllk,
-                       Q0, L0, Qprop, Lprop, inbounds, log_u, beta, accepted);
+                       Q0, L0, Qprop, Lprop, inbounds, log_u, beta, betas, accepted);
     BA_HIP(hipGetLastError());
     return BEATAMD_OK;
 }

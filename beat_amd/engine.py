@@ -67,6 +67,18 @@ class Context(object):
         except Exception:
             pass
 
+    def _adopt_stream(self, *arrays):
+        """Device tensors are produced on torch's current stream: launch there too, so the
+        kernels are ordered after their producers without an explicit synchronisation."""
+        for a in arrays:
+            if _is_dev(a):
+                import torch
+                s = torch.cuda.current_stream(self.device).cuda_stream
+                if s != getattr(self, "_stream", None):
+                    check(self._lib.beatamd_ctx_set_stream(self._h, C.c_void_p(s)))
+                    self._stream = s
+                return
+
     def use_torch_stream(self):
         """Launch on torch's current stream of this device (so torch ops interleave in order)."""
         import torch
@@ -93,6 +105,7 @@ class Context(object):
 
     # -- fast sweep
     def fast_sweep_batch(self, slowness, patch_size, h_strk, h_dip, num_strk, num_dip):
+        self._adopt_stream(slowness)
         slowness = f64(slowness)
         n = int(num_strk) * int(num_dip)
         Cn = int(slowness.shape[0]) if slowness.ndim == 2 else 1
@@ -122,6 +135,7 @@ class Context(object):
         check(self._lib.beatamd_seis_gflib_upload(self._h, lib_id, ptr(a), int(offset), count))
 
     def seis_gflib_adopt(self, lib_id, device_tensor):
+        self._adopt_stream(device_tensor)
         check(self._lib.beatamd_seis_gflib_adopt(self._h, lib_id, ptr(device_tensor)))
 
     def seis_gflib_device_ptr(self, lib_id):
@@ -134,6 +148,7 @@ class Context(object):
 
     def seis_stack_all_batch(self, lib_id, dims, durations, starttimes, slips,
                              interpolation="nearest_neighbor"):
+        self._adopt_stream(durations, starttimes, slips)
         T, P, D, S, N = dims
         it = _interp(interpolation)
         du, st, sl = f64(durations), f64(starttimes), f64(slips)
@@ -158,6 +173,7 @@ class Context(object):
         check(self._lib.beatamd_geo_gflib_destroy(self._h, lib_id))
 
     def geo_stack_all_batch(self, lib_id, nobs, slips, out=None):
+        self._adopt_stream(slips)
         sl = f64(slips)
         Cn = int(sl.shape[0])
         acc = out is not None
@@ -194,6 +210,7 @@ class Context(object):
         check(self._lib.beatamd_weights_destroy(self._h, wset_id))
 
     def mvn_chol_logp_batch(self, wset_id, residuals, hp):
+        self._adopt_stream(residuals, hp)
         r, h = f64(residuals), f64(hp)
         Cn, nd = int(r.shape[0]), int(r.shape[1])
         out = _empty_like(r, (Cn, nd))
@@ -211,6 +228,7 @@ class Context(object):
         check(self._lib.beatamd_laplacian_destroy(self._h, lap_id))
 
     def laplacian_logp_batch(self, lap_id, slips, hp):
+        self._adopt_stream(slips, hp)
         s, h = f64(slips), f64(hp)
         Cn, nvar = int(s.shape[0]), int(s.shape[1])
         out = _empty_like(s, (Cn,))
@@ -259,6 +277,7 @@ class Context(object):
         check(self._lib.beatamd_ffi_model_destroy(self._h, model_id))
 
     def ffi_logp_batch(self, model_id, Q, nllk, out=None):
+        self._adopt_stream(Q)
         Q = f64(Q)
         Cn = int(Q.shape[0])
         if out is None:
@@ -269,15 +288,23 @@ class Context(object):
     def ffi_astep_batch(self, model_id, Q0, L0, delta, scaling, lower, upper, log_u, beta,
                         accepted=None):
         """In-place update of Q0 / L0 (must be contiguous float64); returns accepted (int32)."""
+        self._adopt_stream(Q0, delta)
         Cn = int(Q0.shape[0])
         if accepted is None:
             accepted = _empty_like(Q0, (Cn,), np.int32)
         for a in (Q0, L0):
             if isinstance(a, np.ndarray) and not (a.flags.c_contiguous and a.dtype == np.float64):
                 raise ValueError("Q0 / L0 must be C-contiguous float64 (updated in place)")
-        check(self._lib.beatamd_ffi_astep_batch(self._h, model_id, Cn, ptr(Q0), ptr(L0), ptr(f64(delta)),
-                                                ptr(f64(scaling)), ptr(f64(lower)), ptr(f64(upper)),
-                                                ptr(f64(log_u)), float(beta), ptr(accepted)))
+        if np.ndim(beta) == 0 and not hasattr(beta, "data_ptr"):
+            check(self._lib.beatamd_ffi_astep_batch(self._h, model_id, Cn, ptr(Q0), ptr(L0),
+                                                    ptr(f64(delta)), ptr(f64(scaling)), ptr(f64(lower)),
+                                                    ptr(f64(upper)), ptr(f64(log_u)), float(beta),
+                                                    ptr(accepted)))
+        else:  # one beta per chain (parallel tempering replicas)
+            check(self._lib.beatamd_ffi_astep_batch_betas(self._h, model_id, Cn, ptr(Q0), ptr(L0),
+                                                          ptr(f64(delta)), ptr(f64(scaling)),
+                                                          ptr(f64(lower)), ptr(f64(upper)),
+                                                          ptr(f64(log_u)), ptr(f64(beta)), ptr(accepted)))
         return accepted
 
 

@@ -199,6 +199,12 @@ int beatamd_ffi_astep_batch(beatamd_ctx *ctx, int32_t model_id, int64_t C, doubl
                             double *L0, const double *delta, const double *scaling,
                             const double *lower, const double *upper, const double *log_u,
                             double beta, int32_t *accepted);
+/* same with one beta per chain: the replicas of a parallel-tempering ladder
+ * (worker_process / sample_pt_chain, beat/sampler/pt.py:651-790) advance in one batch */
+int beatamd_ffi_astep_batch_betas(beatamd_ctx *ctx, int32_t model_id, int64_t C, double *Q0,
+                                  double *L0, const double *delta, const double *scaling,
+                                  const double *lower, const double *upper, const double *log_u,
+                                  const double *betas, int32_t *accepted);
 
 #ifdef __cplusplus
 }

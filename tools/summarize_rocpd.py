@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Summarise rocprofv3 (ROCm 7.2, rocpd sqlite output) runs of bench.py into small CSV/JSON
+files for profiles/.  Usage: summarize_rocpd.py <gpurun_out/prof dir> <profiles dir> <tag>"""
+import csv
+import json
+import os
+import sqlite3
+import sys
+
+
+def short(name):
+    name = name.replace("void ", "")
+    if "distribution_elementwise_grid_stride_kernel" in name:
+        return "at::native::distribution_elementwise_grid_stride_kernel<double,...normal_kernel> (torch: library fill)"
+    if len(name) > 110:
+        name = name[:107] + "..."
+    return name
+
+
+def main(src, dst, tag):
+    os.makedirs(dst, exist_ok=True)
+    db = sqlite3.connect(os.path.join(src, "stats", "bench_results.db"))
+    rows = list(db.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+    with open(os.path.join(dst, "%s_kernel_stats.csv" % tag), "w") as fh:
+        w = csv.writer(fh)
+        w.writerow(["kernel", "calls", "total_us", "avg_us", "percent"])
+        for r in rows:
+            w.writerow([short(r[0]), r[1], "%.3f" % r[2], "%.3f" % r[3], "%.3f" % r[4]])
+    # per-dispatch detail of the dominant kernel
+    disp = list(db.execute("select name, duration, grid_x, workgroup_x, vgpr_count, accum_vgpr_count, "
+                           "sgpr_count, lds_size from kernels where name like '%k_gfstack%'"))
+    summary = {"kernel": "k_gfstack", "dispatches": len(disp)}
+    if disp:
+        durs = [d[1] for d in disp]
+        summary.update(avg_us=sum(durs) / len(durs) / 1e3, min_us=min(durs) / 1e3, max_us=max(durs) / 1e3,
+                       grid=disp[0][2], workgroup=disp[0][3], vgpr=disp[0][4], agpr=disp[0][5],
+                       sgpr=disp[0][6], lds=disp[0][7])
+    for sub, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"), ("fetch_order0", "FETCH_SIZE_order0")):
+        p = os.path.join(src, sub, "bench_results.db")
+        if not os.path.exists(p):
+            continue
+        d2 = sqlite3.connect(p)
+        vals = [r[0] for r in d2.execute("select value from counters_collection where kernel_name like "
+                                         "'%k_gfstack%' and counter_name like ?", (key.split("_order")[0],))]
+        if vals:
+            summary[key + "_KB_per_launch_raw"] = sum(vals) / len(vals)
+    # MI355X_MICROARCH.md "HBM": FETCH_SIZE is in KB and, on gfx950, counts a wide (16 B/lane)
+    # coalesced stream at exactly half its bytes -> double the read side.
+    if "FETCH_SIZE_KB_per_launch_raw" in summary:
+        summary["hbm_read_bytes_per_launch_corrected"] = summary["FETCH_SIZE_KB_per_launch_raw"] * 1024 * 2
+    if "FETCH_SIZE_order0_KB_per_launch_raw" in summary:
+        summary["hbm_read_bytes_per_launch_corrected_order0"] = summary["FETCH_SIZE_order0_KB_per_launch_raw"] * 1024 * 2
+    if "WRITE_SIZE_KB_per_launch_raw" in summary:
+        summary["hbm_write_bytes_per_launch"] = summary["WRITE_SIZE_KB_per_launch_raw"] * 1024
+    with open(os.path.join(dst, "%s_gfstack_summary.json" % tag), "w") as fh:
+        json.dump(summary, fh, indent=1)
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
