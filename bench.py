@@ -139,6 +139,9 @@ def main():
     ap.add_argument("--nstarttimes", type=int, default=25)
     ap.add_argument("--ndurations", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "r1_bench_c128_nn_gfstack_summary.json"),
+                    help="rocprofv3 PMC summary (tools/run_profile.sh + tools/summarize_rocpd.py) of THIS "
+                         "command; supplies roofline.traffic when its configuration matches")
     ap.add_argument("--gf-order", type=int, default=None,
                     help="k_gfstack block order: 0 (chain,target,tile) 1 (target,chain,tile)")
     args = ap.parse_args()
@@ -284,6 +287,17 @@ def main():
             "accept_rate_last_step": n_acc / float(B),
             "setup_s": t_build,
         }
+        # HBM traffic of the dominant kernel from the PMC passes of the same command
+        # (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streams, +WRITE_SIZE)
+        default_cfg = (B == 128 and spec.interpolation == "nearest_neighbor" and spec.covariance == "scalar"
+                       and spec.T == 64 and spec.N == 4096 and args.gf_order is None
+                       and "BEATAMD_GF_CGROUP" not in os.environ)
+        if default_cfg and os.path.exists(args.pmc_summary):
+            pmc = json.load(open(args.pmc_summary))
+            if "hbm_read_bytes_per_launch_corrected" in pmc:
+                out["roofline"]["traffic"] = (pmc["hbm_read_bytes_per_launch_corrected"]
+                                              + pmc.get("hbm_write_bytes_per_launch", 0.0))
+                out["roofline"]["traffic_source"] = os.path.relpath(args.pmc_summary, ROOT)
         if stage_ms is not None:
             out["stage_transition_ms"] = stage_ms
         if world == 1 and not args.no_cpu_baseline:
