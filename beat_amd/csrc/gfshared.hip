@@ -1,0 +1,381 @@
+// gfshared.hip -- chain-shared Green's-function stacking for gfx950.
+//
+// Same arithmetic as k_gfstack (gfstack.hip; reference beat/ffi/base.py:607-709), different
+// mapping.  In a batch of C chains the chains of a group choose, for a given (target, patch),
+// among at most D*S library rows, and nearby chains choose the SAME row: for BASELINE config 3
+// (D*S = 75) 256 chains use ~20 distinct rows per patch.  k_gfstack streams every chain's
+// rows (C x 841 MB per batch; duplicates are caught by L2 at best).  Here a workgroup owns
+// (chain group, target, 64-sample tile) and every DISTINCT row segment is fetched from HBM once,
+// staged in LDS, and applied to all chains of the group that selected it:
+//
+//   lane  <-> chain (64 chains per wavefront, WAVES wavefronts share the staged rows)
+//   acc[] <-> the 64 samples of the tile, in registers with static indices (128 VGPRs)
+//   per patch: the group's distinct rows (k_gf_group_tables) are loaded 16 B/lane into LDS;
+//   each lane then reads ITS row from LDS (ds_read_b128, per-lane address: row pitch 66
+//   doubles keeps the 16-lane groups on distinct banks) and does 64 fp64 FMAs with its own
+//   weight.  No cross-lane traffic, no dynamic register indexing, no atomics.
+//
+// HBM bytes per batch drop from C x T x P x N x 8 to (distinct rows) x N x 8; the on-chip work
+// (LDS reads = algorithmic bytes, fp64 FMAs) is unchanged.  Per chain the patches and rows are
+// accumulated in the same order with the same fma() as in k_gfstack: for one slip variable the
+// two kernels produce bitwise identical synthetics (tests/test_gpu_parity.py).
+#include <cstdlib>
+
+#include "kernels.hpp"
+
+namespace beatamd {
+
+constexpr int GS_NT = 64;             // samples per tile (per lane: 64 accumulators)
+constexpr int GS_PITCH = GS_NT + 2;   // doubles; 132 dwords = 4 (mod 64) -> distinct bank quads
+
+struct GroupTabArgs {
+    int nrow, nvar, CG;
+    int64_t C, T, P, DS;
+    const uint32_t *rowoff;  // [C,T,P,nrow] global row ids (k_gf_tables)
+    const double *fac;       // ml: [C,T,P,4]
+    ChainVec slips[4];
+    int ucap;
+    uint32_t *urows;   // [(g*T+t)*P+p][ucap]
+    uint32_t *ucount;  // [(g*T+t)*P+p]
+    uint16_t *slot;    // [((g*T+t)*P+p)*nrow + k][CG]
+    double *w;         // nn: [v][(g*P+p)][CG]   ml: [v][((g*T+t)*P+p)*4 + k][CG]
+    int64_t w_var_stride;
+};
+
+// one workgroup of CG threads per (group, target, patch); thread <-> chain
+__global__ void k_gf_group_tables(GroupTabArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
+    uint32_t *flags = sm;                 // [DS] presence -> slot
+    uint32_t *wsum = sm + a.DS;           // [CG] per-thread partial counts
+    const int tid = threadIdx.x, CG = a.CG;
+    const int64_t gtp = blockIdx.x;       // (g*T + t)*P + p
+    const int64_t p = gtp % a.P;
+    const int64_t gt = gtp / a.P;
+    const int64_t t = gt % a.T;
+    const int64_t g = gt / a.T;
+    const int64_t c = g * CG + tid;
+    const bool live = c < a.C;
+    const int64_t row0 = (t * a.P + p) * a.DS;
+
+    for (int64_t i = tid; i < a.DS; i += CG) flags[i] = 0;
+    __syncthreads();
+    uint32_t v[4] = {0, 0, 0, 0};
+    if (live)
+        for (int k = 0; k < a.nrow; k++) {
+            v[k] = a.rowoff[((c * a.T + t) * a.P + p) * a.nrow + k] - (uint32_t)row0;
+            flags[v[k]] = 1;  // benign race: every writer stores 1
+        }
+    __syncthreads();
+    // exclusive scan of flags in row order -> slot numbers (deterministic)
+    const int64_t chunk = (a.DS + CG - 1) / CG;
+    const int64_t lo = min((int64_t)tid * chunk, a.DS), hi = min(lo + chunk, a.DS);
+    uint32_t cnt = 0;
+    for (int64_t i = lo; i < hi; i++) cnt += flags[i];
+    wsum[tid] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < CG; i++) { uint32_t x = wsum[i]; wsum[i] = run; run += x; }
+        a.ucount[gtp] = run;
+    }
+    __syncthreads();
+    uint32_t run = wsum[tid];
+    for (int64_t i = lo; i < hi; i++) {
+        if (flags[i]) {
+            a.urows[gtp * a.ucap + run] = (uint32_t)(row0 + i);
+            flags[i] = run++;
+        }
+    }
+    __syncthreads();
+    for (int k = 0; k < a.nrow; k++)
+        a.slot[(gtp * a.nrow + k) * CG + tid] = live ? (uint16_t)flags[v[k]] : (uint16_t)0;
+    // weights, transposed so that lane <-> chain loads are coalesced
+    for (int iv = 0; iv < a.nvar; iv++) {
+        double s = 0.0;
+        if (live) s = a.slips[iv].base[c * a.slips[iv].stride + a.slips[iv].off + p];
+        double *w = a.w + (int64_t)iv * a.w_var_stride;
+        if (a.nrow == 1) {
+            if (t == 0) w[(g * a.P + p) * CG + tid] = s;
+        } else {
+            for (int k = 0; k < 4; k++) {
+                // base.py:676-679: ((1-st)(1-rt)) * slip etc.; factor product from k_gf_tables
+                double f = live ? a.fac[((c * a.T + t) * a.P + p) * 4 + k] : 0.0;
+                w[(gtp * 4 + k) * CG + tid] = f * s;
+            }
+        }
+    }
+}
+
+struct GsArgs {
+    const double *G[4];
+    int nvar, nrow;
+    int64_t C, T, P, N;
+    int CG, ucap, ntile;
+    const uint32_t *urows, *ucount;
+    const uint16_t *slot;
+    const double *w;
+    int64_t w_var_stride;
+    const double *data, *wscalar;
+    double *out, *partial;
+};
+
+// Staging: per (patch, variable) step the distinct rows of the group are loaded 16 B per lane
+// (half a wavefront per row) through registers into one LDS buffer; two barriers per step.  A
+// workgroup keeps ~10 KB in flight per step, three workgroups fit per CU (166 VGPRs, 40 KB LDS).
+//
+// Measured alternatives on config 3 / 256 chains (same box, ms per launch): this form 6.2;
+// double-buffered with the next step's loads issued before the FMAs 7.8; the same plus 4-byte
+// LDS-DMA touches six steps ahead as an L2 prefetch 10.1 (the fabric fetches 32/64 B sectors, the
+// touches doubled the traffic); 6-8 steps staged per barrier interval with 16 B LDS-DMA 9.1, of
+// which 6.4 is the LDS-read + FMA phase alone (ablation) -- the kernel is bound by the per-lane
+// LDS gather (34 % of its LDS cycles are bank conflicts: 20 distinct rows vs 16 b128 windows), not
+// by HBM latency, so the deeper load pipelines only cost occupancy.
+template <int WAVES, int NROW, int MODE>
+__global__ void __launch_bounds__(WAVES * 64) k_gfstack_shared(GsArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double xbuf[];  // [ucap][GS_PITCH]
+    constexpr int CG = WAVES * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row ids via s_load
+    const int tile = blockIdx.x % a.ntile;
+    const int64_t gt = blockIdx.x / a.ntile;  // g*T + t
+    const int64_t t = gt % a.T;
+    const int64_t g = gt / a.T;
+    const int64_t c = g * CG + tid;
+    const int64_t N = a.N;
+    const int64_t n0 = (int64_t)tile * GS_NT;
+    // half-wave row loads: lanes 0-31 one row, lanes 32-63 the next; 16 B per lane
+    const int hl = lane & 31, hsel = lane >> 5;
+    int64_t nload = n0 + hl * 2;
+    const bool load_ok = nload < N;      // N even: a pair is never split (launcher guarantees)
+    if (!load_ok) nload = 0;
+
+    double acc[GS_NT];
+#pragma unroll
+    for (int i = 0; i < GS_NT; i++) acc[i] = 0.0;
+
+    const int P = (int)a.P;
+    for (int p = 0; p < P; p++) {
+        const int64_t gtp = gt * a.P + p;
+        const int U = __builtin_amdgcn_readfirstlane((int)a.ucount[gtp]);
+        const uint32_t *ur = a.urows + gtp * a.ucap;
+        for (int iv = 0; iv < a.nvar; iv++) {
+            // per-lane (= per-chain) slot and weight of this step; issued before the staging
+            // so that their latency overlaps it
+            int sl[NROW];
+            double wl[NROW];
+#pragma unroll
+            for (int k = 0; k < NROW; k++) {
+                sl[k] = a.slot[(gtp * NROW + k) * CG + tid];
+                wl[k] = (NROW == 1)
+                    ? a.w[(int64_t)iv * a.w_var_stride + (g * a.P + p) * CG + tid]
+                    : a.w[(int64_t)iv * a.w_var_stride + (gtp * 4 + k) * CG + tid];
+            }
+            __syncthreads();  // everyone finished reading the previous rows
+            // ---- stage the distinct rows of this (group, target, patch) in LDS
+            const double *Gv = a.G[iv];
+            for (int j0 = wave * 2; j0 < U; j0 += WAVES * 2 * 4) {
+                double2 x[4];
+                int ju[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int j = j0 + u * WAVES * 2;
+                    const int ja = min(j, U - 1), jb = min(j + 1, U - 1);
+                    const uint32_t ra = ur[ja], rb = ur[jb];          // wave-uniform
+                    const uint32_t r = hsel ? rb : ra;
+                    ju[u] = j + hsel;
+                    x[u] = *reinterpret_cast<const double2 *>(Gv + (int64_t)r * N + nload);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (ju[u] < U)
+                        *reinterpret_cast<double2 *>(xbuf + ju[u] * GS_PITCH + hl * 2) =
+                            load_ok ? x[u] : double2{0.0, 0.0};
+            }
+            __syncthreads();
+            // ---- every lane applies ITS rows with ITS weights
+#pragma unroll
+            for (int k = 0; k < NROW; k++) {
+                const double *xs = xbuf + sl[k] * GS_PITCH;
+                const double w = wl[k];
+#pragma unroll
+                for (int i = 0; i < GS_NT; i += 2) {
+                    const double2 xv = *reinterpret_cast<const double2 *>(xs + i);
+                    acc[i] = fma(xv.x, w, acc[i]);
+                    acc[i + 1] = fma(xv.y, w, acc[i + 1]);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: lane = chain c, acc[i] = synthetics[c, t, n0 + i]
+    const bool live = c < a.C;
+    const int nvalid = (int)min((int64_t)GS_NT, N - n0);
+    if (MODE == GF_STORE_SYN) {
+        if (live) {
+            double *o = a.out + (c * a.T + t) * N + n0;
+#pragma unroll
+            for (int i = 0; i < GS_NT; i++)
+                if (i < nvalid) o[i] = acc[i];
+        }
+        return;
+    }
+    // data of this tile, broadcast through LDS
+    __syncthreads();
+    if (tid < GS_NT) xbuf[tid] = (tid < nvalid) ? a.data[t * N + n0 + tid] : 0.0;
+    __syncthreads();
+    // (processed 8 samples at a time with scheduling fences: hoisting all 64 LDS reads next
+    // to the 64 live accumulators would exceed the register budget and spill)
+    if (MODE == GF_RESID_STORE) {
+        double *o = a.out + (c * a.T + t) * N + n0;
+#pragma unroll
+        for (int i0 = 0; i0 < GS_NT; i0 += 8) {
+#pragma unroll
+            for (int i = i0; i < i0 + 8; i++)
+                if (live && i < nvalid) o[i] = xbuf[i] - acc[i];  // seismic.py:1332
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        // distributions.py:128-136 with W = w I, summed in sample order
+        const double w = a.wscalar[t];
+        double q = 0.0;
+#pragma unroll
+        for (int i0 = 0; i0 < GS_NT; i0 += 8) {
+#pragma unroll
+            for (int i = i0; i < i0 + 8; i++)
+                if (i < nvalid) {
+                    const double tt = w * (xbuf[i] - acc[i]);
+                    q = fma(tt, tt, q);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (live) a.partial[(c * a.T + t) * a.ntile + tile] = q;
+    }
+}
+
+template <int WAVES, int NROW, int MODE>
+static void launch_shared_one(dim3 grid, size_t lds, hipStream_t s, const GsArgs &a)
+{
+    auto kern = k_gfstack_shared<WAVES, NROW, MODE>;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, s, a);
+}
+
+template <int WAVES, int NROW>
+static void launch_shared_mode(int mode, dim3 grid, size_t lds, hipStream_t s, const GsArgs &a)
+{
+    if (mode == GF_STORE_SYN) launch_shared_one<WAVES, NROW, GF_STORE_SYN>(grid, lds, s, a);
+    else if (mode == GF_RESID_SCALAR) launch_shared_one<WAVES, NROW, GF_RESID_SCALAR>(grid, lds, s, a);
+    else launch_shared_one<WAVES, NROW, GF_RESID_STORE>(grid, lds, s, a);
+}
+
+template <int WAVES>
+static void launch_shared_nrow(int nrow, int mode, dim3 grid, size_t lds, hipStream_t s,
+                               const GsArgs &a)
+{
+    if (nrow == 1) launch_shared_mode<WAVES, 1>(mode, grid, lds, s, a);
+    else launch_shared_mode<WAVES, 4>(mode, grid, lds, s, a);
+}
+
+// chains per group for a batch of C chains: the largest of {256,128,64} wasting < 15 % lanes
+static int pick_group(int64_t C)
+{
+    const int cand[3] = {256, 128, 64};
+    for (int i = 0; i < 3; i++) {
+        const int64_t padded = (C + cand[i] - 1) / cand[i] * cand[i];
+        if (padded * 100 <= C * 115) return cand[i];
+    }
+    return 64;
+}
+
+bool gfstack_shared_applicable(const GfStackCall &k, int *cg_out, int *ucap_out)
+{
+    const SeisLib &L = *k.libs[0];
+    const int nrow = k.interp == BEATAMD_MULTILINEAR ? 4 : 1;
+    if (L.N % 2 != 0) return false;
+    const char *e = getenv("BEATAMD_GF_KERNEL");  // 0 = streaming kernel, 1 = shared kernel
+    if (e && atoi(e) == 0) return false;
+    const bool forced = e && atoi(e) == 1;
+    if (!forced && k.C < 48) return false;  // too few chains to share rows
+    int cg = pick_group(k.C);
+    const char *gq = getenv("BEATAMD_GS_CG");
+    if (gq && (atoi(gq) == 64 || atoi(gq) == 128 || atoi(gq) == 256)) cg = atoi(gq);
+    const int64_t DS = L.D * L.S;
+    int64_t ucap = std::min<int64_t>((int64_t)cg * nrow, DS);
+    // the distinct rows of one step must fit in LDS; prefer >= 2 workgroups per CU
+    while (ucap * GS_PITCH * 8 > 72 * 1024 && cg > 64) {
+        cg /= 2;
+        ucap = std::min<int64_t>((int64_t)cg * nrow, DS);
+    }
+    if (ucap * GS_PITCH * 8 > 150 * 1024) return false;
+    if (DS * 4 + cg * 4 > 60 * 1024) return false;  // presence map of k_gf_group_tables
+    *cg_out = cg;
+    *ucap_out = (int)std::max<int64_t>(ucap, 2);
+    return true;
+}
+
+int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *rowoff,
+                          const double *fac, int CG, int ucap)
+{
+    const SeisLib &L = *k.libs[0];
+    const int nrow = k.interp == BEATAMD_MULTILINEAR ? 4 : 1;
+    const int64_t ngroups = (k.C + CG - 1) / CG;
+    const int64_t GTP = ngroups * L.T * L.P;
+    void *p = nullptr;
+
+    GroupTabArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.nrow = nrow; ga.nvar = k.nvar; ga.CG = CG;
+    ga.C = k.C; ga.T = L.T; ga.P = L.P; ga.DS = L.D * L.S;
+    ga.rowoff = rowoff; ga.fac = fac;
+    for (int v = 0; v < k.nvar; v++) ga.slips[v] = k.slips[v];
+    ga.ucap = ucap;
+    BA_TRY(ctx->get_scratch(SL_GS_UROWS, (size_t)GTP * ucap * sizeof(uint32_t), &p));
+    ga.urows = (uint32_t *)p;
+    BA_TRY(ctx->get_scratch(SL_GS_UCOUNT, (size_t)GTP * sizeof(uint32_t), &p));
+    ga.ucount = (uint32_t *)p;
+    BA_TRY(ctx->get_scratch(SL_GS_SLOT, (size_t)GTP * nrow * CG * sizeof(uint16_t), &p));
+    ga.slot = (uint16_t *)p;
+    ga.w_var_stride = (nrow == 1) ? ngroups * L.P * CG : GTP * 4 * CG;
+    BA_TRY(ctx->get_scratch(SL_GS_W, (size_t)ga.w_var_stride * k.nvar * sizeof(double), &p));
+    ga.w = (double *)p;
+    {
+        ScopedTimer tm(ctx, "grouptables");
+        const size_t lds = (size_t)(ga.DS + CG) * sizeof(uint32_t);
+        hipLaunchKernelGGL(k_gf_group_tables, dim3((unsigned)GTP), dim3(CG), lds, ctx->stream, ga);
+    }
+    BA_HIP(hipGetLastError());
+
+    GsArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int v = 0; v < k.nvar; v++) a.G[v] = k.libs[v]->g;
+    a.nvar = k.nvar; a.nrow = nrow;
+    a.C = k.C; a.T = L.T; a.P = L.P; a.N = L.N;
+    a.CG = CG; a.ucap = ucap;
+    a.ntile = (int)((L.N + GS_NT - 1) / GS_NT);
+    a.urows = ga.urows; a.ucount = ga.ucount; a.slot = ga.slot; a.w = ga.w;
+    a.w_var_stride = ga.w_var_stride;
+    a.data = k.data; a.wscalar = k.wscalar; a.out = k.out;
+    if (k.mode == GF_RESID_SCALAR) {
+        BA_TRY(ctx->get_scratch(SL_PARTIAL, (size_t)k.C * L.T * a.ntile * sizeof(double), &p));
+        a.partial = (double *)p;
+    }
+    const int64_t nblocks = ngroups * L.T * a.ntile;
+    BA_CHECK(nblocks < (int64_t)0x7fffffff, BEATAMD_EINVAL, "gfstack: batch too large");
+    const size_t lds = (size_t)ucap * GS_PITCH * sizeof(double);
+    {
+        ScopedTimer tm(ctx, "gfstack");
+        dim3 grid((unsigned)nblocks);
+        if (CG == 256) launch_shared_nrow<4>(nrow, k.mode, grid, lds, ctx->stream, a);
+        else if (CG == 128) launch_shared_nrow<2>(nrow, k.mode, grid, lds, ctx->stream, a);
+        else launch_shared_nrow<1>(nrow, k.mode, grid, lds, ctx->stream, a);
+    }
+    BA_HIP(hipGetLastError());
+    if (k.mode == GF_RESID_SCALAR) BA_TRY(launch_sum_tiles(ctx, a.partial, k.C * L.T, a.ntile, k.quad));
+    return BEATAMD_OK;
+}
+
+}  // namespace beatamd

@@ -281,6 +281,14 @@ __global__ void __launch_bounds__(256) k_sum_tiles(const double *partial, int64_
     quad[i] = s;
 }
 
+int launch_sum_tiles(beatamd_ctx *ctx, const double *partial, int64_t n, int ntile, double *quad)
+{
+    hipLaunchKernelGGL(k_sum_tiles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       partial, n, ntile, quad);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
 template <int INTERP, int NVAR, int VEC, int W>
 static void launch_mode(int mode, dim3 grid, hipStream_t s, const GfArgs &a)
 {
@@ -339,6 +347,12 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &k)
     }
     BA_HIP(hipGetLastError());
 
+    {
+        int cg = 0, ucap = 0;
+        if (gfstack_shared_applicable(k, &cg, &ucap))
+            return launch_gfstack_shared(ctx, k, ta.rowoff, ta.fac, cg, ucap);
+    }
+
     GfArgs a;
     memset(&a, 0, sizeof(a));
     for (int v = 0; v < k.nvar; v++) {
@@ -382,12 +396,7 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &k)
         }
     }
     BA_HIP(hipGetLastError());
-    if (k.mode == GF_RESID_SCALAR) {
-        const int64_t n = k.C * L.T;
-        hipLaunchKernelGGL(k_sum_tiles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                           a.partial, n, a.ntile, k.quad);
-        BA_HIP(hipGetLastError());
-    }
+    if (k.mode == GF_RESID_SCALAR) BA_TRY(launch_sum_tiles(ctx, a.partial, k.C * L.T, a.ntile, k.quad));
     return BEATAMD_OK;
 }
 

@@ -241,8 +241,8 @@ def main():
         assert Qall.shape[0] == world * B
 
     gf_ms, gf_n = ctx.kernel_time("gfstack")
-    times = {k: ctx.kernel_time(k) for k in ("sweep", "tables", "gfstack", "quadform", "finish",
-                                             "astep")}
+    times = {k: ctx.kernel_time(k) for k in ("sweep", "tables", "grouptables", "gfstack", "quadform",
+                                             "finish", "astep")}
     if rank == 0:
         alg = algorithmic_bytes_per_chain_step(spec) * B  # per launch
         avg_ms = gf_ms / max(gf_n, 1)

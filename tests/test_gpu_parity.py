@@ -147,6 +147,52 @@ def test_stack_block_orders_identical(ctx, orc, monkeypatch, order, cgroup):
         assert np.abs(out[c] - ref).max() <= 1e-11 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("C", [5, 64, 70, 130, 300])
+@pytest.mark.parametrize("interp", ["nearest_neighbor", "multilinear"])
+def test_shared_row_kernel_equals_streaming_kernel(ctx, orc, monkeypatch, C, interp):
+    """k_gfstack_shared (distinct rows staged once per chain group) vs k_gfstack: bitwise equal
+    synthetics for one slip variable, and both equal to the oracle"""
+    rng = np.random.default_rng(C)
+    T, P, D, S, N = 3, 17, 3, 6, 200
+    G = rng.standard_normal((T, P, D, S, N))
+    gf = _make_lib(ctx, G, 0.0, 0.5, 0.5, 0.25)
+    dur = rng.uniform(0.5, 1.0, (C, P))
+    st = rng.uniform(0.0, 2.5, (C, T, P))
+    sl = rng.uniform(0, 5, (C, P))
+    monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
+    a = gf.stack_all_batch(dur, st, sl, interpolation=interp)
+    monkeypatch.setenv("BEATAMD_GF_KERNEL", "1")
+    b = gf.stack_all_batch(dur, st, sl, interpolation=interp)
+    assert np.array_equal(a, b)
+    for c in (0, C // 2, C - 1):
+        ref = orc.stack_all(G, dur[c], st[c], sl[c], 0.5, 0.25, 0.0, 0.5, interp)
+        assert np.abs(b[c] - ref).max() <= 1e-11 * np.abs(ref).max()
+    for cg in ("64", "128", "256"):
+        monkeypatch.setenv("BEATAMD_GS_CG", cg)
+        assert np.array_equal(gf.stack_all_batch(dur, st, sl, interpolation=interp), a)
+
+
+@pytest.mark.parametrize("name", ["seis_dense_ml_shifts", "joint_multifault", "all_nn_odd_N",
+                                  "seis_scalar_nn"])
+def test_fused_model_with_shared_row_kernel(ctx, monkeypatch, name):
+    """the fused log-likelihood through both stacking kernels, 100 chains"""
+    from beat_amd.synthetic import build_problem, draw_population
+    from oracle import problem_oracle
+    spec = _specs()[name]
+    prob, host = build_problem(spec)
+    f = prob.compile(ctx)
+    Q = draw_population(spec, host["layout"], host["lower"], host["upper"], 100)
+    monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
+    A = f.batch(Q)
+    monkeypatch.setenv("BEATAMD_GF_KERNEL", "1")
+    B = f.batch(Q)
+    np.testing.assert_allclose(A, B, rtol=1e-11, atol=1e-9)
+    for c in (0, 57, 99):
+        ref, _ = problem_oracle.forward(host, Q[c])
+        np.testing.assert_allclose(B[c], ref, rtol=RTOL)
+        np.testing.assert_allclose(B[c], ref, rtol=1e-9, atol=1e-9)
+
+
 def test_stack_closed_form_and_linearity(ctx):
     """reference test/test_ffi.py:22-89 recipe: out[t,n] = t*n*sum(slips); plus linearity"""
     T, P, D, S, N = 30, 40, 11, 31, 10
