@@ -9,10 +9,13 @@
 // chains it is a GEMM  Y_d = A_d (MxM) * X_d (MxC)  followed by a column-wise squared norm:
 // A is read once per 64 chains instead of once per chain, and the arithmetic moves to MFMA.
 //
-// Tiling: 256-thread workgroup = 4 wavefronts; block tile 64 rows x 64 chains; each wave owns
-// 16 rows x 64 chains = four 16x16 f64 accumulators (8 VGPRs each).  K is walked in steps of
-// 16 through LDS (row pitch 17 doubles -> conflict-free ds_read_b64 of the MFMA operands).
-// For upper-triangular W the K loop starts at the block's first row (half the flops/bytes).
+// Tiling: 256-thread workgroup = 4 wavefronts; block tile 64 rows x 128 chains (64 for small
+// batches); each wave owns 16 rows x 128 chains = eight 16x16 f64 accumulators (8 VGPRs each).
+// K is walked in steps of 16 through a double-buffered LDS stage (row pitch 17 doubles ->
+// conflict-free ds_read_b64 of the MFMA operands); the global loads of tile k+1 are issued
+// before the MFMAs of tile k, one barrier per tile.  For upper-triangular W the K loop starts
+// at the block's first row (half the flops/bytes).  Workgroups are numbered so that the chain
+// blocks sharing an A tile run on the same XCD (L2 reuse of W).
 // f64 MFMA layouts (cdna_hip_programming.md section 3): A lane l -> A[i=l&15][k=l>>4],
 // B lane l -> B[k=l>>4][j=l&15], C/D reg r of lane l -> row (l>>4)+4r, col l&15.
 #include "kernels.hpp"
@@ -21,7 +24,7 @@ namespace beatamd {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-constexpr int QF_BM = 64, QF_BC = 64, QF_KB = 16, QF_PITCH = QF_KB + 1;
+constexpr int QF_BM = 64, QF_KB = 16, QF_PITCH = QF_KB + 1;
 
 struct QfArgs {
     const double *A;
@@ -30,64 +33,104 @@ struct QfArgs {
     int64_t xs_c, xs_d;
     int upper_tri;
     double *partial;  // [nd, nrb, C]
-    int nrb;
+    int nrb, ncb;
+    int vec_ok;  // rows of A and X are 16-byte aligned -> double2 loads
 };
 
+// 4 doubles of row `p` starting at k (zero beyond M)
+__device__ __forceinline__ void load4(const double *p, int64_t k, int64_t M, bool row_ok, int vec_ok,
+                                      double (&v)[4])
+{
+    if (row_ok && vec_ok && k + 4 <= M) {
+        const double2 a = *reinterpret_cast<const double2 *>(p + k);
+        const double2 b = *reinterpret_cast<const double2 *>(p + k + 2);
+        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = (row_ok && k + e < M) ? p[k + e] : 0.0;
+    }
+}
+
+// BC = chains per block (64 or 128); each of the 4 waves owns 16 rows x BC chains
+template <int BC>
 __global__ void __launch_bounds__(256) k_quadform(QfArgs a)
 {
-    __shared__ double As[QF_BM * QF_PITCH];
-    __shared__ double Xs[QF_BC * QF_PITCH];
-    __shared__ double red[4][QF_BC];
+    constexpr int NJ = BC / 16;   // 16x16 accumulators per wave
+    constexpr int XR = BC / 64;   // X rows staged per thread
+    __shared__ double As[2][QF_BM * QF_PITCH];
+    __shared__ double Xs[2][BC * QF_PITCH];
+    __shared__ double red[4][BC];
 
-    const int rb = blockIdx.x, cb = blockIdx.y, d = blockIdx.z;
+    // XCD-aware decode: workgroups b, b+8, b+16, ... run on the same XCD (round-robin dispatch),
+    // so consecutive chain blocks of one (row block, dataset) are placed there: the A tile they
+    // share is read from HBM once and served from that XCD's L2 afterwards.
+    const int64_t b = blockIdx.x;
+    const int64_t nwork = (int64_t)a.nrb * a.nd;          // (row block, dataset) items
+    const int64_t q = b / 8, xcd = b % 8;
+    const int cb = (int)(q % a.ncb);
+    const int64_t item = (q / a.ncb) * 8 + xcd;
+    if (item >= nwork) return;
+    const int rb = (int)(item % a.nrb), d = (int)(item / a.nrb);
+
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t M = a.M;
-    const int64_t i0 = (int64_t)rb * QF_BM, c0 = (int64_t)cb * QF_BC;
+    const int64_t i0 = (int64_t)rb * QF_BM, c0 = (int64_t)cb * BC;
     const double *A = a.A + (int64_t)d * a.a_stride;
 
-    const int lr = tid >> 2;        // tile row (A) / tile chain (X) loaded by this thread
+    const int lr = tid >> 2;        // tile row (A) / chain (X) staged by this thread
     const int lk = (tid & 3) * 4;   // first of its 4 k entries
     const int64_t arow = i0 + lr;
-    const int64_t xch = c0 + lr;
+    const bool arow_ok = arow < M;
     const double *Ap = A + arow * M;
-    const double *Xp = a.X + xch * a.xs_c + (int64_t)d * a.xs_d;
-    const bool arow_ok = arow < M, xch_ok = xch < a.C;
-
-    v4f64 acc[4];
+    const double *Xp[XR];
+    bool x_ok[XR];
 #pragma unroll
-    for (int j = 0; j < 4; j++) acc[j] = v4f64{0.0, 0.0, 0.0, 0.0};
+    for (int r = 0; r < XR; r++) {
+        const int64_t ch = c0 + lr + 64 * r;
+        x_ok[r] = ch < a.C;
+        Xp[r] = a.X + ch * a.xs_c + (int64_t)d * a.xs_d;
+    }
+
+    v4f64 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) acc[j] = v4f64{0.0, 0.0, 0.0, 0.0};
 
     const int64_t kstart = a.upper_tri ? i0 : 0;
+    double av[4], xv[XR][4];
+    load4(Ap, kstart + lk, M, arow_ok, a.vec_ok, av);
+#pragma unroll
+    for (int r = 0; r < XR; r++) load4(Xp[r], kstart + lk, M, x_ok[r], a.vec_ok, xv[r]);
+    int buf = 0;
     for (int64_t k0 = kstart; k0 < M; k0 += QF_KB) {
-        double av[4], xv[4];
+        // stage tile k0 (already in registers) into LDS buffer `buf`
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            const int64_t k = k0 + lk + e;
-            const bool kok = k < M;
-            av[e] = (arow_ok && kok) ? Ap[k] : 0.0;
-            xv[e] = (xch_ok && kok) ? Xp[k] : 0.0;
-        }
-        __syncthreads();  // previous tile fully consumed
+            As[buf][lr * QF_PITCH + lk + e] = av[e];
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            As[lr * QF_PITCH + lk + e] = av[e];
-            Xs[lr * QF_PITCH + lk + e] = xv[e];
+            for (int r = 0; r < XR; r++) Xs[buf][(lr + 64 * r) * QF_PITCH + lk + e] = xv[r][e];
         }
         __syncthreads();
+        // global loads of the next tile fly during this tile's MFMAs
+        if (k0 + QF_KB < M) {
+            load4(Ap, k0 + QF_KB + lk, M, arow_ok, a.vec_ok, av);
+#pragma unroll
+            for (int r = 0; r < XR; r++) load4(Xp[r], k0 + QF_KB + lk, M, x_ok[r], a.vec_ok, xv[r]);
+        }
 #pragma unroll
         for (int kk = 0; kk < QF_KB / 4; kk++) {
             const int kcol = kk * 4 + (lane >> 4);
-            const double aop = As[(wave * 16 + (lane & 15)) * QF_PITCH + kcol];
+            const double aop = As[buf][(wave * 16 + (lane & 15)) * QF_PITCH + kcol];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const double bop = Xs[(j * 16 + (lane & 15)) * QF_PITCH + kcol];
+            for (int j = 0; j < NJ; j++) {
+                const double bop = Xs[buf][(j * 16 + (lane & 15)) * QF_PITCH + kcol];
                 acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc[j], 0, 0, 0);
             }
         }
+        buf ^= 1;  // the other buffer was last read two iterations ago: one barrier per tile
     }
     // column-wise squared norm of this wave's 16 rows
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < NJ; j++) {
         double s = acc[j][0] * acc[j][0];
         s = fma(acc[j][1], acc[j][1], s);
         s = fma(acc[j][2], acc[j][2], s);
@@ -97,7 +140,7 @@ __global__ void __launch_bounds__(256) k_quadform(QfArgs a)
         if (lane < 16) red[wave][j * 16 + lane] = s;
     }
     __syncthreads();
-    if (tid < QF_BC) {
+    if (tid < BC) {
         const int64_t c = c0 + tid;
         if (c < a.C) {
             const double s = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
@@ -126,15 +169,22 @@ int launch_quadform(beatamd_ctx *ctx, const QuadformCall &k)
     a.X = k.X; a.xs_c = k.xs_c; a.xs_d = k.xs_d;
     a.upper_tri = k.upper_tri;
     a.nrb = (int)((k.M + QF_BM - 1) / QF_BM);
+    a.vec_ok = (k.M % 2 == 0) && (k.a_stride % 2 == 0) && (k.xs_c % 2 == 0) && (k.xs_d % 2 == 0) &&
+               (((uintptr_t)k.A | (uintptr_t)k.X) % 16 == 0);
     void *p = nullptr;
     BA_TRY(ctx->get_scratch(SL_PARTIAL, (size_t)k.nd * a.nrb * k.C * sizeof(double), &p));
     a.partial = (double *)p;
-    const int64_t ncb = (k.C + QF_BC - 1) / QF_BC;
-    BA_CHECK(ncb <= 65535 && k.nd <= 65535, BEATAMD_EINVAL, "quadform: batch too large");
+    const int BC = (k.C > 64) ? 128 : 64;
+    a.ncb = (int)((k.C + BC - 1) / BC);
+    const int64_t nwork = (int64_t)a.nrb * k.nd;
+    const int64_t nblocks = ((nwork + 7) / 8) * 8 * a.ncb;
+    BA_CHECK(nblocks < (int64_t)0x7fffffff, BEATAMD_EINVAL, "quadform: batch too large");
     {
         ScopedTimer tm(ctx, "quadform");
-        hipLaunchKernelGGL(k_quadform, dim3((unsigned)a.nrb, (unsigned)ncb, (unsigned)k.nd),
-                           dim3(256), 0, ctx->stream, a);
+        if (BC == 128)
+            hipLaunchKernelGGL(k_quadform<128>, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL(k_quadform<64>, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, a);
     }
     BA_HIP(hipGetLastError());
     const int64_t n = k.C * k.nd;

@@ -130,7 +130,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--chains", type=int, default=128, help="chains per GPU per step")
+    ap.add_argument("--chains", type=int, default=512, help="chains per GPU per step")
     ap.add_argument("--interp", default="nearest_neighbor",
                     choices=["nearest_neighbor", "multilinear"])
     ap.add_argument("--covariance", default="scalar", choices=["scalar", "toeplitz"])
@@ -139,7 +139,7 @@ def main():
     ap.add_argument("--nstarttimes", type=int, default=25)
     ap.add_argument("--ndurations", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "r1_bench_c128_nn_gfstack_summary.json"),
+    ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "r1_bench_c512_nn_gfstack_summary.json"),
                     help="rocprofv3 PMC summary (tools/run_profile.sh + tools/summarize_rocpd.py) of THIS "
                          "command; supplies roofline.traffic when its configuration matches")
     ap.add_argument("--gf-order", type=int, default=None,
@@ -273,7 +273,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_gfstack",
+                "kernel": "k_gfstack_shared" if B >= 48 and not os.environ.get("BEATAMD_GF_KERNEL") == "0"
+                          else "k_gfstack",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -289,9 +290,9 @@ def main():
         }
         # HBM traffic of the dominant kernel from the PMC passes of the same command
         # (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streams, +WRITE_SIZE)
-        default_cfg = (B == 128 and spec.interpolation == "nearest_neighbor" and spec.covariance == "scalar"
+        default_cfg = (B == 512 and spec.interpolation == "nearest_neighbor" and spec.covariance == "scalar"
                        and spec.T == 64 and spec.N == 4096 and args.gf_order is None
-                       and "BEATAMD_GF_CGROUP" not in os.environ)
+                       and not any(k.startswith("BEATAMD_G") for k in os.environ))
         if default_cfg and os.path.exists(args.pmc_summary):
             pmc = json.load(open(args.pmc_summary))
             if "hbm_read_bytes_per_launch_corrected" in pmc:

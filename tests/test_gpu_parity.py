@@ -420,7 +420,7 @@ def test_smc_on_device_small_ffi(ctx):
     assert betas[-1] == 1.0 and len(betas) >= 3
     # the carried likelihood vectors are exactly the forward model at the end points
     LL = f.batch(np.ascontiguousarray(pop))
-    np.testing.assert_array_equal(LL, lp)
+    np.testing.assert_allclose(LL, lp, rtol=1e-12)
     ref, _ = problem_oracle.forward(host, pop[5])
     np.testing.assert_allclose(lp[5], ref, rtol=1e-9)
     # sampling moved the population towards the data
@@ -441,5 +441,7 @@ def test_pt_on_device_small_ffi(ctx):
                            n_samples=64, swap_interval=(5, 10), beta_tune_interval=2,
                            device=torch.device("cuda", 0), random_seed=2)
     assert s.shape == (64, host["layout"].size) and np.isfinite(ls).all()
-    np.testing.assert_array_equal(f.batch(np.ascontiguousarray(s[:8])), ls[:8])
+    # (a batch of 8 takes the streaming kernel, the replicas ran through the chain-shared one:
+    # same values up to the summation order of the misfit)
+    np.testing.assert_allclose(f.batch(np.ascontiguousarray(s[:8])), ls[:8], rtol=1e-12)
     assert man.sample_count.sum() >= 0 and len(man.history) >= 1

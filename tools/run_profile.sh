@@ -7,7 +7,7 @@ CMD="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/stats -o bench -- $CMD > $R/gpurun_out/prof/stats_run.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/prof/fetch -o bench -- $CMD > $R/gpurun_out/prof/fetch_run.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/prof/write -o bench -- $CMD > $R/gpurun_out/prof/write_run.log 2>&1
-BEATAMD_GF_ORDER=0 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/prof/fetch_order0 -o bench -- $CMD > $R/gpurun_out/prof/fetch_order0_run.log 2>&1
+BEATAMD_GF_KERNEL=0 BEATAMD_GF_ORDER=0 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/prof/fetch_order0 -o bench -- $CMD > $R/gpurun_out/prof/fetch_order0_run.log 2>&1
 cd $R/gpurun_out/prof
 find . -type f | head -50
 du -sh .

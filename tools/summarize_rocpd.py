@@ -29,7 +29,7 @@ def main(src, dst, tag):
     # per-dispatch detail of the dominant kernel
     disp = list(db.execute("select name, duration, grid_x, workgroup_x, vgpr_count, accum_vgpr_count, "
                            "sgpr_count, lds_size from kernels where name like '%k_gfstack%'"))
-    summary = {"kernel": "k_gfstack", "dispatches": len(disp)}
+    summary = {"kernel": disp[0][0].replace("void ", "") if disp else "k_gfstack", "dispatches": len(disp)}
     if disp:
         durs = [d[1] for d in disp]
         summary.update(avg_us=sum(durs) / len(durs) / 1e3, min_us=min(durs) / 1e3, max_us=max(durs) / 1e3,
