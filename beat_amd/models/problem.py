@@ -93,6 +93,54 @@ class SeismicWavemap(object):
     def n_t(self):
         return self.data.shape[0]
 
+    def prewhitened(self, ctx=None, inplace=False):
+        """Pre-whitened twin of this wavemap: every library row
+        and the data are multiplied by W_t once, G'[t,p,d,s,:] = W_t . G[t,p,d,s,:] and
+        d'_t = W_t . d_t, so that ||W_t (d_t - syn_t)||^2 = ||d'_t - syn'_t||^2 and the dense
+        W.r product (distributions.py:128) drops out of the per-step path.  Legal because
+        the sampler records likelihoods, not synthetics (metropolis.py:160-162); the values
+        agree with the unwhitened path to rounding.  Re-run after ``update_weights``
+        (seismic.py:1509-1534).  The row products are plain FP64 GEMMs (rocBLAS through
+        torch.matmul), done once per weight update, chunked so no second library copy is needed
+        when ``inplace``."""
+        import torch
+
+        from ..engine import get_context
+        from ..ffi import SeismicGFLibrary, SeismicGFLibraryConfig
+        w = np.asarray(self.weights, dtype=np.float64)
+        if w.ndim != 3:
+            return self  # scalar weights need no whitening
+        ctx = ctx or get_context()
+        dev = torch.device("cuda", ctx.device)
+        T, N = self.data.shape
+        W = torch.from_numpy(np.ascontiguousarray(w)).to(dev)
+        gfs = {}
+        for name, gf in self.gfs.items():
+            if gf._device_tensor is not None:
+                G = gf._device_tensor if inplace else gf._device_tensor.clone()
+            else:
+                G = torch.from_numpy(gf._gfmatrix).to(dev)
+            rows = G.view(T, -1, N)
+            step = max(1, (1 << 28) // (N * 8))  # ~256 MB of rows per GEMM
+            for t in range(T):
+                Wt = W[t].T.contiguous()
+                for o in range(0, rows.shape[1], step):
+                    blk = rows[t, o:o + step]
+                    blk.copy_(blk @ Wt)  # (W x)_i = sum_k W[i,k] x[k]
+            cfg = gf.config
+            g2 = SeismicGFLibrary(SeismicGFLibraryConfig(
+                dimensions=cfg.dimensions, starttime_sampling=cfg.starttime_sampling,
+                duration_sampling=cfg.duration_sampling, starttime_min=cfg.starttime_min,
+                duration_min=cfg.duration_min, component=cfg.component, datatype=cfg.datatype,
+                mapnumber=cfg.mapnumber, wavename=cfg.wavename, crust_ind=cfg.crust_ind))
+            g2.adopt_device_tensor(G)
+            gfs[name] = g2
+        d = torch.from_numpy(self.data).to(dev)
+        dw = torch.einsum("tik,tk->ti", W, d).cpu().numpy()
+        torch.cuda.synchronize(dev)
+        return SeismicWavemap(gfs, dw, np.ones(T), self.slog_pdet, self.hypers, self.time_shifts,
+                              self.interpolation, self.name)
+
 
 class GeodeticData(object):
     """The geodetic composite (geodetic.py:1030-1084).
@@ -167,11 +215,15 @@ class FFIProblem(object):
         L.h_laplacian_off = lay.offsets.get(hyper_name_laplacian, -1)
         return L
 
-    def compile(self, ctx=None):
-        """Upload to HBM and return the batched log-likelihood function (``logp_forw``)."""
+    def compile(self, ctx=None, prewhiten=False):
+        """Upload to HBM and return the batched log-likelihood function (``logp_forw``).
+        prewhiten: False | True (whitened copy of the library) | "inplace"."""
         ctx = ctx or get_context()
         lay = self.layout
         seismic = len(self.wavemaps) > 0
+        if prewhiten:
+            self.wavemaps = [wm.prewhitened(ctx, inplace=(prewhiten == "inplace"))
+                             for wm in self.wavemaps]
         mid = ctx.ffi_model_create(self.c_layout(),
                                    self.n_patch_dip if seismic else [],
                                    self.n_patch_strike if seismic else [],

@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--samples", type=int, default=4096)
     ap.add_argument("--nstarttimes", type=int, default=25)
     ap.add_argument("--ndurations", type=int, default=3)
+    ap.add_argument("--prewhiten", action="store_true",
+                    help="toeplitz only: whiten the library once (W.G), no dense W.r per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "r1_bench_c512_nn_gfstack_summary.json"),
                     help="rocprofv3 PMC summary (tools/run_profile.sh + tools/summarize_rocpd.py) of THIS "
@@ -177,7 +179,7 @@ def main():
                          interpolation=args.interp, nuc_margin=6.0, time_bounds=(0.0, 0.5))
     t_build = time.perf_counter()
     prob, host = build_problem(spec, device_library=True, ctx=ctx)
-    f = prob.compile(ctx)
+    f = prob.compile(ctx, prewhiten="inplace" if args.prewhiten else False)
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
 
@@ -264,9 +266,10 @@ def main():
             "config": {
                 "workload": "BASELINE configs[2]: FFI seismic gfstacking, 400 patches x %d targets x "
                             "%d samples, library (%d,%d,%d,%d,%d) f64 = %.1f GB in HBM, %s, "
-                            "covariance %s" % (spec.T, spec.N, spec.T, spec.P, spec.D, spec.S, spec.N,
-                                               spec.lib_bytes / 1e9, spec.interpolation,
-                                               spec.covariance),
+                            "covariance %s%s" % (spec.T, spec.N, spec.T, spec.P, spec.D, spec.S, spec.N,
+                                                 spec.lib_bytes / 1e9, spec.interpolation,
+                                                 spec.covariance,
+                                                 " (library pre-whitened)" if args.prewhiten else ""),
                 "chains_per_gpu": B,
                 "global_chains": world * B,
                 "parallelism": "chains sharded over %d GPU(s), library replicated" % world,

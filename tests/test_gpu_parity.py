@@ -445,3 +445,22 @@ def test_pt_on_device_small_ffi(ctx):
     # same values up to the summation order of the misfit)
     np.testing.assert_allclose(f.batch(np.ascontiguousarray(s[:8])), ls[:8], rtol=1e-12)
     assert man.sample_count.sum() >= 0 and len(man.history) >= 1
+
+
+def test_prewhitened_library_matches_dense_weights(ctx):
+    """W.G / W.d computed once; per step only the scalar misfit remains"""
+    from beat_amd.synthetic import build_problem, draw_population
+    from oracle import problem_oracle
+    for name in ("seis_dense_ml_shifts", "joint_multifault"):
+        spec = _specs()[name]
+        prob, host = build_problem(spec)
+        f0 = prob.compile(ctx)
+        Q = draw_population(spec, host["layout"], host["lower"], host["upper"], 60)
+        A = f0.batch(Q)
+        prob2, _ = build_problem(spec)
+        f1 = prob2.compile(ctx, prewhiten=True)
+        assert np.ndim(prob2.wavemaps[0].weights) == 1  # dense W is gone from the per-step path
+        B = f1.batch(Q)
+        np.testing.assert_allclose(B, A, rtol=1e-9, atol=1e-7)
+        ref, _ = problem_oracle.forward(host, Q[7])
+        np.testing.assert_allclose(B[7], ref, rtol=RTOL)
