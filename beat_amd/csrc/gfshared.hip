@@ -25,8 +25,7 @@
 
 namespace beatamd {
 
-constexpr int GS_NT = 64;             // samples per tile (per lane: 64 accumulators)
-constexpr int GS_PITCH = GS_NT + 2;   // doubles; 132 dwords = 4 (mod 64) -> distinct bank quads
+constexpr int GS_NT_MAX = 64;         // samples per tile (per lane: that many accumulators)
 
 struct GroupTabArgs {
     int nrow, nvar, CG;
@@ -111,7 +110,7 @@ struct GsArgs {
     const double *G[4];
     int nvar, nrow;
     int64_t C, T, P, N;
-    int CG, ucap, ntile;
+    int CG, ucap, ntile, nt;
     const uint32_t *urows, *ucount;
     const uint16_t *slot;
     const double *w;
@@ -131,9 +130,13 @@ struct GsArgs {
 // which 6.4 is the LDS-read + FMA phase alone (ablation) -- the kernel is bound by the per-lane
 // LDS gather (34 % of its LDS cycles are bank conflicts: 20 distinct rows vs 16 b128 windows), not
 // by HBM latency, so the deeper load pipelines only cost occupancy.
-template <int WAVES, int NROW, int MODE>
+template <int WAVES, int NROW, int MODE, int NT>
 __global__ void __launch_bounds__(WAVES * 64) k_gfstack_shared(GsArgs a)
 {
+    constexpr int GS_NT = NT;           // samples per tile = accumulators per lane
+    constexpr int GS_PITCH = NT + 2;    // doubles; 2*NT+4 dwords = 4 (mod 64) for NT = 32, 64
+    constexpr int LPR = NT / 2;         // lanes moving one row segment (16 B each)
+    constexpr int RPI = 64 / LPR;       // rows per load instruction
     extern __shared__ __attribute__((aligned(16))) double xbuf[];  // [ucap][GS_PITCH]
     constexpr int CG = WAVES * 64;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -145,8 +148,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_gfstack_shared(GsArgs a)
     const int64_t c = g * CG + tid;
     const int64_t N = a.N;
     const int64_t n0 = (int64_t)tile * GS_NT;
-    // half-wave row loads: lanes 0-31 one row, lanes 32-63 the next; 16 B per lane
-    const int hl = lane & 31, hsel = lane >> 5;
+    // LPR lanes per row segment, 16 B per lane: RPI rows per load instruction
+    const int hl = lane % LPR, hsel = lane / LPR;
     int64_t nload = n0 + hl * 2;
     const bool load_ok = nload < N;      // N even: a pair is never split (launcher guarantees)
     if (!load_ok) nload = 0;
@@ -175,15 +178,20 @@ __global__ void __launch_bounds__(WAVES * 64) k_gfstack_shared(GsArgs a)
             __syncthreads();  // everyone finished reading the previous rows
             // ---- stage the distinct rows of this (group, target, patch) in LDS
             const double *Gv = a.G[iv];
-            for (int j0 = wave * 2; j0 < U; j0 += WAVES * 2 * 4) {
+            for (int j0 = wave * RPI; j0 < U; j0 += WAVES * RPI * 4) {
                 double2 x[4];
                 int ju[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    const int j = j0 + u * WAVES * 2;
-                    const int ja = min(j, U - 1), jb = min(j + 1, U - 1);
-                    const uint32_t ra = ur[ja], rb = ur[jb];          // wave-uniform
-                    const uint32_t r = hsel ? rb : ra;
+                    const int j = j0 + u * WAVES * RPI;
+                    uint32_t r;
+                    if (RPI == 2) {
+                        const int ja = min(j, U - 1), jb = min(j + 1, U - 1);
+                        const uint32_t ra = ur[ja], rb = ur[jb];      // wave-uniform: scalar loads
+                        r = hsel ? rb : ra;
+                    } else {
+                        r = ur[min(j + hsel, U - 1)];                 // per-lane row id
+                    }
                     ju[u] = j + hsel;
                     x[u] = *reinterpret_cast<const double2 *>(Gv + (int64_t)r * N + nload);
                 }
@@ -257,7 +265,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_gfstack_shared(GsArgs a)
 template <int WAVES, int NROW, int MODE>
 static void launch_shared_one(dim3 grid, size_t lds, hipStream_t s, const GsArgs &a)
 {
-    auto kern = k_gfstack_shared<WAVES, NROW, MODE>;
+    auto kern = (a.nt == 32) ? k_gfstack_shared<WAVES, NROW, MODE, 32>
+                             : k_gfstack_shared<WAVES, NROW, MODE, 64>;
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
@@ -306,6 +315,7 @@ bool gfstack_shared_applicable(const GfStackCall &k, int *cg_out, int *ucap_out)
     const int64_t DS = L.D * L.S;
     int64_t ucap = std::min<int64_t>((int64_t)cg * nrow, DS);
     // the distinct rows of one step must fit in LDS; prefer >= 2 workgroups per CU
+    const int GS_PITCH = GS_NT_MAX + 2;
     while (ucap * GS_PITCH * 8 > 72 * 1024 && cg > 64) {
         cg /= 2;
         ucap = std::min<int64_t>((int64_t)cg * nrow, DS);
@@ -355,7 +365,12 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     a.nvar = k.nvar; a.nrow = nrow;
     a.C = k.C; a.T = L.T; a.P = L.P; a.N = L.N;
     a.CG = CG; a.ucap = ucap;
-    a.ntile = (int)((L.N + GS_NT - 1) / GS_NT);
+    a.nt = 64;
+    {
+        const char *e = getenv("BEATAMD_GS_NT");
+        if (e && atoi(e) == 32) a.nt = 32;
+    }
+    a.ntile = (int)((L.N + a.nt - 1) / a.nt);
     a.urows = ga.urows; a.ucount = ga.ucount; a.slot = ga.slot; a.w = ga.w;
     a.w_var_stride = ga.w_var_stride;
     a.data = k.data; a.wscalar = k.wscalar; a.out = k.out;
@@ -365,7 +380,7 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     }
     const int64_t nblocks = ngroups * L.T * a.ntile;
     BA_CHECK(nblocks < (int64_t)0x7fffffff, BEATAMD_EINVAL, "gfstack: batch too large");
-    const size_t lds = (size_t)ucap * GS_PITCH * sizeof(double);
+    const size_t lds = (size_t)ucap * (a.nt + 2) * sizeof(double);
     {
         ScopedTimer tm(ctx, "gfstack");
         dim3 grid((unsigned)nblocks);
