@@ -47,6 +47,7 @@ _PROTOS = {
     "beatamd_ctx_create": [C.c_int, C.POINTER(_vp)],
     "beatamd_ctx_destroy": [_vp],
     "beatamd_ctx_set_stream": [_vp, _vp],
+    "beatamd_ctx_use_own_stream": [_vp],
     "beatamd_ctx_synchronize": [_vp],
     "beatamd_ctx_enable_timing": [_vp, C.c_int],
     "beatamd_ctx_kernel_time": [_vp, C.c_char_p, C.POINTER(_f64), _pi64],

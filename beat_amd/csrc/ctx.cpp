@@ -19,6 +19,8 @@ int DevBuf::reserve(size_t bytes)
     // grow geometrically so that a sampler with slowly varying batch sizes settles
     size_t want = bytes + bytes / 4;
     if (p) {
+        // kernels of earlier calls may still read the old buffer (any stream): drain first
+        BA_HIP(hipDeviceSynchronize());
         BA_HIP(hipFree(p));
         p = nullptr;
         cap = 0;
@@ -259,7 +261,14 @@ int beatamd_ctx_set_stream(beatamd_ctx *c, void *s)
 {
     BA_CHECK(c, BEATAMD_EINVAL, "ctx is NULL");
     BA_HIP(hipSetDevice(c->device));
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->stream = (hipStream_t)s;  // NULL = the HIP null stream
+    return BEATAMD_OK;
+}
+
+int beatamd_ctx_use_own_stream(beatamd_ctx *c)
+{
+    BA_CHECK(c, BEATAMD_EINVAL, "ctx is NULL");
+    c->stream = c->own_stream;
     return BEATAMD_OK;
 }
 

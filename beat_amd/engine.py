@@ -84,9 +84,16 @@ class Context(object):
         import torch
         s = torch.cuda.current_stream(self.device).cuda_stream
         check(self._lib.beatamd_ctx_set_stream(self._h, C.c_void_p(s)))
+        self._stream = s
 
     def set_stream(self, stream_ptr):
+        """stream_ptr 0 / None = the HIP null stream (torch's default stream)"""
         check(self._lib.beatamd_ctx_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+        self._stream = stream_ptr or 0
+
+    def use_own_stream(self):
+        check(self._lib.beatamd_ctx_use_own_stream(self._h))
+        self._stream = None
 
     def synchronize(self):
         check(self._lib.beatamd_ctx_synchronize(self._h))

@@ -50,9 +50,12 @@ int beatamd_version(void);
 /* ---------------------------------------------------------------- context --------- */
 int beatamd_ctx_create(int device, beatamd_ctx **out);
 int beatamd_ctx_destroy(beatamd_ctx *ctx);
-/* launch on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream);
- * NULL restores the context's own stream */
+/* launch on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream).
+ * NULL is a valid handle: the HIP null (legacy default) stream, which is what torch uses
+ * unless a side stream is current.  beatamd_ctx_use_own_stream goes back to the context's
+ * private non-blocking stream. */
 int beatamd_ctx_set_stream(beatamd_ctx *ctx, void *hip_stream);
+int beatamd_ctx_use_own_stream(beatamd_ctx *ctx);
 int beatamd_ctx_synchronize(beatamd_ctx *ctx);
 /* per-kernel HIP-event timing on the launch stream (bench.py roofline leg).
  * kernel names: "sweep", "tables", "gfstack", "quadform", "geostack", "finish", "astep" */

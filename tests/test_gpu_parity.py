@@ -464,3 +464,44 @@ def test_prewhitened_library_matches_dense_weights(ctx):
         np.testing.assert_allclose(B, A, rtol=1e-9, atol=1e-7)
         ref, _ = problem_oracle.forward(host, Q[7])
         np.testing.assert_allclose(B[7], ref, rtol=RTOL)
+
+
+def test_astep_bookkeeping_on_torch_stream(ctx):
+    """Kernels run on torch's CURRENT stream (the null stream by default), so torch ops that
+    produce the inputs / consume the outputs are ordered with them without host syncs.
+    Regression: a NULL stream handle once selected the context's private stream -> races."""
+    import torch
+    from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
+    spec = SyntheticSpec((4,), (4,), (1.0,), T=2, N=16, D=3, S=25, geodetic_nobs=(6,), laplacian=True)
+    prob, host = build_problem(spec)
+    f = prob.compile(ctx)
+    lay = host["layout"]
+    lo, up = lay.bounds(host["lower"], host["upper"])
+    dev = torch.device("cuda", 0)
+    C = 48
+    Q0 = torch.from_numpy(draw_population(spec, lay, host["lower"], host["upper"], C)).to(dev)
+    L0 = f.batch(Q0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1)
+    lo_d, up_d = torch.from_numpy(lo).to(dev), torch.from_numpy(up).to(dev)
+    span = torch.from_numpy((up - lo) * 0.02).to(dev)
+    acc = torch.zeros(C, dtype=torch.int32, device=dev)
+    betas = torch.linspace(1.0, 0.3, C, dtype=torch.float64, device=dev)
+    ones = torch.ones(C, dtype=torch.float64, device=dev)
+    n_acc = 0
+    for i in range(40):
+        delta = torch.randn((C, lay.size), generator=gen, device=dev, dtype=torch.float64) * span
+        logu = torch.log(torch.rand((C,), generator=gen, device=dev, dtype=torch.float64))
+        f.astep_batch(Q0, L0, delta, ones, lo_d, up_d, logu, betas, acc)
+        n_acc += int(acc.sum().item())
+        Lr = f.batch(Q0)  # the carried likelihood vectors are the forward model at the states
+        assert torch.equal(Lr, L0), "step %d" % i
+    assert n_acc > 0
+    # a side stream works the same way
+    s = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(s):
+        Q1 = Q0 * 1.0
+        L1 = f.batch(Q1)
+        d = (L1 - L0).abs().max()
+    s.synchronize()
+    assert float(d) == 0.0
