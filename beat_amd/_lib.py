@@ -77,6 +77,8 @@ _PROTOS = {
     "beatamd_ffi_model_destroy": [_vp, _i32],
     "beatamd_ffi_logp_batch": [_vp, _i32, _i64, _vp, _vp],
     "beatamd_ffi_astep_batch": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp],
+    "beatamd_autocovariance_batch": [_vp, _i64, _i64, _vp, _vp, _vp],
+    "beatamd_scaled_toeplitz_batch": [_vp, _i64, _i64, _vp, _vp, _vp],
     "beatamd_ffi_astep_batch_betas": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 

@@ -767,4 +767,37 @@ int beatamd_ffi_astep_batch_betas(beatamd_ctx *ctx, int32_t model_id, int64_t C,
                       accepted);
 }
 
+// ------------------------------------------------------------------ noise covariance
+int beatamd_autocovariance_batch(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *data,
+                                 const double *mean, double *out)
+{
+    ENTER(ctx);
+    BA_CHECK(data && mean && out && nd >= 0 && n >= 0, BEATAMD_EINVAL, "autocovariance: bad argument");
+    if (nd == 0 || n == 0) return BEATAMD_OK;
+    const void *d_d, *d_m;
+    void *d_o;
+    Arg rec;
+    BA_TRY(stage_in(ctx, SL_IN0, data, (size_t)nd * n * 8, &d_d));
+    BA_TRY(stage_in(ctx, SL_IN1, mean, (size_t)nd * 8, &d_m));
+    BA_TRY(stage_out(ctx, SL_OUT0, out, (size_t)nd * n * 8, &d_o, &rec));
+    BA_TRY(launch_autocovariance(ctx, nd, n, (const double *)d_d, (const double *)d_m, (double *)d_o));
+    return finish_out(ctx, &rec, 1);
+}
+
+int beatamd_scaled_toeplitz_batch(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *coeffs,
+                                  const double *stds, double *out)
+{
+    ENTER(ctx);
+    BA_CHECK(coeffs && stds && out && nd >= 0 && n >= 0, BEATAMD_EINVAL, "scaled_toeplitz: bad argument");
+    if (nd == 0 || n == 0) return BEATAMD_OK;
+    const void *d_c, *d_s;
+    void *d_o;
+    Arg rec;
+    BA_TRY(stage_in(ctx, SL_IN0, coeffs, (size_t)nd * n * 8, &d_c));
+    BA_TRY(stage_in(ctx, SL_IN1, stds, (size_t)nd * n * 8, &d_s));
+    BA_TRY(stage_out(ctx, SL_OUT0, out, (size_t)nd * n * n * 8, &d_o, &rec));
+    BA_TRY(launch_scaled_toeplitz(ctx, nd, n, (const double *)d_c, (const double *)d_s, (double *)d_o));
+    return finish_out(ctx, &rec, 1);
+}
+
 }  // extern "C"

@@ -110,4 +110,10 @@ int launch_accept(beatamd_ctx *ctx, int64_t C, int64_t nparams, int64_t nllk, do
                   double *L0, const double *Qprop, const double *Lprop, const int32_t *inbounds,
                   const double *log_u, double beta, const double *betas, int32_t *accepted);
 
+// covariance.py:716-771 on device
+int launch_autocovariance(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *data,
+                          const double *mean, double *out);
+int launch_scaled_toeplitz(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *coeffs,
+                           const double *stds, double *out);
+
 }  // namespace beatamd

@@ -270,4 +270,64 @@ int launch_accept(beatamd_ctx *ctx, int64_t C, int64_t nparams, int64_t nllk, do
     return BEATAMD_OK;
 }
 
+// ---------------------------------------------------------------- noise covariance estimation
+// covariance.py:716-736 autocovariance: autocov[j] = (1/n) sum_k (d[j+k]-m)(d[k]-m).  One thread
+// per lag walks k in the reference's order with separate multiply and add (no contraction), so the
+// result is bitwise the reference's O(n^2) Python loop; the trace sits in LDS.
+__global__ void __launch_bounds__(256) k_autocovariance(const double *data, int64_t n,
+                                                       const double *mean, double *out)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_d[];
+    const int64_t d = blockIdx.y;
+    const double *x = data + d * n;
+    const double m = mean[d];
+    for (int64_t k = threadIdx.x; k < n; k += 256) s_d[k] = x[k] - m;
+    __syncthreads();
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    double a = 0.0;
+    for (int64_t k = 0; k < n - j; k++) a += s_d[j + k] * s_d[k];
+    out[d * n + j] = a / (double)n;
+}
+
+int launch_autocovariance(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *data,
+                          const double *mean, double *out)
+{
+    if (nd == 0 || n == 0) return BEATAMD_OK;
+    BA_CHECK(n * 8 <= 150 * 1024, BEATAMD_EINVAL, "autocovariance: trace longer than 19200 samples");
+    BA_CHECK(nd <= 65535, BEATAMD_EINVAL, "autocovariance: too many datasets");
+    const size_t lds = (size_t)n * sizeof(double);
+    if (lds > 64 * 1024)
+        BA_HIP(hipFuncSetAttribute((const void *)k_autocovariance,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_autocovariance, dim3((unsigned)((n + 255) / 256), (unsigned)nd), dim3(256),
+                       lds, ctx->stream, data, n, mean, out);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
+// covariance.py:739-771: C[i,j] = coeffs[|i-j|] * stds[i] * stds[j]
+__global__ void __launch_bounds__(256) k_scaled_toeplitz(int64_t nd, int64_t n, const double *coeffs,
+                                                        const double *stds, double *out)
+{
+    const int64_t total = nd * n * n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t c = i % n, r = (i / n) % n, d = i / (n * n);
+        const int64_t l = r > c ? r - c : c - r;
+        out[i] = coeffs[d * n + l] * stds[d * n + r] * stds[d * n + c];
+    }
+}
+
+int launch_scaled_toeplitz(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *coeffs,
+                           const double *stds, double *out)
+{
+    const int64_t total = nd * n * n;
+    if (total == 0) return BEATAMD_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 65536);
+    hipLaunchKernelGGL(k_scaled_toeplitz, dim3(grid), dim3(256), 0, ctx->stream, nd, n, coeffs, stds,
+                       out);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
 }  // namespace beatamd

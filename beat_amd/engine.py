@@ -242,6 +242,27 @@ class Context(object):
         check(self._lib.beatamd_laplacian_logp_batch(self._h, lap_id, Cn, nvar, ptr(s), ptr(h), ptr(out)))
         return out
 
+    # -- noise covariance estimation
+    def autocovariance_batch(self, data):
+        d = f64(data)
+        self._adopt_stream(d)
+        if _is_dev(d):
+            mean = d.mean(dim=1).contiguous()
+        else:
+            mean = np.ascontiguousarray(d.mean(axis=1))
+        out = _empty_like(d, tuple(d.shape))
+        check(self._lib.beatamd_autocovariance_batch(self._h, int(d.shape[0]), int(d.shape[1]), ptr(d),
+                                                     ptr(mean), ptr(out)))
+        return out
+
+    def scaled_toeplitz_batch(self, coeffs, stds):
+        c, s = f64(coeffs), f64(stds)
+        self._adopt_stream(c, s)
+        nd, n = int(c.shape[0]), int(c.shape[1])
+        out = _empty_like(c, (nd, n, n))
+        check(self._lib.beatamd_scaled_toeplitz_batch(self._h, nd, n, ptr(c), ptr(s), ptr(out)))
+        return out
+
     # -- fused FFI model
     def ffi_model_create(self, layout, n_patch_dip, n_patch_strike, patch_size):
         nd = np.ascontiguousarray(n_patch_dip, dtype=np.int32)

@@ -1,2 +1,3 @@
 from .problem import (FFIProblem, GeodeticData, LogpForwFunc, ParameterLayout,  # noqa: F401
                       SeismicWavemap, prior_logp_func)
+from .distributions import get_hyper_name, multivariate_normal_chol  # noqa: F401,E402

@@ -21,3 +21,10 @@ def repair_covariance(x, epsilon=np.finfo(np.float64).eps):
     eigval, eigvec = np.linalg.eigh(x)
     val = np.maximum(eigval, epsilon)
     return eigvec.dot(np.diag(val)).dot(eigvec.T)
+
+
+def running_window_rms(data, window_size, mode="valid"):
+    """utility.py:1141-1161"""
+    data2 = np.power(data, 2)
+    window = np.ones(window_size) / float(window_size)
+    return np.sqrt(np.convolve(data2, window, mode))

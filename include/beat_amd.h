@@ -209,6 +209,20 @@ int beatamd_ffi_astep_batch_betas(beatamd_ctx *ctx, int32_t model_id, int64_t C,
                                   const double *lower, const double *upper, const double *log_u,
                                   const double *betas, int32_t *accepted);
 
+/* ---------------------------------------------------------------- noise covariance -------
+ * Per-stage re-estimation of the data covariances (update_weights with the "non-toeplitz"
+ * structure, seismic.py:1509-1534 -> covariance.py:397-427): the reference runs O(n^2) Python
+ * loops per dataset.
+ * replaces: covariance.autocovariance(data)            beat/covariance.py:716-736
+ *   data [nd,n], mean [nd] (= data.mean(), computed by the caller) -> out [nd,n]
+ *   same term order as the reference loop: bitwise equal results                             */
+int beatamd_autocovariance_batch(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *data,
+                                 const double *mean, double *out);
+/* replaces: toeplitz(coeffs) * stds[:,None] * stds[None,:]   beat/covariance.py:739-771
+ *   coeffs [nd,n], stds [nd,n] -> out [nd,n,n]                                               */
+int beatamd_scaled_toeplitz_batch(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *coeffs,
+                                  const double *stds, double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,7 +15,8 @@ Reference entry points exercised (file:line under /root/reference):
   beat/ffi/base.py:486-568, 607-709            SeismicGFLibrary idx maps + stack_all
   beat/ffi/base.py:292-305                     GeodeticGFLibrary.stack_all
   beat/heart.py:65-89, 104-263                 log_determinant, Covariance
-  beat/covariance.py:24-51                     exponential_data_covariance
+  beat/covariance.py:24-51, 716-771            exponential_data_covariance, autocovariance,
+                                               non_toeplitz_covariance; utility.py:1141-1161
   beat/models/laplacian.py:209-258             get_smoothing_operator_nearest_neighbor
   beat/sampler/smc.py:133-186, 290-324, 558-575  calc_beta, np.cov weights, resample, tune
   beat/sampler/pt.py:37-73                     tune
@@ -241,6 +242,22 @@ def gen_smc():
     save("smc", **out)
 
 
+def gen_noise_cov():
+    rng = np.random.default_rng(21)
+    out = {}
+    for k, (n, win) in enumerate([(64, 8), (97, 11), (200, 20)]):
+        t = np.arange(n)
+        data = np.sin(t / 7.0) * (1 + 0.5 * np.cos(t / 23.0)) + 0.3 * rng.standard_normal(n)
+        out["c%d_data" % k] = data
+        out["c%d_win" % k] = np.array(win)
+        out["c%d_autocov" % k] = rcov.autocovariance(data)
+        out["c%d_rms_same" % k] = utility.running_window_rms(data, win, mode="same")
+        out["c%d_rms_valid" % k] = utility.running_window_rms(data, win)
+        out["c%d_ntc" % k] = rcov.non_toeplitz_covariance(data, win)
+    out["ncase"] = np.array(3)
+    save("noise_covariance", **out)
+
+
 # ---------------------------------------------------------------- Laquila fixture
 def gen_laquila():
     path = os.path.join(ref_import.REFERENCE_ROOT, "data/examples/Laquila/geodetic_data.pkl")
@@ -277,4 +294,5 @@ if __name__ == "__main__":
     gen_cov()
     gen_laplacian()
     gen_smc()
+    gen_noise_cov()
     gen_laquila()

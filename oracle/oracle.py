@@ -335,3 +335,28 @@ def ffi_geodetic_logp(Gs, slips, data, odws, splits, weights, slog_pdets, hps):
         out.append(mvn_chol_logp(W, res[o:o + n], sl, hp))
         o += n
     return np.array(out), mu
+
+
+def running_window_rms(data, window_size, mode="valid"):
+    """utility.py:1141-1161"""
+    data2 = np.power(data, 2)
+    window = np.ones(window_size) / float(window_size)
+    return np.sqrt(np.convolve(data2, window, mode))
+
+
+def autocovariance(data):
+    """covariance.py:716-736"""
+    d = _f64(data).ravel()
+    out = np.empty(d.size)
+    lib().bo_autocovariance(_p(d), C.c_long(d.size), C.c_double(d.mean()), _p(out))
+    return out
+
+
+def non_toeplitz_covariance(data, window_size):
+    """covariance.py:739-771"""
+    d = _f64(data).ravel()
+    stds = running_window_rms(d, window_size=window_size, mode="same")
+    coeffs = autocovariance(d / stds)
+    out = np.empty((d.size, d.size))
+    lib().bo_scaled_toeplitz(_p(coeffs), _p(_f64(stds)), C.c_long(d.size), _p(out))
+    return out

@@ -505,3 +505,61 @@ def test_astep_bookkeeping_on_torch_stream(ctx):
         d = (L1 - L0).abs().max()
     s.synchronize()
     assert float(d) == 0.0
+
+
+# ----------------------------------------------------------------------------- per-stage setup rows
+def test_noise_covariance_estimators_vs_reference_golden(ctx):
+    """covariance.py:716-771 on the GPU, bitwise against arrays captured from the reference"""
+    from beat_amd import covariance as cov
+    g = load_golden("noise_covariance")
+    for k in range(int(g["ncase"])):
+        d, w = g["c%d_data" % k], int(g["c%d_win" % k])
+        np.testing.assert_array_equal(cov.running_window_rms(d, w, "same"), g["c%d_rms_same" % k])
+        np.testing.assert_array_equal(cov.running_window_rms(d, w), g["c%d_rms_valid" % k])
+        assert np.array_equal(cov.autocovariance(d), g["c%d_autocov" % k])
+        assert np.array_equal(cov.non_toeplitz_covariance(d, w), g["c%d_ntc" % k])
+    rng = np.random.default_rng(0)
+    data = rng.standard_normal((5, 700))
+    out = cov.non_toeplitz_covariance_batch(data, 30)
+    from oracle import oracle as orc
+    for i in range(5):
+        np.testing.assert_allclose(out[i], orc.non_toeplitz_covariance(data[i], 30), rtol=1e-12, atol=1e-14)
+
+
+def test_covariance_class_and_mvn_adaptor(ctx):
+    """heart.Covariance interface + multivariate_normal_chol(datasets, weights, hyperparams,
+    residuals) adaptor against the reference golden / scipy (test_models.py:149-222)"""
+    import scipy.stats
+    from types import SimpleNamespace
+
+    from beat_amd.heart import Covariance, chol_inverse_batch, log_determinant
+    from beat_amd.models import multivariate_normal_chol
+    g = load_golden("covariance")
+    for k in g["names"]:
+        c = Covariance(data=g[k + "_C"])
+        np.testing.assert_allclose(c.chol_inverse, g[k + "_W"], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(c.log_pdet, g[k + "_logpdet"], rtol=1e-13)
+        np.testing.assert_allclose(c.inverse(), g[k + "_inv"], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(float(c.slog_pdet.get_value()), g[k + "_logpdet"], rtol=1e-13)
+        np.testing.assert_allclose(log_determinant(g[k + "_C"]), g[k + "_logdet_fn"], rtol=1e-13)
+    ct = Covariance(data=g["toeplitz_C"], pred_v=0.1 * np.eye(48))
+    np.testing.assert_allclose(ct.chol_inverse, g["total_W"], rtol=1e-10, atol=1e-12)
+    # batched factorisation on the GPU: W^T W == inv(C) (test_covariance.py:71-112 criterion)
+    Cs = np.stack([g["toeplitz_C"] * s for s in (0.5, 1.0, 2.0)])
+    W, lp = chol_inverse_batch(Cs)
+    for i in range(3):
+        np.testing.assert_allclose(W[i].T @ W[i], np.linalg.inv(Cs[i]), rtol=0, atol=1e-6)
+        np.testing.assert_allclose(lp[i], Covariance(data=Cs[i]).log_pdet, rtol=1e-12)
+    # adaptor: 2 datasets x 10 samples, C = 0.001 I, hyper 0 -> scipy logpdf
+    rng = np.random.default_rng(1)
+    Cd = 0.001 * np.eye(10)
+    dsets = [SimpleNamespace(typ="any_P_T", samples=10, covariance=Covariance(data=Cd)) for _ in range(2)]
+    weights = [d.covariance.chol_inverse for d in dsets]
+    res = 0.03 * rng.standard_normal((2, 10))
+    out = multivariate_normal_chol(dsets, weights, {"h_any_P_T": 0.0}, res)
+    for i in range(2):
+        np.testing.assert_allclose(out[i], scipy.stats.multivariate_normal.logpdf(res[i], np.zeros(10), Cd),
+                                   rtol=0, atol=1e-6)
+    outb = multivariate_normal_chol(dsets, weights, {"h_any_P_T": np.array([[0.0, 0.3]] * 4)},
+                                    np.stack([res] * 4), hp_specific=True)
+    assert outb.shape == (4, 2) and np.allclose(outb[:, 0], out[0])
