@@ -14,6 +14,7 @@ Same stage logic and method names as the reference (``calc_beta`` :133-165,
     arrays and the same seeded draw -- no rank-0 bottleneck, no files.
 """
 import logging
+import os
 
 import numpy as np
 
@@ -145,19 +146,51 @@ class SMC(object):
         return Q, L
 
 
-def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200):
+def _dump_stage(step, homepath, layout, out_names, backend):
+    """stage directory with one-draw traces of every chain (rank 0 writes; every rank holds the
+    same gathered arrays) + the sampler state needed to resume (smc.py:549-557)"""
+    if homepath is None or step.rank != 0:
+        return
+    from ..backend import stage_path, write_population
+    path = write_population(homepath, step.stage, layout, out_names, step.array_population,
+                            step.array_lpoints, backend)
+    np.savez(os.path.join(path, "sampler_state.npz"), beta=step.beta, old_beta=step.old_beta,
+             stage=step.stage, population=step.array_population, lpoints=step.array_lpoints,
+             covariance=step.covariance if step.covariance is not None else np.zeros(0),
+             scaling=step.stepper.scaling.cpu().numpy())
+
+
+def load_stage(step, homepath, stage):
+    """resume: restore the population and tempering state of a completed stage
+    (init_stage / load_sampler_params, sampler/base.py:618-661, backend.py:1049-1071)"""
+    from ..backend import stage_path
+    z = np.load(os.path.join(stage_path(homepath, stage), "sampler_state.npz"))
+    step.beta, step.old_beta, step.stage = float(z["beta"]), float(z["old_beta"]), int(z["stage"])
+    step.array_population, step.array_lpoints = z["population"], z["lpoints"]
+    step.likelihoods = step.array_lpoints[:, -1].copy()
+    return step
+
+
+def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, homepath=None,
+               layout=None, out_names=None, backend="bin", resume_stage=None):
     """smc.py:333-546 stage loop.  Returns the final population (n_chains, nparams), the
-    likelihood vectors and the list of betas."""
+    likelihood vectors and the list of betas.  With ``homepath`` every stage leaves a
+    ``stage_<k>`` / ``stage_final`` directory of NumpyChain/TextChain traces (beat_amd.backend)."""
     import torch
     step.n_steps = int(n_steps)
     if n_steps < 1:
         raise TypeError("Argument `n_steps` should be above 0.")
-    # stage 0: evaluate the prior population (draws = 1, no move)
-    if step.array_population is None:
-        step.initialize_population()
-    Q = step._local(step.array_population)
-    L = step.stepper.evaluate(Q)
-    step.select_end_points(Q, L if torch.is_tensor(L) else torch.from_numpy(np.asarray(L)))
+    if resume_stage is not None:
+        load_stage(step, homepath, resume_stage)
+    else:
+        # stage 0: evaluate the prior population (draws = 1, no move)
+        if step.array_population is None:
+            step.initialize_population()
+        Q = step._local(step.array_population)
+        L = step.stepper.evaluate(Q)
+        step.select_end_points(Q, L if torch.is_tensor(L) else torch.from_numpy(np.asarray(L)))
+        if layout is not None:
+            _dump_stage(step, homepath, layout, out_names, backend)
     betas = [step.beta]
     while step.beta < 1.0 and step.stage < max_stages:
         step.beta, step.old_beta, step.weights = step.calc_beta()
@@ -172,6 +205,8 @@ def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200):
         Q, L = step.sample_stage(n_steps)
         step.select_end_points(Q, L)
         betas.append(step.beta)
+        if layout is not None:
+            _dump_stage(step, homepath, layout, out_names, backend)
         if on_stage is not None:
             on_stage(step)
     # final stage at beta = 1 (smc.py:526-543)
@@ -185,6 +220,8 @@ def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200):
     Q, L = step.sample_stage(n_steps * sample_factor_final_stage)
     step.select_end_points(Q, L)
     betas.append(1.0)
+    if layout is not None:
+        _dump_stage(step, homepath, layout, out_names, backend)
     step.stage_betas = betas
     return step.array_population, step.array_lpoints, betas
 

@@ -101,3 +101,12 @@ def test_laquila_fixture(golden):
         np.testing.assert_allclose(orc.cov_log_pdet(C), g["d%d_logpdet" % i], rtol=1e-12)
         los = orc.los_vectors(g["d%d_incidence" % i], g["d%d_heading" % i])
         assert np.array_equal(los, g["d%d_los" % i])
+
+
+def test_noise_covariance(golden):
+    g = golden("noise_covariance")
+    for k in range(int(g["ncase"])):
+        d, w = g["c%d_data" % k], int(g["c%d_win" % k])
+        assert np.array_equal(orc.autocovariance(d), g["c%d_autocov" % k])
+        assert np.array_equal(orc.running_window_rms(d, w, "same"), g["c%d_rms_same" % k])
+        assert np.array_equal(orc.non_toeplitz_covariance(d, w), g["c%d_ntc" % k])
