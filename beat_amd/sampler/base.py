@@ -130,13 +130,16 @@ class DeviceMvNormalProposal(object):
 
     def __init__(self, cov, device, seed=0):
         import torch
-        cov = np.atleast_2d(np.asarray(cov, dtype=np.float64))
-        try:
-            L = np.linalg.cholesky(cov)
-        except np.linalg.LinAlgError:
-            w, v = np.linalg.eigh(cov)
-            L = v * np.sqrt(np.maximum(w, 0.0))
-        self.LT = torch.from_numpy(np.ascontiguousarray(L.T)).to(device)
+        covd = torch.as_tensor(np.atleast_2d(np.asarray(cov, dtype=np.float64))).to(device)
+        # factor on the device; a population smaller than the parameter count gives a singular
+        # sample covariance: repair it like utility.repair_covariance (eigenvalues clipped at
+        # machine epsilon, utility.py:1113-1138) and take L = V sqrt(lambda) -- one eigh instead
+        # of the reference's Cholesky attempt + eigh repair + SVD inside multivariate_normal
+        L, info = torch.linalg.cholesky_ex(covd)
+        if int(info.item()) != 0 or not bool(torch.isfinite(L).all()):
+            w, v = torch.linalg.eigh(covd)
+            L = v * torch.sqrt(torch.clamp(w, min=float(np.finfo(np.float64).eps)))
+        self.LT = L.T.contiguous()
         self.gen = torch.Generator(device=device)
         self.gen.manual_seed(int(seed))
         self.device = device

@@ -86,10 +86,13 @@ class SMC(object):
         weights = temp / np.sum(temp)
         return current_beta, old_beta, weights
 
-    def calc_covariance(self):
-        """smc.py:167-186"""
+    def calc_covariance(self, repair=True):
+        """smc.py:167-186.  repair=False skips ensure_cov_psd on the host: the device proposal
+        repairs and factors the matrix in one eigendecomposition."""
         cov = np.cov(self.array_population, aweights=self.weights.ravel(), bias=False, rowvar=0)
-        cov = ensure_cov_psd(np.atleast_2d(cov))
+        cov = np.atleast_2d(cov)
+        if repair:
+            cov = ensure_cov_psd(cov)
         if np.isnan(cov).any() or np.isinf(cov).any():
             raise ValueError("Sample covariances contains Inf or NaN! Please try reducing the"
                              " upper and lower bounds of hyper parameters!")
@@ -197,7 +200,7 @@ def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, 
         if step.beta > 1.0:
             step.beta = 1.0
             break
-        step.covariance = step.calc_covariance()
+        step.covariance = step.calc_covariance(repair=False)
         step.stepper.set_proposal(step.covariance)
         step.resampling_indexes = step.resample()
         step.stage += 1
@@ -213,7 +216,7 @@ def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, 
     step.stage = -1
     temp = np.exp((1 - step.old_beta) * (step.likelihoods - step.likelihoods.max()))
     step.weights = temp / np.sum(temp)
-    step.covariance = step.calc_covariance()
+    step.covariance = step.calc_covariance(repair=False)
     step.stepper.set_proposal(step.covariance)
     step.resampling_indexes = step.resample()
     step.beta = 1.0
