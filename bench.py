@@ -195,12 +195,12 @@ def main():
     span = torch.from_numpy(up - lo).to(dev)
     # proposal rows: proposal_samples_array[stage_sample] of every chain (metropolis.py:289-313)
     delta = torch.randn((K + W, B, lay.size), generator=gen, device=dev, dtype=torch.float64) \
-        * (0.01 * span)
+        * (0.004 * span)
     log_u = torch.log(torch.rand((K + W, B), generator=gen, device=dev, dtype=torch.float64))
     scaling = torch.ones(B, device=dev, dtype=torch.float64)
     lo_d, up_d = torch.from_numpy(lo).to(dev), torch.from_numpy(up).to(dev)
     accepted = torch.zeros(B, device=dev, dtype=torch.int32)
-    beta = 0.05
+    beta = 2e-6  # an early SMC stage on this problem (tools/smc_app.py): acceptance ~0.2-0.4
     ctx.synchronize()
 
     def step(i):

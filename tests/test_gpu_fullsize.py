@@ -138,3 +138,41 @@ def test_fullsize_properties(full):
     # checksum of checksums: sum over samples of the stack = sum_p slip * rowsum(row)
     rs = np.array([_row_values([r]).sum() for r in range(0, 3)])
     assert np.isfinite(rs).all()
+
+
+def test_config4_joint_multifault_shape():
+    """BASELINE configs[3] shape (test_ffi_gfstacking_multifault.py): 2 subfaults (10x20 patches
+    of 2 km), 35 targets, station time shifts, N = 120, joint with the geodetic composite on the
+    real Laquila SAR scenes (214 + 205 points, full covariances) and the Laplacian-free prior;
+    256 chains through the chain-shared kernel, sampled chains against the oracle."""
+    import beat_amd
+    from beat_amd.ffi import (GeodeticGFLibrary, GeodeticGFLibraryConfig)
+    from beat_amd.models.problem import GeodeticData
+    from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
+    from conftest import load_golden
+    from oracle import oracle as orc
+    from oracle import problem_oracle
+    ctx = beat_amd.get_context(0)
+    g = load_golden("laquila_geodetic")
+    sizes = tuple(int(g["d%d_displacement" % i].size) for i in range(int(g["n"])))
+    spec = SyntheticSpec((10, 10), (20, 20), (2.0, 2.0), T=35, N=120, D=2, S=60, st_dt=0.5,
+                         slip_varnames=("uparr", "uperp"), covariance="toeplitz", station_shifts=True,
+                         geodetic_nobs=sizes, vel_bounds=(3.0, 4.0), time_bounds=(0.0, 2.0))
+    prob, host = build_problem(spec)
+    # replace the synthetic geodetic observations by the real scenes
+    gd = prob.geodetic
+    data = np.concatenate([g["d%d_displacement" % i] for i in range(len(sizes))])
+    odw = np.concatenate([g["d%d_odw" % i] for i in range(len(sizes))])
+    Ws = [orc.cov_chol_inverse(g["d%d_C" % i]) for i in range(len(sizes))]
+    sl = [float(g["d%d_logpdet" % i]) for i in range(len(sizes))]
+    prob.geodetic = GeodeticData(gd.gfs, data, odw, sizes, Ws, sl, gd.hypers)
+    host.update(gdata=data, godw=odw, gW=Ws, gslog=sl)
+    f = prob.compile(ctx)
+    C = 256
+    Q = draw_population(spec, host["layout"], host["lower"], host["upper"], C)
+    LL = f.batch(Q)
+    assert LL.shape == (C, 35 + 2 + 1)
+    for c in (0, 100, 255):
+        ref, _ = problem_oracle.forward(host, Q[c])
+        np.testing.assert_allclose(LL[c], ref, rtol=1e-6)
+        np.testing.assert_allclose(LL[c], ref, rtol=1e-9, atol=1e-8)
