@@ -4,7 +4,7 @@ mkdir -p $R/gpurun_out/pmc
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L > $R/gpurun_out/pmc/counters_list.txt 2>&1
 CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --chains 256"
-export BEATAMD_GF_KERNEL=1
+
 run() { name=$1; shift; timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc/$name -o p -- $CMD > $R/gpurun_out/pmc/$name.log 2>&1; }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
 run sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT
