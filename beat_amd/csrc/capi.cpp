@@ -165,8 +165,6 @@ int ffi_logp_device(beatamd_ctx *ctx, FfiModel &m, int64_t C, const double *Q, d
         q.X = sl; q.xs_c = nvar * lp->P; q.xs_d = lp->P;
         q.quad = quad; q.q_stride = nvar;
         BA_TRY(launch_quadform(ctx, q));
-        static const int64_t zero_off = 0;
-        (void)zero_off;
         BA_TRY(launch_laplacian_finish(ctx, C, nvar, lp->P, lp->logdet, quad,
                                        HpSrc{Q + m.layout.h_laplacian_off, np, nullptr}, LL + col,
                                        nllk));
@@ -599,7 +597,6 @@ int beatamd_ffi_model_add_geodetic(beatamd_ctx *ctx, int32_t model_id, const int
                  "add_geodetic: weight set of dataset %d must be 1 x %lld", d, (long long)sizes[d]);
         g.sizes.push_back(sizes[d]);
         g.wsets.push_back(wset_ids[d]);
-        g.hp_off_host.push_back(hp_off[d]);
         nobs += sizes[d];
     }
     for (int v = 0; v < m->layout.nvar; v++) {

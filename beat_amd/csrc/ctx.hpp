@@ -96,7 +96,6 @@ struct Geodetic {
     std::vector<int64_t> sizes;
     std::vector<int32_t> wsets;
     int64_t *hp_off = nullptr;  // device [nd]
-    std::vector<int64_t> hp_off_host;
 };
 
 struct FfiModel {
@@ -176,7 +175,7 @@ struct ScopedTimer {
 enum Slot : int {
     SL_IN0 = 0, SL_IN1, SL_IN2, SL_IN3, SL_IN4, SL_IN5, SL_IN6, SL_IN7,
     SL_OUT0, SL_OUT1, SL_OUT2,
-    SL_ROWOFF, SL_WEIGHTS, SL_ST0, SL_RESID, SL_PARTIAL, SL_QUAD, SL_MU, SL_HP, SL_SLIPS,
+    SL_ROWOFF, SL_WEIGHTS, SL_ST0, SL_RESID, SL_PARTIAL, SL_QUAD, SL_MU, SL_SLIPS,
     SL_QPROP, SL_LPROP, SL_MISC, SL_GS_UROWS, SL_GS_UCOUNT, SL_GS_SLOT, SL_GS_W, SL_COUNT
 };
 

@@ -134,9 +134,10 @@ template <int WAVES, int NROW, int MODE, int NT>
 __global__ void __launch_bounds__(WAVES * 64) k_gfstack_shared(GsArgs a)
 {
     constexpr int GS_NT = NT;           // samples per tile = accumulators per lane
-    constexpr int GS_PITCH = NT + 2;    // doubles; 2*NT+4 dwords = 4 (mod 64) for NT = 32, 64
+    constexpr int GS_PITCH = NT + 2;    // doubles; row starts step through 16 distinct 4-bank
+                                        // windows for NT = 32, 40, 48, 64 (2*NT+4 dwords)
     constexpr int LPR = NT / 2;         // lanes moving one row segment (16 B each)
-    constexpr int RPI = 64 / LPR;       // rows per load instruction
+    constexpr int RPI = 64 / LPR;       // rows per load instruction (lanes >= RPI*LPR idle)
     extern __shared__ __attribute__((aligned(16))) double xbuf[];  // [ucap][GS_PITCH]
     constexpr int CG = WAVES * 64;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -151,6 +152,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_gfstack_shared(GsArgs a)
     // LPR lanes per row segment, 16 B per lane: RPI rows per load instruction
     const int hl = lane % LPR, hsel = lane / LPR;
     int64_t nload = n0 + hl * 2;
+    const bool lane_ok = hsel < RPI;
     const bool load_ok = nload < N;      // N even: a pair is never split (launcher guarantees)
     if (!load_ok) nload = 0;
 
@@ -190,14 +192,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_gfstack_shared(GsArgs a)
                         const uint32_t ra = ur[ja], rb = ur[jb];      // wave-uniform: scalar loads
                         r = hsel ? rb : ra;
                     } else {
-                        r = ur[min(j + hsel, U - 1)];                 // per-lane row id
+                        r = ur[min(j + min(hsel, RPI - 1), U - 1)];   // per-lane row id
                     }
                     ju[u] = j + hsel;
                     x[u] = *reinterpret_cast<const double2 *>(Gv + (int64_t)r * N + nload);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++)
-                    if (ju[u] < U)
+                    if (ju[u] < U && lane_ok)
                         *reinterpret_cast<double2 *>(xbuf + ju[u] * GS_PITCH + hl * 2) =
                             load_ok ? x[u] : double2{0.0, 0.0};
             }
@@ -266,6 +268,8 @@ template <int WAVES, int NROW, int MODE>
 static void launch_shared_one(dim3 grid, size_t lds, hipStream_t s, const GsArgs &a)
 {
     auto kern = (a.nt == 32) ? k_gfstack_shared<WAVES, NROW, MODE, 32>
+              : (a.nt == 40) ? k_gfstack_shared<WAVES, NROW, MODE, 40>
+              : (a.nt == 48) ? k_gfstack_shared<WAVES, NROW, MODE, 48>
                              : k_gfstack_shared<WAVES, NROW, MODE, 64>;
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -368,7 +372,7 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     a.nt = 64;
     {
         const char *e = getenv("BEATAMD_GS_NT");
-        if (e && atoi(e) == 32) a.nt = 32;
+        if (e && (atoi(e) == 32 || atoi(e) == 40 || atoi(e) == 48)) a.nt = atoi(e);
     }
     a.ntile = (int)((L.N + a.nt - 1) / a.nt);
     a.urows = ga.urows; a.ucount = ga.ucount; a.slot = ga.slot; a.w = ga.w;
