@@ -72,6 +72,8 @@ _PROTOS = {
     "beatamd_ffi_model_create": [_vp, C.POINTER(FfiLayout), _i32, _vp, _vp, _vp, _pi32],
     "beatamd_ffi_model_add_wavemap": [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32],
     "beatamd_ffi_model_add_geodetic": [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
+    "beatamd_ffi_model_add_geodetic_geometry": [_vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f64,
+                                                _vp, _vp, _i32, _vp, _vp, _vp],
     "beatamd_ffi_model_set_laplacian": [_vp, _i32, _i32],
     "beatamd_ffi_model_nllk": [_vp, _i32, _pi64],
     "beatamd_ffi_model_destroy": [_vp, _i32],

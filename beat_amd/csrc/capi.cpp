@@ -130,10 +130,14 @@ int ffi_logp_device(beatamd_ctx *ctx, FfiModel &m, int64_t C, const double *Q, d
         Geodetic &g = m.geo;
         BA_TRY(ctx->get_scratch(SL_MU, (size_t)C * g.Nobs * 2 * sizeof(double), &p));
         double *mu = (double *)p, *res = mu + C * g.Nobs;
-        for (int v = 0; v < m.layout.nvar; v++) {
-            GeoLib *gl = get_obj(ctx->geolibs, g.libs[v]);
-            BA_CHECK(gl, BEATAMD_EINVAL, "geodetic composite refers to a destroyed GF library");
-            BA_TRY(launch_geo_stack(ctx, *gl, C, slips[v], v > 0, mu));
+        if (m.geo_is_geometry) {
+            BA_TRY(launch_geom_los(ctx, m.geom, Q, np, C, mu));
+        } else {
+            for (int v = 0; v < m.layout.nvar; v++) {
+                GeoLib *gl = get_obj(ctx->geolibs, g.libs[v]);
+                BA_CHECK(gl, BEATAMD_EINVAL, "geodetic composite refers to a destroyed GF library");
+                BA_TRY(launch_geo_stack(ctx, *gl, C, slips[v], v > 0, mu));
+            }
         }
         BA_TRY(launch_geo_residual(ctx, C, g.Nobs, g.data, g.odws, mu, res));
         BA_TRY(ctx->get_scratch(SL_QUAD, (size_t)C * sizeof(double), &p));
@@ -502,8 +506,8 @@ int beatamd_ffi_model_create(beatamd_ctx *ctx, const beatamd_ffi_layout *layout,
 {
     ENTER(ctx);
     BA_CHECK(layout && model_id, BEATAMD_EINVAL, "ffi_model_create: bad argument");
-    BA_CHECK(layout->nvar >= 1 && layout->nvar <= 3, BEATAMD_EINVAL,
-             "1..3 slip variables supported, got %d", layout->nvar);
+    BA_CHECK(layout->nvar >= 0 && layout->nvar <= 3, BEATAMD_EINVAL,
+             "0..3 slip variables supported, got %d", layout->nvar);
     BA_CHECK(nsub >= 0 && (nsub == 0 || (ndip && nstrike && patch_size)), BEATAMD_EINVAL,
              "ffi_model_create: subfault description missing");
     std::unique_ptr<FfiModel> m(new FfiModel());
@@ -618,6 +622,63 @@ int beatamd_ffi_model_add_geodetic(beatamd_ctx *ctx, int32_t model_id, const int
     return BEATAMD_OK;
 }
 
+int beatamd_ffi_model_add_geodetic_geometry(beatamd_ctx *ctx, int32_t model_id, int32_t nsrc,
+                                            const int32_t *kind, const int64_t *param_off,
+                                            const double *param_fixed, int64_t nobs,
+                                            const double *east, const double *north,
+                                            const double *los, double nu, const double *data,
+                                            const double *odws, int32_t nd, const int64_t *sizes,
+                                            const int32_t *wset_ids, const int64_t *hp_off)
+{
+    ENTER(ctx);
+    FfiModel *m = get_obj(ctx->models, model_id);
+    BA_CHECK(m, BEATAMD_EINVAL, "unknown model %d", model_id);
+    BA_CHECK(!m->has_geo, BEATAMD_EINVAL, "model already has a geodetic composite");
+    BA_CHECK(nsrc > 0 && kind && param_off && param_fixed && east && north && los && data && odws &&
+                 sizes && wset_ids && hp_off && nd > 0 && nobs > 0,
+             BEATAMD_EINVAL, "add_geodetic_geometry: bad argument");
+    BA_CHECK(nu > -1.0 && nu < 0.5, BEATAMD_EINVAL, "Poisson ratio outside (-1, 0.5)");
+    Geodetic g;
+    int64_t tot = 0;
+    for (int d = 0; d < nd; d++) {
+        BA_CHECK(sizes[d] > 0, BEATAMD_EINVAL, "add_geodetic_geometry: empty dataset %d", d);
+        BA_CHECK(hp_off[d] >= 0 && hp_off[d] < m->layout.nparams, BEATAMD_EINVAL,
+                 "add_geodetic_geometry: hp_off[%d] outside q", d);
+        WeightSet *ws = get_obj(ctx->wsets, wset_ids[d]);
+        BA_CHECK(ws && ws->nd == 1 && ws->M == sizes[d], BEATAMD_EINVAL,
+                 "add_geodetic_geometry: weight set of dataset %d must be 1 x %lld", d,
+                 (long long)sizes[d]);
+        g.sizes.push_back(sizes[d]);
+        g.wsets.push_back(wset_ids[d]);
+        tot += sizes[d];
+    }
+    BA_CHECK(tot == nobs, BEATAMD_EINVAL, "add_geodetic_geometry: dataset sizes sum to %lld, not %lld",
+             (long long)tot, (long long)nobs);
+    for (int i = 0; i < nsrc * 10; i++)
+        BA_CHECK(param_off[i] < m->layout.nparams, BEATAMD_EINVAL,
+                 "add_geodetic_geometry: parameter offset %d outside q", i);
+    for (int i = 0; i < nsrc; i++)
+        BA_CHECK(kind[i] == 0 || kind[i] == 1, BEATAMD_EINVAL, "unknown source kind %d", kind[i]);
+    g.Nobs = nobs;
+    BA_TRY(dev_alloc_copy(ctx, data, (size_t)nobs * 8, (void **)&g.data));
+    BA_TRY(dev_alloc_copy(ctx, odws, (size_t)nobs * 8, (void **)&g.odws));
+    BA_TRY(dev_alloc_copy(ctx, hp_off, (size_t)nd * 8, (void **)&g.hp_off));
+    GeomSources &gs = m->geom;
+    gs.nsrc = nsrc;
+    gs.Nobs = nobs;
+    gs.nu = nu;
+    BA_TRY(dev_alloc_copy(ctx, kind, (size_t)nsrc * 4, (void **)&gs.kind));
+    BA_TRY(dev_alloc_copy(ctx, param_off, (size_t)nsrc * 10 * 8, (void **)&gs.poff));
+    BA_TRY(dev_alloc_copy(ctx, param_fixed, (size_t)nsrc * 10 * 8, (void **)&gs.pfix));
+    BA_TRY(dev_alloc_copy(ctx, east, (size_t)nobs * 8, (void **)&gs.east));
+    BA_TRY(dev_alloc_copy(ctx, north, (size_t)nobs * 8, (void **)&gs.north));
+    BA_TRY(dev_alloc_copy(ctx, los, (size_t)nobs * 3 * 8, (void **)&gs.los));
+    m->geo = std::move(g);
+    m->has_geo = true;
+    m->geo_is_geometry = true;
+    return BEATAMD_OK;
+}
+
 int beatamd_ffi_model_set_laplacian(beatamd_ctx *ctx, int32_t model_id, int32_t lap_id)
 {
     ENTER(ctx);
@@ -656,6 +717,12 @@ int beatamd_ffi_model_destroy(beatamd_ctx *ctx, int32_t model_id)
     if (m->geo.data) (void)hipFree(m->geo.data);
     if (m->geo.odws) (void)hipFree(m->geo.odws);
     if (m->geo.hp_off) (void)hipFree(m->geo.hp_off);
+    if (m->geom.kind) (void)hipFree(m->geom.kind);
+    if (m->geom.poff) (void)hipFree(m->geom.poff);
+    if (m->geom.pfix) (void)hipFree(m->geom.pfix);
+    if (m->geom.east) (void)hipFree(m->geom.east);
+    if (m->geom.north) (void)hipFree(m->geom.north);
+    if (m->geom.los) (void)hipFree(m->geom.los);
     if (m->d_ndip) (void)hipFree(m->d_ndip);
     if (m->d_nstrike) (void)hipFree(m->d_nstrike);
     if (m->d_patch_off) (void)hipFree(m->d_patch_off);

@@ -239,6 +239,12 @@ int beatamd_ctx_destroy(beatamd_ctx *c)
             if (m->geo.data) (void)hipFree(m->geo.data);
             if (m->geo.odws) (void)hipFree(m->geo.odws);
             if (m->geo.hp_off) (void)hipFree(m->geo.hp_off);
+            if (m->geom.kind) (void)hipFree(m->geom.kind);
+            if (m->geom.poff) (void)hipFree(m->geom.poff);
+            if (m->geom.pfix) (void)hipFree(m->geom.pfix);
+            if (m->geom.east) (void)hipFree(m->geom.east);
+            if (m->geom.north) (void)hipFree(m->geom.north);
+            if (m->geom.los) (void)hipFree(m->geom.los);
             if (m->d_ndip) (void)hipFree(m->d_ndip);
             if (m->d_nstrike) (void)hipFree(m->d_nstrike);
             if (m->d_patch_off) (void)hipFree(m->d_patch_off);

@@ -98,6 +98,17 @@ struct Geodetic {
     int64_t *hp_off = nullptr;  // device [nd]
 };
 
+// geometry-mode sources of the geodetic composite (analytic half space)
+struct GeomSources {
+    int nsrc = 0;
+    int32_t *kind = nullptr;   // device [nsrc]
+    int64_t *poff = nullptr;   // device [nsrc*10]
+    double *pfix = nullptr;    // device [nsrc*10]
+    double *east = nullptr, *north = nullptr, *los = nullptr;  // device [Nobs], [Nobs], [Nobs,3]
+    int64_t Nobs = 0;
+    double nu = 0.25;
+};
+
 struct FfiModel {
     beatamd_ffi_layout layout;
     int32_t nsub = 0;
@@ -109,6 +120,8 @@ struct FfiModel {
     std::vector<Wavemap> wavemaps;
     bool has_geo = false;
     Geodetic geo;
+    bool geo_is_geometry = false;  // mu from analytic sources instead of G.T . slips
+    GeomSources geom;
     int32_t lap = -1;
     int64_t nllk() const;
 };

@@ -110,6 +110,9 @@ int launch_accept(beatamd_ctx *ctx, int64_t C, int64_t nparams, int64_t nllk, do
                   double *L0, const double *Qprop, const double *Lprop, const int32_t *inbounds,
                   const double *log_u, double beta, const double *betas, int32_t *accepted);
 
+// geometry.hip: line-of-sight synthetics of rectangular / Mogi sources, mu [C, Nobs]
+int launch_geom_los(beatamd_ctx *ctx, const GeomSources &g, const double *Q, int64_t nparams,
+                    int64_t C, double *mu);
 // covariance.py:716-771 on device
 int launch_autocovariance(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *data,
                           const double *mean, double *out);

@@ -293,6 +293,24 @@ class Context(object):
         check(self._lib.beatamd_ffi_model_add_geodetic(self._h, model_id, ptr(libs), ptr(data), ptr(odws),
                                                        int(sizes.size), ptr(sizes), ptr(ws), ptr(hp)))
 
+    def ffi_model_add_geodetic_geometry(self, model_id, kinds, param_off, param_fixed, east, north,
+                                        los, nu, data, odws, sizes, wset_ids, hp_off):
+        kinds = np.ascontiguousarray(kinds, dtype=np.int32)
+        po = np.ascontiguousarray(param_off, dtype=np.int64)
+        pf = np.ascontiguousarray(param_fixed, dtype=np.float64)
+        east = np.ascontiguousarray(east, dtype=np.float64)
+        north = np.ascontiguousarray(north, dtype=np.float64)
+        los = np.ascontiguousarray(los, dtype=np.float64)
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        odws = np.ascontiguousarray(odws, dtype=np.float64)
+        sizes = _i64arr(sizes)
+        ws = np.ascontiguousarray(wset_ids, dtype=np.int32)
+        hp = _i64arr(hp_off)
+        check(self._lib.beatamd_ffi_model_add_geodetic_geometry(
+            self._h, model_id, int(kinds.size), ptr(kinds), ptr(po), ptr(pf), int(east.size), ptr(east),
+            ptr(north), ptr(los), float(nu), ptr(data), ptr(odws), int(sizes.size), ptr(sizes), ptr(ws),
+            ptr(hp)))
+
     def ffi_model_set_laplacian(self, model_id, lap_id):
         check(self._lib.beatamd_ffi_model_set_laplacian(self._h, model_id, lap_id))
 

@@ -182,6 +182,25 @@ int beatamd_ffi_model_add_geodetic(beatamd_ctx *ctx, int32_t model_id, const int
                                    const double *data, const double *odws, int32_t ndatasets,
                                    const int64_t *dataset_sizes, const int32_t *wset_ids,
                                    const int64_t *hp_off);
+/* geometry-mode geodetic composite (GeodeticGeometryComposite.get_formula,
+ * beat/models/geodetic.py:605-659): the displacements come from analytic half-space sources
+ * instead of a linear GF library -- rectangular dislocations (Okada 1985; kind 0) and Mogi
+ * point sources (kind 1) -- then LOS projection (:642), residual * odw and
+ * multivariate_normal_chol exactly as above.  The reference obtains the displacements from
+ * pyrocko's GF-store engine (heart.geo_synthetics, heart.py:4158-4239; not in its tree):
+ * parity with BEAT is unpinned for this entry, it is pinned to Okada's published check values.
+ *   per source 10 parameters: east_shift north_shift depth [km] (centre of the top edge),
+ *   strike dip rake [deg], length width [km], slip [m] (Mogi: volume change [m^3]),
+ *   opening_fraction;  param_off[nsrc*10] = offset in q or -1 -> param_fixed value
+ *   east/north [Nobs] observation points [km], los [Nobs,3] = (Sn, Se, Su) (heart.py:1381-1410) */
+int beatamd_ffi_model_add_geodetic_geometry(beatamd_ctx *ctx, int32_t model_id, int32_t nsrc,
+                                            const int32_t *kind, const int64_t *param_off,
+                                            const double *param_fixed, int64_t nobs,
+                                            const double *east, const double *north,
+                                            const double *los, double nu, const double *data,
+                                            const double *odws, int32_t ndatasets,
+                                            const int64_t *dataset_sizes, const int32_t *wset_ids,
+                                            const int64_t *hp_off);
 int beatamd_ffi_model_set_laplacian(beatamd_ctx *ctx, int32_t model_id, int32_t lap_id);
 int beatamd_ffi_model_nllk(beatamd_ctx *ctx, int32_t model_id, int64_t *nllk);
 int beatamd_ffi_model_destroy(beatamd_ctx *ctx, int32_t model_id);

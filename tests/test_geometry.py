@@ -1,0 +1,153 @@
+"""Geometry-mode geodetic composite (BASELINE configs 1 and 2): the analytic half-space
+sources.  Parity with BEAT/pyrocko is UNPINNED here (layered GF stores, arithmetic not in the
+reference tree); the pins are Okada's (1985) published check values and closed forms."""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import okada_oracle as ok
+from oracle import oracle as orc
+
+
+def test_okada85_published_check_values():
+    """Okada (1985) Table 2, case 2 (dip 70 deg) and case 3 (vertical fault)"""
+    want = {(1, 0, 0): (-8.689e-3, -4.298e-3, -2.747e-3),
+            (0, 1, 0): (-4.682e-3, -3.527e-2, -3.564e-2),
+            (0, 0, 1): (-2.660e-4, 1.056e-2, 3.214e-3)}
+    for U, ref in want.items():
+        got = ok.okada85_local(2.0, 3.0, 4.0, 70.0, 3.0, 2.0, *U)
+        np.testing.assert_allclose(got, ref, rtol=6e-4)
+    want90 = {(1, 0, 0): (0.0, 5.253e-3, 0.0), (0, 1, 0): (0.0, 0.0, 0.0),
+              (0, 0, 1): (1.223e-2, 0.0, -1.606e-2)}
+    for U, ref in want90.items():
+        got = ok.okada85_local(0.0, 0.0, 4.0, 90.0, 3.0, 2.0, *U)
+        np.testing.assert_allclose(got, ref, rtol=6e-4, atol=1e-12)
+
+
+def test_rect_source_symmetries_and_mogi():
+    e, n = np.meshgrid(np.linspace(-9, 9, 7), np.linspace(-9, 9, 7))
+    # vertical strike-slip fault striking north through the origin: un odd in e, uz = 0 on n = 0
+    ue, un, uz = ok.rect_source(e, n, 0, 0, 1.0, 0.0, 90.0, 0.0, 6.0, 4.0, 1.0)
+    np.testing.assert_allclose(un[3], -un[3, ::-1], atol=1e-14)
+    np.testing.assert_allclose(uz[3], 0.0, atol=1e-14)
+    # rotating the source rotates the field
+    ue2, un2, uz2 = ok.rect_source(n, -e, 0, 0, 1.0, 90.0, 90.0, 0.0, 6.0, 4.0, 1.0)
+    np.testing.assert_allclose(uz2, uz, atol=1e-14)
+    # a small horizontal tensile square far away looks like a Mogi-type vertical pattern: uz > 0 above
+    _, _, uzs = ok.rect_source(np.zeros(1), np.zeros(1), 0, 0, 3.0, 0.0, 0.0, 0.0, 1.0, 1.0, 1.0, 1.0)
+    assert uzs[0] > 0
+    # Mogi closed form
+    ue, un, uz = ok.mogi(np.array([0.0, 2.0]), np.array([0.0, 0.0]), 0, 0, 2.0, 1e6)
+    np.testing.assert_allclose(uz[0], 0.75 / np.pi * 1e6 / 2000.0 ** 2)
+    np.testing.assert_allclose(ue[1] / uz[1], 1.0)
+
+
+def _problem(rng, sizes, two_sources=False):
+    from beat_amd.models import GeodeticGeometryProblem, ParameterLayout, los_vectors
+    g = load_golden("laquila_geodetic")
+    nobs = sum(sizes)
+    east, north = rng.uniform(-15, 15, nobs), rng.uniform(-15, 15, nobs)
+    inc = np.concatenate([g["d%d_incidence" % i][:n] for i, n in enumerate(sizes)])
+    head = np.concatenate([g["d%d_heading" % i][:n] for i, n in enumerate(sizes)])
+    los = los_vectors(inc, head)
+    ns = 2 if two_sources else 1
+    names = OrderedDict([("depth", ns), ("dip", ns), ("east_shift", ns), ("length", 1 if two_sources else ns),
+                         ("north_shift", ns), ("slip", ns), ("strike", ns), ("width", 1 if two_sources else ns),
+                         ("h_SAR", 1)])
+    lay = ParameterLayout(names)
+    lower = dict(depth=0.5, dip=5.0, east_shift=-5.0, length=0.5, north_shift=-5.0, slip=0.01, strike=0.0,
+                 width=0.5, h_SAR=-2.0)
+    upper = dict(depth=9.0, dip=85.0, east_shift=5.0, length=10.0, north_shift=5.0, slip=1.0, strike=360.0,
+                 width=8.0, h_SAR=2.0)
+    data = 0.01 * rng.standard_normal(nobs)
+    odw = 0.5 + rng.random(nobs)
+    Ws, sls, o = [], [], 0
+    for i, n in enumerate(sizes):
+        C = g["d%d_C" % i][:n, :n]
+        Ws.append(orc.cov_chol_inverse(C))
+        sls.append(orc.cov_log_pdet(C))
+    sources = ["rectangular", "mogi"] if two_sources else ["rectangular"]
+    fixed = dict(rake=[0.0, 0.0], opening_fraction=[1.0, 0.0]) if two_sources else \
+        dict(rake=30.0, opening_fraction=0.25)
+    prob = GeodeticGeometryProblem(lay, sources, east, north, los, data, odw, sizes, Ws, sls,
+                                   [("h_SAR", 0)] * len(sizes), fixed=fixed, lower=lower, upper=upper)
+    return prob, lay, lower, upper
+
+
+def _oracle_forward(prob, lay, q):
+    pt = lay.rmap(q)
+    mu = np.zeros(prob.east.size)
+    for s, kind in enumerate(prob.sources):
+        def val(name):
+            if name in lay.offsets:
+                return pt[name][s if lay.varsizes[name] > 1 else 0]
+            return np.atleast_1d(prob.fixed.get(name, 0.0))[min(s, np.size(prob.fixed.get(name, 0.0)) - 1)]
+        if kind == "mogi":
+            ue, un, uz = ok.mogi(prob.east, prob.north, val("east_shift"), val("north_shift"), val("depth"),
+                                 val("slip"), prob.nu)
+        else:
+            ue, un, uz = ok.rect_source(prob.east, prob.north, val("east_shift"), val("north_shift"),
+                                        val("depth"), val("strike"), val("dip"), val("rake"), val("length"),
+                                        val("width"), val("slip"), val("opening_fraction"), prob.nu)
+        mu += (un * prob.los[:, 0] + ue * prob.los[:, 1]) + uz * prob.los[:, 2]
+    res = (prob.data - mu) * prob.odws
+    out, o = [], 0
+    for n, W, sl in zip(prob.sizes, prob.weights, prob.slog_pdets):
+        out.append(orc.mvn_chol_logp(W, res[o:o + n], sl, pt["h_SAR"][0]))
+        o += n
+    return np.array(out + [sum(out)])
+
+
+def test_source_tables_host_logic():
+    prob, lay, lower, upper = _problem(np.random.default_rng(0), (20, 10), two_sources=True)
+    off, fix = prob.source_tables()
+    assert off.shape == (2, 10) and off[0, 2] == lay.offset("depth", 0) and off[1, 2] == lay.offset("depth", 1)
+    assert off[0, 6] == off[1, 6] == lay.offset("length", 0)  # shared scalar variable
+    assert off[0, 9] == -1 and fix[0, 9] == 1.0 and fix[1, 9] == 0.0
+    assert prob.out_names == ["geo_like_0", "geo_like_1", "like"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("two", [False, True])
+def test_geometry_logp_batch_vs_oracle(two):
+    import beat_amd
+    ctx = beat_amd.get_context(0)
+    rng = np.random.default_rng(5 + two)
+    prob, lay, lower, upper = _problem(rng, (214, 205) if not two else (60, 41), two_sources=two)
+    f = prob.compile(ctx)
+    lo, up = lay.bounds(lower, upper)
+    C = 70
+    Q = lo + (up - lo) * rng.random((C, lay.size))
+    if two:
+        Q[:, lay.offset("slip", 1)] *= 1e6  # Mogi volume change [m^3]
+    LL = f.batch(Q)
+    assert LL.shape == (C, len(prob.sizes) + 1)
+    for c in range(0, C, 9):
+        ref = _oracle_forward(prob, lay, Q[c])
+        np.testing.assert_allclose(LL[c], ref, rtol=1e-6)   # north_star tolerance
+        np.testing.assert_allclose(LL[c], ref, rtol=1e-9)
+
+
+@pytest.mark.gpu
+def test_geometry_config2_smc_1024_chains():
+    """BASELINE configs[1]: rectangular-source geodetic composite, 1024 SMC chains batched on one
+    GPU (Laquila observation geometry, Fernandina-style priors)"""
+    import torch
+
+    import beat_amd
+    from beat_amd.sampler import SMC, smc_sample
+    ctx = beat_amd.get_context(0)
+    rng = np.random.default_rng(11)
+    prob, lay, lower, upper = _problem(rng, (214, 205))
+    lo, up = lay.bounds(lower, upper)
+    truth = lo + (up - lo) * rng.random(lay.size)
+    truth[lay.offset("h_SAR")] = 0.0
+    mu_ll = _oracle_forward(prob, lay, truth)  # noqa: F841  (exercise the oracle at the truth)
+    f = prob.compile(ctx)
+    step = SMC(f, lo, up, n_chains=1024, tune_interval=10, device=torch.device("cuda", 0), random_seed=2)
+    pop, lp, betas = smc_sample(15, step, max_stages=6)
+    assert pop.shape == (1024, lay.size) and np.isfinite(lp).all()
+    np.testing.assert_allclose(f.batch(np.ascontiguousarray(pop[:64])), lp[:64], rtol=1e-12)
+    assert lp[:, -1].mean() > f.batch(lo + (up - lo) * rng.random((256, lay.size)))[:, -1].mean()
