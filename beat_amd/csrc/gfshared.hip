@@ -33,8 +33,8 @@ struct GroupTabArgs {
     const uint32_t *rowoff;  // [C,T,P,nrow] global row ids (k_gf_tables)
     const double *fac;       // ml: [C,T,P,4]
     ChainVec slips[4];
-    int ucap;
-    uint32_t *urows;   // [(g*T+t)*P+p][ucap]
+    int ucap, ustride;
+    uint32_t *urows;   // [(g*T+t)*P+p][ustride], padded with the last id
     uint32_t *ucount;  // [(g*T+t)*P+p]
     uint16_t *slot;    // [((g*T+t)*P+p)*nrow + k][CG]
     double *w;         // nn: [v][(g*P+p)][CG]   ml: [v][((g*T+t)*P+p)*4 + k][CG]
@@ -77,16 +77,23 @@ __global__ void k_gf_group_tables(GroupTabArgs a)
         uint32_t run = 0;
         for (int i = 0; i < CG; i++) { uint32_t x = wsum[i]; wsum[i] = run; run += x; }
         a.ucount[gtp] = run;
+        wsum[CG] = run;
     }
     __syncthreads();
     uint32_t run = wsum[tid];
     for (int64_t i = lo; i < hi; i++) {
         if (flags[i]) {
-            a.urows[gtp * a.ucap + run] = (uint32_t)(row0 + i);
+            a.urows[gtp * a.ustride + run] = (uint32_t)(row0 + i);
             flags[i] = run++;
         }
     }
     __syncthreads();
+    {
+        // pad to the stride with the last id: the stacking kernel reads ids unclamped
+        const int total = (int)wsum[CG];
+        const uint32_t last = total > 0 ? a.urows[gtp * a.ustride + total - 1] : (uint32_t)row0;
+        for (int i = total + tid; i < a.ustride; i += CG) a.urows[gtp * a.ustride + i] = last;
+    }
     for (int k = 0; k < a.nrow; k++)
         a.slot[(gtp * a.nrow + k) * CG + tid] = live ? (uint16_t)flags[v[k]] : (uint16_t)0;
     // weights, transposed so that lane <-> chain loads are coalesced
@@ -110,7 +117,7 @@ struct GsArgs {
     const double *G[4];
     int nvar, nrow;
     int64_t C, T, P, N;
-    int CG, ucap, ntile, nt;
+    int CG, ucap, ustride, ntile, nt;
     const uint32_t *urows, *ucount;
     const uint16_t *slot;
     const double *w;
@@ -138,6 +145,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_gfstack_shared(GsArgs a)
                                         // windows for NT = 32, 40, 48, 64 (2*NT+4 dwords)
     constexpr int LPR = NT / 2;         // lanes moving one row segment (16 B each)
     constexpr int RPI = 64 / LPR;       // rows per load instruction (lanes >= RPI*LPR idle)
+    static_assert(RPI == 2, "two row segments per load instruction (NT = 64 or 48)");
     extern __shared__ __attribute__((aligned(16))) double xbuf[];  // [ucap][GS_PITCH]
     constexpr int CG = WAVES * 64;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -160,40 +168,83 @@ __global__ void __launch_bounds__(WAVES * 64) k_gfstack_shared(GsArgs a)
 #pragma unroll
     for (int i = 0; i < GS_NT; i++) acc[i] = 0.0;
 
+    // A step = (patch p, slip variable iv).  Everything a step needs besides the row data --
+    // the lane's slot and weight (vector loads), the group's distinct-row count and this
+    // wavefront's first row ids (scalar loads) -- is fetched ONE STEP AHEAD, right after the
+    // current step's row loads have been issued: a step's critical path is then one row-load
+    // latency + the LDS phase instead of table latency + row-id latency + row-load latency.
+    // (urows is padded with its last id up to a multiple of 32, so ids are read unclamped.)
     const int P = (int)a.P;
+    constexpr int SPAN = WAVES * RPI * 4;  // rows staged per pass of the workgroup
+    int sl_n[NROW];
+    double wl_n[NROW];
+    int U_n = 0;
+    uint32_t ra_n[4], rb_n[4];
+    auto fetch_tabs = [&](int p, int iv) {
+        const int64_t gtq = gt * a.P + p;
+#pragma unroll
+        for (int k = 0; k < NROW; k++) {
+            sl_n[k] = a.slot[(gtq * NROW + k) * CG + tid];
+            wl_n[k] = (NROW == 1)
+                ? a.w[(int64_t)iv * a.w_var_stride + (g * a.P + p) * CG + tid]
+                : a.w[(int64_t)iv * a.w_var_stride + (gtq * 4 + k) * CG + tid];
+        }
+        U_n = __builtin_amdgcn_readfirstlane((int)a.ucount[gtq]);
+        const uint32_t *uq = a.urows + gtq * a.ustride + wave * RPI;   // wave-uniform: scalar loads
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            ra_n[u] = uq[u * WAVES * RPI];
+            rb_n[u] = uq[u * WAVES * RPI + (RPI == 2 ? 1 : 0)];
+        }
+    };
+    fetch_tabs(0, 0);
     for (int p = 0; p < P; p++) {
         const int64_t gtp = gt * a.P + p;
-        const int U = __builtin_amdgcn_readfirstlane((int)a.ucount[gtp]);
-        const uint32_t *ur = a.urows + gtp * a.ucap;
+        const uint32_t *ur = a.urows + gtp * a.ustride;
         for (int iv = 0; iv < a.nvar; iv++) {
-            // per-lane (= per-chain) slot and weight of this step; issued before the staging
-            // so that their latency overlaps it
             int sl[NROW];
             double wl[NROW];
 #pragma unroll
-            for (int k = 0; k < NROW; k++) {
-                sl[k] = a.slot[(gtp * NROW + k) * CG + tid];
-                wl[k] = (NROW == 1)
-                    ? a.w[(int64_t)iv * a.w_var_stride + (g * a.P + p) * CG + tid]
-                    : a.w[(int64_t)iv * a.w_var_stride + (gtp * 4 + k) * CG + tid];
-            }
+            for (int k = 0; k < NROW; k++) { sl[k] = sl_n[k]; wl[k] = wl_n[k]; }
+            const int U = U_n;
+            uint32_t ra[4], rb[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { ra[u] = ra_n[u]; rb[u] = rb_n[u]; }
+            const double *Gv = a.G[iv];
             __syncthreads();  // everyone finished reading the previous rows
             // ---- stage the distinct rows of this (group, target, patch) in LDS
-            const double *Gv = a.G[iv];
-            for (int j0 = wave * RPI; j0 < U; j0 += WAVES * RPI * 4) {
+            {
+                double2 x[4];
+                int ju[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t r = (RPI == 2) ? (hsel ? rb[u] : ra[u]) : ra[u];
+                    ju[u] = wave * RPI + u * WAVES * RPI + hsel;
+                    x[u] = *reinterpret_cast<const double2 *>(Gv + (int64_t)r * N + nload);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // next step's tables, younger than the row loads above
+                {
+                    int pn = p, ivn = iv + 1;
+                    if (ivn == a.nvar) { ivn = 0; pn = p + 1; }
+                    if (pn == P) { pn = p; ivn = iv; }
+                    fetch_tabs(pn, ivn);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (ju[u] < U && lane_ok)
+                        *reinterpret_cast<double2 *>(xbuf + ju[u] * GS_PITCH + hl * 2) =
+                            load_ok ? x[u] : double2{0.0, 0.0};
+            }
+            for (int j0 = wave * RPI + SPAN; j0 < U; j0 += SPAN) {
                 double2 x[4];
                 int ju[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int j = j0 + u * WAVES * RPI;
-                    uint32_t r;
-                    if (RPI == 2) {
-                        const int ja = min(j, U - 1), jb = min(j + 1, U - 1);
-                        const uint32_t ra = ur[ja], rb = ur[jb];      // wave-uniform: scalar loads
-                        r = hsel ? rb : ra;
-                    } else {
-                        r = ur[min(j + min(hsel, RPI - 1), U - 1)];   // per-lane row id
-                    }
+                    const uint32_t qa = ur[j], qb = ur[j + (RPI == 2 ? 1 : 0)];
+                    const uint32_t r = (RPI == 2) ? (hsel ? qb : qa) : qa;
                     ju[u] = j + hsel;
                     x[u] = *reinterpret_cast<const double2 *>(Gv + (int64_t)r * N + nload);
                 }
@@ -267,9 +318,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_gfstack_shared(GsArgs a)
 template <int WAVES, int NROW, int MODE>
 static void launch_shared_one(dim3 grid, size_t lds, hipStream_t s, const GsArgs &a)
 {
-    auto kern = (a.nt == 32) ? k_gfstack_shared<WAVES, NROW, MODE, 32>
-              : (a.nt == 40) ? k_gfstack_shared<WAVES, NROW, MODE, 40>
-              : (a.nt == 48) ? k_gfstack_shared<WAVES, NROW, MODE, 48>
+    auto kern = (a.nt == 48) ? k_gfstack_shared<WAVES, NROW, MODE, 48>
                              : k_gfstack_shared<WAVES, NROW, MODE, 64>;
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -347,7 +396,8 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     ga.rowoff = rowoff; ga.fac = fac;
     for (int v = 0; v < k.nvar; v++) ga.slips[v] = k.slips[v];
     ga.ucap = ucap;
-    BA_TRY(ctx->get_scratch(SL_GS_UROWS, (size_t)GTP * ucap * sizeof(uint32_t), &p));
+    ga.ustride = (ucap + 31) / 32 * 32;
+    BA_TRY(ctx->get_scratch(SL_GS_UROWS, (size_t)GTP * ga.ustride * sizeof(uint32_t), &p));
     ga.urows = (uint32_t *)p;
     BA_TRY(ctx->get_scratch(SL_GS_UCOUNT, (size_t)GTP * sizeof(uint32_t), &p));
     ga.ucount = (uint32_t *)p;
@@ -358,7 +408,7 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     ga.w = (double *)p;
     {
         ScopedTimer tm(ctx, "grouptables");
-        const size_t lds = (size_t)(ga.DS + CG) * sizeof(uint32_t);
+        const size_t lds = (size_t)(ga.DS + CG + 1) * sizeof(uint32_t);
         hipLaunchKernelGGL(k_gf_group_tables, dim3((unsigned)GTP), dim3(CG), lds, ctx->stream, ga);
     }
     BA_HIP(hipGetLastError());
@@ -368,11 +418,11 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     for (int v = 0; v < k.nvar; v++) a.G[v] = k.libs[v]->g;
     a.nvar = k.nvar; a.nrow = nrow;
     a.C = k.C; a.T = L.T; a.P = L.P; a.N = L.N;
-    a.CG = CG; a.ucap = ucap;
+    a.CG = CG; a.ucap = ucap; a.ustride = ga.ustride;
     a.nt = 64;
     {
         const char *e = getenv("BEATAMD_GS_NT");
-        if (e && (atoi(e) == 32 || atoi(e) == 40 || atoi(e) == 48)) a.nt = atoi(e);
+        if (e && atoi(e) == 48) a.nt = atoi(e);
     }
     a.ntile = (int)((L.N + a.nt - 1) / a.nt);
     a.urows = ga.urows; a.ucount = ga.ucount; a.slot = ga.slot; a.w = ga.w;

@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "r1_bench_c512_nn_gfstack_summary.json"),
                     help="rocprofv3 PMC summary (tools/run_profile.sh + tools/summarize_rocpd.py) of THIS "
                          "command; supplies roofline.traffic when its configuration matches")
+    ap.add_argument("--sort-chains", default=None,
+                    help="experiment: order the population by this key before the run (nuc | time)")
     ap.add_argument("--gf-order", type=int, default=None,
                     help="k_gfstack block order: 0 (chain,target,tile) 1 (target,chain,tile)")
     args = ap.parse_args()
@@ -189,6 +191,33 @@ def main():
     # chain c of rank r is global chain r*B + c (seed 1000 + id)
     Q0 = torch.from_numpy(draw_population(spec, lay, host["lower"], host["upper"], B,
                                           seed_offset=1000 + rank * B)).to(dev)
+    if args.sort_chains:
+        q = Q0.cpu().numpy()
+        ns, nd_, tt = (q[:, lay.offset(k)] for k in ("nucleation_strike", "nucleation_dip", "time"))
+        if args.sort_chains == "nuc":
+            key = np.lexsort((nd_, np.floor(ns / 2.0)))
+        elif args.sort_chains in ("pc1", "pc12", "pc1x16"):
+            # start-time index field of every chain (what selects the library rows)
+            from beat_amd.utility import positions2idxs
+            vel = q[:, lay.offset("velocities"):lay.offset("velocities") + spec.P]
+            hs = positions2idxs(ns, spec.patch_size[0], min_pos=0.0)
+            hd = positions2idxs(nd_, spec.patch_size[0], min_pos=0.0)
+            st = ctx.fast_sweep_batch(1.0 / vel, spec.patch_size[0], hs, hd, spec.n_patch_strike[0], spec.n_patch_dip[0])
+            sidx = np.rint((st + tt[:, None] - spec.st_min) / spec.st_dt)
+            X = sidx - sidx.mean(0)
+            U, S_, Vt = np.linalg.svd(X, full_matrices=False)
+            pc1, pc2 = U[:, 0] * S_[0], U[:, 1] * S_[1]
+            if args.sort_chains == "pc1":
+                key = np.argsort(pc1)
+            elif args.sort_chains == "pc12":
+                r1 = np.argsort(np.argsort(pc1)) // 256      # workgroup by PC1, lanes by PC2
+                key = np.lexsort((pc2, r1))
+            else:
+                r1 = np.argsort(np.argsort(pc1)) // 16       # 16-lane groups by PC1, inside by PC2
+                key = np.lexsort((pc2, r1))
+        else:
+            key = np.argsort(tt)
+        Q0 = Q0[torch.from_numpy(key).to(dev)].contiguous()
     L0 = f.batch(Q0)
     gen = torch.Generator(device=dev)
     gen.manual_seed(4242 + rank)
