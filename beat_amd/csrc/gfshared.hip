@@ -118,6 +118,7 @@ struct GsArgs {
     int nvar, nrow;
     int64_t C, T, P, N;
     int CG, ucap, ustride, ntile, nt;
+    int dma;  // 1: k_gfstack_dma (two LDS row buffers filled by LDS-DMA)
     const uint32_t *urows, *ucount;
     const uint16_t *slot;
     const double *w;
@@ -315,10 +316,230 @@ __global__ void __launch_bounds__(WAVES * 64) k_gfstack_shared(GsArgs a)
     }
 }
 
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// 8 x ds_read_b128 of consecutive 16-byte units starting OFF bytes behind `addr` (per-lane LDS
+// byte address).  Not volatile (see k_gfstack_dma); `tok` is a loop-variant input so that equal
+// addresses of different steps are never merged.  The data is valid after lds_wait8.
+template <int OFF>
+__device__ __forceinline__ void lds_rd8(v2d (&x)[8], uint32_t addr, int tok)
+{
+    asm("ds_read_b128 %0, %8 offset:%c10\n\t"
+        "ds_read_b128 %1, %8 offset:%c10+16\n\t"
+        "ds_read_b128 %2, %8 offset:%c10+32\n\t"
+        "ds_read_b128 %3, %8 offset:%c10+48\n\t"
+        "ds_read_b128 %4, %8 offset:%c10+64\n\t"
+        "ds_read_b128 %5, %8 offset:%c10+80\n\t"
+        "ds_read_b128 %6, %8 offset:%c10+96\n\t"
+        "ds_read_b128 %7, %8 offset:%c10+112"
+        : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7])
+        : "v"(addr), "s"(tok), "n"(OFF));
+}
+
+// wait until at most NLEFT LDS/scalar operations are outstanding; names the 8 destinations
+template <int NLEFT>
+__device__ __forceinline__ void lds_wait8(v2d (&x)[8])
+{
+    asm("s_waitcnt lgkmcnt(%c8)"
+        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])
+        : "n"(NLEFT));
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gfstack_dma: the same mapping (lane <-> chain, 64 static accumulators, distinct rows staged
+// once per workgroup) with the row staging taken off the waves' critical path:
+//   * two LDS row buffers; the rows of step s+1 are written by LDS-DMA
+//     (global_load_lds_dwordx4, 16 B per lane, no staging VGPRs, no ds_write pass) while the
+//     wavefronts run the LDS-gather + FMA phase of step s -- ONE barrier per step;
+//   * row ids (scalar) are fetched two steps ahead, the lane's slot/weight one step ahead.
+// hipcc does not count asm memory operations: the only vector loads it knows of are the table
+// loads, which are consumed at the top of the next step by the statement that also carries the
+// explicit `s_waitcnt vmcnt(0)` for the DMA -- at that point nothing else is in flight, so none
+// of its own (under-counting) vmcnt(N) can stall on a DMA.  The DMA statements are not volatile
+// (a volatile asm is a memory clobber for hipcc and would turn the scalar row-id loads into
+// waited vector loads); sched_barrier(0) pins them between the barrier and the FMA phase.
+template <int WAVES, int NROW, int MODE, int NT>
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_gfstack_dma(GsArgs a)
+{
+    constexpr int GS_NT = NT;
+    constexpr int GS_PITCH = NT + 2;
+    constexpr int LPR = NT / 2;         // lanes moving one row segment (16 B each)
+    constexpr int KPRE = 8;             // row ids per wavefront fetched ahead (scalar registers)
+    extern __shared__ __attribute__((aligned(16))) double xbuf[];  // [2][ucap][GS_PITCH]
+    constexpr int CG = WAVES * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x % a.ntile;
+    const int64_t gt = blockIdx.x / a.ntile;  // g*T + t
+    const int64_t t = gt % a.T;
+    const int64_t g = gt / a.T;
+    const int64_t c = g * CG + tid;
+    const int64_t N = a.N;
+    const int64_t n0 = (int64_t)tile * GS_NT;
+    const bool dma_lane = (lane < LPR) && (n0 + lane * 2 < N);   // N even (launcher)
+    const uint32_t voff = (uint32_t)((n0 + lane * 2) * 8);      // byte offset inside a row
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)xbuf;
+    const int bufsz = a.ucap * GS_PITCH;                          // doubles per buffer
+
+    double acc[GS_NT];
+#pragma unroll
+    for (int i = 0; i < GS_NT; i++) acc[i] = 0.0;
+    uint32_t keep = 0;  // results of the DMA statements (always 0): keeps them alive
+
+    const int P = (int)a.P, nvar = a.nvar;
+    const int nsteps = P * nvar;
+
+    // row j of the step lands at buf*bufsz + j*PITCH; lanes 0..LPR-1 move its NT samples
+    auto dma_row = [&](const double *Gv, uint32_t r, int j, int buf) {
+        const double *rowp = Gv + (int64_t)r * N;
+        const uint32_t dst = lds0 + (uint32_t)((buf * bufsz + j * GS_PITCH) * 8);
+        if (dma_lane) {
+            uint32_t tok;
+            asm("s_mov_b32 m0, %3\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, %2\n\t"
+                "s_mov_b32 %0, 0"
+                : "=s"(tok) : "v"(voff), "s"(rowp), "s"(dst));
+            keep |= tok;
+        }
+    };
+    // distinct-row count + this wavefront's first KPRE row ids of step s (wave-uniform)
+    auto fetch_ids = [&](int s, int &U, uint32_t (&rid)[KPRE]) {
+        const int64_t gtq = gt * a.P + s / nvar;
+        U = __builtin_amdgcn_readfirstlane((int)a.ucount[gtq]);
+        const uint32_t *uq = a.urows + gtq * a.ustride + wave;
+#pragma unroll
+        for (int k = 0; k < KPRE; k++) rid[k] = uq[k * WAVES];   // padded: always in bounds
+    };
+    auto issue_rows = [&](int s, int U, const uint32_t (&rid)[KPRE]) {
+        const double *Gv = a.G[s % nvar];
+        const int buf = s & 1;
+#pragma unroll
+        for (int k = 0; k < KPRE; k++)
+            if (wave + k * WAVES < U) dma_row(Gv, rid[k], wave + k * WAVES, buf);
+        if (U > KPRE * WAVES) {   // rare: more distinct rows than the prefetched ids cover
+            const uint32_t *uq = a.urows + (gt * a.P + s / nvar) * a.ustride;
+            for (int j = wave + KPRE * WAVES; j < U; j += WAVES) dma_row(Gv, uq[j], j, buf);
+        }
+    };
+    int sl_n[NROW];
+    double wl_n[NROW];
+    auto fetch_tabs = [&](int s) {
+        const int p = s / nvar, iv = s % nvar;
+        const int64_t gtq = gt * a.P + p;
+#pragma unroll
+        for (int k = 0; k < NROW; k++) {
+            sl_n[k] = a.slot[(gtq * NROW + k) * CG + tid];
+            wl_n[k] = (NROW == 1)
+                ? a.w[(int64_t)iv * a.w_var_stride + (g * a.P + p) * CG + tid]
+                : a.w[(int64_t)iv * a.w_var_stride + (gtq * 4 + k) * CG + tid];
+        }
+    };
+
+    int U_a;
+    uint32_t rid_a[KPRE];
+    fetch_ids(0, U_a, rid_a);
+    issue_rows(0, U_a, rid_a);
+    fetch_ids(min(1, nsteps - 1), U_a, rid_a);
+    fetch_tabs(0);
+    for (int s = 0; s < nsteps; s++) {
+        int sl[NROW];
+        double wl[NROW];
+#pragma unroll
+        for (int k = 0; k < NROW; k++) { sl[k] = sl_n[k]; wl[k] = wl_n[k]; }
+        // the tables of this step and (older) the DMA of this step's rows have landed
+        __builtin_amdgcn_sched_barrier(0);
+        asm("s_waitcnt vmcnt(0)" : "+v"(sl[0]), "+v"(wl[0]));
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();  // rows of step s visible; everyone has left the FMA phase of step s-1
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < nsteps) {
+            issue_rows(s + 1, U_a, rid_a);                       // -> buffer (s+1)&1
+            fetch_ids(min(s + 2, nsteps - 1), U_a, rid_a);
+            fetch_tabs(s + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- every lane applies ITS rows with ITS weights.  The 2*NT/4 ds_read_b128 of a row
+        // are issued by hand in groups of 8, two groups in flight (hipcc keeps 3-4 reads in
+        // flight, which leaves the phase bound by LDS latency instead of LDS throughput); the
+        // wait statements name the destination registers, so no FMA can move above its wait.
+#pragma unroll
+        for (int k = 0; k < NROW; k++) {
+            const uint32_t xs = lds0 + (uint32_t)(((s & 1) * bufsz + sl[k] * GS_PITCH) * 8);
+            const double w = wl[k];
+            constexpr int NG = GS_NT / 16;   // groups of 8 reads = 16 samples
+            v2d xa[8], xb[8];
+            lds_rd8<0>(xa, xs, s);
+            if (NG > 1) lds_rd8<128>(xb, xs, s);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int gq = 0; gq < NG; gq++) {
+                v2d(&cur)[8] = (gq & 1) ? xb : xa;
+                if (gq + 1 < NG) lds_wait8<8>(cur); else lds_wait8<0>(cur);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    acc[gq * 16 + 2 * q] = fma(cur[q].x, w, acc[gq * 16 + 2 * q]);
+                    acc[gq * 16 + 2 * q + 1] = fma(cur[q].y, w, acc[gq * 16 + 2 * q + 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (gq + 2 < NG) {
+                    if (gq + 2 == 2) lds_rd8<256>(cur, xs, s);
+                    else if (gq + 2 == 3) lds_rd8<384>(cur, xs, s);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ---- epilogue: lane = chain c, acc[i] = synthetics[c, t, n0 + i]
+    const bool live = (c < a.C) && (keep == 0);
+    const int nvalid = (int)min((int64_t)GS_NT, N - n0);
+    if (MODE == GF_STORE_SYN) {
+        if (live) {
+            double *o = a.out + (c * a.T + t) * N + n0;
+#pragma unroll
+            for (int i = 0; i < GS_NT; i++)
+                if (i < nvalid) o[i] = acc[i];
+        }
+        return;
+    }
+    __syncthreads();
+    if (tid < GS_NT) xbuf[tid] = (tid < nvalid) ? a.data[t * N + n0 + tid] : 0.0;
+    __syncthreads();
+    if (MODE == GF_RESID_STORE) {
+        double *o = a.out + (c * a.T + t) * N + n0;
+#pragma unroll
+        for (int i0 = 0; i0 < GS_NT; i0 += 8) {
+#pragma unroll
+            for (int i = i0; i < i0 + 8; i++)
+                if (live && i < nvalid) o[i] = xbuf[i] - acc[i];  // seismic.py:1332
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        const double w = a.wscalar[t];
+        double q = 0.0;
+#pragma unroll
+        for (int i0 = 0; i0 < GS_NT; i0 += 8) {
+#pragma unroll
+            for (int i = i0; i < i0 + 8; i++)
+                if (i < nvalid) {
+                    const double tt = w * (xbuf[i] - acc[i]);
+                    q = fma(tt, tt, q);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (live) a.partial[(c * a.T + t) * a.ntile + tile] = q;
+    }
+}
+
 template <int WAVES, int NROW, int MODE>
 static void launch_shared_one(dim3 grid, size_t lds, hipStream_t s, const GsArgs &a)
 {
-    auto kern = (a.nt == 48) ? k_gfstack_shared<WAVES, NROW, MODE, 48>
+    auto kern = a.dma ? k_gfstack_dma<WAVES, NROW, MODE, 64>
+              : (a.nt == 48) ? k_gfstack_shared<WAVES, NROW, MODE, 48>
                              : k_gfstack_shared<WAVES, NROW, MODE, 64>;
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -434,7 +655,13 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     }
     const int64_t nblocks = ngroups * L.T * a.ntile;
     BA_CHECK(nblocks < (int64_t)0x7fffffff, BEATAMD_EINVAL, "gfstack: batch too large");
-    const size_t lds = (size_t)ucap * (a.nt + 2) * sizeof(double);
+    size_t lds = (size_t)ucap * (a.nt + 2) * sizeof(double);
+    {
+        // two row buffers when they fit (BEATAMD_GS_DMA=0 forces the single-buffer kernel)
+        const char *e = getenv("BEATAMD_GS_DMA");
+        a.dma = (a.nt == 64 && 2 * lds <= 158 * 1024 && !(e && atoi(e) == 0)) ? 1 : 0;
+        if (a.dma) lds *= 2;
+    }
     {
         ScopedTimer tm(ctx, "gfstack");
         dim3 grid((unsigned)nblocks);
