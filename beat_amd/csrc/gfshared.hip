@@ -119,6 +119,7 @@ struct GsArgs {
     int64_t C, T, P, N;
     int CG, ucap, ustride, ntile, nt;
     int dma;  // 1: k_gfstack_dma (two LDS row buffers filled by LDS-DMA)
+    int pf;   // k_gfstack_dma: L2 warm-up distance in steps (0 = none)
     const uint32_t *urows, *ucount;
     const uint16_t *slot;
     const double *w;
@@ -174,7 +175,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_gfstack_shared(GsArgs a)
     // wavefront's first row ids (scalar loads) -- is fetched ONE STEP AHEAD, right after the
     // current step's row loads have been issued: a step's critical path is then one row-load
     // latency + the LDS phase instead of table latency + row-id latency + row-load latency.
-    // (urows is padded with its last id up to a multiple of 32, so ids are read unclamped.)
+    // (urows is padded with its last id up to a multiple of 64, so ids are read unclamped.)
     const int P = (int)a.P;
     constexpr int SPAN = WAVES * RPI * 4;  // rows staged per pass of the workgroup
     int sl_n[NROW];
@@ -346,6 +347,31 @@ __device__ __forceinline__ void lds_wait8(v2d (&x)[8])
         : "n"(NLEFT));
 }
 
+// 8 x ds_read_b64 of consecutive doubles (row pitch NT+1 doubles: the 32 lanes of a ds_read_b64
+// lane group then hit 32 distinct two-bank windows for up to 32 different rows)
+template <int OFF>
+__device__ __forceinline__ void lds_rd8_b64(double (&x)[8], uint32_t addr, int tok)
+{
+    asm("ds_read_b64 %0, %8 offset:%c10\n\t"
+        "ds_read_b64 %1, %8 offset:%c10+8\n\t"
+        "ds_read_b64 %2, %8 offset:%c10+16\n\t"
+        "ds_read_b64 %3, %8 offset:%c10+24\n\t"
+        "ds_read_b64 %4, %8 offset:%c10+32\n\t"
+        "ds_read_b64 %5, %8 offset:%c10+40\n\t"
+        "ds_read_b64 %6, %8 offset:%c10+48\n\t"
+        "ds_read_b64 %7, %8 offset:%c10+56"
+        : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7])
+        : "v"(addr), "s"(tok), "n"(OFF));
+}
+
+template <int NLEFT>
+__device__ __forceinline__ void lds_wait8_b64(double (&x)[8])
+{
+    asm("s_waitcnt lgkmcnt(%c8)"
+        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])
+        : "n"(NLEFT));
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_gfstack_dma: the same mapping (lane <-> chain, 64 static accumulators, distinct rows staged
 // once per workgroup) with the row staging taken off the waves' critical path:
@@ -359,15 +385,17 @@ __device__ __forceinline__ void lds_wait8(v2d (&x)[8])
 // of its own (under-counting) vmcnt(N) can stall on a DMA.  The DMA statements are not volatile
 // (a volatile asm is a memory clobber for hipcc and would turn the scalar row-id loads into
 // waited vector loads); sched_barrier(0) pins them between the barrier and the FMA phase.
-template <int WAVES, int NROW, int MODE, int NT>
+template <int WAVES, int NROW, int MODE, int NT, int PFN, int B64>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_gfstack_dma(GsArgs a)
 {
     constexpr int GS_NT = NT;
-    constexpr int GS_PITCH = NT + 2;
+    constexpr int GS_PITCH = B64 ? NT + 1 : NT + 2;
     constexpr int LPR = NT / 2;         // lanes moving one row segment (16 B each)
     constexpr int KPRE = 8;             // row ids per wavefront fetched ahead (scalar registers)
     extern __shared__ __attribute__((aligned(16))) double xbuf[];  // [2][ucap][GS_PITCH]
+    // landing zone of the L2-prefetch DMAs (never read)
+    __shared__ __attribute__((aligned(16))) double pfdump[PFN > 0 ? WAVES : 1][128];
     constexpr int CG = WAVES * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -390,75 +418,142 @@ k_gfstack_dma(GsArgs a)
 
     const int P = (int)a.P, nvar = a.nvar;
     const int nsteps = P * nvar;
-
-    // row j of the step lands at buf*bufsz + j*PITCH; lanes 0..LPR-1 move its NT samples
+    // steps run patch-major over (patch, variable); (p, iv) of the steps ahead are advanced
+    // incrementally (no integer divisions in the loop) and clamp at the last step
+    auto advance = [&](int &p, int &iv) {
+        if (++iv == nvar) { iv = 0; ++p; }
+        if (p >= P) { p = P - 1; iv = nvar - 1; }
+    };
+    // row j of the step lands at buf*bufsz + j*PITCH; lanes 0..LPR-1 move its NT samples.
+    // (scalar address arithmetic kept short: 32 x 32 -> 64 bit products, one exec region per step)
+    const uint32_t rowbytes = (uint32_t)(N * 8);
     auto dma_row = [&](const double *Gv, uint32_t r, int j, int buf) {
-        const double *rowp = Gv + (int64_t)r * N;
+        const uint64_t off = (uint64_t)r * (uint64_t)rowbytes;
+        const char *rowp = reinterpret_cast<const char *>(Gv) + off;
         const uint32_t dst = lds0 + (uint32_t)((buf * bufsz + j * GS_PITCH) * 8);
-        if (dma_lane) {
-            uint32_t tok;
-            asm("s_mov_b32 m0, %3\n\t"
-                "s_nop 0\n\t"
-                "global_load_lds_dwordx4 %1, %2\n\t"
-                "s_mov_b32 %0, 0"
-                : "=s"(tok) : "v"(voff), "s"(rowp), "s"(dst));
-            keep |= tok;
-        }
+        uint32_t tok;
+        asm("s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %2\n\t"
+            "s_mov_b32 %0, 0"
+            : "=s"(tok) : "v"(voff), "s"(rowp), "s"(dst));
+        keep |= tok;
     };
     // distinct-row count + this wavefront's first KPRE row ids of step s (wave-uniform)
-    auto fetch_ids = [&](int s, int &U, uint32_t (&rid)[KPRE]) {
-        const int64_t gtq = gt * a.P + s / nvar;
+    auto fetch_ids = [&](int p, int &U, uint32_t (&rid)[KPRE]) {
+        const int64_t gtq = gt * a.P + p;
         U = __builtin_amdgcn_readfirstlane((int)a.ucount[gtq]);
         const uint32_t *uq = a.urows + gtq * a.ustride + wave;
 #pragma unroll
         for (int k = 0; k < KPRE; k++) rid[k] = uq[k * WAVES];   // padded: always in bounds
     };
-    auto issue_rows = [&](int s, int U, const uint32_t (&rid)[KPRE]) {
-        const double *Gv = a.G[s % nvar];
-        const int buf = s & 1;
+    auto issue_rows = [&](int p, int iv, int buf, int U, const uint32_t (&rid)[KPRE]) {
+        const double *Gv = a.G[iv];
+        if (dma_lane) {
 #pragma unroll
-        for (int k = 0; k < KPRE; k++)
-            if (wave + k * WAVES < U) dma_row(Gv, rid[k], wave + k * WAVES, buf);
-        if (U > KPRE * WAVES) {   // rare: more distinct rows than the prefetched ids cover
-            const uint32_t *uq = a.urows + (gt * a.P + s / nvar) * a.ustride;
-            for (int j = wave + KPRE * WAVES; j < U; j += WAVES) dma_row(Gv, uq[j], j, buf);
+            for (int k = 0; k < KPRE; k++)
+                if (wave + k * WAVES < U) dma_row(Gv, rid[k], wave + k * WAVES, buf);
+            if (U > KPRE * WAVES) {   // rare: more distinct rows than the prefetched ids cover
+                const uint32_t *uq = a.urows + (gt * a.P + p) * a.ustride;
+                for (int j = wave + KPRE * WAVES; j < U; j += WAVES) dma_row(Gv, uq[j], j, buf);
+            }
         }
     };
-    int sl_n[NROW];
+    // L2 warm-up of the rows of a later step: exactly PFN full-wave DMAs per wavefront and step
+    // (two row segments each, ids padded/clamped) into the dump zone.  The count is static so
+    // that the step-top wait can be `vmcnt(PFN)`: everything older -- the row DMAs and the table
+    // loads of the next step -- has landed, the warm-ups may still be in flight.
+    constexpr int PFR = PFN > 0 ? 2 * PFN : 1;   // row ids per wavefront
+    const int hsel = lane / LPR;
+    const bool pf_lane = (hsel < 2) && (n0 + (lane % LPR) * 2 < N);
+    const uint32_t pf_voff = (uint32_t)((n0 + (lane % LPR) * 2) * 8);
+    const uint32_t pf_dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)
+                                &pfdump[PFN > 0 ? wave : 0][0];
+    auto fetch_pids = [&](int p, uint32_t (&pid)[PFR]) {
+        const int64_t gtq = gt * a.P + p;
+        const uint32_t *uq = a.urows + gtq * a.ustride;
+        // rows wave*PFR .. wave*PFR+PFR-1, clamped into the padded id list
+#pragma unroll
+        for (int k = 0; k < PFR; k++) pid[k] = uq[min(wave * PFR + k, a.ustride - 1)];
+    };
+    auto issue_prefetch = [&](int iv, int s, const uint32_t (&pid)[PFR]) {
+        const double *Gv = a.G[iv];
+#pragma unroll
+        for (int k = 0; k < PFN; k++) {
+            const uint32_t r = hsel ? pid[2 * k + 1] : pid[2 * k];
+            const double *src = Gv + (int64_t)r * N;
+            uint32_t tok;
+            // every lane takes part (lanes past the tile re-read the row start): the count of
+            // DMA instructions must not depend on the exec mask
+            const uint32_t vo = pf_lane ? pf_voff : 0u;
+            asm("s_mov_b32 m0, %3\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, off\n\t"
+                "s_mov_b32 %0, 0"
+                : "=s"(tok) : "v"(reinterpret_cast<const char *>(src) + vo), "s"(s), "s"(pf_dst));
+            keep |= tok;
+        }
+    };
+    // the lane's slot and weight of step s: asm loads (hipcc must not count them, see above);
+    // valid after the step-top wait statement, which names them
+    uint32_t sl_n[NROW];
     double wl_n[NROW];
-    auto fetch_tabs = [&](int s) {
-        const int p = s / nvar, iv = s % nvar;
+    auto fetch_tabs = [&](int p, int iv) {
         const int64_t gtq = gt * a.P + p;
 #pragma unroll
         for (int k = 0; k < NROW; k++) {
-            sl_n[k] = a.slot[(gtq * NROW + k) * CG + tid];
-            wl_n[k] = (NROW == 1)
-                ? a.w[(int64_t)iv * a.w_var_stride + (g * a.P + p) * CG + tid]
-                : a.w[(int64_t)iv * a.w_var_stride + (gtq * 4 + k) * CG + tid];
+            const uint16_t *ps = a.slot + (gtq * NROW + k) * CG + tid;
+            const double *pw = (NROW == 1)
+                ? a.w + (int64_t)iv * a.w_var_stride + (g * a.P + p) * CG + tid
+                : a.w + (int64_t)iv * a.w_var_stride + (gtq * 4 + k) * CG + tid;
+            asm("global_load_ushort %0, %1, off" : "=v"(sl_n[k]) : "v"(ps));
+            asm("global_load_dwordx2 %0, %1, off" : "=v"(wl_n[k]) : "v"(pw));
         }
     };
 
+    const int PD = a.pf;   // warm-up distance in steps
+    int p1 = 0, iv1 = 0;          // step s+1
+    advance(p1, iv1);
+    int p2 = p1, iv2 = iv1;       // step s+2
+    advance(p2, iv2);
+    int pw = 0, ivw = 0;          // warm-up target: step s+1+PD
+    if (PFN > 0) for (int i = 0; i < 1 + PD; i++) advance(pw, ivw);
     int U_a;
     uint32_t rid_a[KPRE];
+    uint32_t pid_a[PFR];
     fetch_ids(0, U_a, rid_a);
-    issue_rows(0, U_a, rid_a);
-    fetch_ids(min(1, nsteps - 1), U_a, rid_a);
-    fetch_tabs(0);
+    if (PFN > 0) fetch_pids(pw, pid_a);
+    issue_rows(0, 0, 0, U_a, rid_a);
+    fetch_tabs(0, 0);
+    if (PFN > 0) issue_prefetch(ivw, -1, pid_a);
+    fetch_ids(p1, U_a, rid_a);
     for (int s = 0; s < nsteps; s++) {
-        int sl[NROW];
-        double wl[NROW];
-#pragma unroll
-        for (int k = 0; k < NROW; k++) { sl[k] = sl_n[k]; wl[k] = wl_n[k]; }
         // the tables of this step and (older) the DMA of this step's rows have landed
         __builtin_amdgcn_sched_barrier(0);
-        asm("s_waitcnt vmcnt(0)" : "+v"(sl[0]), "+v"(wl[0]));
+        // (the copy into this step's registers is part of the statement: hipcc would otherwise
+        // place it in front of the wait and copy registers whose loads are still in flight)
+        uint32_t sl[NROW];
+        double wl[NROW];
+#pragma unroll
+        for (int k = 0; k < NROW; k++)
+            asm("s_waitcnt vmcnt(%c4)\n\t"
+                "v_mov_b32 %0, %2\n\t"
+                "v_mov_b64 %1, %3"
+                : "=&v"(sl[k]), "=&v"(wl[k]) : "v"(sl_n[k]), "v"(wl_n[k]), "n"(PFN));
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();  // rows of step s visible; everyone has left the FMA phase of step s-1
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < nsteps) {
-            issue_rows(s + 1, U_a, rid_a);                       // -> buffer (s+1)&1
-            fetch_ids(min(s + 2, nsteps - 1), U_a, rid_a);
-            fetch_tabs(s + 1);
+        {
+            if (s + 1 < nsteps) issue_rows(p1, iv1, (s + 1) & 1, U_a, rid_a);   // -> other buffer
+            fetch_tabs(p1, iv1);
+            if (PFN > 0) {
+                fetch_pids(pw, pid_a);
+                issue_prefetch(ivw, s, pid_a);
+                advance(pw, ivw);
+            }
+            fetch_ids(p2, U_a, rid_a);
+            p1 = p2; iv1 = iv2;
+            advance(p2, iv2);
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- every lane applies ITS rows with ITS weights.  The 2*NT/4 ds_read_b128 of a row
@@ -467,8 +562,34 @@ k_gfstack_dma(GsArgs a)
         // wait statements name the destination registers, so no FMA can move above its wait.
 #pragma unroll
         for (int k = 0; k < NROW; k++) {
-            const uint32_t xs = lds0 + (uint32_t)(((s & 1) * bufsz + sl[k] * GS_PITCH) * 8);
+            const uint32_t xs = lds0 + (uint32_t)(((s & 1) * bufsz + (int)sl[k] * GS_PITCH) * 8);
             const double w = wl[k];
+            if (B64) {
+                constexpr int NG8 = GS_NT / 8;   // groups of 8 reads = 8 samples
+                double ya[8], yb[8];
+                lds_rd8_b64<0>(ya, xs, s);
+                lds_rd8_b64<64>(yb, xs, s);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int gq = 0; gq < NG8; gq++) {
+                    double(&cur)[8] = (gq & 1) ? yb : ya;
+                    if (gq + 1 < NG8) lds_wait8_b64<8>(cur); else lds_wait8_b64<0>(cur);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) acc[gq * 8 + q] = fma(cur[q], w, acc[gq * 8 + q]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    switch (gq + 2) {
+                    case 2: lds_rd8_b64<128>(cur, xs, s); break;
+                    case 3: lds_rd8_b64<192>(cur, xs, s); break;
+                    case 4: lds_rd8_b64<256>(cur, xs, s); break;
+                    case 5: lds_rd8_b64<320>(cur, xs, s); break;
+                    case 6: lds_rd8_b64<384>(cur, xs, s); break;
+                    case 7: lds_rd8_b64<448>(cur, xs, s); break;
+                    default: break;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
             constexpr int NG = GS_NT / 16;   // groups of 8 reads = 16 samples
             v2d xa[8], xb[8];
             lds_rd8<0>(xa, xs, s);
@@ -491,8 +612,11 @@ k_gfstack_dma(GsArgs a)
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            }
         }
     }
+    // drain the warm-up DMAs before the epilogue reuses LDS / the kernel ends
+    asm volatile("s_waitcnt vmcnt(0)");
 
     // ---- epilogue: lane = chain c, acc[i] = synthetics[c, t, n0 + i]
     const bool live = (c < a.C) && (keep == 0);
@@ -538,7 +662,9 @@ k_gfstack_dma(GsArgs a)
 template <int WAVES, int NROW, int MODE>
 static void launch_shared_one(dim3 grid, size_t lds, hipStream_t s, const GsArgs &a)
 {
-    auto kern = a.dma ? k_gfstack_dma<WAVES, NROW, MODE, 64>
+    auto kern = (a.dma && a.pf > 0) ? k_gfstack_dma<WAVES, NROW, MODE, 64, 3, 0>
+              : (a.dma == 2) ? k_gfstack_dma<WAVES, NROW, MODE, 64, 0, 1>
+              : a.dma ? k_gfstack_dma<WAVES, NROW, MODE, 64, 0, 0>
               : (a.nt == 48) ? k_gfstack_shared<WAVES, NROW, MODE, 48>
                              : k_gfstack_shared<WAVES, NROW, MODE, 64>;
     if (lds > 64 * 1024)
@@ -563,11 +689,11 @@ static void launch_shared_nrow(int nrow, int mode, dim3 grid, size_t lds, hipStr
     else launch_shared_mode<WAVES, 4>(mode, grid, lds, s, a);
 }
 
-// chains per group for a batch of C chains: the largest of {256,128,64} wasting < 15 % lanes
+// chains per group for a batch of C chains: the largest of {512,256,128,64} wasting < 15 % lanes
 static int pick_group(int64_t C)
 {
-    const int cand[3] = {256, 128, 64};
-    for (int i = 0; i < 3; i++) {
+    const int cand[4] = {512, 256, 128, 64};
+    for (int i = 0; i < 4; i++) {
         const int64_t padded = (C + cand[i] - 1) / cand[i] * cand[i];
         if (padded * 100 <= C * 115) return cand[i];
     }
@@ -585,7 +711,7 @@ bool gfstack_shared_applicable(const GfStackCall &k, int *cg_out, int *ucap_out)
     if (!forced && k.C < 48) return false;  // too few chains to share rows
     int cg = pick_group(k.C);
     const char *gq = getenv("BEATAMD_GS_CG");
-    if (gq && (atoi(gq) == 64 || atoi(gq) == 128 || atoi(gq) == 256)) cg = atoi(gq);
+    if (gq && (atoi(gq) == 64 || atoi(gq) == 128 || atoi(gq) == 256 || atoi(gq) == 512)) cg = atoi(gq);
     const int64_t DS = L.D * L.S;
     int64_t ucap = std::min<int64_t>((int64_t)cg * nrow, DS);
     // the distinct rows of one step must fit in LDS; prefer >= 2 workgroups per CU
@@ -617,7 +743,7 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     ga.rowoff = rowoff; ga.fac = fac;
     for (int v = 0; v < k.nvar; v++) ga.slips[v] = k.slips[v];
     ga.ucap = ucap;
-    ga.ustride = (ucap + 31) / 32 * 32;
+    ga.ustride = (ucap + 63) / 64 * 64;   // covers the unclamped first-pass ids of 8 waves
     BA_TRY(ctx->get_scratch(SL_GS_UROWS, (size_t)GTP * ga.ustride * sizeof(uint32_t), &p));
     ga.urows = (uint32_t *)p;
     BA_TRY(ctx->get_scratch(SL_GS_UCOUNT, (size_t)GTP * sizeof(uint32_t), &p));
@@ -660,12 +786,16 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         // two row buffers when they fit (BEATAMD_GS_DMA=0 forces the single-buffer kernel)
         const char *e = getenv("BEATAMD_GS_DMA");
         a.dma = (a.nt == 64 && 2 * lds <= 158 * 1024 && !(e && atoi(e) == 0)) ? 1 : 0;
+        if (a.dma && !(e && atoi(e) == 1)) a.dma = 2;   // ds_read_b64 / pitch NT+1 (default); 1 = b128 / pitch NT+2
         if (a.dma) lds *= 2;
+        const char *q = getenv("BEATAMD_GS_PF");
+        a.pf = q ? std::max(0, std::min(atoi(q), 16)) : 0;
     }
     {
         ScopedTimer tm(ctx, "gfstack");
         dim3 grid((unsigned)nblocks);
-        if (CG == 256) launch_shared_nrow<4>(nrow, k.mode, grid, lds, ctx->stream, a);
+        if (CG == 512) launch_shared_nrow<8>(nrow, k.mode, grid, lds, ctx->stream, a);
+        else if (CG == 256) launch_shared_nrow<4>(nrow, k.mode, grid, lds, ctx->stream, a);
         else if (CG == 128) launch_shared_nrow<2>(nrow, k.mode, grid, lds, ctx->stream, a);
         else launch_shared_nrow<1>(nrow, k.mode, grid, lds, ctx->stream, a);
     }
