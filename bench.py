@@ -305,8 +305,9 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_gfstack_shared" if B >= 48 and not os.environ.get("BEATAMD_GF_KERNEL") == "0"
-                          else "k_gfstack",
+                "kernel": "k_gfstack" if (B < 48 or os.environ.get("BEATAMD_GF_KERNEL") == "0")
+                          else "k_gfstack_shared" if os.environ.get("BEATAMD_GS_DMA") == "0"
+                          else "k_gfstack_dma",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

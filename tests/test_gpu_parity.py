@@ -147,11 +147,12 @@ def test_stack_block_orders_identical(ctx, orc, monkeypatch, order, cgroup):
         assert np.abs(out[c] - ref).max() <= 1e-11 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("C", [5, 64, 70, 130, 300])
+@pytest.mark.parametrize("C", [5, 64, 70, 130, 300, 530])
 @pytest.mark.parametrize("interp", ["nearest_neighbor", "multilinear"])
 def test_shared_row_kernel_equals_streaming_kernel(ctx, orc, monkeypatch, C, interp):
-    """k_gfstack_shared (distinct rows staged once per chain group) vs k_gfstack: bitwise equal
-    synthetics for one slip variable, and both equal to the oracle"""
+    """the chain-shared kernels (distinct rows staged once per chain group: k_gfstack_dma with
+    ds_read_b64 / ds_read_b128 layouts, single-buffer k_gfstack_shared) vs k_gfstack: bitwise
+    equal synthetics for one slip variable, and all equal to the oracle"""
     rng = np.random.default_rng(C)
     T, P, D, S, N = 3, 17, 3, 6, 200
     G = rng.standard_normal((T, P, D, S, N))
@@ -167,9 +168,11 @@ def test_shared_row_kernel_equals_streaming_kernel(ctx, orc, monkeypatch, C, int
     for c in (0, C // 2, C - 1):
         ref = orc.stack_all(G, dur[c], st[c], sl[c], 0.5, 0.25, 0.0, 0.5, interp)
         assert np.abs(b[c] - ref).max() <= 1e-11 * np.abs(ref).max()
-    for cg in ("64", "128", "256"):
+    for cg in ("64", "128", "256", "512"):
         monkeypatch.setenv("BEATAMD_GS_CG", cg)
-        assert np.array_equal(gf.stack_all_batch(dur, st, sl, interpolation=interp), a)
+        for dma in ("2", "1", "0"):
+            monkeypatch.setenv("BEATAMD_GS_DMA", dma)
+            assert np.array_equal(gf.stack_all_batch(dur, st, sl, interpolation=interp), a), (cg, dma)
 
 
 @pytest.mark.parametrize("name", ["seis_dense_ml_shifts", "joint_multifault", "all_nn_odd_N",
