@@ -66,25 +66,34 @@ __global__ void k_gf_group_tables(GroupTabArgs a)
             flags[v[k]] = 1;  // benign race: every writer stores 1
         }
     __syncthreads();
-    // exclusive scan of flags in row order -> slot numbers (deterministic)
-    const int64_t chunk = (a.DS + CG - 1) / CG;
-    const int64_t lo = min((int64_t)tid * chunk, a.DS), hi = min(lo + chunk, a.DS);
-    uint32_t cnt = 0;
-    for (int64_t i = lo; i < hi; i++) cnt += flags[i];
-    wsum[tid] = cnt;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (int i = 0; i < CG; i++) { uint32_t x = wsum[i]; wsum[i] = run; run += x; }
-        a.ucount[gtp] = run;
-        wsum[CG] = run;
-    }
-    __syncthreads();
-    uint32_t run = wsum[tid];
-    for (int64_t i = lo; i < hi; i++) {
-        if (flags[i]) {
-            a.urows[gtp * a.ustride + run] = (uint32_t)(row0 + i);
-            flags[i] = run++;
+    // exclusive scan of flags in row order -> slot numbers (deterministic): chunks of CG flags,
+    // rank inside a wavefront by ballot/popcount, wavefront offsets through LDS
+    {
+        const int lane = tid & 63, wv = tid >> 6, nw = CG >> 6;
+        uint32_t run = 0;   // distinct rows before this chunk (same in every thread)
+        for (int64_t base = 0; base < a.DS; base += CG) {
+            const int64_t i = base + tid;
+            const uint32_t f = (i < a.DS) ? flags[i] : 0u;
+            const uint64_t m = __ballot(f != 0);
+            if (lane == 0) wsum[wv] = (uint32_t)__popcll(m);
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+            for (int q = 0; q < nw; q++) {
+                const uint32_t x = wsum[q];
+                if (q < wv) before += x;
+                total += x;
+            }
+            if (f) {
+                const uint32_t pos = run + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                a.urows[gtp * a.ustride + pos] = (uint32_t)(row0 + i);
+                flags[i] = pos;
+            }
+            run += total;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            a.ucount[gtp] = run;
+            wsum[CG] = run;
         }
     }
     __syncthreads();
