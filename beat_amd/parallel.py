@@ -54,9 +54,9 @@ def allgather_population(Q, L):
     Q (c_local, nparams), L (c_local, nllk) torch tensors (cuda or cpu) -> (Qall, Lall)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return Q, L
-    world = dist.get_world_size()
+    world = dist.get_world_size()   # (a single rank runs through the same collectives)
     n_local = torch.tensor([Q.shape[0]], device=Q.device, dtype=torch.int64)
     counts = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(counts, n_local)

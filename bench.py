@@ -164,8 +164,11 @@ def main():
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`"
                              % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # BEATAMD_BENCH_FORCE_DIST=1: exercise the RCCL path with a single rank (1-GPU boxes)
+    use_dist = world > 1 or bool(os.environ.get("BEATAMD_BENCH_FORCE_DIST"))
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
@@ -241,28 +244,28 @@ def main():
     ctx.enable_timing(True)
     ctx.reset_timing()
     n_acc = 0
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(W, W + K):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     ctx.synchronize()
     n_acc = int(accepted.sum().item())
 
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt_max = float(tmax.item())
 
     # SMC stage transition exchange (select_end_points, smc.py:188-240): all-gather of the
     # per-rank end points + likelihoods; outside the timed steps, reported separately
     stage_ms = None
-    if world > 1:
+    if use_dist:
         from beat_amd import parallel
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -338,7 +341,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(spec)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
