@@ -8,17 +8,24 @@
 // (chain group, target, 64-sample tile) and every DISTINCT row segment is fetched from HBM once,
 // staged in LDS, and applied to all chains of the group that selected it:
 //
-//   lane  <-> chain (64 chains per wavefront, WAVES wavefronts share the staged rows)
+//   lane  <-> chain (64 chains per wavefront, WAVES <= 8 wavefronts share the staged rows)
 //   acc[] <-> the 64 samples of the tile, in registers with static indices (128 VGPRs)
-//   per patch: the group's distinct rows (k_gf_group_tables) are loaded 16 B/lane into LDS;
-//   each lane then reads ITS row from LDS (ds_read_b128, per-lane address: row pitch 66
-//   doubles keeps the 16-lane groups on distinct banks) and does 64 fp64 FMAs with its own
-//   weight.  No cross-lane traffic, no dynamic register indexing, no atomics.
+//   per (patch, slip variable) step: the group's distinct rows (k_gf_group_tables) are staged in
+//   LDS; each lane then reads ITS row from LDS (per-lane address) and does 64 fp64 FMAs with
+//   its own weight.  No cross-lane traffic, no dynamic register indexing, no atomics.
+//
+// Two kernels share this mapping:
+//   k_gfstack_dma     (shipped) rows by LDS-DMA into two LDS buffers one step ahead, one barrier
+//                     per step, hand-issued conflict-free ds_read_b64 (row pitch 65 doubles) or
+//                     ds_read_b128 (pitch 66); all global accesses of its loop are asm statements
+//   k_gfstack_shared  single LDS buffer filled through registers, two barriers per step; used
+//                     when two row buffers do not fit LDS, and as A/B (BEATAMD_GS_DMA=0)
 //
 // HBM bytes per batch drop from C x T x P x N x 8 to (distinct rows) x N x 8; the on-chip work
-// (LDS reads = algorithmic bytes, fp64 FMAs) is unchanged.  Per chain the patches and rows are
-// accumulated in the same order with the same fma() as in k_gfstack: for one slip variable the
-// two kernels produce bitwise identical synthetics (tests/test_gpu_parity.py).
+// (LDS reads = algorithmic bytes, fp64 FMAs) is unchanged: the LDS gather is what bounds these
+// kernels.  Per chain the patches and rows are accumulated in the same order with
+// the same fma() as in k_gfstack: for one slip variable all kernels produce bitwise identical
+// synthetics (tests/test_gpu_parity.py).
 #include <cstdlib>
 
 #include "kernels.hpp"
@@ -128,7 +135,6 @@ struct GsArgs {
     int64_t C, T, P, N;
     int CG, ucap, ustride, ntile, nt;
     int dma;  // 1: k_gfstack_dma (two LDS row buffers filled by LDS-DMA)
-    int pf;   // k_gfstack_dma: L2 warm-up distance in steps (0 = none)
     const uint32_t *urows, *ucount;
     const uint16_t *slot;
     const double *w;
@@ -388,13 +394,15 @@ __device__ __forceinline__ void lds_wait8_b64(double (&x)[8])
 //     (global_load_lds_dwordx4, 16 B per lane, no staging VGPRs, no ds_write pass) while the
 //     wavefronts run the LDS-gather + FMA phase of step s -- ONE barrier per step;
 //   * row ids (scalar) are fetched two steps ahead, the lane's slot/weight one step ahead.
-// hipcc does not count asm memory operations: the only vector loads it knows of are the table
-// loads, which are consumed at the top of the next step by the statement that also carries the
-// explicit `s_waitcnt vmcnt(0)` for the DMA -- at that point nothing else is in flight, so none
-// of its own (under-counting) vmcnt(N) can stall on a DMA.  The DMA statements are not volatile
-// (a volatile asm is a memory clobber for hipcc and would turn the scalar row-id loads into
-// waited vector loads); sched_barrier(0) pins them between the barrier and the FMA phase.
-template <int WAVES, int NROW, int MODE, int NT, int PFN, int B64>
+// hipcc does not count asm memory operations, and any vmcnt(N) it emits for loads it does know of
+// would under-count and stall on the DMAs: every global access of the loop is therefore an asm
+// statement (row DMAs, slot/weight loads), and the only vmcnt wait is the explicit one at the top
+// of a step, in the statement that also copies the freshly loaded slot/weight registers (hipcc
+// would otherwise copy them before the wait).  The statements are not volatile (a volatile asm is
+// a memory clobber for hipcc and turns the scalar row-id loads into waited vector loads);
+// sched_barrier(0) pins them between the barrier and the FMA phase, and the destination
+// registers of in-flight loads were checked in the ISA to be untouched until their wait.
+template <int WAVES, int NROW, int MODE, int NT, int B64>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_gfstack_dma(GsArgs a)
 {
@@ -403,8 +411,6 @@ k_gfstack_dma(GsArgs a)
     constexpr int LPR = NT / 2;         // lanes moving one row segment (16 B each)
     constexpr int KPRE = 8;             // row ids per wavefront fetched ahead (scalar registers)
     extern __shared__ __attribute__((aligned(16))) double xbuf[];  // [2][ucap][GS_PITCH]
-    // landing zone of the L2-prefetch DMAs (never read)
-    __shared__ __attribute__((aligned(16))) double pfdump[PFN > 0 ? WAVES : 1][128];
     constexpr int CG = WAVES * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -468,41 +474,6 @@ k_gfstack_dma(GsArgs a)
             }
         }
     };
-    // L2 warm-up of the rows of a later step: exactly PFN full-wave DMAs per wavefront and step
-    // (two row segments each, ids padded/clamped) into the dump zone.  The count is static so
-    // that the step-top wait can be `vmcnt(PFN)`: everything older -- the row DMAs and the table
-    // loads of the next step -- has landed, the warm-ups may still be in flight.
-    constexpr int PFR = PFN > 0 ? 2 * PFN : 1;   // row ids per wavefront
-    const int hsel = lane / LPR;
-    const bool pf_lane = (hsel < 2) && (n0 + (lane % LPR) * 2 < N);
-    const uint32_t pf_voff = (uint32_t)((n0 + (lane % LPR) * 2) * 8);
-    const uint32_t pf_dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)
-                                &pfdump[PFN > 0 ? wave : 0][0];
-    auto fetch_pids = [&](int p, uint32_t (&pid)[PFR]) {
-        const int64_t gtq = gt * a.P + p;
-        const uint32_t *uq = a.urows + gtq * a.ustride;
-        // rows wave*PFR .. wave*PFR+PFR-1, clamped into the padded id list
-#pragma unroll
-        for (int k = 0; k < PFR; k++) pid[k] = uq[min(wave * PFR + k, a.ustride - 1)];
-    };
-    auto issue_prefetch = [&](int iv, int s, const uint32_t (&pid)[PFR]) {
-        const double *Gv = a.G[iv];
-#pragma unroll
-        for (int k = 0; k < PFN; k++) {
-            const uint32_t r = hsel ? pid[2 * k + 1] : pid[2 * k];
-            const double *src = Gv + (int64_t)r * N;
-            uint32_t tok;
-            // every lane takes part (lanes past the tile re-read the row start): the count of
-            // DMA instructions must not depend on the exec mask
-            const uint32_t vo = pf_lane ? pf_voff : 0u;
-            asm("s_mov_b32 m0, %3\n\t"
-                "s_nop 0\n\t"
-                "global_load_lds_dwordx4 %1, off\n\t"
-                "s_mov_b32 %0, 0"
-                : "=s"(tok) : "v"(reinterpret_cast<const char *>(src) + vo), "s"(s), "s"(pf_dst));
-            keep |= tok;
-        }
-    };
     // the lane's slot and weight of step s: asm loads (hipcc must not count them, see above);
     // valid after the step-top wait statement, which names them
     uint32_t sl_n[NROW];
@@ -520,21 +491,15 @@ k_gfstack_dma(GsArgs a)
         }
     };
 
-    const int PD = a.pf;   // warm-up distance in steps
     int p1 = 0, iv1 = 0;          // step s+1
     advance(p1, iv1);
     int p2 = p1, iv2 = iv1;       // step s+2
     advance(p2, iv2);
-    int pw = 0, ivw = 0;          // warm-up target: step s+1+PD
-    if (PFN > 0) for (int i = 0; i < 1 + PD; i++) advance(pw, ivw);
     int U_a;
     uint32_t rid_a[KPRE];
-    uint32_t pid_a[PFR];
     fetch_ids(0, U_a, rid_a);
-    if (PFN > 0) fetch_pids(pw, pid_a);
     issue_rows(0, 0, 0, U_a, rid_a);
     fetch_tabs(0, 0);
-    if (PFN > 0) issue_prefetch(ivw, -1, pid_a);
     fetch_ids(p1, U_a, rid_a);
     for (int s = 0; s < nsteps; s++) {
         // the tables of this step and (older) the DMA of this step's rows have landed
@@ -545,21 +510,16 @@ k_gfstack_dma(GsArgs a)
         double wl[NROW];
 #pragma unroll
         for (int k = 0; k < NROW; k++)
-            asm("s_waitcnt vmcnt(%c4)\n\t"
+            asm("s_waitcnt vmcnt(0)\n\t"
                 "v_mov_b32 %0, %2\n\t"
                 "v_mov_b64 %1, %3"
-                : "=&v"(sl[k]), "=&v"(wl[k]) : "v"(sl_n[k]), "v"(wl_n[k]), "n"(PFN));
+                : "=&v"(sl[k]), "=&v"(wl[k]) : "v"(sl_n[k]), "v"(wl_n[k]));
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();  // rows of step s visible; everyone has left the FMA phase of step s-1
         __builtin_amdgcn_sched_barrier(0);
         {
             if (s + 1 < nsteps) issue_rows(p1, iv1, (s + 1) & 1, U_a, rid_a);   // -> other buffer
             fetch_tabs(p1, iv1);
-            if (PFN > 0) {
-                fetch_pids(pw, pid_a);
-                issue_prefetch(ivw, s, pid_a);
-                advance(pw, ivw);
-            }
             fetch_ids(p2, U_a, rid_a);
             p1 = p2; iv1 = iv2;
             advance(p2, iv2);
@@ -624,8 +584,6 @@ k_gfstack_dma(GsArgs a)
             }
         }
     }
-    // drain the warm-up DMAs before the epilogue reuses LDS / the kernel ends
-    asm volatile("s_waitcnt vmcnt(0)");
 
     // ---- epilogue: lane = chain c, acc[i] = synthetics[c, t, n0 + i]
     const bool live = (c < a.C) && (keep == 0);
@@ -671,9 +629,8 @@ k_gfstack_dma(GsArgs a)
 template <int WAVES, int NROW, int MODE>
 static void launch_shared_one(dim3 grid, size_t lds, hipStream_t s, const GsArgs &a)
 {
-    auto kern = (a.dma && a.pf > 0) ? k_gfstack_dma<WAVES, NROW, MODE, 64, 3, 0>
-              : (a.dma == 2) ? k_gfstack_dma<WAVES, NROW, MODE, 64, 0, 1>
-              : a.dma ? k_gfstack_dma<WAVES, NROW, MODE, 64, 0, 0>
+    auto kern = (a.dma == 2) ? k_gfstack_dma<WAVES, NROW, MODE, 64, 1>
+              : a.dma ? k_gfstack_dma<WAVES, NROW, MODE, 64, 0>
               : (a.nt == 48) ? k_gfstack_shared<WAVES, NROW, MODE, 48>
                              : k_gfstack_shared<WAVES, NROW, MODE, 64>;
     if (lds > 64 * 1024)
@@ -797,8 +754,6 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         a.dma = (a.nt == 64 && 2 * lds <= 158 * 1024 && !(e && atoi(e) == 0)) ? 1 : 0;
         if (a.dma && !(e && atoi(e) == 1)) a.dma = 2;   // ds_read_b64 / pitch NT+1 (default); 1 = b128 / pitch NT+2
         if (a.dma) lds *= 2;
-        const char *q = getenv("BEATAMD_GS_PF");
-        a.pf = q ? std::max(0, std::min(atoi(q), 16)) : 0;
     }
     {
         ScopedTimer tm(ctx, "gfstack");

@@ -159,3 +159,28 @@ def test_chain_block_partition():
         assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
         sizes = [b - a for a, b in blocks]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_isa_audit_of_hidden_asm_loads(tmp_path):
+    """k_gfstack_dma hides its slot/weight loads from hipcc; tools/audit_hidden_loads.py checks in
+    the generated ISA that their destination registers are not named before the covering wait.
+    The detector itself is checked on a synthetic hazard first."""
+    import importlib.util
+    import os
+    import shutil
+    spec = importlib.util.spec_from_file_location(
+        "audit_hidden_loads", os.path.join(os.path.dirname(__file__), "..", "tools", "audit_hidden_loads.py"))
+    aud = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(aud)
+    bad = [".LBB0_1:", "s_waitcnt vmcnt(0)", "s_barrier", "global_load_ushort v9, v[2:3], off",
+           "global_load_dwordx2 v[4:5], v[6:7], off", "v_fma_f64 v[10:11], v[12:13], v[14:15], v[10:11]",
+           "s_cbranch_scc1 .LBB0_1", "s_endpgm"]
+    n, problems = aud.audit(bad)
+    assert n == 2 and not problems
+    bad.insert(0, "v_mov_b32_e32 v20, v9")          # before the loop: not on the path
+    bad.insert(2, "v_mov_b64_e32 v[30:31], v[4:5]")  # at the loop header, before the wait
+    n, problems = aud.audit(bad)
+    assert len(problems) == 1 and "v[30:31]" in problems[0][3]
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    assert aud.main() == 0
