@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""ISA audit of k_gfstack_dma (beat_amd/csrc/gfshared.hip).
+"""ISA audit of k_gfstack_dma / k_gfstack_ws (beat_amd/csrc/gfshared.hip).
 
 The kernel hides its slot/weight loads from hipcc (asm `global_load_ushort` / `global_load_dwordx2`
 whose completion is awaited by a hand-placed `s_waitcnt vmcnt(0)` one step later).  hipcc treats
@@ -33,7 +33,7 @@ def vregs(text):
 def functions(lines):
     name, body = None, []
     for ln in lines:
-        m = re.match(r"^(_ZN7beatamd13k_gfstack_dma\w+):", ln)
+        m = re.match(r"^(_ZN7beatamd1[23]k_gfstack_(?:dma|ws)\w+):", ln)
         if m:
             name, body = m.group(1), []
             continue
@@ -52,8 +52,7 @@ def audit(body):
     labels = {ln[:-1]: i for i, ln in enumerate(body) if ln.endswith(":")}
     problems, nchecked = [], 0
     for i, ln in enumerate(body):
-        if not (ln.startswith("global_load_ushort") or
-                (ln.startswith("global_load_dwordx2") and ", off" in ln and "s[" not in ln)):
+        if not (ln.startswith("global_load_ushort") or ln.startswith("global_load_dwordx2")):
             continue
         dest = vregs(ln.split(",")[0])
         nchecked += 1
