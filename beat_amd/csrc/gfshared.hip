@@ -627,240 +627,6 @@ k_gfstack_dma(GsArgs a)
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// k_gfstack_ws: k_gfstack_dma with wave specialisation.  A workgroup is CW consumer wavefronts
-// (lane <-> chain, the accumulators, the LDS gather + FMA phase) plus LW loader wavefronts that
-// do nothing but issue the row DMAs, two steps ahead, into a ring of three LDS row buffers.
-// The consumers' step is then: wait for the slot/weight of the step, barrier, gather + FMA -- the
-// DMA issue phase (a quarter of k_gfstack_dma's time by ablation) runs beside it on the loaders.
-// One s_barrier per step, executed by every wavefront:
-//   loader   : barrier(s); wait until its DMAs of step s+1 have landed; issue its share of
-//              the rows of step s+2 into buffer (s+2) mod 3 (read last in step s-1)
-//   consumer : wait for its slot/weight of step s (asm loads, one step ahead); barrier(s);
-//              issue the loads of step s+1; gather + FMA from buffer s mod 3
-template <int CW, int LW, int NROW, int MODE>
-__global__ void __launch_bounds__((CW + LW) * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
-k_gfstack_ws(GsArgs a)
-{
-    constexpr int GS_NT = 64;
-    constexpr int GS_PITCH = GS_NT + 1;   // ds_read_b64 layout
-    constexpr int LPR = GS_NT / 2;        // lanes moving one row segment (16 B each)
-    constexpr int KPRE = 8;               // row ids per loader fetched with the step's count
-    extern __shared__ __attribute__((aligned(16))) double xbuf[];  // [3][ucap][GS_PITCH]
-    constexpr int CG = CW * 64;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x % a.ntile;
-    const int64_t gt = blockIdx.x / a.ntile;  // g*T + t
-    const int64_t t = gt % a.T;
-    const int64_t g = gt / a.T;
-    const int64_t N = a.N;
-    const int64_t n0 = (int64_t)tile * GS_NT;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)xbuf;
-    const int bufsz = a.ucap * GS_PITCH;                          // doubles per buffer
-    const int P = (int)a.P, nvar = a.nvar;
-    const int nsteps = P * nvar;
-    auto advance = [&](int &p, int &iv) {
-        if (++iv == nvar) { iv = 0; ++p; }
-        if (p >= P) { p = P - 1; iv = nvar - 1; }
-    };
-
-    double acc[GS_NT];
-#pragma unroll
-    for (int i = 0; i < GS_NT; i++) acc[i] = 0.0;
-    uint32_t keep = 0;  // results of the DMA statements (always 0): keeps them alive
-
-    if (wave >= CW) {
-        // ================================ loader ================================
-        const int lw = wave - CW;
-        const bool dma_lane = (lane < LPR) && (n0 + lane * 2 < N);   // N even (launcher)
-        const uint32_t voff = (uint32_t)((n0 + lane * 2) * 8);      // byte offset inside a row
-        const uint32_t rowbytes = (uint32_t)(N * 8);
-        auto dma_row = [&](const double *Gv, uint32_t r, int j, int buf) {
-            const uint64_t off = (uint64_t)r * (uint64_t)rowbytes;
-            const char *rowp = reinterpret_cast<const char *>(Gv) + off;
-            const uint32_t dst = lds0 + (uint32_t)((buf * bufsz + j * GS_PITCH) * 8);
-            uint32_t tok;
-            asm("s_mov_b32 m0, %3\n\t"
-                "s_nop 0\n\t"
-                "global_load_lds_dwordx4 %1, %2\n\t"
-                "s_mov_b32 %0, 0"
-                : "=s"(tok) : "v"(voff), "s"(rowp), "s"(dst));
-            keep |= tok;
-        };
-        auto issue_rows = [&](int p, int iv, int buf) {
-            const int64_t gtq = gt * a.P + p;
-            const int U = __builtin_amdgcn_readfirstlane((int)a.ucount[gtq]);
-            const uint32_t *uq = a.urows + gtq * a.ustride;
-            const double *Gv = a.G[iv];
-            uint32_t rid[KPRE];
-#pragma unroll
-            for (int k = 0; k < KPRE; k++) rid[k] = uq[lw + k * LW];   // padded: always in bounds
-            if (dma_lane) {
-#pragma unroll
-                for (int k = 0; k < KPRE; k++)
-                    if (lw + k * LW < U) dma_row(Gv, rid[k], lw + k * LW, buf);
-                for (int j = lw + KPRE * LW; j < U; j += LW) dma_row(Gv, uq[j], j, buf);
-            }
-        };
-        int pa = 0, iva = 0;
-        // (not volatile, with a dummy result fed into `keep`: a volatile asm is a memory clobber
-        // for hipcc and the row ids would no longer arrive by scalar loads)
-        auto wait_dma = [&](int tag) {
-            uint32_t tok;
-            asm("s_waitcnt vmcnt(0)\n\ts_mov_b32 %0, 0" : "=s"(tok) : "s"(tag));
-            keep |= tok;
-        };
-        issue_rows(0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        wait_dma(-1);
-        __builtin_amdgcn_sched_barrier(0);
-        advance(pa, iva);
-        if (nsteps > 1) issue_rows(pa, iva, 1);
-        advance(pa, iva);                 // step 2
-        int bnext = 2;                    // buffer of step s+2
-        for (int s = 0; s < nsteps; s++) {
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();   // rows of step s are published (waited one iteration ago)
-            __builtin_amdgcn_sched_barrier(0);
-            wait_dma(s);   // this loader's rows of step s+1 have landed
-            __builtin_amdgcn_sched_barrier(0);
-            if (s + 2 < nsteps) {
-                issue_rows(pa, iva, bnext);
-                advance(pa, iva);
-                bnext = bnext == 2 ? 0 : bnext + 1;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        wait_dma(nsteps);
-    } else {
-        // ================================ consumer ================================
-        uint32_t sl_n[NROW];
-        double wl_n[NROW];
-        // (scalar base + 32-bit lane offset: no 64-bit pointers in VGPRs)
-        const uint32_t voff_s = (uint32_t)tid * 2u, voff_w = (uint32_t)tid * 8u;
-        auto fetch_tabs = [&](int p, int iv) {
-            const int64_t gtq = gt * a.P + p;
-#pragma unroll
-            for (int k = 0; k < NROW; k++) {
-                const uint16_t *ps = a.slot + (gtq * NROW + k) * CG;
-                const double *pw = (NROW == 1)
-                    ? a.w + (int64_t)iv * a.w_var_stride + (g * a.P + p) * CG
-                    : a.w + (int64_t)iv * a.w_var_stride + (gtq * 4 + k) * CG;
-                asm("global_load_ushort %0, %1, %2" : "=v"(sl_n[k]) : "v"(voff_s), "s"(ps));
-                asm("global_load_dwordx2 %0, %1, %2" : "=v"(wl_n[k]) : "v"(voff_w), "s"(pw));
-            }
-        };
-        int p1 = 0, iv1 = 0;          // step s+1
-        advance(p1, iv1);
-        int bcur = 0;
-        fetch_tabs(0, 0);
-        for (int s = 0; s < nsteps; s++) {
-            __builtin_amdgcn_sched_barrier(0);
-            uint32_t sl[NROW];
-            double wl[NROW];
-#pragma unroll
-            for (int k = 0; k < NROW; k++)
-                asm("s_waitcnt vmcnt(0)\n\t"
-                    "v_mov_b32 %0, %2\n\t"
-                    "v_mov_b64 %1, %3"
-                    : "=&v"(sl[k]), "=&v"(wl[k]) : "v"(sl_n[k]), "v"(wl_n[k]));
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();   // rows of step s visible; buffer (s+2) mod 3 is free
-            __builtin_amdgcn_sched_barrier(0);
-            fetch_tabs(p1, iv1);
-            advance(p1, iv1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < NROW; k++) {
-                const uint32_t xs = lds0 + (uint32_t)((bcur * bufsz + (int)sl[k] * GS_PITCH) * 8);
-                const double w = wl[k];
-                constexpr int NG8 = GS_NT / 8;
-                double ya[8], yb[8];
-                lds_rd8_b64<0>(ya, xs, s);
-                lds_rd8_b64<64>(yb, xs, s);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int gq = 0; gq < NG8; gq++) {
-                    double(&cur)[8] = (gq & 1) ? yb : ya;
-                    if (gq + 1 < NG8) lds_wait8_b64<8>(cur); else lds_wait8_b64<0>(cur);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int q = 0; q < 8; q++) acc[gq * 8 + q] = fma(cur[q], w, acc[gq * 8 + q]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    switch (gq + 2) {
-                    case 2: lds_rd8_b64<128>(cur, xs, s); break;
-                    case 3: lds_rd8_b64<192>(cur, xs, s); break;
-                    case 4: lds_rd8_b64<256>(cur, xs, s); break;
-                    case 5: lds_rd8_b64<320>(cur, xs, s); break;
-                    case 6: lds_rd8_b64<384>(cur, xs, s); break;
-                    case 7: lds_rd8_b64<448>(cur, xs, s); break;
-                    default: break;
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            bcur = bcur == 2 ? 0 : bcur + 1;
-        }
-        {   // the clamped table loads issued in the last step
-            uint32_t tok;
-            asm("s_waitcnt vmcnt(0)\n\ts_mov_b32 %0, 0" : "=s"(tok) : "s"(nsteps));
-            keep |= tok;
-        }
-    }
-
-    // ---- epilogue (loaders only take part in the barriers): lane = chain c
-    const int64_t c = g * CG + tid;
-    const bool live = (wave < CW) && (c < a.C) && (keep == 0);
-    const int nvalid = (int)min((int64_t)GS_NT, N - n0);
-    if (MODE == GF_STORE_SYN) {
-        if (live) {
-            double *o = a.out + (c * a.T + t) * N + n0;
-#pragma unroll
-            for (int i = 0; i < GS_NT; i++)
-                if (i < nvalid) o[i] = acc[i];
-        }
-        return;
-    }
-    __syncthreads();
-    if (tid < GS_NT) xbuf[tid] = (tid < nvalid) ? a.data[t * N + n0 + tid] : 0.0;
-    __syncthreads();
-    if (MODE == GF_RESID_STORE) {
-        double *o = a.out + (c * a.T + t) * N + n0;
-#pragma unroll
-        for (int i0 = 0; i0 < GS_NT; i0 += 8) {
-#pragma unroll
-            for (int i = i0; i < i0 + 8; i++)
-                if (live && i < nvalid) o[i] = xbuf[i] - acc[i];  // seismic.py:1332
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else {
-        const double w = a.wscalar[t];
-        double q = 0.0;
-#pragma unroll
-        for (int i0 = 0; i0 < GS_NT; i0 += 8) {
-#pragma unroll
-            for (int i = i0; i < i0 + 8; i++)
-                if (i < nvalid) {
-                    const double tt = w * (xbuf[i] - acc[i]);
-                    q = fma(tt, tt, q);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (live) a.partial[(c * a.T + t) * a.ntile + tile] = q;
-    }
-}
-
-template <int NROW>
-static void launch_ws_mode(int mode, dim3 grid, size_t lds, hipStream_t s, const GsArgs &a)
-{
-    auto kern = (mode == GF_STORE_SYN) ? k_gfstack_ws<8, 4, NROW, GF_STORE_SYN>
-              : (mode == GF_RESID_SCALAR) ? k_gfstack_ws<8, 4, NROW, GF_RESID_SCALAR>
-                                          : k_gfstack_ws<8, 4, NROW, GF_RESID_STORE>;
-    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, grid, dim3(12 * 64), lds, s, a);
-}
-
 template <int WAVES, int NROW, int MODE>
 static void launch_shared_one(dim3 grid, size_t lds, hipStream_t s, const GsArgs &a)
 {
@@ -987,26 +753,12 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         // two row buffers when they fit (BEATAMD_GS_DMA=0 forces the single-buffer kernel)
         const char *e = getenv("BEATAMD_GS_DMA");
         a.dma = (a.nt == 64 && 2 * lds <= 158 * 1024 && !(e && atoi(e) == 0)) ? 1 : 0;
-        if (a.dma && !(e && atoi(e) == 1)) a.dma = 2;   // (4 = wave-specialised, below)   // ds_read_b64 / pitch NT+1 (default); 1 = b128 / pitch NT+2
+        if (a.dma && !(e && atoi(e) == 1)) a.dma = 2;   // ds_read_b64 / pitch NT+1 (default); 1 = b128 / pitch NT+2
         if (a.dma) lds *= 2;
-    }
-    // wave-specialised kernel: 512-chain groups, three row buffers (BEATAMD_GS_DMA=4 only for now)
-    bool ws = false;
-    {
-        const char *e = getenv("BEATAMD_GS_DMA");
-        const size_t lds3 = (size_t)3 * ucap * (a.nt + 1) * sizeof(double);
-        // (nearest-neighbour only: the multilinear instance does not fit 168 VGPRs, hipcc spills
-        // around the in-flight asm loads -- tools/audit_hidden_loads.py flags it)
-        if (CG == 512 && nrow == 1 && a.dma == 2 && lds3 <= 158 * 1024 && e && atoi(e) == 4) {
-            ws = true;
-            lds = lds3;
-        }
     }
     {
         ScopedTimer tm(ctx, "gfstack");
         dim3 grid((unsigned)nblocks);
-        if (ws) launch_ws_mode<1>(k.mode, grid, lds, ctx->stream, a);
-        else
         if (CG == 512) launch_shared_nrow<8>(nrow, k.mode, grid, lds, ctx->stream, a);
         else if (CG == 256) launch_shared_nrow<4>(nrow, k.mode, grid, lds, ctx->stream, a);
         else if (CG == 128) launch_shared_nrow<2>(nrow, k.mode, grid, lds, ctx->stream, a);

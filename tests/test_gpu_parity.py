@@ -170,7 +170,7 @@ def test_shared_row_kernel_equals_streaming_kernel(ctx, orc, monkeypatch, C, int
         assert np.abs(b[c] - ref).max() <= 1e-11 * np.abs(ref).max()
     for cg in ("64", "128", "256", "512"):
         monkeypatch.setenv("BEATAMD_GS_CG", cg)
-        for dma in ("4", "2", "1", "0"):
+        for dma in ("2", "1", "0"):
             monkeypatch.setenv("BEATAMD_GS_DMA", dma)
             assert np.array_equal(gf.stack_all_batch(dur, st, sl, interpolation=interp), a), (cg, dma)
 
