@@ -196,6 +196,29 @@ def test_fused_model_with_shared_row_kernel(ctx, monkeypatch, name):
         np.testing.assert_allclose(B[c], ref, rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("name", ["seis_dense_ml_shifts", "joint_multifault", "seis_scalar_nn"])
+def test_fused_model_512_chain_groups(ctx, monkeypatch, name):
+    """the fused log-likelihood with 530 chains: 512-chain workgroups of k_gfstack_dma (two slip
+    variables, multilinear, station shifts, dense/scalar misfit epilogues) against the streaming
+    kernel and sampled chains against the oracle"""
+    from beat_amd.synthetic import build_problem, draw_population
+    from oracle import problem_oracle
+    spec = _specs()[name]
+    prob, host = build_problem(spec)
+    f = prob.compile(ctx)
+    Q = draw_population(spec, host["layout"], host["lower"], host["upper"], 530)
+    monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
+    A = f.batch(Q)
+    monkeypatch.setenv("BEATAMD_GF_KERNEL", "1")
+    monkeypatch.setenv("BEATAMD_GS_CG", "512")
+    B = f.batch(Q)
+    np.testing.assert_allclose(A, B, rtol=1e-11, atol=1e-9)
+    for c in (0, 511, 512, 529):
+        ref, _ = problem_oracle.forward(host, Q[c])
+        np.testing.assert_allclose(B[c], ref, rtol=RTOL)
+        np.testing.assert_allclose(B[c], ref, rtol=1e-9, atol=1e-9)
+
+
 def test_stack_closed_form_and_linearity(ctx):
     """reference test/test_ffi.py:22-89 recipe: out[t,n] = t*n*sum(slips); plus linearity"""
     T, P, D, S, N = 30, 40, 11, 31, 10
