@@ -138,3 +138,26 @@ def test_weights_update_and_reuse(ctx, orc):
     for c in range(5):
         ref, _ = problem_oracle.forward(host, Q[c])
         np.testing.assert_allclose(b[c], ref, rtol=1e-9)
+
+
+@pytest.mark.parametrize("D,S,C,interp", [(12, 20, 300, "multilinear"), (12, 20, 300, "nearest_neighbor"),
+                                          (40, 64, 130, "multilinear"), (3, 11, 600, "nearest_neighbor")])
+def test_kernel_selection_by_lds_capacity(ctx, orc, monkeypatch, D, S, C, interp):
+    """libraries with many (duration, start-time) rows: the chain-shared kernels are chosen by
+    what fits LDS (two row buffers -> k_gfstack_dma, one -> k_gfstack_shared, none -> the
+    streaming kernel); every choice gives the streaming kernel's bits and the oracle's values"""
+    T, P, N = 2, 5, 64
+    rng = np.random.default_rng(D * S + C)
+    G = rng.standard_normal((T, P, D, S, N))
+    gf = _lib(ctx, G)
+    dur = 0.5 + 0.5 * rng.uniform(0, D - 1, (C, P))
+    st = 0.5 * rng.uniform(0, S - 1, (C, T, P))
+    sl = rng.uniform(-2, 2, (C, P))
+    monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
+    a = gf.stack_all_batch(dur, st, sl, interpolation=interp)
+    monkeypatch.delenv("BEATAMD_GF_KERNEL")
+    b = gf.stack_all_batch(dur, st, sl, interpolation=interp)   # default selection
+    assert np.array_equal(a, b)
+    for c in (0, C // 3, C - 1):
+        ref = orc.stack_all(G, dur[c], st[c], sl[c], 0.5, 0.5, 0.0, 0.5, interp)
+        np.testing.assert_allclose(b[c], ref, rtol=1e-11, atol=1e-12)
