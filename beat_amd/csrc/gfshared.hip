@@ -43,6 +43,7 @@ struct GroupTabArgs {
     int ucap, ustride;
     uint32_t *urows;   // [(g*T+t)*P+p][ustride], padded with the last id
     uint32_t *ucount;  // [(g*T+t)*P+p]
+    uint32_t *umax;    // max over ucount (atomicMax; zeroed by the launcher)
     uint16_t *slot;    // [((g*T+t)*P+p)*nrow + k][CG]
     double *w;         // nn: [v][(g*P+p)][CG]   ml: [v][((g*T+t)*P+p)*4 + k][CG]
     int64_t w_var_stride;
@@ -100,6 +101,7 @@ __global__ void k_gf_group_tables(GroupTabArgs a)
         }
         if (tid == 0) {
             a.ucount[gtp] = run;
+            atomicMax(a.umax, run);
             wsum[CG] = run;
         }
     }
@@ -656,15 +658,22 @@ static void launch_shared_nrow(int nrow, int mode, dim3 grid, size_t lds, hipStr
     else launch_shared_mode<WAVES, 4>(mode, grid, lds, s, a);
 }
 
-// chains per group for a batch of C chains: the largest of {512,256,128,64} wasting < 15 % lanes
+// chains per group for a batch of C chains: the group size that minimises
+// (number of groups) x (cost of one group's launch share).  Relative costs measured on config 3
+// (ms per single-group launch: 64 chains 2.4, 128 2.9, 256 3.6, 512 6.2): a larger group is much
+// cheaper per chain (the distinct rows are staged once for more lanes), so padding a batch up to
+// the next size usually beats splitting it (192 chains: one 256-group 3.6 ms, three 64-groups 6.9 ms).
 static int pick_group(int64_t C)
 {
     const int cand[4] = {512, 256, 128, 64};
+    const double cost[4] = {2.55, 1.5, 1.2, 1.0};
+    int best = 64;
+    double bestc = 1e300;
     for (int i = 0; i < 4; i++) {
-        const int64_t padded = (C + cand[i] - 1) / cand[i] * cand[i];
-        if (padded * 100 <= C * 115) return cand[i];
+        const double c = (double)((C + cand[i] - 1) / cand[i]) * cost[i];
+        if (c < bestc - 1e-12) { bestc = c; best = cand[i]; }
     }
-    return 64;
+    return best;
 }
 
 bool gfstack_shared_applicable(const GfStackCall &k, int *cg_out, int *ucap_out)
@@ -720,6 +729,9 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     ga.w_var_stride = (nrow == 1) ? ngroups * L.P * CG : GTP * 4 * CG;
     BA_TRY(ctx->get_scratch(SL_GS_W, (size_t)ga.w_var_stride * k.nvar * sizeof(double), &p));
     ga.w = (double *)p;
+    BA_TRY(ctx->get_scratch(SL_GS_UMAX, sizeof(uint32_t), &p));
+    ga.umax = (uint32_t *)p;
+    BA_HIP(hipMemsetAsync(ga.umax, 0, sizeof(uint32_t), ctx->stream));
     {
         ScopedTimer tm(ctx, "grouptables");
         const size_t lds = (size_t)(ga.DS + CG + 1) * sizeof(uint32_t);
@@ -748,6 +760,20 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     }
     const int64_t nblocks = ngroups * L.T * a.ntile;
     BA_CHECK(nblocks < (int64_t)0x7fffffff, BEATAMD_EINVAL, "gfstack: batch too large");
+    // Small chain groups (1-2 wavefronts per workgroup) reach the 2 waves/SIMD the kernels are
+    // built for only if several workgroups fit a CU's LDS: size the row buffers by the largest
+    // distinct-row count that actually occurs in this batch instead of the bound min(chains*rows,
+    // D*S).  Costs one 4-byte read-back (a stream synchronisation) per launch; skipped for the
+    // large groups, whose occupancy is register-bound anyway.
+    if (CG <= 128 && !(getenv("BEATAMD_GS_FIT") && atoi(getenv("BEATAMD_GS_FIT")) == 0)) {
+        uint32_t umax = 0;
+        BA_HIP(hipMemcpyAsync(&umax, ga.umax, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        BA_HIP(hipStreamSynchronize(ctx->stream));
+        BA_CHECK((int)umax <= ucap, BEATAMD_EINVAL, "gfstack: distinct-row count %u exceeds its bound %d",
+                 umax, ucap);
+        ucap = std::max<int>((int)umax, 2);
+        a.ucap = ucap;
+    }
     size_t lds = (size_t)ucap * (a.nt + 2) * sizeof(double);
     {
         // two row buffers when they fit (BEATAMD_GS_DMA=0 forces the single-buffer kernel)
