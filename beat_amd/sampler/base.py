@@ -124,12 +124,13 @@ def metrop_select(mr, q, q0):
 
 
 class DeviceMvNormalProposal(object):
-    """MultivariateNormal proposal rows generated on the GPU (replaces the per-chain
+    """MultivariateNormal (df = inf) / MultivariateCauchy (df = 1) proposal rows generated on the GPU (replaces the per-chain
     ``proposal_dist(n_steps)`` host draws of metropolis.py:289-292): rows = z @ chol(cov).T.
     torch is plumbing here (RNG + one library GEMM per step)."""
 
-    def __init__(self, cov, device, seed=0):
+    def __init__(self, cov, device, seed=0, df=np.inf):
         import torch
+        self.df = float(df)   # inf: MultivariateNormal; 1: MultivariateCauchy (base.py:163-186)
         covd = torch.as_tensor(np.atleast_2d(np.asarray(cov, dtype=np.float64))).to(device)
         # factor on the device; a population smaller than the parameter count gives a singular
         # sample covariance: repair it like utility.repair_covariance (eigenvalues clipped at
@@ -148,7 +149,16 @@ class DeviceMvNormalProposal(object):
         import torch
         z = torch.randn((n_chains, self.LT.shape[0]), generator=self.gen, device=self.device,
                         dtype=torch.float64)
-        return z @ self.LT
+        rows = z @ self.LT
+        if np.isfinite(self.df):
+            # multivariate_t_rvs (base.py:35-71): z / sqrt(chi2(df) / df), one draw per row
+            k = int(self.df)
+            if k != self.df or k < 1:
+                raise ValueError("degrees of freedom must be a positive integer")
+            g = torch.randn((n_chains, k), generator=self.gen, device=self.device, dtype=torch.float64)
+            x = (g * g).sum(1) / self.df
+            rows = rows / torch.sqrt(x)[:, None]
+        return rows
 
     def log_uniform(self, n_chains):
         import torch

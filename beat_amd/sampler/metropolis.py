@@ -107,8 +107,11 @@ class BatchedMetropolis(object):
         self._acc = torch.zeros(self.n_chains, dtype=torch.int32, device=self.device)
         self.seed = seed
 
-    def set_proposal(self, cov):
-        self.proposal = DeviceMvNormalProposal(cov, self.device, seed=self.seed + 7919 * (1 + self.n_steps_total))
+    def set_proposal(self, cov, proposal_name="MultivariateNormal"):
+        if proposal_name not in multivariate_proposals:
+            raise NotImplementedError("device proposals: %s" % ", ".join(multivariate_proposals))
+        self.proposal = DeviceMvNormalProposal(cov, self.device, seed=self.seed + 7919 * (1 + self.n_steps_total),
+                                               df=1 if proposal_name == "MultivariateCauchy" else np.inf)
 
     def evaluate(self, Q):
         """stage 0 (metropolis.py:277-286): one evaluation, no move; NaN -> ValueError"""

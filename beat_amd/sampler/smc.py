@@ -33,8 +33,8 @@ class SMC(object):
     def __init__(self, target, lower, upper, n_chains=100, tune=True, tune_interval=100,
                  coef_variation=1.0, check_bound=True, proposal_name="MultivariateNormal",
                  device=None, random_seed=42, scale=1.0):
-        if proposal_name != "MultivariateNormal":
-            raise NotImplementedError("the GPU SMC uses the MultivariateNormal proposal")
+        if proposal_name not in ("MultivariateNormal", "MultivariateCauchy"):
+            raise NotImplementedError("the GPU SMC uses the MultivariateNormal / MultivariateCauchy proposals")
         if not check_bound:
             raise NotImplementedError("check_bound=False is not supported")
         self.target = target
@@ -201,7 +201,7 @@ def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, 
             step.beta = 1.0
             break
         step.covariance = step.calc_covariance(repair=False)
-        step.stepper.set_proposal(step.covariance)
+        step.stepper.set_proposal(step.covariance, step.proposal_name)
         step.resampling_indexes = step.resample()
         step.stage += 1
         logger.info("Beta: %f Stage: %i", step.beta, step.stage)
@@ -217,7 +217,7 @@ def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, 
     temp = np.exp((1 - step.old_beta) * (step.likelihoods - step.likelihoods.max()))
     step.weights = temp / np.sum(temp)
     step.covariance = step.calc_covariance(repair=False)
-    step.stepper.set_proposal(step.covariance)
+    step.stepper.set_proposal(step.covariance, step.proposal_name)
     step.resampling_indexes = step.resample()
     step.beta = 1.0
     Q, L = step.sample_stage(n_steps * sample_factor_final_stage)

@@ -2,6 +2,7 @@
 test/test_smc.py (two-Gaussian mixture, mean |x| = 0.5 +- 0.03) and the decision rules of
 metropolis.py / pt.py pinned through the oracle."""
 import numpy as np
+import pytest
 
 from conftest import load_golden
 
@@ -172,3 +173,31 @@ def test_smc_stage_traces_and_resume(tmp_path):
     pop2, lp2, betas2 = smc_sample(20, step2, homepath=str(tmp_path), layout=None, resume_stage=1)
     assert betas2[0] == betas[1] and betas2[-1] == 1.0 and pop2.shape == pop.shape
     assert nstage >= 2
+
+
+def test_device_proposals_normal_and_cauchy_statistics():
+    """DeviceMvNormalProposal on the torch CPU device (the same code draws on the GPU): rows have the
+    requested covariance (MultivariateNormal), resp. are multivariate t with one degree of
+    freedom (MultivariateCauchy, base.py:35-71,163-186: z / sqrt(chi2(1)))"""
+    import torch
+    from beat_amd.sampler.base import DeviceMvNormalProposal
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((4, 4))
+    cov = A @ A.T + 0.5 * np.eye(4)
+    pn = DeviceMvNormalProposal(cov, torch.device("cpu"), seed=5)
+    x = pn(200000).numpy()
+    np.testing.assert_allclose(np.cov(x.T), cov, rtol=0.03, atol=0.03)
+    pc = DeviceMvNormalProposal(cov, torch.device("cpu"), seed=6, df=1)
+    y = pc(200000).numpy()
+    # marginals of a multivariate Cauchy are Cauchy with scale sqrt(cov_ii): median |y_i| = scale
+    np.testing.assert_allclose(np.median(np.abs(y), axis=0), np.sqrt(np.diag(cov)), rtol=0.03)
+    # heavy tails: P(|y| > 10 scale) = 1 - 2/pi atan(10) = 0.0635
+    frac = (np.abs(y[:, 0]) > 10 * np.sqrt(cov[0, 0])).mean()
+    assert abs(frac - 0.0635) < 0.004
+    # a singular covariance (population smaller than the parameter count) is repaired, not rejected
+    B = rng.standard_normal((6, 2))
+    ps = DeviceMvNormalProposal(B @ B.T, torch.device("cpu"), seed=1)
+    z = ps(50000).numpy()
+    np.testing.assert_allclose(np.cov(z.T), B @ B.T, rtol=0.05, atol=0.05)
+    with pytest.raises(ValueError):
+        DeviceMvNormalProposal(cov, torch.device("cpu"), df=0.5)(3)
