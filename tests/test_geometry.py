@@ -151,3 +151,35 @@ def test_geometry_config2_smc_1024_chains():
     assert pop.shape == (1024, lay.size) and np.isfinite(lp).all()
     np.testing.assert_allclose(f.batch(np.ascontiguousarray(pop[:64])), lp[:64], rtol=1e-12)
     assert lp[:, -1].mean() > f.batch(lo + (up - lo) * rng.random((256, lay.size)))[:, -1].mean()
+
+
+@pytest.mark.gpu
+def test_geometry_special_points_match_oracle():
+    """observation points on the fault trace, above the corners and on the strike line; vertical
+    and nearly horizontal faults; a surface-breaking fault: kernel and oracle agree, including
+    where Okada's expressions are singular (both NaN/inf or both finite, never one of each)"""
+    import beat_amd
+    from beat_amd.models import GeodeticGeometryProblem, ParameterLayout
+    ctx = beat_amd.get_context(0)
+    xs = np.array([-6.0, -3.0, -1.5, 0.0, 1.5, 3.0, 6.0])
+    east, north = [a.ravel() for a in np.meshgrid(xs, xs)]
+    nobs = east.size
+    los = np.tile(np.array([[0.3, -0.5, 0.81]]), (nobs, 1))
+    lay = ParameterLayout(OrderedDict([("depth", 1), ("dip", 1), ("strike", 1), ("slip", 1), ("h_SAR", 1)]))
+    prob = GeodeticGeometryProblem(lay, ["rectangular"], east, north, los, np.zeros(nobs), np.ones(nobs), (nobs,),
+                                   [1.0], [0.0], [("h_SAR", 0)],
+                                   fixed=dict(east_shift=0.0, north_shift=0.0, rake=45.0, length=6.0, width=3.0,
+                                              opening_fraction=0.2))
+    f = prob.compile(ctx)
+    cases = np.array([[1.0, 90.0, 0.0, 1.0, 0.0],      # vertical, striking north through grid points
+                      [0.0, 45.0, 90.0, 1.0, 0.0],     # surface breaking, striking east
+                      [2.0, 1e-3, 30.0, 0.5, 0.0],     # nearly horizontal
+                      [1.5, 89.999, 180.0, 2.0, 0.5],
+                      [0.5, 30.0, 270.0, 1.0, -0.5]])
+    LL = f.batch(cases)
+    for i, q in enumerate(cases):
+        ref = _oracle_forward(prob, lay, q)
+        both_bad = ~np.isfinite(ref) & ~np.isfinite(LL[i])
+        ok = np.isfinite(ref) & np.isfinite(LL[i])
+        assert (both_bad | ok).all(), (i, ref, LL[i])
+        np.testing.assert_allclose(LL[i][ok], ref[ok], rtol=1e-8)
