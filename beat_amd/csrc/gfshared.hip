@@ -101,7 +101,8 @@ __global__ void k_gf_group_tables(GroupTabArgs a)
         }
         if (tid == 0) {
             a.ucount[gtp] = run;
-            atomicMax(a.umax, run);
+            // (only needed for small groups; a plain read first keeps 25k workgroups off one atomic)
+            if (a.umax && run > *(volatile uint32_t *)a.umax) atomicMax(a.umax, run);
             wsum[CG] = run;
         }
     }
@@ -729,9 +730,13 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     ga.w_var_stride = (nrow == 1) ? ngroups * L.P * CG : GTP * 4 * CG;
     BA_TRY(ctx->get_scratch(SL_GS_W, (size_t)ga.w_var_stride * k.nvar * sizeof(double), &p));
     ga.w = (double *)p;
-    BA_TRY(ctx->get_scratch(SL_GS_UMAX, sizeof(uint32_t), &p));
-    ga.umax = (uint32_t *)p;
-    BA_HIP(hipMemsetAsync(ga.umax, 0, sizeof(uint32_t), ctx->stream));
+    const bool fit_lds = CG <= 128 && !(getenv("BEATAMD_GS_FIT") && atoi(getenv("BEATAMD_GS_FIT")) == 0);
+    ga.umax = nullptr;
+    if (fit_lds) {
+        BA_TRY(ctx->get_scratch(SL_GS_UMAX, sizeof(uint32_t), &p));
+        ga.umax = (uint32_t *)p;
+        BA_HIP(hipMemsetAsync(ga.umax, 0, sizeof(uint32_t), ctx->stream));
+    }
     {
         ScopedTimer tm(ctx, "grouptables");
         const size_t lds = (size_t)(ga.DS + CG + 1) * sizeof(uint32_t);
@@ -765,7 +770,7 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     // distinct-row count that actually occurs in this batch instead of the bound min(chains*rows,
     // D*S).  Costs one 4-byte read-back (a stream synchronisation) per launch; skipped for the
     // large groups, whose occupancy is register-bound anyway.
-    if (CG <= 128 && !(getenv("BEATAMD_GS_FIT") && atoi(getenv("BEATAMD_GS_FIT")) == 0)) {
+    if (fit_lds) {
         uint32_t umax = 0;
         BA_HIP(hipMemcpyAsync(&umax, ga.umax, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         BA_HIP(hipStreamSynchronize(ctx->stream));

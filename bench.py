@@ -279,6 +279,7 @@ def main():
                                              "finish", "astep")}
     if rank == 0:
         alg = algorithmic_bytes_per_chain_step(spec) * B  # per launch
+        rows_per_patch = 4 if spec.interpolation == "multilinear" else 1
         avg_ms = gf_ms / max(gf_n, 1)
         achieved = alg / (avg_ms * 1e-3) / 1e9 if gf_n else 0.0
         out = {
@@ -319,6 +320,17 @@ def main():
                 "algorithmic_bytes_per_launch": alg,
                 "avg_launch_ms": avg_ms,
                 "launches": gf_n,
+                # frac > 1 on the chain-shared kernels: `achieved` credits no cross-chain reuse
+                #  while rows shared by chains are fetched once (`traffic`).  What
+                # binds those kernels is the per-lane LDS gather: one 8-byte LDS operand per FMA.
+                "lds_gather": {
+                    "bytes_per_launch": float(B) * spec.T * spec.P * spec.N * 8 * rows_per_patch,
+                    "floor_ms": float(B) * spec.T * spec.P * spec.N * 8 * rows_per_patch
+                                / (256.0 * 256 * 2.4e9) * 1e3,
+                    "ceiling_ms_measured": 3.53 * (float(B) * spec.T * spec.P * spec.N * rows_per_patch)
+                                           / (512.0 * 64 * 400 * 4096),
+                    "source": "tools/micro/ldsgather.hip (profiles/r1_variants.md)",
+                },
             },
             "kernel_ms_per_step": {k: (v[0] / K) for k, v in times.items() if v[1]},
             "accept_rate_last_step": n_acc / float(B),
