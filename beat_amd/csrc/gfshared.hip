@@ -412,7 +412,9 @@ k_gfstack_dma(GsArgs a)
     constexpr int GS_NT = NT;
     constexpr int GS_PITCH = B64 ? NT + 1 : NT + 2;
     constexpr int LPR = NT / 2;         // lanes moving one row segment (16 B each)
-    constexpr int KPRE = 8;             // row ids per wavefront fetched ahead (scalar registers)
+    // row ids per wavefront fetched ahead (scalar registers): 32 rows per workgroup and step are
+    // covered by the unrolled DMA slots, more (rare) go through a loop
+    constexpr int KPRE = WAVES >= 4 ? 32 / WAVES : 8;
     extern __shared__ __attribute__((aligned(16))) double xbuf[];  // [2][ucap][GS_PITCH]
     constexpr int CG = WAVES * 64;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -465,8 +467,11 @@ k_gfstack_dma(GsArgs a)
 #pragma unroll
         for (int k = 0; k < KPRE; k++) rid[k] = uq[k * WAVES];   // padded: always in bounds
     };
+    // (library base pointers in registers: indexing a.G[] by a run-time iv is a kernarg load with
+    // its latency in front of every step's DMAs)
+    const double *const G0 = a.G[0], *const G1 = a.G[1], *const G2 = a.G[2], *const G3 = a.G[3];
     auto issue_rows = [&](int p, int iv, int buf, int U, const uint32_t (&rid)[KPRE]) {
-        const double *Gv = a.G[iv];
+        const double *Gv = iv == 0 ? G0 : iv == 1 ? G1 : iv == 2 ? G2 : G3;
         if (dma_lane) {
 #pragma unroll
             for (int k = 0; k < KPRE; k++)
