@@ -145,6 +145,29 @@ class DeviceMvNormalProposal(object):
         self.gen.manual_seed(int(seed))
         self.device = device
 
+    @classmethod
+    def from_population(cls, population, weights, device, seed=0, df=np.inf):
+        """Proposal with the weighted sample covariance of ``population`` (n, nparams) --
+        ``np.cov(population, aweights=weights, bias=False, rowvar=0)`` as in SMC.calc_covariance
+        (smc.py:167-186) -- WITHOUT forming or factoring it: with
+        X_c = sqrt(w / (1 - sum w^2)) (x - weighted mean), rows = z @ X_c (z of n standard normals)
+        have exactly that covariance.  For populations smaller than the parameter count the
+        sample covariance is singular and the factorisation route ends in an eigendecomposition
+        per stage (tens of ms for 1200 parameters); this route is one GEMM per step either way."""
+        import torch
+        self = cls.__new__(cls)
+        self.df = float(df)
+        X = torch.as_tensor(np.asarray(population, dtype=np.float64)).to(device)
+        w = torch.as_tensor(np.asarray(weights, dtype=np.float64).ravel()).to(device)
+        w = w / w.sum()
+        mean = (w[:, None] * X).sum(0)
+        fact = torch.sqrt(w / (1.0 - (w * w).sum()))
+        self.LT = (fact[:, None] * (X - mean)).contiguous()      # (n, nparams)
+        self.gen = torch.Generator(device=device)
+        self.gen.manual_seed(int(seed))
+        self.device = device
+        return self
+
     def __call__(self, n_chains):
         import torch
         z = torch.randn((n_chains, self.LT.shape[0]), generator=self.gen, device=self.device,

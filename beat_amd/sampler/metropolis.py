@@ -113,6 +113,15 @@ class BatchedMetropolis(object):
         self.proposal = DeviceMvNormalProposal(cov, self.device, seed=self.seed + 7919 * (1 + self.n_steps_total),
                                                df=1 if proposal_name == "MultivariateCauchy" else np.inf)
 
+    def set_proposal_from_population(self, population, weights, proposal_name="MultivariateNormal"):
+        """the same distribution as ``set_proposal(np.cov(population, aweights=weights))`` without the
+        factorisation (DeviceMvNormalProposal.from_population)"""
+        if proposal_name not in multivariate_proposals:
+            raise NotImplementedError("device proposals: %s" % ", ".join(multivariate_proposals))
+        self.proposal = DeviceMvNormalProposal.from_population(
+            population, weights, self.device, seed=self.seed + 7919 * (1 + self.n_steps_total),
+            df=1 if proposal_name == "MultivariateCauchy" else np.inf)
+
     def evaluate(self, Q):
         """stage 0 (metropolis.py:277-286): one evaluation, no move; NaN -> ValueError"""
         L = self.target.batch(Q)

@@ -98,6 +98,16 @@ class SMC(object):
                              " upper and lower bounds of hyper parameters!")
         return cov
 
+    def set_stage_proposal(self):
+        """Proposal of the coming stage: N(0, weighted population covariance) (smc.py:452-466).
+        Populations up to twice the parameter count draw straight from the weighted, centred
+        population (no factorisation of a singular / ill-conditioned matrix); larger ones
+        factor ``self.covariance`` once."""
+        if self.n_chains <= 2 * self.array_population.shape[1]:
+            self.stepper.set_proposal_from_population(self.array_population, self.weights, self.proposal_name)
+        else:
+            self.stepper.set_proposal(self.covariance, self.proposal_name)
+
     def resample(self):
         """smc.py:290-324 Kitagawa's deterministic resampling; the single auxiliary draw
         comes from the rank-shared RandomState.  Guarded against cumulative-sum overrun
@@ -201,7 +211,7 @@ def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, 
             step.beta = 1.0
             break
         step.covariance = step.calc_covariance(repair=False)
-        step.stepper.set_proposal(step.covariance, step.proposal_name)
+        step.set_stage_proposal()
         step.resampling_indexes = step.resample()
         step.stage += 1
         logger.info("Beta: %f Stage: %i", step.beta, step.stage)
@@ -217,7 +227,7 @@ def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, 
     temp = np.exp((1 - step.old_beta) * (step.likelihoods - step.likelihoods.max()))
     step.weights = temp / np.sum(temp)
     step.covariance = step.calc_covariance(repair=False)
-    step.stepper.set_proposal(step.covariance, step.proposal_name)
+    step.set_stage_proposal()
     step.resampling_indexes = step.resample()
     step.beta = 1.0
     Q, L = step.sample_stage(n_steps * sample_factor_final_stage)

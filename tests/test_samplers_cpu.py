@@ -201,3 +201,21 @@ def test_device_proposals_normal_and_cauchy_statistics():
     np.testing.assert_allclose(np.cov(z.T), B @ B.T, rtol=0.05, atol=0.05)
     with pytest.raises(ValueError):
         DeviceMvNormalProposal(cov, torch.device("cpu"), df=0.5)(3)
+
+
+def test_population_proposal_equals_weighted_covariance():
+    """DeviceMvNormalProposal.from_population draws with np.cov(X, aweights=w) (SMC.calc_covariance)
+    without factoring it, also when the population is smaller than the parameter count"""
+    import torch
+    from beat_amd.sampler.base import DeviceMvNormalProposal
+    rng = np.random.default_rng(11)
+    for n, d in ((40, 6), (5, 9)):
+        X = rng.standard_normal((n, d)) * rng.uniform(0.5, 3.0, d) + rng.standard_normal(d)
+        w = rng.random(n)
+        w /= w.sum()
+        cov = np.cov(X, aweights=w, bias=False, rowvar=0)
+        prop = DeviceMvNormalProposal.from_population(X, w, torch.device("cpu"), seed=2)
+        np.testing.assert_allclose(prop.LT.numpy().T @ prop.LT.numpy(), cov, rtol=1e-12, atol=1e-12)
+        rows = prop(300000).numpy()
+        assert rows.shape == (300000, d)
+        np.testing.assert_allclose(np.cov(rows.T), cov, rtol=0.04, atol=0.04 * np.abs(cov).max())

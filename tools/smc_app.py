@@ -32,7 +32,7 @@ for stage in range(3):
     t0 = time.perf_counter()
     step.beta, step.old_beta, step.weights = step.calc_beta()
     step.covariance = step.calc_covariance(repair=False)
-    step.stepper.set_proposal(step.covariance, step.proposal_name)
+    step.set_stage_proposal()
     step.resampling_indexes = step.resample()
     step.stage += 1
     t1 = time.perf_counter()
