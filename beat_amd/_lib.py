@@ -63,7 +63,7 @@ _PROTOS = {
     "beatamd_geo_gflib_destroy": [_vp, _i32],
     "beatamd_geo_stack_all_batch": [_vp, _i32, _i64, _vp, _i32, _vp],
     "beatamd_weights_create": [_vp, _i32, _i64, _i64, _vp, _vp, _pi32],
-    "beatamd_weights_update": [_vp, _i32, _vp, _vp],
+    "beatamd_weights_update": [_vp, _i32, _i32, _i64, _vp, _vp],
     "beatamd_weights_destroy": [_vp, _i32],
     "beatamd_mvn_chol_logp_batch": [_vp, _i32, _i64, _vp, _vp, _vp],
     "beatamd_laplacian_create": [_vp, _i64, _vp, _f64, _pi32],
@@ -82,6 +82,16 @@ _PROTOS = {
     "beatamd_autocovariance_batch": [_vp, _i64, _i64, _vp, _vp, _vp],
     "beatamd_scaled_toeplitz_batch": [_vp, _i64, _i64, _vp, _vp, _vp],
     "beatamd_ffi_astep_batch_betas": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "beatamd_ctx_last_kernel": [_vp, C.c_char_p, _i64],
+    "beatamd_ctx_gf_group_stats": [_vp, _pi64, C.POINTER(_f64), _pi64, _pi64],
+    "beatamd_smc_calc_beta": [_vp, _i64, _vp, _i64, _f64, _f64, C.POINTER(_f64), _vp],
+    "beatamd_smc_stage_weights": [_vp, _i64, _vp, _i64, _f64, _vp],
+    "beatamd_smc_resample": [_vp, _i64, _vp, _f64, _vp],
+    "beatamd_smc_population_factor": [_vp, _i64, _i64, _vp, _vp, _vp],
+    "beatamd_proposal_draw": [_vp, _i64, _i64, _i64, _vp, C.c_uint64, C.c_uint32, _i64, _i32, _vp, _vp],
+    "beatamd_gather_rows": [_vp, _i64, _i64, _vp, _i64, _vp, _vp],
+    "beatamd_metropolis_tune": [_vp, _i64, _vp, _vp, _i32],
+    "beatamd_whiten_rows": [_vp, _vp, _i64, _i64, _vp],
 }
 
 EXPORTS = sorted(list(_PROTOS) + ["beatamd_last_error", "beatamd_version"])

@@ -83,10 +83,16 @@ int ffi_logp_device(beatamd_ctx *ctx, FfiModel &m, int64_t C, const double *Q, d
     ChainVec slips[4];
     for (int v = 0; v < m.layout.nvar; v++) slips[v] = ChainVec{Q, np, m.layout.slip_off[v]};
 
+    // chains whose indices leave the library grid / the patch grid: like = NaN (rejected by the
+    // Metropolis step) in addition to the status word that the next synchronisation raises
+    BA_TRY(ctx->get_scratch(SL_CHAINBAD, (size_t)C * sizeof(int32_t), &p));
+    int32_t *chain_bad = (int32_t *)p;
+    BA_HIP(hipMemsetAsync(chain_bad, 0, (size_t)C * sizeof(int32_t), ctx->stream));
+
     if (!m.wavemaps.empty()) {
         BA_TRY(ctx->get_scratch(SL_ST0, (size_t)C * m.P * sizeof(double), &p));
         double *st0 = (double *)p;
-        BA_TRY(launch_sweep_model(ctx, m, Q, C, st0));
+        BA_TRY(launch_sweep_model(ctx, m, Q, C, st0, chain_bad));
         for (auto &wm : m.wavemaps) {
             WeightSet *ws = get_obj(ctx->wsets, wm.wset);
             BA_CHECK(ws, BEATAMD_EINVAL, "wavemap refers to a destroyed weight set");
@@ -103,6 +109,7 @@ int ffi_logp_device(beatamd_ctx *ctx, FfiModel &m, int64_t C, const double *Q, d
             k.st.Q = Q;
             k.st.nparams = np;
             k.st.shift_off = wm.shift_off;
+            k.st.chain_bad = chain_bad;
             k.interp = wm.interp;
             k.C = C;
             k.data = wm.data;
@@ -176,7 +183,7 @@ int ffi_logp_device(beatamd_ctx *ctx, FfiModel &m, int64_t C, const double *Q, d
         grp.end[grp.n++] = (int32_t)col;
     }
     BA_CHECK(col == nllk - 1, BEATAMD_EINVAL, "internal: llk layout mismatch");
-    return launch_like_sum(ctx, C, nllk, grp, LL);
+    return launch_like_sum(ctx, C, nllk, grp, LL, chain_bad);
 }
 
 }  // namespace
@@ -407,12 +414,19 @@ int beatamd_weights_create(beatamd_ctx *ctx, int32_t kind, int64_t nd, int64_t M
     return BEATAMD_OK;
 }
 
-int beatamd_weights_update(beatamd_ctx *ctx, int32_t wset_id, const double *weights,
-                           const double *slog_pdet)
+int beatamd_weights_update(beatamd_ctx *ctx, int32_t wset_id, int32_t kind, int64_t count,
+                           const double *weights, const double *slog_pdet)
 {
     ENTER(ctx);
     WeightSet *w = get_obj(ctx->wsets, wset_id);
     BA_CHECK(w && weights && slog_pdet, BEATAMD_EINVAL, "weights_update: bad argument");
+    BA_CHECK(kind == w->kind, BEATAMD_EINVAL,
+             "weights_update: weight set %d holds %s weights, got %s ones (a pre-whitened wavemap "
+             "keeps scalar weights: re-whiten the library instead)", wset_id,
+             w->kind == BEATAMD_W_SCALAR ? "scalar" : "dense", kind == BEATAMD_W_SCALAR ? "scalar" : "dense");
+    const int64_t want = w->kind == BEATAMD_W_SCALAR ? w->nd : w->nd * w->M * w->M;
+    BA_CHECK(count == want, BEATAMD_EINVAL, "weights_update: %lld elements given, the set holds %lld",
+             (long long)count, (long long)want);
     BA_HIP(hipStreamSynchronize(ctx->stream));
     return wset_fill(ctx, w, weights, slog_pdet);
 }
@@ -862,6 +876,221 @@ int beatamd_scaled_toeplitz_batch(beatamd_ctx *ctx, int64_t nd, int64_t n, const
     BA_TRY(stage_out(ctx, SL_OUT0, out, (size_t)nd * n * n * 8, &d_o, &rec));
     BA_TRY(launch_scaled_toeplitz(ctx, nd, n, (const double *)d_c, (const double *)d_s, (double *)d_o));
     return finish_out(ctx, &rec, 1);
+}
+
+// ------------------------------------------------------------------ introspection
+int beatamd_ctx_last_kernel(beatamd_ctx *ctx, char *buf, int64_t buflen)
+{
+    BA_CHECK(ctx && buf && buflen > 0, BEATAMD_EINVAL, "last_kernel: bad argument");
+    snprintf(buf, (size_t)buflen, "%s", ctx->last_gf_kernel);
+    return BEATAMD_OK;
+}
+
+int beatamd_ctx_gf_group_stats(beatamd_ctx *ctx, int64_t *chains_per_group, double *mean_rows,
+                               int64_t *max_rows, int64_t *row_bytes)
+{
+    ENTER(ctx);
+    BA_CHECK(chains_per_group && mean_rows && max_rows && row_bytes, BEATAMD_EINVAL,
+             "gf_group_stats: NULL argument");
+    *chains_per_group = ctx->gs_cg;
+    *mean_rows = 0.0;
+    *max_rows = 0;
+    *row_bytes = 0;
+    if (ctx->gs_ngtp == 0) return BEATAMD_OK;  // the last launch was the streaming kernel
+    BA_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<uint32_t> uc((size_t)ctx->gs_ngtp);
+    BA_HIP(hipMemcpy(uc.data(), ctx->scratch[SL_GS_UCOUNT].p, uc.size() * sizeof(uint32_t),
+                     hipMemcpyDeviceToHost));
+    int64_t tot = 0, mx = 0;
+    for (uint32_t u : uc) {
+        tot += u;
+        mx = std::max<int64_t>(mx, u);
+    }
+    *mean_rows = (double)tot / (double)uc.size();
+    *max_rows = mx;
+    *row_bytes = tot * ctx->gs_N * 8;   // every distinct row is staged once per (group, target)
+    return BEATAMD_OK;
+}
+
+// ------------------------------------------------------------------ SMC stage transition
+int beatamd_smc_calc_beta(beatamd_ctx *ctx, int64_t C, const double *likelihoods, int64_t stride,
+                          double beta, double coef_variation, double *beta_new, double *weights)
+{
+    ENTER(ctx);
+    BA_CHECK(likelihoods && beta_new && weights && C > 0 && stride > 0, BEATAMD_EINVAL,
+             "smc_calc_beta: bad argument");
+    const void *d_l;
+    void *d_w, *p;
+    Arg rec;
+    BA_TRY(stage_in(ctx, SL_IN0, likelihoods, (size_t)((C - 1) * stride + 1) * 8, &d_l));
+    BA_TRY(stage_out(ctx, SL_OUT0, weights, (size_t)C * 8, &d_w, &rec));
+    BA_TRY(ctx->get_scratch(SL_STAGE2, 64, &p));
+    BA_TRY(launch_smc_calc_beta(ctx, C, (const double *)d_l, stride, beta, coef_variation, 0, 0.0,
+                                (double *)p, (double *)d_w));
+    double out[2];
+    BA_HIP(hipMemcpyAsync(out, p, sizeof(out), hipMemcpyDeviceToHost, ctx->stream));
+    BA_TRY(finish_out(ctx, &rec, 1));
+    BA_HIP(hipStreamSynchronize(ctx->stream));
+    *beta_new = out[0];
+    return BEATAMD_OK;
+}
+
+int beatamd_smc_stage_weights(beatamd_ctx *ctx, int64_t C, const double *likelihoods, int64_t stride,
+                              double dbeta, double *weights)
+{
+    ENTER(ctx);
+    BA_CHECK(likelihoods && weights && C > 0 && stride > 0, BEATAMD_EINVAL, "smc_stage_weights: bad argument");
+    const void *d_l;
+    void *d_w, *p;
+    Arg rec;
+    BA_TRY(stage_in(ctx, SL_IN0, likelihoods, (size_t)((C - 1) * stride + 1) * 8, &d_l));
+    BA_TRY(stage_out(ctx, SL_OUT0, weights, (size_t)C * 8, &d_w, &rec));
+    BA_TRY(ctx->get_scratch(SL_STAGE2, 64, &p));
+    BA_TRY(launch_smc_calc_beta(ctx, C, (const double *)d_l, stride, 0.0, 0.0, 1, dbeta, (double *)p,
+                                (double *)d_w));
+    return finish_out(ctx, &rec, 1);
+}
+
+int beatamd_smc_resample(beatamd_ctx *ctx, int64_t C, const double *weights, double aux,
+                         int32_t *indexes)
+{
+    ENTER(ctx);
+    BA_CHECK(weights && indexes && C > 0, BEATAMD_EINVAL, "smc_resample: bad argument");
+    BA_CHECK(C < (int64_t)0x7fffffff, BEATAMD_EINVAL, "smc_resample: too many chains");
+    const void *d_w;
+    void *d_i, *p;
+    Arg rec;
+    BA_TRY(stage_in(ctx, SL_IN0, weights, (size_t)C * 8, &d_w));
+    BA_TRY(stage_out(ctx, SL_OUT0, indexes, (size_t)C * 4, &d_i, &rec));
+    BA_TRY(ctx->get_scratch(SL_CUM, (size_t)C * 8, &p));
+    BA_TRY(launch_smc_resample(ctx, C, (const double *)d_w, aux, (double *)p, (int32_t *)d_i));
+    return finish_out(ctx, &rec, 1);
+}
+
+int beatamd_smc_population_factor(beatamd_ctx *ctx, int64_t C, int64_t nparams,
+                                  const double *population, const double *weights, double *factor)
+{
+    ENTER(ctx);
+    BA_CHECK(population && weights && factor && C > 0 && nparams > 0, BEATAMD_EINVAL,
+             "smc_population_factor: bad argument");
+    const void *d_x, *d_w;
+    void *d_f;
+    Arg rec;
+    BA_TRY(stage_in(ctx, SL_IN0, population, (size_t)C * nparams * 8, &d_x));
+    BA_TRY(stage_in(ctx, SL_IN1, weights, (size_t)C * 8, &d_w));
+    BA_TRY(stage_out(ctx, SL_OUT0, factor, (size_t)C * nparams * 8, &d_f, &rec));
+    BA_TRY(launch_pop_factor(ctx, C, nparams, (const double *)d_x, nparams, (const double *)d_w,
+                             (double *)d_f));
+    return finish_out(ctx, &rec, 1);
+}
+
+int beatamd_proposal_draw(beatamd_ctx *ctx, int64_t C, int64_t K, int64_t nparams,
+                          const double *factor, uint64_t seed, uint32_t step, int64_t first_chain,
+                          int32_t df, double *delta, double *log_u)
+{
+    ENTER(ctx);
+    BA_CHECK(factor && delta && C >= 0 && K > 0 && nparams > 0 && df >= 0 && first_chain >= 0,
+             BEATAMD_EINVAL, "proposal_draw: bad argument");
+    BA_CHECK(df <= 64, BEATAMD_EINVAL, "proposal_draw: at most 64 degrees of freedom");
+    if (C == 0) return BEATAMD_OK;
+    const void *d_f;
+    void *d_d, *d_u = nullptr, *p;
+    Arg recs[2];
+    int nrec = 1;
+    BA_TRY(stage_in(ctx, SL_IN0, factor, (size_t)K * nparams * 8, &d_f));
+    BA_TRY(stage_out(ctx, SL_OUT0, delta, (size_t)C * nparams * 8, &d_d, &recs[0]));
+    if (log_u) {
+        BA_TRY(stage_out(ctx, SL_OUT1, log_u, (size_t)C * 8, &d_u, &recs[1]));
+        nrec = 2;
+    }
+    BA_TRY(ctx->get_scratch(SL_Z, (size_t)C * K * 8, &p));
+    double *z = (double *)p;
+    double *rs = nullptr;
+    if (df > 0) {
+        BA_TRY(ctx->get_scratch(SL_ROWSCALE, (size_t)C * 8, &p));
+        rs = (double *)p;
+    }
+    BA_TRY(launch_philox_normal(ctx, z, C, K, seed, step, (uint64_t)first_chain));
+    if (d_u || rs)
+        BA_TRY(launch_philox_chain(ctx, C, seed, step, (uint64_t)first_chain, df, (double *)d_u, rs));
+    GemmCall g;
+    g.A = z; g.lda = K;
+    g.B = (const double *)d_f; g.ldb = nparams; g.b_kn = 1;
+    g.O = (double *)d_d; g.ldo = nparams;
+    g.M = C; g.N = nparams; g.K = K;
+    g.row_scale = rs;
+    g.timer = "proposal";
+    BA_TRY(launch_gemm_f64(ctx, g));
+    return finish_out(ctx, recs, nrec);
+}
+
+int beatamd_gather_rows(beatamd_ctx *ctx, int64_t nout, int64_t ncols, const double *src,
+                        int64_t nrows_src, const int32_t *indexes, double *out)
+{
+    ENTER(ctx);
+    BA_CHECK(src && indexes && out && nout >= 0 && ncols > 0 && nrows_src > 0, BEATAMD_EINVAL,
+             "gather_rows: bad argument");
+    if (nout == 0) return BEATAMD_OK;
+    const void *d_s, *d_i;
+    void *d_o;
+    Arg rec;
+    BA_TRY(stage_in(ctx, SL_IN0, src, (size_t)nrows_src * ncols * 8, &d_s));
+    BA_TRY(stage_in(ctx, SL_IN1, indexes, (size_t)nout * 4, &d_i));
+    BA_TRY(stage_out(ctx, SL_OUT0, out, (size_t)nout * ncols * 8, &d_o, &rec));
+    BA_CHECK(d_o != d_s, BEATAMD_EINVAL, "gather_rows: out must not alias src");
+    BA_TRY(launch_gather_rows(ctx, nout, ncols, (const double *)d_s, ncols, nrows_src,
+                              (const int32_t *)d_i, (double *)d_o, ncols));
+    return finish_out(ctx, &rec, 1);
+}
+
+int beatamd_metropolis_tune(beatamd_ctx *ctx, int64_t C, double *scaling, int32_t *accepted,
+                            int32_t tune_interval)
+{
+    ENTER(ctx);
+    BA_CHECK(scaling && accepted && C >= 0 && tune_interval > 0, BEATAMD_EINVAL,
+             "metropolis_tune: bad argument");
+    if (C == 0) return BEATAMD_OK;
+    void *d_s, *d_a;
+    Arg recs[2];
+    BA_TRY(stage_out(ctx, SL_OUT0, scaling, (size_t)C * 8, &d_s, &recs[0], true));
+    BA_TRY(stage_out(ctx, SL_OUT1, accepted, (size_t)C * 4, &d_a, &recs[1], true));
+    BA_TRY(launch_tune_scaling(ctx, C, (double *)d_s, (int32_t *)d_a, (double)tune_interval));
+    return finish_out(ctx, recs, 2);
+}
+
+// ------------------------------------------------------------------ library whitening
+int beatamd_whiten_rows(beatamd_ctx *ctx, double *rows, int64_t nrows, int64_t N, const double *W)
+{
+    ENTER(ctx);
+    BA_CHECK(rows && W && nrows >= 0 && N > 0, BEATAMD_EINVAL, "whiten_rows: bad argument");
+    BA_CHECK(is_device_ptr(rows), BEATAMD_EINVAL, "whiten_rows: rows must live in HBM");
+    if (nrows == 0) return BEATAMD_OK;
+    const void *d_w;
+    void *p;
+    BA_TRY(stage_in(ctx, SL_IN0, W, (size_t)N * N * 8, &d_w));
+    BA_TRY(ctx->get_scratch(SL_MISC, 64, &p));
+    BA_TRY(launch_check_upper_tri(ctx, (const double *)d_w, 1, N, (int *)p));
+    int upper = 0;
+    BA_HIP(hipMemcpyAsync(&upper, p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    BA_HIP(hipStreamSynchronize(ctx->stream));
+    // out-of-place per chunk (every column block of a chunk reads all of its rows), then copied back
+    int64_t chunk = std::max<int64_t>(64, ((int64_t)1 << 28) / (N * 8));
+    chunk = std::min(chunk, nrows);
+    BA_TRY(ctx->get_scratch(SL_WHITEN, (size_t)chunk * N * 8, &p));
+    double *tmp = (double *)p;
+    for (int64_t r0 = 0; r0 < nrows; r0 += chunk) {
+        const int64_t nr = std::min(chunk, nrows - r0);
+        GemmCall g;
+        g.A = rows + r0 * N; g.lda = N;
+        g.B = (const double *)d_w; g.ldb = N; g.b_kn = 0; g.b_upper = upper;
+        g.O = tmp; g.ldo = N;
+        g.M = nr; g.N = N; g.K = N;
+        g.timer = "whiten";
+        BA_TRY(launch_gemm_f64(ctx, g));
+        BA_HIP(hipMemcpyAsync(rows + r0 * N, tmp, (size_t)nr * N * 8, hipMemcpyDeviceToDevice,
+                              ctx->stream));
+    }
+    return BEATAMD_OK;
 }
 
 }  // extern "C"

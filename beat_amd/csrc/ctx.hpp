@@ -148,6 +148,11 @@ struct beatamd_ctx {
     std::vector<std::unique_ptr<beatamd::Laplacian>> laps;
     std::vector<std::unique_ptr<beatamd::FfiModel>> models;
     int num_cu = 256;
+    // name of the stacking kernel of the most recent launch (tests assert which kernel ran)
+    char last_gf_kernel[96] = "";
+    // distinct-row statistics of the most recent chain-shared launch (bench.py roofline leg)
+    int64_t gs_ngtp = 0, gs_N = 0;
+    int gs_cg = 0;
 
     // grow-only scratch slot
     int get_scratch(int slot, size_t bytes, void **out);
@@ -189,7 +194,8 @@ enum Slot : int {
     SL_IN0 = 0, SL_IN1, SL_IN2, SL_IN3, SL_IN4, SL_IN5, SL_IN6, SL_IN7,
     SL_OUT0, SL_OUT1, SL_OUT2,
     SL_ROWOFF, SL_WEIGHTS, SL_ST0, SL_RESID, SL_PARTIAL, SL_QUAD, SL_MU, SL_SLIPS,
-    SL_QPROP, SL_LPROP, SL_MISC, SL_GS_UROWS, SL_GS_UCOUNT, SL_GS_SLOT, SL_GS_W, SL_GS_UMAX, SL_COUNT
+    SL_QPROP, SL_LPROP, SL_MISC, SL_GS_UROWS, SL_GS_UCOUNT, SL_GS_SLOT, SL_GS_W, SL_GS_UMAX,
+    SL_CHAINBAD, SL_Z, SL_ROWSCALE, SL_CUM, SL_STAGE2, SL_WHITEN, SL_COUNT
 };
 
 }  // namespace beatamd

@@ -792,6 +792,11 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         if (a.dma && !(e && atoi(e) == 1)) a.dma = 2;   // ds_read_b64 / pitch NT+1 (default); 1 = b128 / pitch NT+2
         if (a.dma) lds *= 2;
     }
+    snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "%s<%d,%d,%d,%d,%d>",
+             a.dma ? "k_gfstack_dma" : "k_gfstack_shared", CG / 64, nrow, k.mode, a.nt, a.dma == 2 ? 1 : 0);
+    ctx->gs_ngtp = GTP;
+    ctx->gs_N = L.N;
+    ctx->gs_cg = CG;
     {
         ScopedTimer tm(ctx, "gfstack");
         dim3 grid((unsigned)nblocks);

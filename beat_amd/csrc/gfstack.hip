@@ -98,7 +98,10 @@ __global__ void __launch_bounds__(256) k_gf_tables(TabArgs a)
         fa[2] = (1 - stf) * rtf;
         fa[3] = stf * rtf;
     }
-    if (!ok) atomicOr(a.status, ST_INDEX_OOB);
+    if (!ok) {
+        atomicOr(a.status, ST_INDEX_OOB);
+        if (a.st.chain_bad) a.st.chain_bad[c] = 1;
+    }
 }
 
 // ------------------------------------------------------------------------ stacking
@@ -385,6 +388,9 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &k)
     BA_CHECK(nblocks < (int64_t)0x7fffffff, BEATAMD_EINVAL, "gfstack: batch too large (%lld blocks)",
              (long long)nblocks);
     dim3 grid((unsigned)nblocks);
+    snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack<%d,%d,%d,%d,%d>",
+             k.interp == BEATAMD_MULTILINEAR ? 1 : 0, k.nvar, VEC, W, k.mode);
+    ctx->gs_ngtp = 0;
     {
         ScopedTimer tm(ctx, "gfstack");
         if (k.interp == BEATAMD_NEAREST_NEIGHBOR) {

@@ -10,7 +10,7 @@ namespace beatamd {
 int launch_sweep_explicit(beatamd_ctx *ctx, const double *slow, double h, const int32_t *hi,
                           const int32_t *hj, int ni, int nj, int64_t C, double *out);
 int launch_sweep_model(beatamd_ctx *ctx, const FfiModel &m, const double *Q, int64_t C,
-                       double *starttimes0);
+                       double *starttimes0, int32_t *chain_bad);
 
 // ---- gfstack.hip -----------------------------------------------------------------
 // Where the per-(chain,target,patch) start times come from.
@@ -22,6 +22,9 @@ struct StartTimeSrc {
     const double *Q = nullptr;
     int64_t nparams = 0;
     const int64_t *shift_off = nullptr;  // device [T] or nullptr (no station corrections)
+    // model mode: chains whose times fall outside the library grid are marked here (their
+    // `like` becomes NaN, which the Metropolis step rejects); nullptr in the explicit API
+    int32_t *chain_bad = nullptr;
 };
 
 // a strided view of per-chain vectors: value(c, k) = base[c*stride + off + k]
@@ -98,7 +101,9 @@ struct LikeGroups {  // composite boundaries inside the llk vector (exclusive en
     int32_t end[8];
     int n = 0;
 };
-int launch_like_sum(beatamd_ctx *ctx, int64_t C, int64_t nllk, const LikeGroups &grp, double *LL);
+// chain_bad (nullable): chains flagged by the index maps / the sweep get like = NaN
+int launch_like_sum(beatamd_ctx *ctx, int64_t C, int64_t nllk, const LikeGroups &grp, double *LL,
+                    const int32_t *chain_bad);
 // gather slips of all variables into a dense [C, nvar, P] buffer
 int launch_gather_slips(beatamd_ctx *ctx, int64_t C, int nvar, int64_t P, const ChainVec *slips,
                         double *out);
@@ -118,5 +123,33 @@ int launch_autocovariance(beatamd_ctx *ctx, int64_t nd, int64_t n, const double 
                           const double *mean, double *out);
 int launch_scaled_toeplitz(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *coeffs,
                            const double *stds, double *out);
+
+
+// ---- gemm.hip: O[m,n] = (sum_k A[m,k] Bop[k,n]) * row_scale[m] on the FP64 matrix cores
+struct GemmCall {
+    const double *A = nullptr, *B = nullptr, *row_scale = nullptr;
+    double *O = nullptr;
+    int64_t lda = 0, ldb = 0, ldo = 0, M = 0, N = 0, K = 0;
+    int b_kn = 0;     // 0: Bop[k,n] = B[n*ldb + k] ("NT")   1: Bop[k,n] = B[k*ldb + n] ("NN")
+    int b_upper = 0;  // NT only: B[n,k] == 0 for k < n
+    const char *timer = nullptr;
+};
+int launch_gemm_f64(beatamd_ctx *ctx, const GemmCall &call);
+
+// ---- smc.hip: sampler steps on the device
+int launch_smc_calc_beta(beatamd_ctx *ctx, int64_t n, const double *lik, int64_t stride, double beta,
+                         double cv, int mode, double dbeta, double *out2, double *weights);
+int launch_smc_resample(beatamd_ctx *ctx, int64_t n, const double *weights, double aux, double *cum,
+                        int32_t *idx);
+int launch_pop_factor(beatamd_ctx *ctx, int64_t n, int64_t np, const double *X, int64_t ldx,
+                      const double *w, double *F);
+int launch_gather_rows(beatamd_ctx *ctx, int64_t nout, int64_t ncol, const double *src, int64_t lds,
+                       int64_t nrow_src, const int32_t *idx, double *out, int64_t ldo);
+int launch_tune_scaling(beatamd_ctx *ctx, int64_t C, double *scaling, int32_t *accepted, double interval);
+int launch_accumulate_i32(beatamd_ctx *ctx, int64_t C, const int32_t *a, int32_t *acc);
+int launch_philox_normal(beatamd_ctx *ctx, double *z, int64_t C, int64_t K, uint64_t seed,
+                         uint32_t step, uint64_t first_chain);
+int launch_philox_chain(beatamd_ctx *ctx, int64_t C, uint64_t seed, uint32_t step, uint64_t first_chain,
+                        int df, double *log_u, double *row_scale);
 
 }  // namespace beatamd

@@ -147,7 +147,7 @@ int launch_laplacian_finish(beatamd_ctx *ctx, int64_t C, int64_t nvar, int64_t P
 
 // problems.py:227-247: like = sum over composites of (composite llk vector).sum()
 __global__ void __launch_bounds__(256) k_like_sum(int64_t C, int64_t nllk, LikeGroups grp,
-                                                 double *LL)
+                                                 double *LL, const int32_t *chain_bad)
 {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
@@ -159,14 +159,18 @@ __global__ void __launch_bounds__(256) k_like_sum(int64_t C, int64_t nllk, LikeG
         for (; k < grp.end[g]; k++) s += l[k];
         total += s;
     }
+    // a chain whose start times / durations left the library grid (the reference raises
+    // IndexError there) carries NaN: metrop_select rejects it (isfinite test in k_accept)
+    if (chain_bad && chain_bad[c]) total = __builtin_nan("");
     l[nllk - 1] = total;
 }
 
-int launch_like_sum(beatamd_ctx *ctx, int64_t C, int64_t nllk, const LikeGroups &grp, double *LL)
+int launch_like_sum(beatamd_ctx *ctx, int64_t C, int64_t nllk, const LikeGroups &grp, double *LL,
+                    const int32_t *chain_bad)
 {
     if (C == 0) return BEATAMD_OK;
     hipLaunchKernelGGL(k_like_sum, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, ctx->stream, C,
-                       nllk, grp, LL);
+                       nllk, grp, LL, chain_bad);
     BA_HIP(hipGetLastError());
     return BEATAMD_OK;
 }

@@ -129,6 +129,7 @@ struct SweepParams {
     // common
     double *out;
     int *status;
+    int32_t *chain_bad;  // mode 1, nullable: chain flagged when its hypocentre index is off the grid
     int32_t nmax;  // LDS doubles reserved per array per wave
 };
 
@@ -175,7 +176,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_fast_sweep(SweepParams a)
     }
     if (hi < 0 || hi >= ni || hj < 0 || hj >= nj) {
         // the reference writes outside its array here; we flag and clamp
-        if (lane == 0) atomicOr(a.status, ST_BAD_HYPO);
+        if (lane == 0) {
+            atomicOr(a.status, ST_BAD_HYPO);
+            if (a.mode == 1 && a.chain_bad) a.chain_bad[prob / a.nsub] = 1;
+        }
         hi = min(max(hi, 0), ni - 1);
         hj = min(max(hj, 0), nj - 1);
     }
@@ -229,7 +233,7 @@ int launch_sweep_explicit(beatamd_ctx *ctx, const double *slow, double h, const 
 }
 
 int launch_sweep_model(beatamd_ctx *ctx, const FfiModel &m, const double *Q, int64_t C,
-                       double *starttimes0)
+                       double *starttimes0, int32_t *chain_bad)
 {
     SweepParams p;
     memset(&p, 0, sizeof(p));
@@ -248,6 +252,7 @@ int launch_sweep_model(beatamd_ctx *ctx, const FfiModel &m, const double *Q, int
     p.sf_h = m.d_patch_size;
     p.nsub = m.nsub;
     p.out = starttimes0;
+    p.chain_bad = chain_bad;
     int nmax = 0;
     for (int s = 0; s < m.nsub; s++) nmax = std::max(nmax, m.ndip[s] * m.nstrike[s]);
     return launch_sweep(ctx, p, nmax);

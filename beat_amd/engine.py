@@ -210,8 +210,12 @@ class Context(object):
         return wid.value
 
     def weights_update(self, wset_id, weights, slog_pdet):
+        """new weights of an existing set; scalar (nd,) or dense (nd, M, M) -- kind and size are
+        checked against the set by the library"""
         W, sl = f64(weights), f64(slog_pdet).ravel()
-        check(self._lib.beatamd_weights_update(self._h, wset_id, ptr(W), ptr(sl)))
+        kind = _lib.W_DENSE if W.ndim >= 2 else _lib.W_SCALAR
+        count = int(W.numel()) if _is_dev(W) else int(W.size)
+        check(self._lib.beatamd_weights_update(self._h, wset_id, kind, count, ptr(W), ptr(sl)))
 
     def weights_destroy(self, wset_id):
         check(self._lib.beatamd_weights_destroy(self._h, wset_id))
@@ -341,17 +345,111 @@ class Context(object):
         for a in (Q0, L0):
             if isinstance(a, np.ndarray) and not (a.flags.c_contiguous and a.dtype == np.float64):
                 raise ValueError("Q0 / L0 must be C-contiguous float64 (updated in place)")
+        # converted arrays are bound to locals: a temporary would be freed before the call reads it
+        de, sc, lo, up, lu = f64(delta), f64(scaling), f64(lower), f64(upper), f64(log_u)
         if np.ndim(beta) == 0 and not hasattr(beta, "data_ptr"):
-            check(self._lib.beatamd_ffi_astep_batch(self._h, model_id, Cn, ptr(Q0), ptr(L0),
-                                                    ptr(f64(delta)), ptr(f64(scaling)), ptr(f64(lower)),
-                                                    ptr(f64(upper)), ptr(f64(log_u)), float(beta),
+            check(self._lib.beatamd_ffi_astep_batch(self._h, model_id, Cn, ptr(Q0), ptr(L0), ptr(de),
+                                                    ptr(sc), ptr(lo), ptr(up), ptr(lu), float(beta),
                                                     ptr(accepted)))
         else:  # one beta per chain (parallel tempering replicas)
+            be = f64(beta)
             check(self._lib.beatamd_ffi_astep_batch_betas(self._h, model_id, Cn, ptr(Q0), ptr(L0),
-                                                          ptr(f64(delta)), ptr(f64(scaling)),
-                                                          ptr(f64(lower)), ptr(f64(upper)),
-                                                          ptr(f64(log_u)), ptr(f64(beta)), ptr(accepted)))
+                                                          ptr(de), ptr(sc), ptr(lo), ptr(up), ptr(lu),
+                                                          ptr(be), ptr(accepted)))
         return accepted
+
+    # -- introspection
+    def last_kernel(self):
+        """name<template arguments> of the stacking kernel the most recent call launched"""
+        buf = C.create_string_buffer(128)
+        check(self._lib.beatamd_ctx_last_kernel(self._h, buf, 128))
+        return buf.value.decode()
+
+    def gf_group_stats(self):
+        """-> dict(chains_per_group, mean_rows, max_rows, row_bytes) of the last chain-shared launch"""
+        cg, mx, rb, mean = C.c_int64(), C.c_int64(), C.c_int64(), C.c_double()
+        check(self._lib.beatamd_ctx_gf_group_stats(self._h, C.byref(cg), C.byref(mean), C.byref(mx),
+                                                   C.byref(rb)))
+        return dict(chains_per_group=cg.value, mean_rows=mean.value, max_rows=mx.value,
+                    row_bytes=rb.value)
+
+    # -- sampler steps on the device (SMC stage transition, proposals, exchange)
+    def smc_calc_beta(self, likelihoods, beta, coef_variation, stride=1, n=None):
+        """smc.py:133-165 -> (beta_new, weights); likelihoods: (C,) array or a strided view
+        described by (tensor, stride, n)"""
+        self._adopt_stream(likelihoods)
+        lk = f64(likelihoods)
+        Cn = int(n if n is not None else (lk.numel() if _is_dev(lk) else lk.size))
+        w = _empty_like(lk, (Cn,))
+        b = C.c_double()
+        check(self._lib.beatamd_smc_calc_beta(self._h, Cn, ptr(lk), int(stride), float(beta),
+                                              float(coef_variation), C.byref(b), ptr(w)))
+        return b.value, w
+
+    def smc_stage_weights(self, likelihoods, dbeta, stride=1, n=None):
+        self._adopt_stream(likelihoods)
+        lk = f64(likelihoods)
+        Cn = int(n if n is not None else (lk.numel() if _is_dev(lk) else lk.size))
+        w = _empty_like(lk, (Cn,))
+        check(self._lib.beatamd_smc_stage_weights(self._h, Cn, ptr(lk), int(stride), float(dbeta), ptr(w)))
+        return w
+
+    def smc_resample(self, weights, aux):
+        """smc.py:290-324 -> resampling indexes (int32)"""
+        self._adopt_stream(weights)
+        w = f64(weights)
+        Cn = int(w.numel()) if _is_dev(w) else int(w.size)
+        idx = _empty_like(w, (Cn,), np.int32)
+        check(self._lib.beatamd_smc_resample(self._h, Cn, ptr(w), float(aux), ptr(idx)))
+        return idx
+
+    def smc_population_factor(self, population, weights):
+        self._adopt_stream(population, weights)
+        X, w = f64(population), f64(weights)
+        Cn, npar = int(X.shape[0]), int(X.shape[1])
+        F = _empty_like(X, (Cn, npar))
+        check(self._lib.beatamd_smc_population_factor(self._h, Cn, npar, ptr(X), ptr(w), ptr(F)))
+        return F
+
+    def proposal_draw(self, factor, n_chains, seed, step, first_chain=0, df=0, delta=None, log_u=None,
+                      want_log_u=True):
+        """delta (n_chains, nparams) = z . factor with z from Philox4x32-10; -> (delta, log_u)"""
+        self._adopt_stream(factor)
+        F = f64(factor)
+        K, npar = int(F.shape[0]), int(F.shape[1])
+        if delta is None:
+            delta = _empty_like(F, (int(n_chains), npar))
+        if log_u is None and want_log_u:
+            log_u = _empty_like(F, (int(n_chains),))
+        check(self._lib.beatamd_proposal_draw(self._h, int(n_chains), K, npar, ptr(F), int(seed) & (2 ** 64 - 1),
+                                              int(step) & 0xffffffff, int(first_chain), int(df), ptr(delta),
+                                              ptr(log_u)))
+        return delta, log_u
+
+    def gather_rows(self, src, indexes, out=None):
+        self._adopt_stream(src, indexes)
+        S = f64(src)
+        idx = _i32(indexes)
+        nout = int(idx.numel()) if _is_dev(idx) else int(idx.size)
+        if out is None:
+            out = _empty_like(S, (nout, int(S.shape[1])))
+        check(self._lib.beatamd_gather_rows(self._h, nout, int(S.shape[1]), ptr(S), int(S.shape[0]),
+                                            ptr(idx), ptr(out)))
+        return out
+
+    def metropolis_tune(self, scaling, accepted, tune_interval):
+        """in place: scaling *= pymc tune factor(accepted / interval); accepted = 0"""
+        self._adopt_stream(scaling)
+        check(self._lib.beatamd_metropolis_tune(self._h, int(scaling.shape[0]), ptr(scaling), ptr(accepted),
+                                                int(tune_interval)))
+
+    def whiten_rows(self, rows, W):
+        """rows (R, N) device tensor, in place: rows <- rows . W^T"""
+        self._adopt_stream(rows)
+        Wc = f64(W)
+        check(self._lib.beatamd_whiten_rows(self._h, ptr(rows), int(rows.shape[0]), int(rows.shape[1]),
+                                            ptr(Wc)))
+        return rows
 
 
 _contexts = {}

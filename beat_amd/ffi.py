@@ -47,6 +47,9 @@ class SeismicGFLibraryConfig(object):
 
     @property
     def _mapid(self):
+        """config.py:1914-1919"""
+        if self.mapnumber is None:
+            return self.wavename
         return "_".join((self.wavename, str(self.mapnumber)))
 
 
@@ -72,10 +75,12 @@ class GFLibrary(object):
         self.lib_id = None
 
     def set_stack_mode(self, mode="hip"):
-        """base.py:128-147.  Only the GPU mode exists here."""
-        if mode not in ("hip",):
+        """base.py:128-147.  BEAT switches between "numpy" (export / plotting) and "pytensor"
+        (sampling) arithmetic; here every mode evaluates on the GPU -- the two reference names are
+        accepted so that existing call sites keep working, and there is still no CPU fallback."""
+        if mode not in ("hip", "numpy", "pytensor"):
             raise GFLibraryError(
-                "Stacking mode %s not available! Available modes: hip (no CPU fallback)" % mode)
+                "Stacking mode %s not available! Available modes: hip (aliases: numpy, pytensor)" % mode)
         self._mode = mode
 
     def get_stack_mode(self):
@@ -215,35 +220,94 @@ class SeismicGFLibrary(GFLibrary):
         return self._gfmatrix
 
     def save(self, outdir="", filename=None):
-        """base.py:364-373 on-disk format: <name>.traces.npy / <name>.times.npy"""
+        """base.py:364-373 on-disk format: <name>.traces.npy / <name>.times.npy / <name>.yaml.
+        A library that lives only in HBM is written through a memory-mapped .npy in 1 GiB pieces
+        (no full host copy)."""
         filename = filename or self.filename
         outpath = os.path.join(outdir, filename)
-        np.save(outpath + ".traces", arr=self._gfmatrix, allow_pickle=False)
-        np.save(outpath + ".times", arr=self._tmins, allow_pickle=False)
+        if self._gfmatrix is not None:
+            np.save(outpath + ".traces", arr=self._gfmatrix, allow_pickle=False)
+        elif self._device_tensor is not None:
+            mm = np.lib.format.open_memmap(outpath + ".traces.npy", mode="w+", dtype=np.float64,
+                                           shape=tuple(self.dimensions))
+            flat_h, flat_d = mm.reshape(-1), self._device_tensor.reshape(-1)
+            step = 1 << 27
+            for o in range(0, flat_h.size, step):
+                flat_h[o:o + step] = flat_d[o:o + step].cpu().numpy()
+            mm.flush()
+            del mm
+        else:
+            raise GFLibraryError("Neither shared nor standard GFLibrary is setup!")
+        tmins = self._tmins if self._tmins is not None else np.zeros([self.ntargets])
+        np.save(outpath + ".times", arr=tmins, allow_pickle=False)
+        self.save_config(outdir=outdir, filename=filename)
+
+    def save_config(self, outdir="", filename=None):
+        """base.py:109-116: the library's config next to the arrays, in the guts/YAML layout of
+        beat.config.SeismicGFLibraryConfig (config.py:1900-1926)"""
+        filename = filename or self.filename
+        with open(os.path.join(outdir, filename + ".yaml"), "w") as f:
+            f.write(dump_library_config(self.config))
+
+    def load_config(self, filename):
+        """base.py:118-126"""
+        self.config = load_library_config(filename)
 
     def load(self, outdir, filename=None):
-        """base.py:161-189 load_gf_library (array part)"""
+        """base.py:161-189 load_gf_library for this object: config from the .yaml (when present),
+        traces and times memory-mapped -- ``init_optimization`` then streams the traces to HBM
+        in 1 GiB pieces without materialising the library in host memory."""
         filename = filename or self.filename
         outpath = os.path.join(outdir, filename)
-        self._gfmatrix = np.load(outpath + ".traces.npy", allow_pickle=False)
-        self._tmins = np.load(outpath + ".times.npy", allow_pickle=False)
+        if os.path.exists(outpath + ".yaml"):
+            self.load_config(outpath + ".yaml")
+        self._gfmatrix = np.load(outpath + ".traces.npy", mmap_mode="r", allow_pickle=False)
+        self._tmins = np.load(outpath + ".times.npy", mmap_mode="r", allow_pickle=False)
+        if self._gfmatrix.dtype != np.float64 or self._gfmatrix.ndim != 5:
+            raise GFLibraryError("%s.traces.npy is not a 5-D float64 library" % outpath)
+        if sum(self.config.dimensions) and tuple(self.config.dimensions) != tuple(self._gfmatrix.shape):
+            raise GFLibraryError("config dimensions %s do not match the traces %s"
+                                 % (self.config.dimensions, self._gfmatrix.shape))
         self.dimensions = self._gfmatrix.shape
+        self._device_tensor = None
         self.lib_id_dirty = True
 
     # -- stacking
     def stack_all(self, durations, starttimes, slips, targetidxs=None, patchidxs=None,
                   interpolation="nearest_neighbor"):
-        """base.py:607-709, one chain.  -> (ntargets, nsamples)"""
+        """base.py:607-709, one chain.  -> (len(targetidxs), nsamples).
+        ``patchidxs`` may select a subset of the patches (base.py:651-656 indexes the library
+        with it): durations / starttimes / slips then refer to that subset, the other patches
+        contribute nothing (slip 0 on a valid grid node)."""
         if targetidxs is None:
             raise ValueError("Target indexes have to be defined!")
         targetidxs = np.asarray(targetidxs).ravel()
-        if patchidxs is not None and not np.array_equal(np.asarray(patchidxs).ravel(), self.patchidxs):
-            raise NotImplementedError("stacking a subset of patches is not supported on the GPU path")
         T, P = self.ntargets, self.npatches
-        st = np.broadcast_to(np.asarray(starttimes, dtype=np.float64), (T, P))
-        out = self.stack_all_batch(np.asarray(durations, dtype=np.float64).reshape(1, P),
-                                   st.reshape(1, T, P),
-                                   np.asarray(slips, dtype=np.float64).reshape(1, P),
+        durations = np.asarray(durations, dtype=np.float64).ravel()
+        slips = np.asarray(slips, dtype=np.float64).ravel()
+        starttimes = np.asarray(starttimes, dtype=np.float64)
+        if patchidxs is not None and not np.array_equal(np.asarray(patchidxs).ravel(), self.patchidxs):
+            pidx = np.asarray(patchidxs).ravel().astype(np.int64)
+            if pidx.size != np.unique(pidx).size or (pidx < 0).any() or (pidx >= P).any():
+                raise IndexError("patchidxs must be unique indexes into the %d patches" % P)
+            n = pidx.size
+            d_full = np.full(P, self.duration_min)
+            s_full = np.zeros(P)
+            st_full = np.full((T, P), self.starttime_min)
+            d_full[pidx], s_full[pidx] = durations[:n], slips[:n]
+            st_sub = np.broadcast_to(starttimes, (targetidxs.size, n)) if starttimes.ndim == 2 \
+                and starttimes.shape[0] == targetidxs.size else np.broadcast_to(starttimes, (T, n))
+            if st_sub.shape[0] == T:
+                st_full[:, pidx] = st_sub
+            else:
+                st_full[np.ix_(targetidxs, pidx)] = st_sub
+            durations, slips, starttimes = d_full, s_full, st_full
+        if starttimes.ndim == 2 and starttimes.shape[0] == targetidxs.size != T:
+            full = np.full((T, P), self.starttime_min)
+            full[targetidxs] = starttimes
+            starttimes = full
+        st = np.broadcast_to(starttimes, (T, P))
+        out = self.stack_all_batch(durations.reshape(1, P), st.reshape(1, T, P), slips.reshape(1, P),
                                    interpolation=interpolation)[0]
         if not np.array_equal(targetidxs, np.arange(T)):
             out = out[targetidxs]
@@ -275,6 +339,82 @@ def _time2idx(x, xmin, dx, interpolation):
         c = np.ceil(d).astype("int16")
         return c, c - d
     raise NotImplementedError("Interpolation scheme %s not implemented!" % interpolation)
+
+
+# ---------------------------------------------------------------- library config on disk
+_SEISMIC_TAG, _GEODETIC_TAG = "!beat.SeismicGFLibraryConfig", "!beat.GeodeticGFLibraryConfig"
+
+
+def dump_library_config(cfg):
+    """YAML text in the layout pyrocko.guts writes for beat.config.SeismicGFLibraryConfig /
+    GeodeticGFLibraryConfig (config.py:1879-1926): a tagged top-level mapping; the wave name sits
+    in the nested ``wave_config``.  Fields BEAT fills with defaults on load are omitted."""
+    import yaml
+    if isinstance(cfg, SeismicGFLibraryConfig):
+        body = dict(component=cfg.component, crust_ind=int(cfg.crust_ind),
+                    starttime_sampling=cfg.starttime_sampling, duration_sampling=cfg.duration_sampling,
+                    starttime_min=cfg.starttime_min, duration_min=cfg.duration_min,
+                    dimensions=[int(d) for d in cfg.dimensions], datatype=cfg.datatype,
+                    mapnumber=cfg.mapnumber)
+        text = yaml.safe_dump(body, default_flow_style=False, sort_keys=False)
+        text += "wave_config: !beat.WaveformFitConfig\n  name: %s\n" % cfg.wavename
+        return "--- %s\n%s" % (_SEISMIC_TAG, text)
+    body = dict(component=cfg.component, crust_ind=int(cfg.crust_ind),
+                dimensions=[int(d) for d in cfg.dimensions], datatype=cfg.datatype)
+    return "--- %s\n%s" % (_GEODETIC_TAG, yaml.safe_dump(body, default_flow_style=False, sort_keys=False))
+
+
+def load_library_config(path):
+    """Read a library .yaml written by BEAT (pyrocko.guts dump) or by ``dump_library_config``:
+    application tags (!beat.*, !pf.*) are read as plain mappings; only the fields of the stacking
+    path are kept (base.py:118-126, config.py:1900-1926)."""
+    import yaml
+
+    class _Loader(yaml.SafeLoader):
+        pass
+
+    def _any(loader, suffix, node):
+        if isinstance(node, yaml.MappingNode):
+            return loader.construct_mapping(node, deep=True)
+        if isinstance(node, yaml.SequenceNode):
+            return loader.construct_sequence(node, deep=True)
+        return loader.construct_scalar(node)
+
+    _Loader.add_multi_constructor("!", _any)
+    with open(path) as f:
+        d = yaml.load(f, Loader=_Loader)
+    if not isinstance(d, dict) or "dimensions" not in d:
+        raise GFLibraryError("%s is not a GF library config" % path)
+    if d.get("datatype", "seismic") == "geodetic" or len(d["dimensions"]) == 2:
+        return GeodeticGFLibraryConfig(dimensions=d["dimensions"], component=d.get("component", "uparr"),
+                                       datatype="geodetic", crust_ind=d.get("crust_ind", 0))
+    wc = d.get("wave_config") or {}
+    return SeismicGFLibraryConfig(
+        dimensions=d["dimensions"], starttime_sampling=d.get("starttime_sampling", 0.5),
+        duration_sampling=d.get("duration_sampling", 0.5), starttime_min=d.get("starttime_min", 0.0),
+        duration_min=d.get("duration_min", 0.1), component=d.get("component", "uparr"),
+        datatype=d.get("datatype", "seismic"), mapnumber=d.get("mapnumber", None),
+        wavename=wc.get("name", "any_P") if isinstance(wc, dict) else "any_P",
+        crust_ind=d.get("crust_ind", 0))
+
+
+def load_gf_library(directory="", filename=None):
+    """base.py:161-189: config from <filename>.yaml, traces (and times) memory-mapped; the
+    datatype is the first token of the file name"""
+    inpath = os.path.join(directory, filename)
+    datatype = filename.split("_")[0]
+    if datatype == "seismic":
+        gfs = SeismicGFLibrary()
+        gfs.load_config(inpath + ".yaml")
+        gfs.load(directory, filename)
+    elif datatype == "geodetic":
+        gfs = GeodeticGFLibrary()
+        gfs.config = load_library_config(inpath + ".yaml")
+        gfs._gfmatrix = np.load(inpath + ".traces.npy", mmap_mode="r", allow_pickle=False)
+        gfs.lib_id_dirty = True
+    else:
+        raise ValueError('datatype "%s" not supported!' % datatype)
+    return gfs
 
 
 class GeodeticGFLibrary(GFLibrary):
@@ -320,6 +460,13 @@ class GeodeticGFLibrary(GFLibrary):
 
     def get_all(self):
         return self._gfmatrix
+
+    def save(self, outdir="", filename=None):
+        """base.py:246-257: <name>.traces.npy + <name>.yaml"""
+        filename = filename or self.filename
+        np.save(os.path.join(outdir, filename) + ".traces", arr=self._gfmatrix, allow_pickle=False)
+        with open(os.path.join(outdir, filename + ".yaml"), "w") as f:
+            f.write(dump_library_config(self.config))
 
     def stack_all(self, slips):
         s = np.asarray(slips, dtype=np.float64).reshape(1, -1)

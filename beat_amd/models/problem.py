@@ -88,6 +88,7 @@ class SeismicWavemap(object):
         self.interpolation = interpolation
         self.name = name
         self._wset = None
+        self.is_prewhitened = False
 
     @property
     def n_t(self):
@@ -99,10 +100,11 @@ class SeismicWavemap(object):
         d'_t = W_t . d_t, so that ||W_t (d_t - syn_t)||^2 = ||d'_t - syn'_t||^2 and the dense
         W.r product (distributions.py:128) drops out of the per-step path.  Legal because
         the sampler records likelihoods, not synthetics (metropolis.py:160-162); the values
-        agree with the unwhitened path to rounding.  Re-run after ``update_weights``
-        (seismic.py:1509-1534).  The row products are plain FP64 GEMMs (rocBLAS through
-        torch.matmul), done once per weight update, chunked so no second library copy is needed
-        when ``inplace``."""
+        agree with the unwhitened path to rounding.  The row products run on the FP64 matrix
+        cores (``beatamd_whiten_rows``: rows . W_t^T, the zero half of the upper-triangular W_t
+        skipped), in place on the HBM-resident library, chunked so that no second library copy is
+        needed when ``inplace``.  After a weight update (seismic.py:1509-1534) the wavemap has to
+        be whitened again from the unwhitened library (``LogpForwFunc.update_weights`` refuses)."""
         import torch
 
         from ..engine import get_context
@@ -113,20 +115,15 @@ class SeismicWavemap(object):
         ctx = ctx or get_context()
         dev = torch.device("cuda", ctx.device)
         T, N = self.data.shape
-        W = torch.from_numpy(np.ascontiguousarray(w)).to(dev)
         gfs = {}
         for name, gf in self.gfs.items():
             if gf._device_tensor is not None:
                 G = gf._device_tensor if inplace else gf._device_tensor.clone()
             else:
-                G = torch.from_numpy(gf._gfmatrix).to(dev)
+                G = torch.from_numpy(np.ascontiguousarray(gf._gfmatrix)).to(dev)
             rows = G.view(T, -1, N)
-            step = max(1, (1 << 28) // (N * 8))  # ~256 MB of rows per GEMM
             for t in range(T):
-                Wt = W[t].T.contiguous()
-                for o in range(0, rows.shape[1], step):
-                    blk = rows[t, o:o + step]
-                    blk.copy_(blk @ Wt)  # (W x)_i = sum_k W[i,k] x[k]
+                ctx.whiten_rows(rows[t], w[t])
             cfg = gf.config
             g2 = SeismicGFLibrary(SeismicGFLibraryConfig(
                 dimensions=cfg.dimensions, starttime_sampling=cfg.starttime_sampling,
@@ -135,11 +132,14 @@ class SeismicWavemap(object):
                 mapnumber=cfg.mapnumber, wavename=cfg.wavename, crust_ind=cfg.crust_ind))
             g2.adopt_device_tensor(G)
             gfs[name] = g2
-        d = torch.from_numpy(self.data).to(dev)
-        dw = torch.einsum("tik,tk->ti", W, d).cpu().numpy()
-        torch.cuda.synchronize(dev)
-        return SeismicWavemap(gfs, dw, np.ones(T), self.slog_pdet, self.hypers, self.time_shifts,
-                              self.interpolation, self.name)
+        d = torch.from_numpy(self.data).to(dev).contiguous()
+        for t in range(T):
+            ctx.whiten_rows(d[t:t + 1], w[t])     # (W d)^T = d^T W^T
+        ctx.synchronize()
+        wm = SeismicWavemap(gfs, d.cpu().numpy(), np.ones(T), self.slog_pdet, self.hypers,
+                            self.time_shifts, self.interpolation, self.name)
+        wm.is_prewhitened = True
+        return wm
 
 
 class GeodeticData(object):
@@ -215,9 +215,11 @@ class FFIProblem(object):
         L.h_laplacian_off = lay.offsets.get(hyper_name_laplacian, -1)
         return L
 
-    def compile(self, ctx=None, prewhiten=False):
+    def compile(self, ctx=None, prewhiten=False, return_rvs=False):
         """Upload to HBM and return the batched log-likelihood function (``logp_forw``).
-        prewhiten: False | True (whitened copy of the library) | "inplace"."""
+        prewhiten: False | True (whitened copy of the library) | "inplace".
+        return_rvs: f(q) lists the free variables in front of the deterministics like the
+        reference's compiled function (model.unobserved_RVs)."""
         ctx = ctx or get_context()
         lay = self.layout
         seismic = len(self.wavemaps) > 0
@@ -266,7 +268,7 @@ class FFIProblem(object):
             L, logdet = self.laplacian
             self._lap = ctx.laplacian_create(L, logdet)
             ctx.ffi_model_set_laplacian(mid, self._lap)
-        return LogpForwFunc(ctx, mid, self)
+        return LogpForwFunc(ctx, mid, self, return_rvs=return_rvs)
 
 
 class _SharedView(object):
@@ -288,20 +290,37 @@ class _SharedView(object):
 
 class LogpForwFunc(object):
     """Duck-type of the compiled ``logp_forw_func`` (sampler/base.py:598-615):
-    ``f(q) -> list of arrays`` ordered like the likelihood deterministics, with
-    ``f.trust_input`` and ``f.get_shared()``; plus the batched form ``f.batch(Q)``.
+    ``f(q) -> list of arrays``, ``f.trust_input``, ``f.get_shared()``; plus the batched form
+    ``f.batch(Q)``.
 
-    The reference returns every unobserved RV followed by the deterministics; the
-    parameters themselves are the input, so this function returns the deterministics
-    block only: [seis_like..., geo_like..., laplacian_like, like]
-    (``astep`` reads ``out[_llk_index]``, metropolis.py:160-162, here index -1)."""
+    The reference function returns every entry of ``model.unobserved_RVs``: the free random
+    variables (in the order of q) followed by the deterministics ``seis_like.., geo_like..,
+    laplacian_like, like`` (SURVEY Appendix C "Outputs"); traces store that list
+    (backend.py:156-173) and ``astep`` reads ``out[_llk_index]``.  ``return_rvs=True`` gives exactly
+    that list; the default returns the deterministics block only (the variables are the input).
+    Either way ``f._llk_index`` points at ``like``."""
 
-    def __init__(self, ctx, model_id, problem):
+    def __init__(self, ctx, model_id, problem, return_rvs=False):
         self.ctx, self.model_id, self.problem = ctx, model_id, problem
         self.nllk = ctx.ffi_model_nllk(model_id)
         self.nparams = problem.layout.size
         self.trust_input = True
-        self._llk_index = self.nllk - 1
+        self.return_rvs = bool(return_rvs)
+        nblocks = (len(problem.wavemaps) + (problem.geodetic is not None)
+                   + (problem.laplacian is not None) + 1)
+        self._llk_index = nblocks - 1 + (len(problem.layout.varsizes) if self.return_rvs else 0)
+
+    @property
+    def out_names(self):
+        """names of the entries of ``f(q)`` (model.unobserved_RVs order)"""
+        names = list(self.problem.layout.varsizes) if self.return_rvs else []
+        names += ["seis_like_%s" % wm.name if len(self.problem.wavemaps) > 1 else "seis_like"
+                  for wm in self.problem.wavemaps]
+        if self.problem.geodetic is not None:
+            names.append("geo_like")
+        if self.problem.laplacian is not None:
+            names.append("laplacian_like")
+        return names + ["like"]
 
     def batch(self, Q, out=None):
         """Q (C, nparams) numpy or torch-cuda -> LL (C, nllk)"""
@@ -313,6 +332,8 @@ class LogpForwFunc(object):
         q = np.ascontiguousarray(q, dtype=np.float64).reshape(1, -1)
         ll = self.batch(q)[0]
         out = []
+        if self.return_rvs:
+            out += [v.copy() for v in self.problem.layout.rmap(q[0]).values()]
         o = 0
         for wm in self.problem.wavemaps:
             out.append(ll[o:o + wm.n_t].copy())
@@ -332,17 +353,41 @@ class LogpForwFunc(object):
                                         beta, accepted)
 
     def get_shared(self):
+        """the model's shared storage under the reference's access pattern (name / get_value /
+        set_value; sampler/base.py:274-282, 541-555 uses it to share memory between workers):
+        GF libraries (read-only, HBM resident), observed data, weights and log-determinants."""
         sh = []
-        for wm in self.problem.wavemaps:
+        for i, wm in enumerate(self.problem.wavemaps):
             for v, gf in wm.gfs.items():
                 sh.append(_SharedView(gf.filename, gf.get_all))
+            sh.append(_SharedView("%s_data" % wm.name, lambda wm=wm: wm.data))
+            sh.append(_SharedView("%s_weights" % wm.name, lambda wm=wm: wm.weights,
+                                  lambda value, i=i: self.update_weights(i, value, self.problem.wavemaps[i].slog_pdet)))
+            sh.append(_SharedView("%s_slog_pdet" % wm.name, lambda wm=wm: wm.slog_pdet))
+        if self.problem.geodetic is not None:
+            g = self.problem.geodetic
+            for v, gf in g.gfs.items():
+                sh.append(_SharedView(gf.filename, gf.get_all))
+            sh.append(_SharedView("geodetic_data", lambda: g.data))
+            sh.append(_SharedView("geodetic_odws", lambda: g.odws))
         return sh
 
     def update_weights(self, wavemap_index, weights, slog_pdet):
-        """seismic.py:1509-1534 update_weights: new chol_inverse + slog_pdet per dataset"""
+        """seismic.py:1509-1534 update_weights: new chol_inverse + slog_pdet per dataset.  Kind
+        and size must match the uploaded set (checked by the library)."""
         wm = self.problem.wavemaps[wavemap_index]
-        self.ctx.weights_update(wm._wset, weights, slog_pdet)
-        wm.weights, wm.slog_pdet = weights, np.asarray(slog_pdet, dtype=np.float64)
+        if getattr(wm, "is_prewhitened", False):
+            raise NotImplementedError(
+                "wavemap %s was compiled with a pre-whitened library: its weights are folded into "
+                "the library rows and the data.  Whiten the unwhitened library with the new "
+                "weights and compile again (FFIProblem.compile(prewhiten=True))." % wm.name)
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        sl = np.ascontiguousarray(slog_pdet, dtype=np.float64).ravel()
+        T, N = wm.data.shape
+        if w.shape not in ((T,), (T, N, N)) or sl.shape != (T,):
+            raise ValueError("weights must be (%d,) or (%d,%d,%d) and slog_pdet (%d,)" % (T, T, N, N, T))
+        self.ctx.weights_update(wm._wset, w, sl)
+        wm.weights, wm.slog_pdet = w, sl
 
 
 def prior_logp_func(lower, upper):

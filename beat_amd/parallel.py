@@ -7,10 +7,13 @@ Replaces the reference's two mechanisms:
     :285-439 shared-memory GF library  ->  chains are the batch dimension of the kernels,
     each rank owns a contiguous block of chains and one HBM-resident library copy;
   * the implicit stage gather through trace files (sampler/smc.py:188-240
-    ``select_end_points``)  ->  one all-gather of (end points, likelihood vectors) per stage.
+    ``select_end_points``)  ->  one all-gather of (end points, likelihood vectors) per stage;
+  * the MPI star of parallel tempering (sampler/pt.py:472-704)  ->  per swap round an
+    all-gather of one likelihood per replica (8 B each), the rank-identical swap decision, and
+    point-to-point moves of only the rows that actually change rank.
 
 No collective sits inside a chain step; payloads are a few MB per stage (latency bound), so
-a single flat all-gather is used rather than bucketing.
+flat collectives are used rather than bucketing.
 """
 import os
 
@@ -18,7 +21,14 @@ import numpy as np
 
 
 def dist_info():
-    """-> (rank, world_size, local_rank) from the torchrun environment"""
+    """-> (rank, world_size, local_rank): from the initialised process group when there is one,
+    else from the torchrun environment"""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size(), int(os.environ.get("LOCAL_RANK", "0"))
+    except ImportError:
+        pass
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
             int(os.environ.get("LOCAL_RANK", "0")))
 
@@ -40,6 +50,18 @@ def init(backend=None):
     return rank, world, local
 
 
+def ensure_group():
+    """Samplers shard chains by (rank, world): with WORLD_SIZE > 1 in the environment the process
+    group must exist, otherwise the all-gathers would silently return local blocks only."""
+    rank, world, local = dist_info()
+    if world > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            rank, world, local = init()
+        assert dist.is_initialized() and dist.get_world_size() == world
+    return rank, world, local
+
+
 def chain_block(n_chains, rank, world):
     """Contiguous block of chains owned by ``rank``: -> (start, stop).
     The reference requires n_chains / n_jobs to be whole (smc.py:419-421); here the
@@ -49,28 +71,91 @@ def chain_block(n_chains, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
-def allgather_population(Q, L):
-    """All ranks' end points and likelihood vectors, in global chain order.
-    Q (c_local, nparams), L (c_local, nllk) torch tensors (cuda or cpu) -> (Qall, Lall)."""
+def _active():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
+def allgather_rows(X):
+    """rows of all ranks in rank order; X (n_local, width) -> (n_total, width).  Blocks may differ
+    in length."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
-        return Q, L
+    if not _active():
+        return X
     world = dist.get_world_size()   # (a single rank runs through the same collectives)
-    n_local = torch.tensor([Q.shape[0]], device=Q.device, dtype=torch.int64)
+    n_local = torch.tensor([X.shape[0]], device=X.device, dtype=torch.int64)
     counts = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(counts, n_local)
     counts = [int(c.item()) for c in counts]
     nmax = max(counts)
-    width = Q.shape[1] + L.shape[1]
-    buf = torch.zeros((nmax, width), device=Q.device, dtype=Q.dtype)
-    buf[:Q.shape[0], :Q.shape[1]] = Q
-    buf[:Q.shape[0], Q.shape[1]:] = L
-    out = torch.empty((world * nmax, width), device=Q.device, dtype=Q.dtype)
+    buf = torch.zeros((nmax,) + tuple(X.shape[1:]), device=X.device, dtype=X.dtype)
+    buf[:X.shape[0]] = X
+    out = torch.empty((world * nmax,) + tuple(X.shape[1:]), device=X.device, dtype=X.dtype)
     dist.all_gather_into_tensor(out, buf)
-    parts = [out[r * nmax:r * nmax + counts[r]] for r in range(world)]
-    allp = torch.cat(parts, 0)
+    if all(c == nmax for c in counts):
+        return out
+    return torch.cat([out[r * nmax:r * nmax + counts[r]] for r in range(world)], 0)
+
+
+def allgather_population(Q, L):
+    """All ranks' end points and likelihood vectors, in global chain order.
+    Q (c_local, nparams), L (c_local, nllk) torch tensors (cuda or cpu) -> (Qall, Lall)."""
+    import torch
+    if not _active():
+        return Q, L
+    allp = allgather_rows(torch.cat([Q, L], 1))
     return allp[:, :Q.shape[1]].contiguous(), allp[:, Q.shape[1]:].contiguous()
+
+
+def exchange_rows(X, perm, n_total, gather=None):
+    """Apply a global row permutation to a population sharded in contiguous blocks:
+    new_global[i] = old_global[perm[i]].  X (n_local, width) is this rank's block; perm is the
+    same (n_total,) integer array on every rank.  Rows whose source is local are moved on the
+    device (``gather(src, idx)``, default torch indexing); only rows that change rank travel,
+    point to point (parallel tempering swaps adjacent temperatures, so that is a handful of rows
+    at block boundaries -- pt.py:573-633 ships every state through the master instead)."""
+    import torch
+    import torch.distributed as dist
+    perm = np.asarray(perm, dtype=np.int64)
+    if _active():
+        rank, world = dist.get_rank(), dist.get_world_size()
+    else:
+        rank, world = 0, 1
+    blocks = [chain_block(n_total, r, world) for r in range(world)]
+    start, stop = blocks[rank]
+    owner = np.empty(n_total, dtype=np.int64)
+    for r, (a, b) in enumerate(blocks):
+        owner[a:b] = r
+    src = perm[start:stop]
+    local = owner[src] == rank
+    idx = np.where(local, src - start, 0).astype(np.int32)
+    idx_t = torch.from_numpy(idx).to(X.device)
+    out = gather(X, idx_t) if gather is not None else X[idx_t.long()].contiguous()
+    if world == 1 or local.all() and all((owner[perm[a:b]] == r).all() for r, (a, b) in enumerate(blocks)):
+        return out
+    ops, recv = [], []
+    for r in range(world):
+        if r == rank:
+            continue
+        a, b = blocks[r]
+        # rows rank r needs from this rank, in the order of r's destination rows
+        send_src = perm[a:b][owner[perm[a:b]] == rank] - start
+        if send_src.size:
+            sbuf = X[torch.from_numpy(send_src).to(X.device)].contiguous()
+            ops.append(dist.P2POp(dist.isend, sbuf, r))
+        # rows this rank needs from rank r
+        need = np.nonzero(owner[src] == r)[0]
+        if need.size:
+            rbuf = torch.empty((need.size,) + tuple(X.shape[1:]), device=X.device, dtype=X.dtype)
+            ops.append(dist.P2POp(dist.irecv, rbuf, r))
+            recv.append((need, rbuf))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for need, rbuf in recv:
+        out[torch.from_numpy(need).to(X.device)] = rbuf
+    return out
 
 
 def broadcast_array(a, src=0):
@@ -78,7 +163,7 @@ def broadcast_array(a, src=0):
     every rank; this is only used for values that come from host RNG state)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active() or dist.get_world_size() == 1:
         return a
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)

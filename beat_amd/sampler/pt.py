@@ -5,8 +5,9 @@ The reference runs one MPI rank per tempered chain in a master/worker star: work
 sample a random number of Metropolis steps, send their last point to the master, which
 pairs the first two arrivals and applies ``propose_chain_swap`` (:429-457).  Here all
 replicas of a rank advance in ONE batched device call per step (per-replica beta), and the
-exchange is a synchronous round: an all-gather of the replica states (RCCL), then every rank
-applies the same even/odd adjacent-temperature swap sweep with a shared RandomState.  The
+exchange is a synchronous round: an all-gather of one likelihood per replica (RCCL), the same
+even/odd adjacent-temperature swap sweep on every rank with a shared RandomState, and the swapped
+states moved where they live (device gather; point to point only across rank boundaries).  The
 swap rule, the beta ladder (``update_betas`` :179-221), the beta tuning (``tune_betas``
 :331-354, ``tune`` :37-73) and the swap interval draw are the reference's; the pairing
 order differs (asynchronous first-arrivals are not reproducible) -- statistical, not bit,
@@ -122,41 +123,49 @@ def pt_sample(target, lower, upper, n_chains_posterior=1, n_chains_tempered=7, n
               n_samples=1000, swap_interval=(100, 300), beta_tune_interval=10, proposal_cov=None,
               device=None, random_seed=17, tune_interval=100, record_every=1):
     """pt.py:793-906 driver.  Returns (posterior samples (n, nparams), their likelihood
-    vectors, manager).  Samples of the beta == 1 replicas are recorded after every round."""
+    vectors, manager).  Samples of the beta == 1 replicas are recorded after every round.
+
+    Exchange round: all-gather of ONE likelihood per replica, the swap sweep decided
+    identically on every rank (shared RandomState), then the permutation is applied where the
+    states live: local rows by a device gather, rows that change rank point to point
+    (``parallel.exchange_rows``).  The replica states themselves are never gathered."""
     import torch
-    rank, world, _ = parallel.dist_info()
+    rank, world, _ = parallel.ensure_group()
     man = TemperingManager(n_chains_posterior, n_chains_tempered, n_replicas, swap_interval,
                            beta_tune_interval, random_seed)
     n_total = man.n_workers * n_replicas
     start, stop = parallel.chain_block(n_total, rank, world)
     lower, upper = np.asarray(lower, dtype=np.float64), np.asarray(upper, dtype=np.float64)
     stepper = BatchedMetropolis(target, lower, upper, stop - start, device=device,
-                                tune_interval=tune_interval, seed=random_seed + 7 * rank)
+                                tune_interval=tune_interval, seed=random_seed, first_chain=start)
     dev = stepper.device
+    ops = stepper.ops
     if proposal_cov is None:
         proposal_cov = np.diag(((upper - lower) * 0.05) ** 2)
     stepper.set_proposal(proposal_cov)
     Qall = lower + (upper - lower) * man.rng.random_sample((n_total, lower.size))
     Q = torch.from_numpy(np.ascontiguousarray(Qall[start:stop])).to(dev)
-    L = stepper.evaluate(Q)
-    if not torch.is_tensor(L):
-        L = torch.from_numpy(np.asarray(L))
-    post_rows = np.nonzero(man.chain_betas == 1.0)[0]
+    L = stepper.evaluate(Q).to(dev)
+    npar = Q.shape[1]
+    # posterior replicas (beta == 1) are the first n_posterior * n_replicas global chains
+    n_post = man.n_workers_posterior * n_replicas
+    p0, p1 = min(start, n_post), min(stop, n_post)
     samples, lsamples = [], []
     rounds = 0
     while sum(len(s) for s in samples) < n_samples:
         betas = torch.from_numpy(man.chain_betas[start:stop].copy()).to(dev)
         for _ in range(man.draw_swap_interval()):
             stepper.step(Q, L, betas)
-        Qg, Lg = parallel.allgather_population(Q, L)
-        Qh, Lh = Qg.detach().cpu().numpy(), Lg.detach().cpu().numpy()
+        ops.check()
+        QL = torch.cat([Q, L], 1)
         if rounds % record_every == 0:
-            samples.append(Qh[post_rows].copy())
-            lsamples.append(Lh[post_rows].copy())
-        perm = man.swap_round(Lh[:, -1])
-        Qh, Lh = Qh[perm], Lh[perm]
-        Q = torch.from_numpy(np.ascontiguousarray(Qh[start:stop])).to(dev)
-        L = torch.from_numpy(np.ascontiguousarray(Lh[start:stop])).to(dev)
+            post = parallel.allgather_rows(QL[p0 - start:p1 - start]).cpu().numpy()
+            samples.append(post[:, :npar].copy())
+            lsamples.append(post[:, npar:].copy())
+        like = parallel.allgather_rows(L[:, -1:].contiguous())[:, 0].cpu().numpy()
+        perm = man.swap_round(like)
+        QL = parallel.exchange_rows(QL, perm, n_total, gather=ops.gather)
+        Q, L = QL[:, :npar].contiguous(), QL[:, npar:].contiguous()
         rounds += 1
         if rounds % beta_tune_interval == 0 and man.n_workers_tempered > 0:
             man.tune_betas()

@@ -1,17 +1,21 @@
 """
 Sequential Monte Carlo (CATMIP / TMCMC) -- counterpart of beat/sampler/smc.py.
 
-Same stage logic and method names as the reference (``calc_beta`` :133-165,
-``calc_covariance`` :167-186, ``select_end_points`` :188-240, ``resample`` :290-324,
-``smc_sample`` :333-546).  What changes is where the work runs:
+Stage logic of the reference (``calc_beta`` :133-165, ``calc_covariance`` :167-186,
+``select_end_points`` :188-240, ``resample`` :290-324, ``smc_sample`` :333-546) with a
+different data flow:
 
-  * all chains of a rank advance together on the GPU (``BatchedMetropolis``): the
-    reference's fork pool over chains (sampler/base.py:428-595) becomes the batch
-    dimension of the kernels;
-  * chains are sharded over ranks in contiguous blocks; at every stage boundary the end
-    points and likelihood vectors are all-gathered (RCCL over xGMI) and every rank then
-    computes beta, the weighted covariance and the resampling IDENTICALLY from the same
-    arrays and the same seeded draw -- no rank-0 bottleneck, no files.
+  * all chains of a rank advance together on the GPU (``BatchedMetropolis``): the reference's
+    fork pool over chains (sampler/base.py:428-595) is the batch dimension of the kernels;
+  * chains are sharded over ranks in contiguous blocks; at a stage boundary the end points and
+    likelihood vectors are all-gathered (RCCL over xGMI) and stay ON THE DEVICE: the tempering
+    step, the importance weights, the resampling indices, the proposal factor and the restart
+    points are computed there by the kernels of ``csrc/smc.hip`` -- identically on every rank
+    (fixed-order reductions, one shared auxiliary draw), so there is no rank-0 bottleneck, no
+    files and no host copy of the population.  Only ``beta`` (8 bytes) returns per stage.
+
+``array_population`` / ``array_lpoints`` / ``weights`` / ``resampling_indexes`` /
+``likelihoods`` keep the reference's attribute names as host views for traces and inspection.
 """
 import logging
 import os
@@ -19,8 +23,9 @@ import os
 import numpy as np
 
 from .. import parallel
-from ..utility import ensure_cov_psd
+from .base import proposal_df
 from .metropolis import BatchedMetropolis
+from .ops import ops_for
 
 logger = logging.getLogger("smc")
 
@@ -33,8 +38,9 @@ class SMC(object):
     def __init__(self, target, lower, upper, n_chains=100, tune=True, tune_interval=100,
                  coef_variation=1.0, check_bound=True, proposal_name="MultivariateNormal",
                  device=None, random_seed=42, scale=1.0):
-        if proposal_name not in ("MultivariateNormal", "MultivariateCauchy"):
-            raise NotImplementedError("the GPU SMC uses the MultivariateNormal / MultivariateCauchy proposals")
+        import torch
+        self.torch = torch
+        proposal_df(proposal_name)  # validates the name
         if not check_bound:
             raise NotImplementedError("check_bound=False is not supported")
         self.target = target
@@ -45,111 +51,103 @@ class SMC(object):
         self.proposal_name = proposal_name
         self.beta, self.old_beta = 0.0, 0.0
         self.stage = 0
-        self.likelihoods = np.zeros(self.n_chains)
-        self.weights = None
-        self.covariance = None
-        self.resampling_indexes = np.arange(self.n_chains)
-        self.array_population = None       # (n_chains, nparams) end points, all ranks
-        self.array_lpoints = None          # (n_chains, nllk) likelihood vectors, all ranks
         self.rng = np.random.RandomState(random_seed)  # identical on every rank
-        self.rank, self.world, _ = parallel.dist_info()
+        self.rank, self.world, _ = parallel.ensure_group()
         self.block = parallel.chain_block(self.n_chains, self.rank, self.world)
         n_local = self.block[1] - self.block[0]
         self.stepper = BatchedMetropolis(target, lower, upper, n_local, device=device, tune=tune,
-                                         tune_interval=tune_interval, scale=scale,
-                                         seed=random_seed + 1000003 * self.rank)
+                                         tune_interval=tune_interval, scale=scale, seed=random_seed,
+                                         first_chain=self.block[0])
         self.device = self.stepper.device
+        self.ops = ops_for(self.device, target)
         self.n_steps = 1
         self.stage_betas, self.stage_acceptance = [], []
+        # gathered population of all ranks (tensors on self.device), weights, restart indices
+        self.Q_all = self.L_all = self.w = self.idx = None
+        self.covariance = None  # kept for API parity; the proposal uses the population factor
+
+    # ------------------------------------------------------------------ host views
+    @staticmethod
+    def _host(t):
+        return None if t is None else t.detach().cpu().numpy()
+
+    array_population = property(lambda self: self._host(self.Q_all))
+    array_lpoints = property(lambda self: self._host(self.L_all))
+    weights = property(lambda self: self._host(self.w))
+    resampling_indexes = property(
+        lambda self: np.arange(self.n_chains) if self.idx is None else self._host(self.idx).astype(np.int64))
+
+    @property
+    def likelihoods(self):
+        return None if self.L_all is None else self._host(self.L_all[:, -1])
 
     # ------------------------------------------------------------------ population
     def initialize_population(self):
         """metropolis.py:125-152: prior draws (Uniform boxes) for every chain; identical on
-        every rank because the seeded RandomState is shared."""
+        every rank because the seeded RandomState is shared.  -> this rank's block on the device"""
         u = self.rng.random_sample((self.n_chains, self.lower.size))
-        self.array_population = self.lower + (self.upper - self.lower) * u
-        return self.array_population
-
-    # ------------------------------------------------------------------ reference methods
-    def calc_beta(self):
-        """smc.py:133-165"""
-        low_beta, up_beta, old_beta = self.beta, 2.0, self.beta
-        current_beta = self.beta
-        while up_beta - low_beta > 1e-6:
-            current_beta = (low_beta + up_beta) / 2.0
-            temp = np.exp((current_beta - self.beta) * (self.likelihoods - self.likelihoods.max()))
-            cov_temp = np.std(temp) / np.mean(temp)
-            if cov_temp > self.coef_variation:
-                up_beta = current_beta
-            else:
-                low_beta = current_beta
-        weights = temp / np.sum(temp)
-        return current_beta, old_beta, weights
-
-    def calc_covariance(self, repair=True):
-        """smc.py:167-186.  repair=False skips ensure_cov_psd on the host: the device proposal
-        repairs and factors the matrix in one eigendecomposition."""
-        cov = np.cov(self.array_population, aweights=self.weights.ravel(), bias=False, rowvar=0)
-        cov = np.atleast_2d(cov)
-        if repair:
-            cov = ensure_cov_psd(cov)
-        if np.isnan(cov).any() or np.isinf(cov).any():
-            raise ValueError("Sample covariances contains Inf or NaN! Please try reducing the"
-                             " upper and lower bounds of hyper parameters!")
-        return cov
-
-    def set_stage_proposal(self):
-        """Proposal of the coming stage: N(0, weighted population covariance) (smc.py:452-466).
-        Populations up to twice the parameter count draw straight from the weighted, centred
-        population (no factorisation of a singular / ill-conditioned matrix); larger ones
-        factor ``self.covariance`` once."""
-        if self.n_chains <= 2 * self.array_population.shape[1]:
-            self.stepper.set_proposal_from_population(self.array_population, self.weights, self.proposal_name)
-        else:
-            self.stepper.set_proposal(self.covariance, self.proposal_name)
-
-    def resample(self):
-        """smc.py:290-324 Kitagawa's deterministic resampling; the single auxiliary draw
-        comes from the rank-shared RandomState.  Guarded against cumulative-sum overrun
-        (SURVEY A.15)."""
-        parents = np.arange(self.n_chains)
-        N_childs = np.zeros(self.n_chains, dtype=int)
-        cum_dist = np.cumsum(self.weights)
-        aux = self.rng.rand(1)
-        u = (parents + aux) / self.n_chains
-        j = 0
-        for i in parents:
-            while u[i] > cum_dist[j] and j < self.n_chains - 1:
-                j += 1
-            N_childs[j] += 1
-        return np.repeat(parents, N_childs)
+        pop = self.lower + (self.upper - self.lower) * u
+        a, b = self.block
+        return self.torch.from_numpy(np.ascontiguousarray(pop[a:b])).to(self.device)
 
     def select_end_points(self, Q_local, L_local):
-        """smc.py:188-240 -- instead of reading trace files: all-gather the ranks' blocks."""
-        Qall, Lall = parallel.allgather_population(Q_local, L_local)
-        self.array_population = Qall.detach().cpu().numpy()
-        self.array_lpoints = Lall.detach().cpu().numpy()
-        self.likelihoods = self.array_lpoints[:, -1].copy()
-        return self.array_population, self.likelihoods
+        """smc.py:188-240 -- instead of reading trace files: all-gather the ranks' blocks; the
+        gathered arrays stay on the device."""
+        self.ops.check()  # surfaces an out-of-library index of the finished stage (IndexError)
+        self.Q_all, self.L_all = parallel.allgather_population(Q_local, L_local)
+        if self.Q_all.shape[0] != self.n_chains:
+            raise RuntimeError("gathered %d chains, expected %d (process group not initialised?)"
+                               % (self.Q_all.shape[0], self.n_chains))
+        return self.Q_all, self.L_all
 
     def get_map_end_points(self):
         """smc.py:277-288"""
-        return self.array_population[self.likelihoods.flatten().argmax(), :]
+        return self._host(self.Q_all[int(self.torch.argmax(self.L_all[:, -1]))])
 
-    # ------------------------------------------------------------------ sampling of one stage
-    def _local(self, arr):
-        import torch
-        a = np.ascontiguousarray(arr[self.block[0]:self.block[1]])
-        return torch.from_numpy(a).to(self.device)
+    # ------------------------------------------------------------------ stage transition
+    def calc_beta(self):
+        """smc.py:133-165 on the gathered likelihoods -> (beta, old_beta, weights tensor)"""
+        beta_new, w = self.ops.calc_beta(self.L_all[:, -1], self.beta, self.coef_variation)
+        return beta_new, self.beta, w
+
+    def resample(self):
+        """smc.py:290-324; the single auxiliary draw comes from the rank-shared RandomState"""
+        aux = float(self.rng.rand(1)[0])
+        return self.ops.resample(self.w, aux)
+
+    def calc_covariance(self):
+        """smc.py:167-186, for inspection only (host): the samplers never form it"""
+        F = self._host(self.ops.population_factor(self.Q_all, self.w))
+        return F.T @ F
+
+    def transition(self, final=False):
+        """everything between two stages, on the device: weights (and the next beta), proposal
+        factor of the weighted population, resampling indices.  Returns False when beta passed 1
+        (the caller then runs the final stage)."""
+        if final:
+            # smc.py:526-529: weights towards beta = 1 from the beta the population was sampled at
+            self.w = self.ops.stage_weights(self.L_all[:, -1], 1.0 - self.beta)
+            self.old_beta, self.beta = self.beta, 1.0
+        else:
+            beta_new, old, w = self.calc_beta()
+            if beta_new > 1.0:
+                return False
+            self.beta, self.old_beta, self.w = beta_new, old, w
+        self.stepper.set_proposal_from_population(self.Q_all, self.w, self.proposal_name)
+        self.idx = self.resample()
+        return True
+
+    def restart_points(self):
+        """every local chain starts at its resampled parent (sampler/base.py:541-571)"""
+        a, b = self.block
+        sel = self.idx[a:b].contiguous()
+        return self.ops.gather(self.Q_all, sel), self.ops.gather(self.L_all, sel)
 
     def sample_stage(self, n_steps, on_step=None):
-        """iter_parallel_chains for one stage: every local chain starts at its resampled
-        parent (sampler/base.py:541-571) and takes n_steps Metropolis steps at self.beta."""
-        start = self.array_population[self.resampling_indexes]
-        lstart = self.array_lpoints[self.resampling_indexes]
-        Q, L = self._local(start), self._local(lstart)
-        import torch
-        n_acc = torch.zeros((), dtype=torch.int64, device=Q.device)  # stays on the device
+        """iter_parallel_chains for one stage: n_steps Metropolis steps of every local chain at
+        self.beta"""
+        Q, L = self.restart_points()
+        n_acc = self.torch.zeros((), dtype=self.torch.int64, device=Q.device)
         for i in range(int(n_steps)):
             acc = self.stepper.step(Q, L, self.beta)
             n_acc += acc.sum()
@@ -162,34 +160,55 @@ class SMC(object):
 def _dump_stage(step, homepath, layout, out_names, backend):
     """stage directory with one-draw traces of every chain (rank 0 writes; every rank holds the
     same gathered arrays) + the sampler state needed to resume (smc.py:549-557)"""
-    if homepath is None or step.rank != 0:
+    if homepath is None:
         return
-    from ..backend import stage_path, write_population
-    path = write_population(homepath, step.stage, layout, out_names, step.array_population,
-                            step.array_lpoints, backend)
+    # per-chain step state of all ranks (scaling, acceptance counters) for an exact resume
+    st = step.stepper.state_dict()
+    sc = parallel.allgather_rows(step.stepper.scaling[:, None])[:, 0].cpu().numpy()
+    ac = parallel.allgather_rows(step.stepper.accepted_since_tune[:, None])[:, 0].cpu().numpy()
+    if step.rank != 0:
+        return
+    from ..backend import write_population
+    pop, lp = step.array_population, step.array_lpoints
+    path = write_population(homepath, step.stage, layout, out_names, pop, lp, backend) \
+        if layout is not None else None
+    if path is None:
+        from ..backend import stage_path
+        path = stage_path(homepath, step.stage)
+        os.makedirs(path, exist_ok=True)
+    rs = step.rng.get_state()
     np.savez(os.path.join(path, "sampler_state.npz"), beta=step.beta, old_beta=step.old_beta,
-             stage=step.stage, population=step.array_population, lpoints=step.array_lpoints,
-             covariance=step.covariance if step.covariance is not None else np.zeros(0),
-             scaling=step.stepper.scaling.cpu().numpy())
+             stage=step.stage, population=pop, lpoints=lp, scaling=sc, accepted_since_tune=ac,
+             n_steps_total=st["n_steps_total"], steps_until_tune=st["steps_until_tune"],
+             rng_keys=rs[1], rng_pos=rs[2], rng_has_gauss=rs[3], rng_cached=rs[4])
 
 
 def load_stage(step, homepath, stage):
-    """resume: restore the population and tempering state of a completed stage
-    (init_stage / load_sampler_params, sampler/base.py:618-661, backend.py:1049-1071)"""
+    """resume: restore the population, the tempering state, the per-chain step sizes and the
+    shared random stream of a completed stage (init_stage / load_sampler_params,
+    sampler/base.py:618-661, backend.py:1049-1071)"""
     from ..backend import stage_path
     z = np.load(os.path.join(stage_path(homepath, stage), "sampler_state.npz"))
     step.beta, step.old_beta, step.stage = float(z["beta"]), float(z["old_beta"]), int(z["stage"])
-    step.array_population, step.array_lpoints = z["population"], z["lpoints"]
-    step.likelihoods = step.array_lpoints[:, -1].copy()
+    t = step.torch
+    step.Q_all = t.from_numpy(np.ascontiguousarray(z["population"])).to(step.device)
+    step.L_all = t.from_numpy(np.ascontiguousarray(z["lpoints"])).to(step.device)
+    if "scaling" in z.files and z["scaling"].size == step.n_chains:
+        step.stepper.load_state_dict(dict(scaling=z["scaling"], accepted_since_tune=z["accepted_since_tune"],
+                                          n_steps_total=z["n_steps_total"],
+                                          steps_until_tune=z["steps_until_tune"]), block=step.block)
+    if "rng_keys" in z.files:
+        step.rng.set_state(("MT19937", z["rng_keys"], int(z["rng_pos"]), int(z["rng_has_gauss"]),
+                            float(z["rng_cached"])))
     return step
 
 
 def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, homepath=None,
                layout=None, out_names=None, backend="bin", resume_stage=None):
     """smc.py:333-546 stage loop.  Returns the final population (n_chains, nparams), the
-    likelihood vectors and the list of betas.  With ``homepath`` every stage leaves a
-    ``stage_<k>`` / ``stage_final`` directory of NumpyChain/TextChain traces (beat_amd.backend)."""
-    import torch
+    likelihood vectors (host arrays) and the list of betas.  With ``homepath`` every stage leaves
+    a ``stage_<k>`` / ``stage_final`` directory of NumpyChain/TextChain traces
+    (beat_amd.backend) and the state to resume from."""
     step.n_steps = int(n_steps)
     if n_steps < 1:
         raise TypeError("Argument `n_steps` should be above 0.")
@@ -197,44 +216,29 @@ def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, 
         load_stage(step, homepath, resume_stage)
     else:
         # stage 0: evaluate the prior population (draws = 1, no move)
-        if step.array_population is None:
-            step.initialize_population()
-        Q = step._local(step.array_population)
+        Q = step.initialize_population()
         L = step.stepper.evaluate(Q)
-        step.select_end_points(Q, L if torch.is_tensor(L) else torch.from_numpy(np.asarray(L)))
-        if layout is not None:
-            _dump_stage(step, homepath, layout, out_names, backend)
+        step.select_end_points(Q, L)
+        _dump_stage(step, homepath, layout, out_names, backend)
     betas = [step.beta]
     while step.beta < 1.0 and step.stage < max_stages:
-        step.beta, step.old_beta, step.weights = step.calc_beta()
-        if step.beta > 1.0:
-            step.beta = 1.0
+        if not step.transition():
             break
-        step.covariance = step.calc_covariance(repair=False)
-        step.set_stage_proposal()
-        step.resampling_indexes = step.resample()
         step.stage += 1
         logger.info("Beta: %f Stage: %i", step.beta, step.stage)
         Q, L = step.sample_stage(n_steps)
         step.select_end_points(Q, L)
         betas.append(step.beta)
-        if layout is not None:
-            _dump_stage(step, homepath, layout, out_names, backend)
+        _dump_stage(step, homepath, layout, out_names, backend)
         if on_stage is not None:
             on_stage(step)
     # final stage at beta = 1 (smc.py:526-543)
     step.stage = -1
-    temp = np.exp((1 - step.old_beta) * (step.likelihoods - step.likelihoods.max()))
-    step.weights = temp / np.sum(temp)
-    step.covariance = step.calc_covariance(repair=False)
-    step.set_stage_proposal()
-    step.resampling_indexes = step.resample()
-    step.beta = 1.0
+    step.transition(final=True)
     Q, L = step.sample_stage(n_steps * sample_factor_final_stage)
     step.select_end_points(Q, L)
     betas.append(1.0)
-    if layout is not None:
-        _dump_stage(step, homepath, layout, out_names, backend)
+    _dump_stage(step, homepath, layout, out_names, backend)
     step.stage_betas = betas
     return step.array_population, step.array_lpoints, betas
 

@@ -63,6 +63,15 @@ int beatamd_ctx_enable_timing(beatamd_ctx *ctx, int on);
 int beatamd_ctx_kernel_time(beatamd_ctx *ctx, const char *kernel, double *total_ms,
                             int64_t *launches);
 int beatamd_ctx_reset_timing(beatamd_ctx *ctx);
+/* name and template arguments of the stacking kernel the most recent stack_all / logp / astep call
+ * launched, e.g. "k_gfstack_dma<8,1,1,64,1>" (wavefronts per workgroup, rows per patch, epilogue,
+ * samples per tile, ds_read_b64 layout) or "k_gfstack<0,1,1,2,0>" (streaming form). */
+int beatamd_ctx_last_kernel(beatamd_ctx *ctx, char *buf, int64_t buflen);
+/* chain-shared stacking kernels: distinct library rows per (chain group, target, patch) of the most
+ * recent launch -- mean, maximum, and the bytes of library rows staged from HBM (sum x N x 8).
+ * chains_per_group = 0 / row_bytes = 0 when the streaming kernel ran.  Synchronises. */
+int beatamd_ctx_gf_group_stats(beatamd_ctx *ctx, int64_t *chains_per_group, double *mean_rows,
+                               int64_t *max_rows, int64_t *row_bytes);
 
 /* ---------------------------------------------------------------- fast sweep -------
  * replaces: fast_sweep_ext.fast_sweep(slowness, patch_size, h_strk, h_dip, num_strk,
@@ -123,8 +132,10 @@ int beatamd_geo_stack_all_batch(beatamd_ctx *ctx, int32_t lib_id, int64_t C,
  * update = SeismicComposite.update_weights (seismic.py:1509-1534): same call again. */
 int beatamd_weights_create(beatamd_ctx *ctx, int32_t kind, int64_t ndatasets, int64_t M,
                            const double *weights, const double *slog_pdet, int32_t *wset_id);
-int beatamd_weights_update(beatamd_ctx *ctx, int32_t wset_id, const double *weights,
-                           const double *slog_pdet);
+/* kind and count (number of doubles in `weights`) are validated against the set: a wavemap whose
+ * library was pre-whitened holds scalar weights and rejects a dense update (re-whiten instead). */
+int beatamd_weights_update(beatamd_ctx *ctx, int32_t wset_id, int32_t kind, int64_t count,
+                           const double *weights, const double *slog_pdet);
 int beatamd_weights_destroy(beatamd_ctx *ctx, int32_t wset_id);
 /*   residuals [C, nd, M]   hp [C, nd] (hyperparameter already resolved per dataset,
  *   distributions.py:117-126)   ->   logpts [C, nd]                                  */
@@ -241,6 +252,59 @@ int beatamd_autocovariance_batch(beatamd_ctx *ctx, int64_t nd, int64_t n, const 
  *   coeffs [nd,n], stds [nd,n] -> out [nd,n,n]                                               */
 int beatamd_scaled_toeplitz_batch(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *coeffs,
                                   const double *stds, double *out);
+
+/* ---------------------------------------------------------------- SMC stage transition ----
+ * The population (end points Q [C,nparams], likelihood vectors L [C,nllk]) stays in HBM between
+ * stages; these entries run on device pointers (host pointers are staged like everywhere else).
+ * All reductions have a fixed order, so every rank of a multi-GPU run that holds the same gathered
+ * arrays computes bit-identical decisions.
+ *
+ * replaces: SMC.calc_beta                                   beat/sampler/smc.py:133-165
+ *   likelihoods: C values `stride` doubles apart (the `like` column of L: stride = nllk)
+ *   -> *beta_new (host), weights [C] (importance weights of the last bisection midpoint,
+ *      normalised).  exp() is the device's (<= 1 ulp from glibc/numpy): weights agree with
+ *      the reference to ~1e-15 relative, beta exactly unless a bisection decision sits on a tie. */
+int beatamd_smc_calc_beta(beatamd_ctx *ctx, int64_t C, const double *likelihoods, int64_t stride,
+                          double beta, double coef_variation, double *beta_new, double *weights);
+/* final stage (smc.py:526-529): weights = exp(dbeta (l - max l)) / sum */
+int beatamd_smc_stage_weights(beatamd_ctx *ctx, int64_t C, const double *likelihoods, int64_t stride,
+                              double dbeta, double *weights);
+/* replaces: SMC.resample (Kitagawa's deterministic resampling)   beat/sampler/smc.py:290-324
+ *   weights [C], aux = the single uniform draw (host RNG, shared by all ranks)
+ *   -> indexes [C] int32 = np.repeat(parents, N_childs); sequential cumulative sum as np.cumsum:
+ *      bit-exact indices */
+int beatamd_smc_resample(beatamd_ctx *ctx, int64_t C, const double *weights, double aux,
+                         int32_t *indexes);
+/* replaces: SMC.calc_covariance + MultivariateNormalProposal   smc.py:167-186, base.py:163-167
+ *   factor [C,nparams] with factor^T factor = np.cov(population, aweights=weights, bias=False):
+ *   rows z . factor (z ~ N(0, I_C)) are draws of N(0, cov) without factoring the covariance */
+int beatamd_smc_population_factor(beatamd_ctx *ctx, int64_t C, int64_t nparams,
+                                  const double *population, const double *weights, double *factor);
+/* replaces: proposal_dist(n_steps) rows + the Metropolis uniforms   metropolis.py:289-292, 355-358
+ *           multivariate_t_rvs                                       base.py:35-71
+ *   delta [C,nparams] = z [C,K] . factor [K,nparams] (FP64 MFMA), z from Philox4x32-10 keyed by
+ *   `seed` with counter (pair, first_chain + c, step, stream): a chain's draws do not depend on
+ *   the sharding.  df = 0: multivariate normal; df > 0: multivariate t (1 = Cauchy): rows divided
+ *   by sqrt(chi2(df) / df).  log_u [C] (nullable) = log of U(0,1). */
+int beatamd_proposal_draw(beatamd_ctx *ctx, int64_t C, int64_t K, int64_t nparams,
+                          const double *factor, uint64_t seed, uint32_t step, int64_t first_chain,
+                          int32_t df, double *delta, double *log_u);
+/* out[i,:] = src[indexes[i],:]: chains restart at their resampled parents (sampler/base.py:541-571),
+ * replica exchange permutation (pt.py:573-633).  An index outside [0,nrows_src) is BEATAMD_EINDEX
+ * at the next synchronisation. */
+int beatamd_gather_rows(beatamd_ctx *ctx, int64_t nout, int64_t ncols, const double *src,
+                        int64_t nrows_src, const int32_t *indexes, double *out);
+/* replaces: the per-chain step-size tuning of Metropolis.astep   metropolis.py:294-306
+ *   scaling [C] *= pymc's tune factor of accepted[c] / tune_interval; accepted [C] reset to 0 */
+int beatamd_metropolis_tune(beatamd_ctx *ctx, int64_t C, double *scaling, int32_t *accepted,
+                            int32_t tune_interval);
+
+/* ---------------------------------------------------------------- library whitening ------
+ * rows [nrows, N] (device, in place) <- rows . W^T, W [N,N] = chol_inverse of one dataset: the
+ * dense W.r of multivariate_normal_chol (distributions.py:128) applied once to every library row
+ * of the dataset instead of once per chain step (SeismicWavemap.prewhitened).  FP64 MFMA GEMM;
+ * an upper-triangular W (heart.py:233) skips its zero half. */
+int beatamd_whiten_rows(beatamd_ctx *ctx, double *rows, int64_t nrows, int64_t N, const double *W);
 
 #ifdef __cplusplus
 }

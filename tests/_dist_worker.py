@@ -29,6 +29,21 @@ def main():
     assert Qall.shape == (7, 3) and torch.equal(Qall[:, 0], torch.arange(7, dtype=torch.float64))
     assert torch.equal(Lall[:, 0], -torch.arange(7, dtype=torch.float64))
 
+    # replica exchange: moving only the rows that change place equals the all-gather + permute of
+    # the round-1 implementation, for arbitrary permutations and uneven blocks
+    rs = np.random.RandomState(77)
+    for n_total in (7, 32, 33):
+        a, b = parallel.chain_block(n_total, rank, world)
+        Xg = torch.from_numpy(rs.standard_normal((n_total, 5)))
+        for trial in range(4):
+            perm = rs.permutation(n_total) if trial < 2 else np.arange(n_total)
+            if trial == 3:   # adjacent swaps across the block boundary only
+                b0 = parallel.chain_block(n_total, 0, world)[1]
+                perm[[b0 - 1, b0]] = perm[[b0, b0 - 1]]
+            got = parallel.exchange_rows(Xg[a:b].clone(), perm, n_total)
+            ref = parallel.allgather_rows(Xg[a:b].clone())[torch.from_numpy(perm)][a:b]
+            assert torch.equal(got, ref), (n_total, trial)
+
     # SMC with chains sharded over the 2 ranks
     f, n = _two_gaussians()
     step = SMC(HostTarget(f, n), -2 * np.ones(n), 2 * np.ones(n), n_chains=301, tune_interval=10,

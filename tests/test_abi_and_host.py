@@ -106,8 +106,11 @@ def test_gflibrary_host_interface():
     durs = du_min + du_dt * np.arange(D)
     sts = st_min + st_dt * np.arange(S)
     gf.put(np.ones((D, N))[:, None, :].repeat(S, 1).reshape(D * S, N)[:D], 0, 0, durs, sts[:D])
+    for mode in ("numpy", "pytensor", "hip"):   # the reference's mode names are accepted aliases
+        gf.set_stack_mode(mode)
+        assert gf.get_stack_mode() == mode
     with pytest.raises(GFLibraryError):
-        gf.set_stack_mode("numpy")  # no CPU stacking mode
+        gf.set_stack_mode("cpu")  # there is no CPU stacking mode
     with pytest.raises(NotImplementedError):
         gf.starttimes2idxs(np.zeros(3), "cubic")
 

@@ -28,8 +28,8 @@ def full(request):
     free, _ = torch.cuda.mem_get_info(0)
     if free < 80e9:
         pytest.skip("needs 80 GB of free HBM")
-    spec = SyntheticSpec((20,), (20,), (1.0,), T=T, N=N, D=D, S=S, nuc_margin=6.0,
-                         time_bounds=(0.0, 0.5))
+    # the population of SURVEY 8(d): nucleation anywhere on the fault, origin time 0
+    spec = SyntheticSpec((20,), (20,), (1.0,), T=T, N=N, D=D, S=S, time_bounds=(0.0, 0.0))
     prob, host = build_problem(spec, device_library=True, ctx=ctx)
     gf = prob.wavemaps[0].gfs["uparr"]
     G = gf._device_tensor
@@ -138,6 +138,109 @@ def test_fullsize_properties(full):
     # checksum of checksums: sum over samples of the stack = sum_p slip * rowsum(row)
     rs = np.array([_row_values([r]).sum() for r in range(0, 3)])
     assert np.isfinite(rs).all()
+
+
+def _chain_inputs(full, Q):
+    """durations / start times (with a small per-target offset so that targets differ) / slips of
+    the chains in Q, rupture times through the CPU oracle"""
+    C = Q.shape[0]
+    dur = np.empty((C, P)); st = np.empty((C, T, P)); sl = np.empty((C, P))
+    toff = 0.013 * np.arange(T)[:, None]
+    for c in range(C):
+        st0, pt = _starttimes_oracle(full, Q[c])
+        dur[c], sl[c] = pt["durations"], pt["uparr"]
+        st[c] = st0[None, :] + toff
+    return dur, st, sl
+
+
+def _stack_reference(full, dur_c, st_ct, sl_c, t, interp):
+    """one (chain, target) stack rebuilt on the host from the closed-form library rows and the
+    oracle's index maps"""
+    from oracle import oracle as orc
+    spec = full["spec"]
+    di, df = orc.time2idx(dur_c, spec.du_min, spec.du_dt, interp)
+    si, sf = orc.time2idx(st_ct, spec.st_min, spec.st_dt, interp)
+    base = (t * P + np.arange(P)) * D
+    if interp == "nearest_neighbor":
+        return (_row_values((base + di) * S + si) * sl_c[:, None]).sum(0)
+    ref = np.zeros(N)
+    for dd, ss, w in ((di, si, (1 - sf) * (1 - df)), (di, si - 1, sf * (1.0 - df)),
+                      (di - 1, si, (1 - sf) * df), (di - 1, si - 1, sf * df)):
+        dd = np.where(dd < 0, dd + D, dd); ss = np.where(ss < 0, ss + S, ss)
+        ref += (_row_values((base + dd) * S + ss) * (w * sl_c)[:, None]).sum(0)
+    return ref
+
+
+@pytest.mark.parametrize("C", [512, 530, 1024])
+def test_fullsize_shipped_dma_kernel_at_bench_shape(full, monkeypatch, C):
+    """the kernel bench.py times -- k_gfstack_dma with 8-wavefront (512-chain)
+    workgroups, 400 steps, 64 sample tiles, 62.9 GB addressing -- at the bench shape itself:
+    bitwise equal to the streaming kernel (one slip variable) and, on sampled (chain, target)
+    pairs, equal to the oracle's index maps + closed-form rows at 1e-10; nearest neighbour and
+    multilinear."""
+    import torch
+    ctx, gf = full["ctx"], full["gf"]
+    dev = torch.device("cuda", 0)
+    Q = _population(full, C, seed_offset=9000)
+    dur, st, sl = _chain_inputs(full, Q)
+    dur_d, st_d, sl_d = (torch.from_numpy(a).to(dev) for a in (dur, st, sl))
+    rng = np.random.default_rng(C)
+    pairs = [(0, 0), (C - 1, T - 1), (min(511, C - 1), 31), (min(512, C - 1), 17)] + \
+        [(int(rng.integers(C)), int(rng.integers(T))) for _ in range(4)]
+    # 530 chains: the cost model would pick 256-chain groups; force the bench kernel's 512-chain
+    # workgroups, whose second group then holds 18 live chains of 512
+    monkeypatch.setenv("BEATAMD_GS_CG", "512")
+    for interp, nrow in (("nearest_neighbor", 1), ("multilinear", 4)):
+        monkeypatch.delenv("BEATAMD_GF_KERNEL", raising=False)
+        out = gf.stack_all_batch(dur_d, st_d, sl_d, interpolation=interp)
+        name = ctx.last_kernel()
+        assert name.startswith("k_gfstack_dma<8,%d,0,64," % nrow), name
+        stats = ctx.gf_group_stats()
+        assert stats["chains_per_group"] == 512 and 1 <= stats["max_rows"] <= D * S
+        assert stats["row_bytes"] == round(stats["mean_rows"] * ((C + 511) // 512) * T * P) * N * 8
+        monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
+        ref = gf.stack_all_batch(dur_d, st_d, sl_d, interpolation=interp)
+        assert ctx.last_kernel().startswith("k_gfstack<"), ctx.last_kernel()
+        monkeypatch.delenv("BEATAMD_GF_KERNEL")
+        assert torch.equal(out, ref), "k_gfstack_dma differs from the streaming kernel (%s)" % interp
+        del ref
+        for c, t in pairs:
+            want = _stack_reference(full, dur[c], st[c, t], sl[c], t, interp)
+            got = out[c, t].cpu().numpy()
+            assert np.abs(got - want).max() <= 1e-10 * max(1.0, np.abs(want).max()), (interp, c, t)
+        del out
+    ctx.synchronize()
+
+
+@pytest.mark.parametrize("C", [512, 1024])
+def test_fullsize_fused_logp_through_dma_kernel(full, monkeypatch, C):
+    """f.batch (sweep -> indices -> k_gfstack_dma with the fused misfit epilogue -> logp) at the
+    bench shape against the streaming kernel and the oracle composition"""
+    import torch
+    from oracle import oracle as orc
+    ctx, f, host, spec = full["ctx"], full["f"], full["host"], full["spec"]
+    Q = _population(full, C, seed_offset=20000)
+    Qd = torch.from_numpy(Q).to("cuda:0")
+    monkeypatch.delenv("BEATAMD_GF_KERNEL", raising=False)
+    monkeypatch.setenv("BEATAMD_GS_CG", "512")
+    LL = f.batch(Qd).cpu().numpy()
+    assert ctx.last_kernel().startswith("k_gfstack_dma<8,1,1,64,"), ctx.last_kernel()
+    monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
+    LS = f.batch(Qd).cpu().numpy()
+    monkeypatch.delenv("BEATAMD_GF_KERNEL")
+    np.testing.assert_allclose(LL, LS, rtol=1e-12)
+    assert np.isfinite(LL).all()
+    for c in (0, C // 2 + 1, C - 1):
+        st0, pt = _starttimes_oracle(full, Q[c])
+        di, _ = orc.time2idx(pt["durations"], spec.du_min, spec.du_dt)
+        si, _ = orc.time2idx(st0, spec.st_min, spec.st_dt)
+        hp = pt["h_any_P_0_Z"][0]
+        for t in (0, 40, 63):
+            rows = _row_values(((t * P + np.arange(P)) * D + di) * S + si)
+            syn = (rows * pt["uparr"][:, None]).sum(0)
+            ref = orc.mvn_chol_logp(host["weights"][t], host["data"][t] - syn, host["slog"][t], hp)
+            np.testing.assert_allclose(LL[c, t], ref, rtol=1e-10)
+    ctx.synchronize()
 
 
 def test_config4_joint_multifault_shape():

@@ -1,0 +1,332 @@
+"""GPU tests of the sampler kernels (csrc/smc.hip, csrc/gemm.hip) through the C ABI: SMC stage
+transition against the arrays captured from the reference's methods (tests/golden/smc.npz), the
+proposal generator against its Python twin (tests/philox_ref.py, pinned to the published Philox
+known answers on the CPU), the FP64 MFMA GEMM against numpy, and the failure behaviour the
+advisor asked for (chain-local NaN for an index outside the GF library, weight-update
+validation)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import beat_amd
+    return beat_amd.get_context(0)
+
+
+# ----------------------------------------------------------------------------- stage transition
+def test_calc_beta_resample_factor_vs_reference_golden(ctx):
+    """beatamd_smc_calc_beta / _smc_resample / _smc_population_factor against SMC.calc_beta,
+    SMC.resample and np.cov(aweights) of the reference (smc.py:133-186, 290-324)"""
+    import torch
+    g = load_golden("smc")
+    dev = torch.device("cuda", 0)
+    for k in range(int(g["ncase"])):
+        lk = np.ascontiguousarray(g["c%d_lk" % k])
+        beta_in = float(g["c%d_beta_in" % k])
+        b, w = ctx.smc_calc_beta(lk, beta_in, 1.0)
+        # the bisection takes exactly the reference's decisions: same dyadic beta
+        assert b == float(g["c%d_beta" % k])
+        # exp() of the device vs numpy's: <= 1 ulp per term -> 1e-14 relative on the weights
+        np.testing.assert_allclose(w, g["c%d_w" % k], rtol=1e-13, atol=0)
+        assert abs(w.sum() - 1.0) < 1e-13
+        # strided view: the `like` column of a likelihood matrix on the device
+        L = torch.zeros((lk.size, 5), dtype=torch.float64, device=dev)
+        L[:, -1] = torch.from_numpy(lk).to(dev)
+        from beat_amd.sampler.ops import DeviceOps
+        ops = DeviceOps(ctx)
+        b2, w2 = ops.calc_beta(L[:, -1], beta_in, 1.0)
+        assert b2 == b and np.array_equal(w2.cpu().numpy(), w)
+        # resampling: sequential cumulative sum like np.cumsum -> bit-exact indices
+        aux = float(np.ravel(g["c%d_aux" % k])[0])
+        idx = ctx.smc_resample(np.ascontiguousarray(g["c%d_w" % k]), aux)
+        assert idx.dtype == np.int32 and np.array_equal(idx, g["c%d_idx" % k])
+        # proposal factor: F^T F = np.cov(population, aweights=weights, bias=False)
+        F = ctx.smc_population_factor(np.ascontiguousarray(g["c%d_pop" % k]),
+                                      np.ascontiguousarray(g["c%d_w" % k]))
+        np.testing.assert_allclose(F.T @ F, g["c%d_cov" % k], rtol=1e-11, atol=1e-14)
+        # final-stage weights (smc.py:526-529)
+        wf = ctx.smc_stage_weights(lk, 1.0 - beta_in)
+        t = np.exp((1.0 - beta_in) * (lk - lk.max()))
+        np.testing.assert_allclose(wf, t / t.sum(), rtol=1e-13)
+
+
+def test_stage_ops_large_population_vs_host_ops(ctx):
+    """4096 and 10007 chains (BASELINE configs[3] population; an odd size): device vs host ops"""
+    import torch
+    from beat_amd.sampler.ops import DeviceOps, HostOps
+    dops, hops = DeviceOps(ctx), HostOps()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(4)
+    for n in (4096, 10007):
+        lk = torch.from_numpy(-1e4 * rng.random(n) ** 2)
+        for beta in (0.0, 3e-4):
+            bh, wh = hops.calc_beta(lk, beta, 1.0)
+            bd, wd = dops.calc_beta(lk.to(dev), beta, 1.0)
+            assert bd == bh
+            np.testing.assert_allclose(wd.cpu().numpy(), wh.numpy(), rtol=1e-12, atol=1e-300)
+            for aux in (0.0, 0.37, 0.999999):
+                ih = hops.resample(wh, aux).numpy()
+                idd = dops.resample(wh.to(dev), aux).cpu().numpy()
+                assert np.array_equal(idd, ih)
+        X = torch.from_numpy(rng.standard_normal((n, 37)))
+        Fh = hops.population_factor(X, wh).numpy()
+        Fd = dops.population_factor(X.to(dev), wh.to(dev)).cpu().numpy()
+        np.testing.assert_allclose(Fd, Fh, rtol=1e-10, atol=1e-13)
+        sel = torch.from_numpy(rng.integers(0, n, 100).astype(np.int32))
+        assert torch.equal(dops.gather(X.to(dev), sel.to(dev)).cpu(), X[sel.long()])
+    ctx.synchronize()
+
+
+def test_gather_rows_out_of_range_index_raises(ctx):
+    X = np.arange(12.0).reshape(4, 3)
+    np.testing.assert_array_equal(ctx.gather_rows(X, np.array([3, 0, 0], dtype=np.int32)), X[[3, 0, 0]])
+    with pytest.raises(IndexError):
+        ctx.gather_rows(X, np.array([1, 4], dtype=np.int32))
+
+
+def test_metropolis_tune_kernel_is_pymc_table(ctx):
+    import torch
+    from beat_amd.sampler import step_tune
+    dev = torch.device("cuda", 0)
+    acc = np.array([0, 1, 4, 5, 19, 20, 21, 50, 51, 75, 76, 95, 96, 100], dtype=np.int32)
+    sc = np.linspace(0.5, 2.0, acc.size)
+    s_d, a_d = torch.from_numpy(sc.copy()).to(dev), torch.from_numpy(acc.copy()).to(dev)
+    ctx.metropolis_tune(s_d, a_d, 100)
+    np.testing.assert_array_equal(s_d.cpu().numpy(), step_tune(sc, acc / 100.0))
+    assert int(a_d.abs().sum().item()) == 0
+
+
+# ----------------------------------------------------------------------------- proposal rows
+def test_proposal_normals_match_philox_reference(ctx):
+    """z from the device generator = the Python Philox4x32-10 + Box-Muller twin; draws are a
+    function of (seed, step, global chain) only"""
+    import philox_ref as pr
+    for K in (16, 7, 1):
+        C = 33
+        eye = np.eye(K)
+        z, lu = ctx.proposal_draw(eye, C, seed=0x123456789abcdef, step=5)
+        ref = pr.normals(C, K, 0x123456789abcdef, 5)
+        np.testing.assert_allclose(z, ref, rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(lu, pr.log_uniforms(C, 0x123456789abcdef, 5), rtol=1e-13)
+        # sharding independence: chains 10..32 drawn as a block of their own
+        z2, lu2 = ctx.proposal_draw(eye, C - 10, seed=0x123456789abcdef, step=5, first_chain=10)
+        assert np.array_equal(z2, z[10:]) and np.array_equal(lu2, lu[10:])
+        z3, _ = ctx.proposal_draw(eye, C, seed=0x123456789abcdef, step=6)
+        assert not np.array_equal(z3, z)
+    # multivariate t: rows divided by sqrt(chi2(df)/df)
+    for df in (1, 2, 5):
+        zc, _ = ctx.proposal_draw(np.eye(4), 50, seed=9, step=2, df=df)
+        ref = pr.normals(50, 4, 9, 2) * pr.t_row_scale(50, 9, 2, df)[:, None]
+        np.testing.assert_allclose(zc, ref, rtol=1e-11, atol=1e-13)
+
+
+@pytest.mark.parametrize("C,K,npar", [(5, 3, 2), (130, 70, 200), (512, 512, 1204), (64, 1204, 1204)])
+def test_proposal_gemm_vs_numpy(ctx, C, K, npar):
+    """delta = z . F on the FP64 matrix cores (A = I check with an asymmetric factor included)"""
+    import philox_ref as pr
+    rng = np.random.default_rng(C + K)
+    F = rng.standard_normal((K, npar)) * (1.0 + np.arange(npar))[None, :]   # asymmetric
+    delta, _ = ctx.proposal_draw(F, C, seed=77, step=1)
+    ref = pr.normals(C, K, 77, 1) @ F
+    np.testing.assert_allclose(delta, ref, rtol=1e-11, atol=1e-9 * np.abs(ref).max())
+
+
+def test_proposal_statistics_on_device(ctx):
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((4, 4))
+    cov = A @ A.T + 0.5 * np.eye(4)
+    from beat_amd.sampler.base import covariance_factor
+    F = torch.from_numpy(covariance_factor(cov)).to(dev)
+    x, lu = ctx.proposal_draw(F, 400000, seed=5, step=0)
+    np.testing.assert_allclose(np.cov(x.cpu().numpy().T), cov, rtol=0.02, atol=0.02)
+    u = np.exp(lu.cpu().numpy())
+    assert abs(u.mean() - 0.5) < 0.003 and abs(u.var() - 1.0 / 12) < 0.002
+    y, _ = ctx.proposal_draw(F, 400000, seed=6, step=0, df=1)
+    y = y.cpu().numpy()
+    np.testing.assert_allclose(np.median(np.abs(y), axis=0), np.sqrt(np.diag(cov)), rtol=0.02)
+
+
+# ----------------------------------------------------------------------------- whitening GEMM
+@pytest.mark.parametrize("R,N", [(1, 6), (300, 130), (1000, 512), (70, 1000)])
+def test_whiten_rows_vs_numpy(ctx, R, N):
+    """rows <- rows . W^T (beatamd_whiten_rows) for upper-triangular (chol_inverse) and full W"""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(R + N)
+    rows = rng.standard_normal((R, N))
+    for upper in (True, False):
+        W = rng.standard_normal((N, N)) + 3.0 * np.eye(N)
+        if upper:
+            W = np.triu(W)
+        d = torch.from_numpy(rows.copy()).to(dev)
+        ctx.whiten_rows(d, W)
+        ref = rows @ W.T
+        np.testing.assert_allclose(d.cpu().numpy(), ref, rtol=1e-11, atol=1e-11 * np.abs(ref).max())
+
+
+# ----------------------------------------------------------------------------- failure behaviour
+def _small_model(ctx, **kw):
+    from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
+    spec = SyntheticSpec((4,), (4,), (1.0,), T=3, N=32, D=3, S=25, **kw)
+    prob, host = build_problem(spec)
+    f = prob.compile(ctx)
+    lay = host["layout"]
+    Q = draw_population(spec, lay, host["lower"], host["upper"], 70)
+    return spec, prob, host, f, lay, Q
+
+
+def test_index_outside_library_is_chain_local_nan_on_device(ctx):
+    """An origin time that pushes the start times off the library grid: the reference raises
+    IndexError (numpy fancy indexing).  Host arrays -> IndexError; device tensors (asynchronous)
+    -> that chain's like is NaN, the others are untouched, the Metropolis step rejects it, and the
+    next synchronisation raises IndexError."""
+    import torch
+    spec, prob, host, f, lay, Q = _small_model(ctx)
+    dev = torch.device("cuda", 0)
+    good = f.batch(Q)
+    bad = Q.copy()
+    bad[[3, 64], lay.offset("time")] = 100.0
+    with pytest.raises(IndexError):
+        f.batch(bad)
+    Ld = f.batch(torch.from_numpy(bad).to(dev)).cpu().numpy()
+    assert np.isnan(Ld[[3, 64], -1]).all()
+    keep = np.setdiff1d(np.arange(70), [3, 64])
+    np.testing.assert_array_equal(Ld[keep], good[keep])
+    with pytest.raises(IndexError):
+        ctx.synchronize()
+    ctx.synchronize()  # the status word was cleared
+    # astep: chain 0 proposes the off-grid origin time inside a (deliberately wide) prior box
+    lo, up = lay.bounds(host["lower"], host["upper"])
+    up = up.copy()
+    up[lay.offset("time")] = 1000.0
+    Q0 = torch.from_numpy(Q).to(dev)
+    L0 = torch.from_numpy(good).to(dev)
+    delta = torch.zeros_like(Q0)
+    delta[0, lay.offset("time")] = 100.0
+    acc = f.astep_batch(Q0, L0, delta, torch.ones(70, dtype=torch.float64, device=dev),
+                        torch.from_numpy(lo).to(dev), torch.from_numpy(up).to(dev),
+                        torch.full((70,), -1e300, dtype=torch.float64, device=dev), 1.0)
+    acc = acc.cpu().numpy()
+    assert acc[0] == 0 and acc[1:].all()          # zero moves are accepted (mr = 0 > log u)
+    assert torch.equal(Q0.cpu(), torch.from_numpy(Q))
+    with pytest.raises(IndexError):
+        ctx.synchronize()
+
+
+def test_update_weights_validation(ctx):
+    """a dense update of a pre-whitened (scalar) weight set was silently accepted"""
+    from beat_amd.synthetic import SyntheticSpec, build_problem
+    spec = SyntheticSpec((4,), (4,), (1.0,), T=3, N=32, D=3, S=25, covariance="toeplitz")
+    prob, host = build_problem(spec)
+    W, sl = np.asarray(host["weights"]), np.asarray(host["slog"])
+    f = prob.compile(ctx)
+    f.update_weights(0, 2.0 * W, sl + 1.0)                  # same kind and size: fine
+    with pytest.raises(ValueError):
+        f.update_weights(0, W[:, :16, :16], sl)             # wrong size
+    with pytest.raises(ValueError):
+        ctx.weights_update(prob.wavemaps[0]._wset, np.ones(3), sl)   # scalar into a dense set
+    prob2, _ = build_problem(spec)
+    f2 = prob2.compile(ctx, prewhiten=True)
+    with pytest.raises(NotImplementedError):
+        f2.update_weights(0, W, sl)
+    with pytest.raises(ValueError):
+        ctx.weights_update(prob2.wavemaps[0]._wset, W, sl)  # the library refuses as well
+
+
+# ----------------------------------------------------------------------------- seams
+def test_logp_forw_func_returns_unobserved_rvs(ctx):
+    """B1: with return_rvs the compiled-function twin lists the free variables in q order in
+    front of the deterministics, like model.unobserved_RVs (sampler/base.py:598-615)"""
+    from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
+    spec = SyntheticSpec((4,), (4,), (1.0,), T=2, N=16, D=3, S=25, geodetic_nobs=(6,), laplacian=True)
+    prob, host = build_problem(spec)
+    f = prob.compile(ctx, return_rvs=True)
+    lay = host["layout"]
+    q = draw_population(spec, lay, host["lower"], host["upper"], 1)[0]
+    out = f(q)
+    names = f.out_names
+    assert names[:len(lay.varsizes)] == list(lay.varsizes) and names[-1] == "like"
+    assert len(out) == len(names) and f._llk_index == len(out) - 1
+    for (k, n), v in zip(lay.varsizes.items(), out):
+        assert v.shape == (n,) and np.array_equal(v, q[lay.offset(k):lay.offset(k) + n])
+    ll = f.batch(q[None])[0]
+    assert out[f._llk_index] == ll[-1]
+    assert out[-4].shape == (2,) and out[-3].shape == (1,) and out[-2].shape == ()
+    f0 = prob.compile(ctx)
+    assert len(f0(q)) == 4 and f0._llk_index == 3
+    shared = {s.name: s for s in f.get_shared()}
+    assert "geodetic_data" in shared and np.array_equal(shared["geodetic_data"].get_value(), host["gdata"])
+
+
+def test_stack_all_patch_subset_and_modes(ctx):
+    """B3: patchidxs subsets (base.py:651-656) and the reference's stack-mode names"""
+    from beat_amd.ffi import SeismicGFLibrary, SeismicGFLibraryConfig
+    from oracle import oracle as orc
+    rng = np.random.default_rng(8)
+    T, P, D, S, N = 3, 9, 2, 5, 40
+    G = rng.standard_normal((T, P, D, S, N))
+    gf = SeismicGFLibrary(SeismicGFLibraryConfig(dimensions=(T, P, D, S, N), starttime_sampling=0.5,
+                                                 duration_sampling=0.5, starttime_min=0.0, duration_min=0.5))
+    gf.setup(T, P, D, S, N, allocate=True)
+    gf._gfmatrix[:] = G
+    gf.init_optimization(ctx)
+    for mode in ("numpy", "pytensor", "hip"):
+        gf.set_stack_mode(mode)
+    pidx = np.array([7, 2, 4], dtype="int16")
+    dur, sl = rng.uniform(0.5, 1.0, 3), rng.uniform(0, 5, 3)
+    st = rng.uniform(0, 2, (T, 3))
+    for interp in ("nearest_neighbor", "multilinear"):
+        out = gf.stack_all(dur, st, sl, targetidxs=np.arange(T)[:, None], patchidxs=pidx, interpolation=interp)
+        ref = orc.stack_all(np.ascontiguousarray(G[:, pidx]), dur, st, sl, 0.5, 0.5, 0.0, 0.5, interp)
+        np.testing.assert_allclose(out, ref, rtol=1e-12, atol=1e-12)
+    # target subset
+    out = gf.stack_all(dur, st[[2, 0]], sl, targetidxs=np.array([[2], [0]]), patchidxs=pidx)
+    np.testing.assert_allclose(out, ref_nn(G, pidx, dur, st, sl, orc)[[2, 0]], rtol=1e-12, atol=1e-12)
+    with pytest.raises(IndexError):
+        gf.stack_all(dur, st, sl, targetidxs=np.arange(T), patchidxs=np.array([1, 1, 2]))
+
+
+def ref_nn(G, pidx, dur, st, sl, orc):
+    return orc.stack_all(np.ascontiguousarray(G[:, pidx]), dur, st, sl, 0.5, 0.5, 0.0, 0.5)
+
+
+def test_library_files_round_trip_through_hbm(ctx, tmp_path):
+    """f.2: <name>.traces.npy / .times.npy / .yaml (base.py:161-189, 364-373): save from a host
+    library and from an HBM-only library, load memory-mapped, stream to HBM, same stacks"""
+    import torch
+    from beat_amd.ffi import SeismicGFLibrary, SeismicGFLibraryConfig, load_gf_library
+    rng = np.random.default_rng(2)
+    T, P, D, S, N = 4, 6, 2, 7, 64
+    cfg = dict(dimensions=(T, P, D, S, N), starttime_sampling=0.25, duration_sampling=0.5,
+               starttime_min=-0.5, duration_min=0.5, component="uperp", mapnumber=3, wavename="any_S")
+    gf = SeismicGFLibrary(SeismicGFLibraryConfig(**cfg))
+    gf.setup(T, P, D, S, N, allocate=True)
+    gf._gfmatrix[:] = rng.standard_normal((T, P, D, S, N))
+    for t in range(T):
+        gf.set_patch_time(t, 10.0 + t)
+    C = 50
+    dur, st, sl = rng.uniform(0.5, 1.0, (C, P)), rng.uniform(-0.5, 1.0, (C, T, P)), rng.uniform(0, 5, (C, P))
+    gf.init_optimization(ctx)
+    before = gf.stack_all_batch(dur, st, sl, interpolation="multilinear")
+    gf.save(str(tmp_path))
+    g2 = load_gf_library(str(tmp_path), gf.filename)
+    assert isinstance(g2._gfmatrix, np.memmap) and g2.filename == "seismic_uperp_any_S_3_0"
+    assert g2.starttime_min == -0.5 and g2.starttime_sampling == 0.25 and g2.dimensions == (T, P, D, S, N)
+    np.testing.assert_array_equal(g2._tmins, 10.0 + np.arange(T))
+    g2.init_optimization(ctx)
+    assert np.array_equal(g2.stack_all_batch(dur, st, sl, interpolation="multilinear"), before)
+    # a library that exists only in HBM
+    g3 = SeismicGFLibrary(SeismicGFLibraryConfig(**dict(cfg, component="uparr")))
+    g3.adopt_device_tensor(torch.from_numpy(gf._gfmatrix).to("cuda:0"))
+    g3.save(str(tmp_path))
+    g4 = load_gf_library(str(tmp_path), g3.filename)
+    np.testing.assert_array_equal(np.asarray(g4._gfmatrix), gf._gfmatrix)
+    g4.init_optimization(ctx)
+    assert np.array_equal(g4.stack_all_batch(dur, st, sl, interpolation="multilinear"), before)

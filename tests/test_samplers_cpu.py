@@ -38,32 +38,27 @@ def test_smc_two_gaussians():
     assert lp.shape == (300, 1)
 
 
-def test_smc_methods_match_reference_golden():
-    """calc_beta / resample / weighted covariance against arrays captured from the
-    reference's SMC methods (oracle/gen_golden.py)"""
-    from beat_amd.sampler import SMC
-    from beat_amd.sampler.hosttarget import HostTarget
+def test_host_stage_ops_match_reference_golden():
+    """calc_beta / resample / weighted covariance of the host back end (toy targets) against arrays
+    captured from the reference's SMC methods (oracle/gen_golden.py); the device back end is
+    checked against the same fixtures in tests/test_gpu_samplers.py"""
+    import torch
+    from beat_amd.sampler.ops import HostOps
+    ops = HostOps()
     g = load_golden("smc")
     for k in range(int(g["ncase"])):
-        lk = g["c%d_lk" % k]
-        step = SMC(HostTarget(lambda X: np.zeros(len(X)), 6), -np.ones(6), np.ones(6),
-                   n_chains=lk.size)
-        step.likelihoods = lk
-        step.beta = float(g["c%d_beta_in" % k])
-        b, ob, w = step.calc_beta()
-        assert b == float(g["c%d_beta" % k]) and ob == step.beta
-        np.testing.assert_array_equal(w, g["c%d_w" % k])
-        step.weights = w
-        aux = g["c%d_aux" % k]
-        step.rng = type("R", (), {"rand": staticmethod(lambda n, a=aux: a)})()
-        assert np.array_equal(step.resample(), g["c%d_idx" % k])
-        step.array_population = g["c%d_pop" % k]
-        np.testing.assert_allclose(step.calc_covariance(), g["c%d_cov" % k], rtol=1e-12, atol=1e-15)
+        lk = torch.from_numpy(g["c%d_lk" % k])
+        b, w = ops.calc_beta(lk, float(g["c%d_beta_in" % k]), 1.0)
+        assert b == float(g["c%d_beta" % k])
+        np.testing.assert_array_equal(w.numpy(), g["c%d_w" % k])
+        idx = ops.resample(w, float(np.ravel(g["c%d_aux" % k])[0]))
+        assert np.array_equal(idx.numpy(), g["c%d_idx" % k])
+        F = ops.population_factor(torch.from_numpy(g["c%d_pop" % k]), w).numpy()
+        np.testing.assert_allclose(F.T @ F, g["c%d_cov" % k], rtol=1e-12, atol=1e-15)
 
 
 def test_tune_tables():
-    from beat_amd.sampler import pt, smc
-    from beat_amd.sampler.base import step_tune
+    from beat_amd.sampler import pt, smc, step_tune
     g = load_golden("smc")
     for a, p, s in zip(g["tune_acc"], g["pt_tune"], g["smc_tune"]):
         assert pt.tune(1.2, a) == p and smc.tune(a) == s
@@ -71,50 +66,17 @@ def test_tune_tables():
                                [0.1, 0.5, 0.9, 1.0, 2.0, 10.0])
 
 
-def test_metropolis_astep_semantics():
-    """metropolis.py:276-422 decision sequence on a 1-chain function"""
-    from beat_amd.models import prior_logp_func
-    from beat_amd.sampler import Metropolis
-    from oracle import oracle as orc
-    lo, up = -np.ones(3), np.ones(3)
-    calls = []
-
-    def logp(q):
-        calls.append(q.copy())
-        return [np.array(-50.0 * np.sum(q ** 2))]
-
-    m = Metropolis(logp, prior_logp_func(lo, up), 3, n_chains=1, tune_interval=5,
-                   proposal_scale=np.eye(3) * 0.01)
-    q0 = np.zeros(3)
-    q, l = m.astep(q0)  # stage 0: evaluate, no move
-    assert np.array_equal(q, q0) and len(calls) == 1
-    m.stage, m.n_steps, m.beta = 1, 20, 0.5
-    np.random.seed(4)
-    n_acc = 0
-    for i in range(20):
-        ncalls = len(calls)
-        u_state = np.random.get_state()
-        q_new, l_new = m.astep(q)
-        moved = not np.array_equal(q_new, q)
-        if moved:
-            # accepted proposals satisfy the oracle's rule for some u: mr finite
-            assert orc.metrop_accept(0.5, l_new[-1], l[-1], -np.inf)
-        n_acc += moved
-        q, l = q_new, l_new
-    assert m.stage_sample == 0 and m.cumulative_samples == 20 and 0 < n_acc <= 20
-    # outside the prior box: no forward evaluation, chain stays (metropolis.py:341-343,383-385)
-    m.proposal_samples_array = np.full((20, 3), 100.0)
-    m.stage_sample = 1
-    ncalls = len(calls)
-    q2, l2 = m.astep(q)
-    assert np.array_equal(q2, q) and len(calls) == ncalls
-    # NaN likelihood at stage 0 raises (metropolis.py:279-284)
-    bad = Metropolis(lambda q: [np.array(np.nan)], prior_logp_func(lo, up), 3)
-    try:
-        bad.astep(q0)
-        raise AssertionError("expected ValueError")
-    except ValueError:
-        pass
+def test_philox_reference_known_answers():
+    """the Python twin of the device generator (tests/philox_ref.py) reproduces the published
+    Philox4x32-10 known-answer vectors (Random123 kat_vectors)"""
+    from philox_ref import philox4x32_10
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = philox4x32_10(*[np.array([c], dtype=np.uint32) for c in ctr], key[0], key[1])
+        assert tuple(int(x[0]) for x in got) == want
 
 
 def test_pt_manager_and_toy_sampling():
@@ -175,47 +137,57 @@ def test_smc_stage_traces_and_resume(tmp_path):
     assert nstage >= 2
 
 
-def test_device_proposals_normal_and_cauchy_statistics():
-    """DeviceMvNormalProposal on the torch CPU device (the same code draws on the GPU): rows have the
-    requested covariance (MultivariateNormal), resp. are multivariate t with one degree of
-    freedom (MultivariateCauchy, base.py:35-71,163-186: z / sqrt(chi2(1)))"""
+def test_host_proposal_draws_normal_and_cauchy_statistics():
+    """host back end of the proposal draw (the device back end is tested on the GPU): rows z . F
+    have covariance F^T F (MultivariateNormal), resp. are multivariate t with one degree of freedom
+    (MultivariateCauchy, base.py:35-71,163-186: z / sqrt(chi2(1)))"""
     import torch
-    from beat_amd.sampler.base import DeviceMvNormalProposal
+    from beat_amd.sampler.base import covariance_factor, proposal_df
+    from beat_amd.sampler.ops import HostOps
+    ops = HostOps()
     rng = np.random.default_rng(3)
     A = rng.standard_normal((4, 4))
     cov = A @ A.T + 0.5 * np.eye(4)
-    pn = DeviceMvNormalProposal(cov, torch.device("cpu"), seed=5)
-    x = pn(200000).numpy()
-    np.testing.assert_allclose(np.cov(x.T), cov, rtol=0.03, atol=0.03)
-    pc = DeviceMvNormalProposal(cov, torch.device("cpu"), seed=6, df=1)
-    y = pc(200000).numpy()
+    F = torch.from_numpy(covariance_factor(cov))
+    np.testing.assert_allclose(F.numpy().T @ F.numpy(), cov, rtol=1e-12)
+    x, lu = ops.draw(F, 200000, seed=5, step=0)
+    np.testing.assert_allclose(np.cov(x.numpy().T), cov, rtol=0.03, atol=0.03)
+    assert (lu.numpy() < 0).all() and abs(np.exp(lu.numpy()).mean() - 0.5) < 0.01
+    y, _ = ops.draw(F, 200000, seed=6, step=0, df=proposal_df("MultivariateCauchy"))
+    y = y.numpy()
     # marginals of a multivariate Cauchy are Cauchy with scale sqrt(cov_ii): median |y_i| = scale
     np.testing.assert_allclose(np.median(np.abs(y), axis=0), np.sqrt(np.diag(cov)), rtol=0.03)
     # heavy tails: P(|y| > 10 scale) = 1 - 2/pi atan(10) = 0.0635
     frac = (np.abs(y[:, 0]) > 10 * np.sqrt(cov[0, 0])).mean()
     assert abs(frac - 0.0635) < 0.004
+    # different steps / chains give different rows; the same (seed, step, chain) the same rows
+    a, _ = ops.draw(F, 8, seed=1, step=3)
+    b, _ = ops.draw(F, 8, seed=1, step=3)
+    c, _ = ops.draw(F, 8, seed=1, step=4)
+    assert torch.equal(a, b) and not torch.equal(a, c)
     # a singular covariance (population smaller than the parameter count) is repaired, not rejected
     B = rng.standard_normal((6, 2))
-    ps = DeviceMvNormalProposal(B @ B.T, torch.device("cpu"), seed=1)
-    z = ps(50000).numpy()
-    np.testing.assert_allclose(np.cov(z.T), B @ B.T, rtol=0.05, atol=0.05)
+    Fs = covariance_factor(B @ B.T)
+    np.testing.assert_allclose(Fs.T @ Fs, B @ B.T, atol=1e-10)
+    with pytest.raises(NotImplementedError):
+        proposal_df("Normal")
     with pytest.raises(ValueError):
-        DeviceMvNormalProposal(cov, torch.device("cpu"), df=0.5)(3)
+        covariance_factor(np.array([[np.nan]]))
 
 
-def test_population_proposal_equals_weighted_covariance():
-    """DeviceMvNormalProposal.from_population draws with np.cov(X, aweights=w) (SMC.calc_covariance)
-    without factoring it, also when the population is smaller than the parameter count"""
+def test_population_factor_equals_weighted_covariance():
+    """population_factor reproduces np.cov(X, aweights=w) (SMC.calc_covariance) as F^T F without
+    forming it, also when the population is smaller than the parameter count"""
     import torch
-    from beat_amd.sampler.base import DeviceMvNormalProposal
+    from beat_amd.sampler.ops import HostOps
+    ops = HostOps()
     rng = np.random.default_rng(11)
     for n, d in ((40, 6), (5, 9)):
         X = rng.standard_normal((n, d)) * rng.uniform(0.5, 3.0, d) + rng.standard_normal(d)
         w = rng.random(n)
         w /= w.sum()
         cov = np.cov(X, aweights=w, bias=False, rowvar=0)
-        prop = DeviceMvNormalProposal.from_population(X, w, torch.device("cpu"), seed=2)
-        np.testing.assert_allclose(prop.LT.numpy().T @ prop.LT.numpy(), cov, rtol=1e-12, atol=1e-12)
-        rows = prop(300000).numpy()
-        assert rows.shape == (300000, d)
-        np.testing.assert_allclose(np.cov(rows.T), cov, rtol=0.04, atol=0.04 * np.abs(cov).max())
+        F = ops.population_factor(torch.from_numpy(X), torch.from_numpy(w))
+        np.testing.assert_allclose(F.numpy().T @ F.numpy(), cov, rtol=1e-12, atol=1e-12)
+        rows, _ = ops.draw(F, 300000, seed=2, step=0)
+        np.testing.assert_allclose(np.cov(rows.numpy().T), cov, rtol=0.04, atol=0.04 * np.abs(cov).max())
