@@ -138,6 +138,8 @@ struct GsArgs {
     int64_t C, T, P, N;
     int CG, ucap, ustride, ntile, nt;
     int dma;  // 1: k_gfstack_dma (two LDS row buffers filled by LDS-DMA)
+    int xcd_order;     // k_gfstack_dma: chain groups of a (target, tile) share an XCD
+    int64_t ngroups;
     const uint32_t *urows, *ucount;
     const uint16_t *slot;
     const double *w;
@@ -405,8 +407,13 @@ __device__ __forceinline__ void lds_wait8_b64(double (&x)[8])
 // a memory clobber for hipcc and turns the scalar row-id loads into waited vector loads);
 // sched_barrier(0) pins them between the barrier and the FMA phase, and the destination
 // registers of in-flight loads were checked in the ISA to be untouched until their wait.
+// NT = 64: 204 VGPRs, 2 wavefronts per SIMD (one 8-wavefront workgroup per CU).  NT = 32: half the
+// accumulators, <= 128 VGPRs, 4 wavefronts per SIMD: two 8-wavefront workgroups per CU (one gathers
+// while the other sits in its barrier / DMA-issue phase) or one 16-wavefront workgroup = 1024-chain
+// groups (every distinct row staged once for twice the chains).
 template <int WAVES, int NROW, int MODE, int NT, int B64>
-__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(WAVES * 64)
+    __attribute__((amdgpu_waves_per_eu(NT == 64 ? 2 : 4, NT == 64 ? 2 : 4)))
 k_gfstack_dma(GsArgs a)
 {
     constexpr int GS_NT = NT;
@@ -414,15 +421,33 @@ k_gfstack_dma(GsArgs a)
     constexpr int LPR = NT / 2;         // lanes moving one row segment (16 B each)
     // row ids per wavefront fetched ahead (scalar registers): 32 rows per workgroup and step are
     // covered by the unrolled DMA slots, more (rare) go through a loop
-    constexpr int KPRE = WAVES >= 4 ? 32 / WAVES : 8;
+    constexpr int KPRE = WAVES >= 4 ? 64 / WAVES : 8;
     extern __shared__ __attribute__((aligned(16))) double xbuf[];  // [2][ucap][GS_PITCH]
     constexpr int CG = WAVES * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x % a.ntile;
-    const int64_t gt = blockIdx.x / a.ntile;  // g*T + t
-    const int64_t t = gt % a.T;
-    const int64_t g = gt / a.T;
+    int tile;
+    int64_t t, g;
+    if (a.xcd_order) {
+        // Workgroups b, b+8, b+16, ... run on the same XCD (round-robin dispatch).  The chain
+        // groups of one (target, sample tile) are numbered b = 8*(ngroups*q + g) + x, so they
+        // run on one XCD at about the same time and walk the patches in step: the library rows the
+        // groups have in common are fetched from HBM once and served from that XCD's L2 to the
+        // others.  Scheduling only; results do not depend on it.
+        const int64_t b = blockIdx.x;
+        const int64_t x = b & 7, q = b >> 3;
+        g = q % a.ngroups;
+        const int64_t tt = (q / a.ngroups) * 8 + x;   // t * ntile + tile
+        if (tt >= a.T * a.ntile) return;              // grid padded to a multiple of 8 per group
+        tile = (int)(tt % a.ntile);
+        t = tt / a.ntile;
+    } else {
+        tile = blockIdx.x % a.ntile;
+        const int64_t gt0 = blockIdx.x / a.ntile;  // g*T + t
+        t = gt0 % a.T;
+        g = gt0 / a.T;
+    }
+    const int64_t gt = g * a.T + t;
     const int64_t c = g * CG + tid;
     const int64_t N = a.N;
     const int64_t n0 = (int64_t)tile * GS_NT;
@@ -555,7 +580,7 @@ k_gfstack_dma(GsArgs a)
 #pragma unroll
                     for (int q = 0; q < 8; q++) acc[gq * 8 + q] = fma(cur[q], w, acc[gq * 8 + q]);
                     __builtin_amdgcn_sched_barrier(0);
-                    switch (gq + 2) {
+                    if (gq + 2 < NG8) switch (gq + 2) {
                     case 2: lds_rd8_b64<128>(cur, xs, s); break;
                     case 3: lds_rd8_b64<192>(cur, xs, s); break;
                     case 4: lds_rd8_b64<256>(cur, xs, s); break;
@@ -638,10 +663,16 @@ k_gfstack_dma(GsArgs a)
 template <int WAVES, int NROW, int MODE>
 static void launch_shared_one(dim3 grid, size_t lds, hipStream_t s, const GsArgs &a)
 {
-    auto kern = (a.dma == 2) ? k_gfstack_dma<WAVES, NROW, MODE, 64, 1>
-              : a.dma ? k_gfstack_dma<WAVES, NROW, MODE, 64, 0>
-              : (a.nt == 48) ? k_gfstack_shared<WAVES, NROW, MODE, 48>
-                             : k_gfstack_shared<WAVES, NROW, MODE, 64>;
+    void (*kern)(GsArgs) = nullptr;
+    if constexpr (WAVES == 16) {
+        kern = k_gfstack_dma<WAVES, NROW, MODE, 32, 1>;   // 1024-chain groups exist as NT = 32 only
+    } else {
+        kern = (a.dma == 2 && a.nt == 32) ? k_gfstack_dma<WAVES, NROW, MODE, 32, 1>
+             : (a.dma == 2) ? k_gfstack_dma<WAVES, NROW, MODE, 64, 1>
+             : a.dma ? k_gfstack_dma<WAVES, NROW, MODE, 64, 0>
+             : (a.nt == 48) ? k_gfstack_shared<WAVES, NROW, MODE, 48>
+                            : k_gfstack_shared<WAVES, NROW, MODE, 64>;
+    }
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
@@ -693,7 +724,8 @@ bool gfstack_shared_applicable(const GfStackCall &k, int *cg_out, int *ucap_out)
     if (!forced && k.C < 48) return false;  // too few chains to share rows
     int cg = pick_group(k.C);
     const char *gq = getenv("BEATAMD_GS_CG");
-    if (gq && (atoi(gq) == 64 || atoi(gq) == 128 || atoi(gq) == 256 || atoi(gq) == 512)) cg = atoi(gq);
+    if (gq && (atoi(gq) == 64 || atoi(gq) == 128 || atoi(gq) == 256 || atoi(gq) == 512 ||
+               atoi(gq) == 1024)) cg = atoi(gq);
     const int64_t DS = L.D * L.S;
     int64_t ucap = std::min<int64_t>((int64_t)cg * nrow, DS);
     // the distinct rows of one step must fit in LDS; prefer >= 2 workgroups per CU
@@ -758,8 +790,10 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     a.nt = 64;
     {
         const char *e = getenv("BEATAMD_GS_NT");
-        if (e && atoi(e) == 48) a.nt = atoi(e);
+        if (e && (atoi(e) == 48 || atoi(e) == 32)) a.nt = atoi(e);
+        if (CG == 1024) a.nt = 32;
     }
+    a.ngroups = ngroups;
     a.ntile = (int)((L.N + a.nt - 1) / a.nt);
     a.urows = ga.urows; a.ucount = ga.ucount; a.slot = ga.slot; a.w = ga.w;
     a.w_var_stride = ga.w_var_stride;
@@ -768,7 +802,7 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         BA_TRY(ctx->get_scratch(SL_PARTIAL, (size_t)k.C * L.T * a.ntile * sizeof(double), &p));
         a.partial = (double *)p;
     }
-    const int64_t nblocks = ngroups * L.T * a.ntile;
+    int64_t nblocks = ngroups * L.T * a.ntile;
     BA_CHECK(nblocks < (int64_t)0x7fffffff, BEATAMD_EINVAL, "gfstack: batch too large");
     // Small chain groups (1-2 wavefronts per workgroup) reach the 2 waves/SIMD the kernels are
     // built for only if several workgroups fit a CU's LDS: size the row buffers by the largest
@@ -788,9 +822,19 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     {
         // two row buffers when they fit (BEATAMD_GS_DMA=0 forces the single-buffer kernel)
         const char *e = getenv("BEATAMD_GS_DMA");
-        a.dma = (a.nt == 64 && 2 * lds <= 158 * 1024 && !(e && atoi(e) == 0)) ? 1 : 0;
+        a.dma = ((a.nt == 64 || a.nt == 32) && 2 * lds <= 158 * 1024 && !(e && atoi(e) == 0)) ? 1 : 0;
         if (a.dma && !(e && atoi(e) == 1)) a.dma = 2;   // ds_read_b64 / pitch NT+1 (default); 1 = b128 / pitch NT+2
+        if (a.nt == 32 && a.dma != 2) { a.nt = 64; a.ntile = (int)((L.N + 63) / 64); nblocks = ngroups * L.T * a.ntile;
+                                        lds = (size_t)ucap * (a.nt + 2) * sizeof(double); a.dma = 0; }
+        BA_CHECK(CG != 1024 || a.dma == 2, BEATAMD_EINVAL, "gfstack: 1024-chain groups need the LDS-DMA kernel");
         if (a.dma) lds *= 2;
+    }
+    {
+        // chain groups of one (target, tile) on one XCD (several groups only)
+        const char *e = getenv("BEATAMD_GS_ORDER");
+        a.xcd_order = (a.dma && ngroups > 1 && !(e && atoi(e) == 0)) ? 1 : 0;
+        if (e && atoi(e) == 1 && a.dma) a.xcd_order = 1;
+        if (a.xcd_order) nblocks = ((L.T * a.ntile + 7) / 8) * 8 * ngroups;
     }
     snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "%s<%d,%d,%d,%d,%d>",
              a.dma ? "k_gfstack_dma" : "k_gfstack_shared", CG / 64, nrow, k.mode, a.nt, a.dma == 2 ? 1 : 0);
@@ -800,7 +844,8 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     {
         ScopedTimer tm(ctx, "gfstack");
         dim3 grid((unsigned)nblocks);
-        if (CG == 512) launch_shared_nrow<8>(nrow, k.mode, grid, lds, ctx->stream, a);
+        if (CG == 1024) launch_shared_nrow<16>(nrow, k.mode, grid, lds, ctx->stream, a);
+        else if (CG == 512) launch_shared_nrow<8>(nrow, k.mode, grid, lds, ctx->stream, a);
         else if (CG == 256) launch_shared_nrow<4>(nrow, k.mode, grid, lds, ctx->stream, a);
         else if (CG == 128) launch_shared_nrow<2>(nrow, k.mode, grid, lds, ctx->stream, a);
         else launch_shared_nrow<1>(nrow, k.mode, grid, lds, ctx->stream, a);

@@ -6,7 +6,10 @@ Workload (BASELINE.json configs[2], SURVEY.md 8(d) "config 3"): one 20x20-patch 
 (P=400, 1 km), T=64 targets, N=4096 samples, library (64,400,3,25,4096) float64 = 62.9 GB
 resident in HBM, N(0,1) values generated on device (synthetic), covariance sigma^2 I
 (``--covariance toeplitz`` for the dense-W variant), nearest-neighbour interpolation
-(``--interp multilinear`` for the 4-row blend).
+(``--interp multilinear`` for the 4-row blend).  Chain population exactly as SURVEY 8(d):
+slips U(0,5), durations U(0.5,1.5), velocities U(2.5,4.0), nucleation anywhere on the fault
+(U over the 20x20 patches), origin time 0, chain c from default_rng(1000 + c).  (Round 1 confined
+the hypocentre to the central 7.5 km and is kept as ``--prior narrow`` for comparison only.)
 
 One "step" = one batched Metropolis.astep (reference beat/sampler/metropolis.py:276-422)
 for ``--chains`` chains per GPU: proposal, prior-box check, forward model
@@ -35,6 +38,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+LDS_PEAK_GBS = 256 * 256 * 2.4   # 256 CUs x 256 B/clk (ds_read_b64, MI355X_MICROARCH.md LDS table) x 2.4 GHz
+FP64_VALU_PEAK_TFLOPS = 78.6
 
 
 def algorithmic_bytes_per_chain_step(spec, nvar=1):
@@ -73,7 +78,7 @@ def cpu_baseline(spec, seconds=12.0):
         r = np.random.default_rng(seed)
         params = dict(slips=r.uniform(0, 5, (1, P)), durations=r.uniform(0.55, 0.7, P) if not ml else r.uniform(0.55, 0.95, P),
                       velocities=r.uniform(*spec.vel_bounds, P),
-                      nuc_strike=[r.uniform(6, 13)], nuc_dip=[r.uniform(6, 13)], time=[0.0])
+                      nuc_strike=[r.uniform(0, 19.49)], nuc_dip=[r.uniform(0, 19.49)], time=[0.0])
         orc.ffi_seismic_forward([G], lib_cfg, fault, params, data, w, slog, 0.0,
                                 interpolation=spec.interpolation, return_synthetics=False)
 
@@ -125,6 +130,15 @@ def _cpu_worker_for(a):
     return k
 
 
+def make_spec(args):
+    from beat_amd.synthetic import SyntheticSpec
+    prior = dict(nuc_margin=0.0, time_bounds=(0.0, 0.0)) if args.prior == "survey" \
+        else dict(nuc_margin=6.0, time_bounds=(0.0, 0.5))
+    return SyntheticSpec((20,), (20,), (1.0,), T=args.targets, N=args.samples, D=args.ndurations,
+                         S=args.nstarttimes, covariance=args.covariance, interpolation=args.interp,
+                         **prior)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,14 +152,20 @@ def main():
     ap.add_argument("--samples", type=int, default=4096)
     ap.add_argument("--nstarttimes", type=int, default=25)
     ap.add_argument("--ndurations", type=int, default=3)
+    ap.add_argument("--prior", default="survey", choices=["survey", "narrow"],
+                    help="survey: SURVEY 8(d) population (default); narrow: round 1's confined hypocentre")
+    ap.add_argument("--step-scale", type=float, default=5e-4,
+                    help="proposal standard deviation as a fraction of the prior span of every parameter")
     ap.add_argument("--prewhiten", action="store_true",
                     help="toeplitz only: whiten the library once (W.G), no dense W.r per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "r1_bench_c512_nn_gfstack_summary.json"),
+    ap.add_argument("--no-streaming-leg", action="store_true",
+                    help="skip the reuse-free streaming-kernel leg (roofline_streaming)")
+    ap.add_argument("--no-narrow-leg", action="store_true",
+                    help="skip the labelled round-1 narrow-prior leg")
+    ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "r2_bench_c512_nn_gfstack_summary.json"),
                     help="rocprofv3 PMC summary (tools/run_profile.sh + tools/summarize_rocpd.py) of THIS "
                          "command; supplies roofline.traffic when its configuration matches")
-    ap.add_argument("--sort-chains", default=None,
-                    help="experiment: order the population by this key before the run (nuc | time)")
     ap.add_argument("--gf-order", type=int, default=None,
                     help="k_gfstack block order: 0 (chain,target,tile) 1 (target,chain,tile)")
     args = ap.parse_args()
@@ -173,15 +193,15 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
 
     import beat_amd
-    from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
+    from beat_amd.sampler import SMC
+    from beat_amd.synthetic import build_problem, draw_population
 
     dev = torch.device("cuda", local_rank)
     ctx = beat_amd.get_context(local_rank)
     ctx.use_torch_stream()
+    env_knobs = sorted(k for k in os.environ if k.startswith("BEATAMD_G"))
 
-    spec = SyntheticSpec((20,), (20,), (1.0,), T=args.targets, N=args.samples, D=args.ndurations,
-                         S=args.nstarttimes, covariance=args.covariance,
-                         interpolation=args.interp, nuc_margin=6.0, time_bounds=(0.0, 0.5))
+    spec = make_spec(args)
     t_build = time.perf_counter()
     prob, host = build_problem(spec, device_library=True, ctx=ctx)
     f = prob.compile(ctx, prewhiten="inplace" if args.prewhiten else False)
@@ -191,97 +211,128 @@ def main():
     B, K, W = args.chains, args.steps, args.warmup
     lay = host["layout"]
     lo, up = lay.bounds(host["lower"], host["upper"])
-    # chain c of rank r is global chain r*B + c (seed 1000 + id)
-    Q0 = torch.from_numpy(draw_population(spec, lay, host["lower"], host["upper"], B,
-                                          seed_offset=1000 + rank * B)).to(dev)
-    if args.sort_chains:
-        q = Q0.cpu().numpy()
-        ns, nd_, tt = (q[:, lay.offset(k)] for k in ("nucleation_strike", "nucleation_dip", "time"))
-        if args.sort_chains == "nuc":
-            key = np.lexsort((nd_, np.floor(ns / 2.0)))
-        elif args.sort_chains in ("pc1", "pc12", "pc1x16"):
-            # start-time index field of every chain (what selects the library rows)
-            from beat_amd.utility import positions2idxs
-            vel = q[:, lay.offset("velocities"):lay.offset("velocities") + spec.P]
-            hs = positions2idxs(ns, spec.patch_size[0], min_pos=0.0)
-            hd = positions2idxs(nd_, spec.patch_size[0], min_pos=0.0)
-            st = ctx.fast_sweep_batch(1.0 / vel, spec.patch_size[0], hs, hd, spec.n_patch_strike[0], spec.n_patch_dip[0])
-            sidx = np.rint((st + tt[:, None] - spec.st_min) / spec.st_dt)
-            X = sidx - sidx.mean(0)
-            U, S_, Vt = np.linalg.svd(X, full_matrices=False)
-            pc1, pc2 = U[:, 0] * S_[0], U[:, 1] * S_[1]
-            if args.sort_chains == "pc1":
-                key = np.argsort(pc1)
-            elif args.sort_chains == "pc12":
-                r1 = np.argsort(np.argsort(pc1)) // 256      # workgroup by PC1, lanes by PC2
-                key = np.lexsort((pc2, r1))
-            else:
-                r1 = np.argsort(np.argsort(pc1)) // 16       # 16-lane groups by PC1, inside by PC2
-                key = np.lexsort((pc2, r1))
-        else:
-            key = np.argsort(tt)
-        Q0 = Q0[torch.from_numpy(key).to(dev)].contiguous()
-    L0 = f.batch(Q0)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(4242 + rank)
-    span = torch.from_numpy(up - lo).to(dev)
-    # proposal rows: proposal_samples_array[stage_sample] of every chain (metropolis.py:289-313)
-    delta = torch.randn((K + W, B, lay.size), generator=gen, device=dev, dtype=torch.float64) \
-        * (0.004 * span)
-    log_u = torch.log(torch.rand((K + W, B), generator=gen, device=dev, dtype=torch.float64))
-    scaling = torch.ones(B, device=dev, dtype=torch.float64)
-    lo_d, up_d = torch.from_numpy(lo).to(dev), torch.from_numpy(up).to(dev)
-    accepted = torch.zeros(B, device=dev, dtype=torch.int32)
-    beta = 2e-6  # an early SMC stage on this problem (tools/smc_app.py): acceptance ~0.2-0.4
-    ctx.synchronize()
 
-    def step(i):
-        f.astep_batch(Q0, L0, delta[i], scaling, lo_d, up_d, log_u[i], beta, accepted)
+    def run_leg(spec_leg, f_leg, n_chains, n_steps, n_warm, seed_offset, beta=2e-6):
+        """n_steps timed astep batches of n_chains chains; everything resident in HBM beforehand.
+        -> dict(dt, kernel times, in-box fraction, acceptance)"""
+        lay_l = lay   # the legs share the parameter layout; only the prior box differs
+        box = host_of[spec_leg]
+        Q0 = torch.from_numpy(draw_population(spec_leg, lay_l, box["lower"], box["upper"], n_chains,
+                                              seed_offset=seed_offset)).to(dev)
+        lo_h, up_h = lay_l.bounds(box["lower"], box["upper"])
+        lo_s, up_s = torch.from_numpy(lo_h).to(dev), torch.from_numpy(up_h).to(dev)
+        L0 = f_leg.batch(Q0)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(4242 + rank)
+        # proposal rows: proposal_samples_array[stage_sample] of every chain (metropolis.py:289-313)
+        delta = torch.randn((n_steps + n_warm, n_chains, lay_l.size), generator=gen, device=dev,
+                            dtype=torch.float64) * (args.step_scale * (up_s - lo_s))
+        log_u = torch.log(torch.rand((n_steps + n_warm, n_chains), generator=gen, device=dev,
+                                     dtype=torch.float64))
+        scaling = torch.ones(n_chains, device=dev, dtype=torch.float64)
+        accepted = torch.zeros(n_chains, device=dev, dtype=torch.int32)
+        # fraction of proposals inside the prior box (the reference evaluates the forward model
+        # only for those, metropolis.py:335-385; the batch evaluates every chain)
+        q = Q0[None] + delta[n_warm:]
+        in_box = float(((q >= lo_s) & (q <= up_s)).all(-1).double().mean().item())
+        del q
+        ctx.synchronize()
 
-    for i in range(W):
-        step(i)
-    ctx.synchronize()  # also surfaces an out-of-library index as an exception
-    ctx.enable_timing(True)
-    ctx.reset_timing()
-    n_acc = 0
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(W, W + K):
-        step(i)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    ctx.synchronize()
-    n_acc = int(accepted.sum().item())
+        def step(i):
+            f_leg.astep_batch(Q0, L0, delta[i], scaling, lo_s, up_s, log_u[i], beta, accepted)
 
+        for i in range(n_warm):
+            step(i)
+        ctx.synchronize()  # also surfaces an out-of-library index as an exception
+        ctx.enable_timing(True)
+        ctx.reset_timing()
+        n_acc = 0
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_warm, n_warm + n_steps):
+            step(i)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        ctx.synchronize()
+        n_acc = int(accepted.sum().item())
+        times = {k: ctx.kernel_time(k) for k in ("sweep", "tables", "grouptables", "gfstack", "quadform",
+                                                 "finish", "astep")}
+        ctx.enable_timing(False)
+        return dict(dt=dt, times=times, in_box=in_box, accept_last=n_acc / float(n_chains),
+                    kernel=ctx.last_kernel(), stats=ctx.gf_group_stats(), Q=Q0, L=L0)
+
+    host_of = {spec: host}
+    main_leg = run_leg(spec, f, B, K, W, seed_offset=1000 + rank * B)
+    dt = main_leg["dt"]
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt_max = float(tmax.item())
 
-    # SMC stage transition exchange (select_end_points, smc.py:188-240): all-gather of the
-    # per-rank end points + likelihoods; outside the timed steps, reported separately
-    stage_ms = None
-    if use_dist:
-        from beat_amd import parallel
+    # ---- SMC stage transition on the end points of the timed steps (select_end_points ->
+    # calc_beta -> proposal factor -> resample -> restart points, smc.py:133-324): all-gather over
+    # the ranks + the device kernels; outside the timed steps (it happens once per ~100-400 steps)
+    smc = SMC(f, lo, up, n_chains=world * B, device=dev, random_seed=7)
+    for rep in range(2):   # first pass allocates
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        Qall, Lall = parallel.allgather_population(Q0, L0)
+        smc.beta = 0.0
+        smc.select_end_points(main_leg["Q"], main_leg["L"])
+        smc.transition()
+        Qn, Ln = smc.restart_points()
         torch.cuda.synchronize()
         stage_ms = (time.perf_counter() - t1) * 1e3
-        assert Qall.shape[0] == world * B
+    assert Qn.shape == main_leg["Q"].shape and smc.Q_all.shape[0] == world * B
 
-    gf_ms, gf_n = ctx.kernel_time("gfstack")
-    times = {k: ctx.kernel_time(k) for k in ("sweep", "tables", "grouptables", "gfstack", "quadform",
-                                             "finish", "astep")}
+    out = None
     if rank == 0:
+        gf_ms, gf_n = main_leg["times"]["gfstack"]
         alg = algorithmic_bytes_per_chain_step(spec) * B  # per launch
         rows_per_patch = 4 if spec.interpolation == "multilinear" else 1
         avg_ms = gf_ms / max(gf_n, 1)
-        achieved = alg / (avg_ms * 1e-3) / 1e9 if gf_n else 0.0
+        alg_equiv = alg / (avg_ms * 1e-3) / 1e9 if gf_n else 0.0
+        st = main_leg["stats"]
+        shared = st["row_bytes"] > 0
+        # bytes the kernel has to move from HBM: every distinct row of every (group, target,
+        # patch) once (chain-shared kernels) or every chain's rows (streaming kernel), + tables
+        tables = B * spec.T * spec.P * 4 * rows_per_patch * 2 + spec.T * spec.N * 8
+        need_bytes = (st["row_bytes"] if shared else float(B) * spec.T * spec.P * spec.N * 8 * rows_per_patch) + tables
+        lds_bytes = float(B) * spec.T * spec.P * spec.N * 8 * rows_per_patch
+        lds_floor_ms = lds_bytes / (LDS_PEAK_GBS * 1e9) * 1e3
+        flops = 2.0 * B * spec.T * spec.P * spec.N * rows_per_patch
+        hbm_frac = need_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if gf_n else 0.0
+        lds_frac = lds_floor_ms / avg_ms if (gf_n and shared) else 0.0
+        bound = "lds" if (shared and lds_frac > hbm_frac) else "hbm"
+        roof = {
+            # the resource closest to its peak for this launch (both fractions are reported)
+            "bound": bound,
+            "kernel": main_leg["kernel"],
+            "achieved": (lds_bytes if bound == "lds" else need_bytes) / (avg_ms * 1e-3) / 1e9 if gf_n else 0.0,
+            "peak": LDS_PEAK_GBS if bound == "lds" else HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": lds_frac if bound == "lds" else hbm_frac,
+            # HBM bytes per launch from the PMC counters of the same command (profiles/), else null
+            "traffic": None,
+            "hbm_frac_required_bytes": hbm_frac,
+            "hbm_required_bytes_per_launch": need_bytes,
+            "lds_frac": lds_frac,
+            "lds_gather_bytes_per_launch": lds_bytes,
+            "lds_floor_ms": lds_floor_ms,
+            "fp64_valu_frac": flops / (avg_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS if gf_n else 0.0,
+            # SURVEY 8(d) figure (chains treated independently, no reuse credit): NOT a roofline
+            # fraction for the chain-shared kernels, which fetch a row once for all chains using it
+            "algorithmic_bytes_per_launch": alg,
+            "algorithmic_equiv_GBs": alg_equiv,
+            "avg_launch_ms": avg_ms,
+            "launches": gf_n,
+            "chains_per_group": st["chains_per_group"],
+            "distinct_rows_per_patch": {"mean": st["mean_rows"], "max": st["max_rows"],
+                                        "of": spec.D * spec.S},
+        }
         out = {
             "metric": "SMC chain-steps/s (FFI seismic gfstacking 400 patches x %d targets x %d samples)"
                       % (spec.T, spec.N),
@@ -299,56 +350,77 @@ def main():
             "config": {
                 "workload": "BASELINE configs[2]: FFI seismic gfstacking, 400 patches x %d targets x "
                             "%d samples, library (%d,%d,%d,%d,%d) f64 = %.1f GB in HBM, %s, "
-                            "covariance %s%s" % (spec.T, spec.N, spec.T, spec.P, spec.D, spec.S, spec.N,
-                                                 spec.lib_bytes / 1e9, spec.interpolation,
-                                                 spec.covariance,
-                                                 " (library pre-whitened)" if args.prewhiten else ""),
+                            "covariance %s%s; population %s"
+                            % (spec.T, spec.N, spec.T, spec.P, spec.D, spec.S, spec.N,
+                               spec.lib_bytes / 1e9, spec.interpolation, spec.covariance,
+                               " (library pre-whitened)" if args.prewhiten else "",
+                               "SURVEY 8(d): nucleation U over the 20x20 fault, time 0"
+                               if args.prior == "survey" else "round-1 narrow prior (hypocentre in the "
+                               "central 7.5 km, time U(0,0.5))"),
                 "chains_per_gpu": B,
                 "global_chains": world * B,
                 "parallelism": "chains sharded over %d GPU(s), library replicated" % world,
+                "proposal_step_scale": args.step_scale,
+                "env_knobs": {k: os.environ[k] for k in env_knobs},
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_gfstack" if (B < 48 or os.environ.get("BEATAMD_GF_KERNEL") == "0")
-                          else "k_gfstack_shared" if os.environ.get("BEATAMD_GS_DMA") == "0"
-                          else "k_gfstack_dma",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "algorithmic_bytes_per_launch": alg,
-                "avg_launch_ms": avg_ms,
-                "launches": gf_n,
-                # frac > 1 on the chain-shared kernels: `achieved` credits no cross-chain reuse
-                #  while rows shared by chains are fetched once (`traffic`).  What
-                # binds those kernels is the per-lane LDS gather: one 8-byte LDS operand per FMA.
-                "lds_gather": {
-                    "bytes_per_launch": float(B) * spec.T * spec.P * spec.N * 8 * rows_per_patch,
-                    "floor_ms": float(B) * spec.T * spec.P * spec.N * 8 * rows_per_patch
-                                / (256.0 * 256 * 2.4e9) * 1e3,
-                    "ceiling_ms_measured": 3.53 * (float(B) * spec.T * spec.P * spec.N * rows_per_patch)
-                                           / (512.0 * 64 * 400 * 4096),
-                    "source": "tools/micro/ldsgather.hip (profiles/r1_variants.md)",
-                },
-            },
-            "kernel_ms_per_step": {k: (v[0] / K) for k, v in times.items() if v[1]},
-            "accept_rate_last_step": n_acc / float(B),
+            "roofline": roof,
+            "kernel_ms_per_step": {k: (v[0] / K) for k, v in main_leg["times"].items() if v[1]},
+            "in_box_fraction": main_leg["in_box"],
+            "accept_rate_last_step": main_leg["accept_last"],
+            "stage_transition_ms": stage_ms,
             "setup_s": t_build,
         }
         # HBM traffic of the dominant kernel from the PMC passes of the same command
         # (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streams, +WRITE_SIZE)
         default_cfg = (B == 512 and spec.interpolation == "nearest_neighbor" and spec.covariance == "scalar"
-                       and spec.T == 64 and spec.N == 4096 and args.gf_order is None
-                       and not any(k.startswith("BEATAMD_G") for k in os.environ))
+                       and spec.T == 64 and spec.N == 4096 and args.gf_order is None and args.prior == "survey"
+                       and not env_knobs)
         if default_cfg and os.path.exists(args.pmc_summary):
             pmc = json.load(open(args.pmc_summary))
             if "hbm_read_bytes_per_launch_corrected" in pmc:
-                out["roofline"]["traffic"] = (pmc["hbm_read_bytes_per_launch_corrected"]
-                                              + pmc.get("hbm_write_bytes_per_launch", 0.0))
-                out["roofline"]["traffic_source"] = os.path.relpath(args.pmc_summary, ROOT)
-        if stage_ms is not None:
-            out["stage_transition_ms"] = stage_ms
+                tr = pmc["hbm_read_bytes_per_launch_corrected"] + pmc.get("hbm_write_bytes_per_launch", 0.0)
+                roof["traffic"] = tr
+                roof["traffic_source"] = os.path.relpath(args.pmc_summary, ROOT)
+                roof["hbm_counter_frac"] = tr / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+
+    # ---- reuse-free streaming leg: k_gfstack in (chain, target, tile) order, every chain's rows
+    # streamed from HBM -- the roofline of SURVEY 8(d)'s algorithmic bytes, driver-observed
+    if world == 1 and not args.no_streaming_leg and spec.covariance == "scalar":
+        saved = {k: os.environ.get(k) for k in ("BEATAMD_GF_KERNEL", "BEATAMD_GF_ORDER")}
+        os.environ["BEATAMD_GF_KERNEL"], os.environ["BEATAMD_GF_ORDER"] = "0", "0"
+        Bs = min(B, 128)
+        leg = run_leg(spec, f, Bs, 4, 1, seed_offset=1000)
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        ms, n = leg["times"]["gfstack"]
+        alg_s = algorithmic_bytes_per_chain_step(spec) * Bs
+        ach = alg_s / (ms / max(n, 1) * 1e-3) / 1e9
+        out["roofline_streaming"] = {
+            "bound": "hbm", "kernel": leg["kernel"], "chains": Bs, "achieved": ach, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_s,
+            "avg_launch_ms": ms / max(n, 1), "launches": n,
+            "chain_steps_per_s": Bs * 4 / leg["dt"],
+            "note": "no cross-chain row reuse: algorithmic bytes = HBM bytes (block order chain-major)"}
+    # ---- round 1's narrow prior, labelled, for continuity with BENCH_r01
+    if world == 1 and not args.no_narrow_leg and args.prior == "survey" and spec.covariance == "scalar":
+        import copy
+        a2 = copy.copy(args)
+        a2.prior = "narrow"
+        spec_n = make_spec(a2)
+        from beat_amd.synthetic import _layout_and_bounds
+        _, lo_n, up_n = _layout_and_bounds(spec_n)
+        host_of[spec_n] = dict(lower=lo_n, upper=up_n)
+        leg = run_leg(spec_n, f, B, max(K // 2, 3), 1, seed_offset=1000)
+        ms, n = leg["times"]["gfstack"]
+        out["narrow_prior_leg"] = {
+            "population": "round 1: hypocentre within the central 7.5 km of the fault, time U(0,0.5)",
+            "chain_steps_per_s": B * max(K // 2, 3) / leg["dt"], "gfstack_avg_launch_ms": ms / max(n, 1),
+            "distinct_rows_per_patch_mean": leg["stats"]["mean_rows"], "kernel": leg["kernel"],
+            "hbm_required_bytes_per_launch": leg["stats"]["row_bytes"]}
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -16,7 +16,9 @@ def test_fullsize_two_slip_variables_dma_vs_streaming_vs_rows(monkeypatch):
     import beat_amd
     from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
     from oracle import oracle as orc
+    import gc
     ctx = beat_amd.get_context(0)
+    gc.collect()
     torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info(0)
     if free < 150e9:
