@@ -33,6 +33,7 @@
 namespace beatamd {
 
 constexpr int GS_NT_MAX = 64;         // samples per tile (per lane: that many accumulators)
+constexpr int GS_DEEP_DEFAULT = 0;    // DMA pipeline depth of k_gfstack_dma unless BEATAMD_GS_DEEP says otherwise
 
 struct GroupTabArgs {
     int nrow, nvar, CG;
@@ -138,6 +139,7 @@ struct GsArgs {
     int64_t C, T, P, N;
     int CG, ucap, ustride, ntile, nt;
     int dma;  // 1: k_gfstack_dma (two LDS row buffers filled by LDS-DMA)
+    int deep;          // k_gfstack_dma: 0 two row buffers / 1 three buffers, rows two steps ahead / 2 + staggered issue
     int xcd_order;     // k_gfstack_dma: chain groups of a (target, tile) share an XCD
     int64_t ngroups;
     const uint32_t *urows, *ucount;
@@ -411,11 +413,23 @@ __device__ __forceinline__ void lds_wait8_b64(double (&x)[8])
 // accumulators, <= 128 VGPRs, 4 wavefronts per SIMD: two 8-wavefront workgroups per CU (one gathers
 // while the other sits in its barrier / DMA-issue phase) or one 16-wavefront workgroup = 1024-chain
 // groups (every distinct row staged once for twice the chains).
-template <int WAVES, int NROW, int MODE, int NT, int B64>
+//
+// DEEP = 1, 2: three LDS row buffers, the rows of step s+2 are requested during step s.  With the
+// population of SURVEY 8(d) a 512-chain group stages ~39 distinct rows (20 KB) per step; a CU's
+// share of the HBM stream (~11 B/clk) needs longer than one gather phase for that, so with one step
+// of run-ahead every step ended waiting for its own row requests (8.1 ms per launch, measured).
+// Two steps of run-ahead keep requests in flight all the time.  The step-top wait must then leave
+// the youngest requests (step s+2's, a per-step VARIABLE number) outstanding while covering the
+// slot/weight loads issued just before them: s_waitcnt takes an immediate, hence the switch over
+// the number of row requests this wavefront issued (an over-wait is always safe).
+// DEEP = 2: the odd wavefronts issue their row requests after their gather instead of before it,
+// so that half of the workgroup feeds the LDS pipe while the other half is in its issue phase.
+template <int WAVES, int NROW, int MODE, int NT, int B64, int DEEP = 0>
 __global__ void __launch_bounds__(WAVES * 64)
     __attribute__((amdgpu_waves_per_eu(NT == 64 ? 2 : 4, NT == 64 ? 2 : 4)))
 k_gfstack_dma(GsArgs a)
 {
+    static_assert(DEEP == 0 || B64 == 1, "the three-buffer pipeline exists for the ds_read_b64 layout");
     constexpr int GS_NT = NT;
     constexpr int GS_PITCH = B64 ? NT + 1 : NT + 2;
     constexpr int LPR = NT / 2;         // lanes moving one row segment (16 B each)
@@ -472,16 +486,18 @@ k_gfstack_dma(GsArgs a)
     // row j of the step lands at buf*bufsz + j*PITCH; lanes 0..LPR-1 move its NT samples.
     // (scalar address arithmetic kept short: 32 x 32 -> 64 bit products, one exec region per step)
     const uint32_t rowbytes = (uint32_t)(N * 8);
-    auto dma_row = [&](const double *Gv, uint32_t r, int j, int buf) {
+    // `dep` is an ordering token only (not named in the text): a request that lists the destination
+    // register of the step's slot load as input cannot be placed in front of that load
+    auto dma_row = [&](const double *Gv, uint32_t r, int j, int boff, uint32_t dep) {
         const uint64_t off = (uint64_t)r * (uint64_t)rowbytes;
         const char *rowp = reinterpret_cast<const char *>(Gv) + off;
-        const uint32_t dst = lds0 + (uint32_t)((buf * bufsz + j * GS_PITCH) * 8);
+        const uint32_t dst = lds0 + (uint32_t)((boff + j * GS_PITCH) * 8);
         uint32_t tok;
         asm("s_mov_b32 m0, %3\n\t"
             "s_nop 0\n\t"
             "global_load_lds_dwordx4 %1, %2\n\t"
             "s_mov_b32 %0, 0"
-            : "=s"(tok) : "v"(voff), "s"(rowp), "s"(dst));
+            : "=s"(tok) : "v"(voff), "s"(rowp), "s"(dst), "v"(dep));
         keep |= tok;
     };
     // distinct-row count + this wavefront's first KPRE row ids of step s (wave-uniform)
@@ -495,17 +511,20 @@ k_gfstack_dma(GsArgs a)
     // (library base pointers in registers: indexing a.G[] by a run-time iv is a kernarg load with
     // its latency in front of every step's DMAs)
     const double *const G0 = a.G[0], *const G1 = a.G[1], *const G2 = a.G[2], *const G3 = a.G[3];
-    auto issue_rows = [&](int p, int iv, int buf, int U, const uint32_t (&rid)[KPRE]) {
+    auto issue_rows_dep = [&](int p, int iv, int boff, int U, const uint32_t (&rid)[KPRE], uint32_t dep) {
         const double *Gv = iv == 0 ? G0 : iv == 1 ? G1 : iv == 2 ? G2 : G3;
         if (dma_lane) {
 #pragma unroll
             for (int k = 0; k < KPRE; k++)
-                if (wave + k * WAVES < U) dma_row(Gv, rid[k], wave + k * WAVES, buf);
+                if (wave + k * WAVES < U) dma_row(Gv, rid[k], wave + k * WAVES, boff, dep);
             if (U > KPRE * WAVES) {   // rare: more distinct rows than the prefetched ids cover
                 const uint32_t *uq = a.urows + (gt * a.P + p) * a.ustride;
-                for (int j = wave + KPRE * WAVES; j < U; j += WAVES) dma_row(Gv, uq[j], j, buf);
+                for (int j = wave + KPRE * WAVES; j < U; j += WAVES) dma_row(Gv, uq[j], j, boff, dep);
             }
         }
+    };
+    auto issue_rows = [&](int p, int iv, int buf, int U, const uint32_t (&rid)[KPRE]) {
+        issue_rows_dep(p, iv, buf * bufsz, U, rid, 0u);
     };
     // the lane's slot and weight of step s: asm loads (hipcc must not count them, see above);
     // valid after the step-top wait statement, which names them
@@ -524,16 +543,29 @@ k_gfstack_dma(GsArgs a)
         }
     };
 
+    // number of row requests wavefront `wave` issues for a step with U distinct rows
+    auto dma_count = [&](int U) { return U > wave ? (U - wave + WAVES - 1) / WAVES : 0; };
     int p1 = 0, iv1 = 0;          // step s+1
     advance(p1, iv1);
     int p2 = p1, iv2 = iv1;       // step s+2
     advance(p2, iv2);
+    int p3 = p2, iv3 = iv2;       // step s+3 (DEEP)
+    advance(p3, iv3);
     int U_a;
     uint32_t rid_a[KPRE];
+    int k_young = 0;              // DEEP: row requests issued after the youngest slot/weight loads
+    int boff0 = 0, boff1 = bufsz, boff2 = 2 * bufsz;   // DEEP: buffers of steps s, s+1, s+2 (doubles)
     fetch_ids(0, U_a, rid_a);
     issue_rows(0, 0, 0, U_a, rid_a);
     fetch_tabs(0, 0);
     fetch_ids(p1, U_a, rid_a);
+    if (DEEP) {
+        if (nsteps > 1) {
+            issue_rows_dep(p1, iv1, boff1, U_a, rid_a, sl_n[0]);
+            k_young = dma_count(U_a);
+        }
+        fetch_ids(p2, U_a, rid_a);
+    }
     for (int s = 0; s < nsteps; s++) {
         // the tables of this step and (older) the DMA of this step's rows have landed
         __builtin_amdgcn_sched_barrier(0);
@@ -541,30 +573,61 @@ k_gfstack_dma(GsArgs a)
         // place it in front of the wait and copy registers whose loads are still in flight)
         uint32_t sl[NROW];
         double wl[NROW];
-#pragma unroll
-        for (int k = 0; k < NROW; k++)
-            asm("s_waitcnt vmcnt(0)\n\t"
-                "v_mov_b32 %0, %2\n\t"
-                "v_mov_b64 %1, %3"
-                : "=&v"(sl[k]), "=&v"(wl[k]) : "v"(sl_n[k]), "v"(wl_n[k]));
+#define BA_WAIT_COPY(NOUT)                                                                      \
+        _Pragma("unroll") for (int k = 0; k < NROW; k++)                                        \
+            asm("s_waitcnt vmcnt(" #NOUT ")\n\t"                                                 \
+                "v_mov_b32 %0, %2\n\t"                                                          \
+                "v_mov_b64 %1, %3"                                                              \
+                : "=&v"(sl[k]), "=&v"(wl[k]) : "v"(sl_n[k]), "v"(wl_n[k]))
+        if (DEEP) {
+            // at most k_young row requests (the ones of step s+1, issued after this step's
+            // slot/weight loads) may stay in flight
+            switch (k_young) {
+            case 0: BA_WAIT_COPY(0); break;
+            case 1: BA_WAIT_COPY(1); break;
+            case 2: BA_WAIT_COPY(2); break;
+            case 3: BA_WAIT_COPY(3); break;
+            case 4: BA_WAIT_COPY(4); break;
+            case 5: BA_WAIT_COPY(5); break;
+            case 6: BA_WAIT_COPY(6); break;
+            case 7: BA_WAIT_COPY(7); break;
+            default: BA_WAIT_COPY(8); break;
+            }
+        } else {
+            BA_WAIT_COPY(0);
+        }
+#undef BA_WAIT_COPY
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();  // rows of step s visible; everyone has left the FMA phase of step s-1
         __builtin_amdgcn_sched_barrier(0);
-        {
+        const bool late_issue = (DEEP == 2) && (wave & 1);
+        if (!DEEP) {
             if (s + 1 < nsteps) issue_rows(p1, iv1, (s + 1) & 1, U_a, rid_a);   // -> other buffer
             fetch_tabs(p1, iv1);
             fetch_ids(p2, U_a, rid_a);
             p1 = p2; iv1 = iv2;
             advance(p2, iv2);
+        } else {
+            // slot/weight of step s+1 FIRST, then the rows of step s+2 -> third buffer
+            fetch_tabs(p1, iv1);
+            if (!late_issue) {
+                k_young = 0;
+                if (s + 2 < nsteps) {
+                    issue_rows_dep(p2, iv2, boff2, U_a, rid_a, sl_n[0]);
+                    k_young = dma_count(U_a);
+                }
+                fetch_ids(p3, U_a, rid_a);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
+        const int gbuf = DEEP ? boff0 : (s & 1) * bufsz;   // doubles: the buffer of step s
         // ---- every lane applies ITS rows with ITS weights.  The 2*NT/4 ds_read_b128 of a row
         // are issued by hand in groups of 8, two groups in flight (hipcc keeps 3-4 reads in
         // flight, which leaves the phase bound by LDS latency instead of LDS throughput); the
         // wait statements name the destination registers, so no FMA can move above its wait.
 #pragma unroll
         for (int k = 0; k < NROW; k++) {
-            const uint32_t xs = lds0 + (uint32_t)(((s & 1) * bufsz + (int)sl[k] * GS_PITCH) * 8);
+            const uint32_t xs = lds0 + (uint32_t)((gbuf + (int)sl[k] * GS_PITCH) * 8);
             const double w = wl[k];
             if (B64) {
                 constexpr int NG8 = GS_NT / 8;   // groups of 8 reads = 8 samples
@@ -615,6 +678,22 @@ k_gfstack_dma(GsArgs a)
                 __builtin_amdgcn_sched_barrier(0);
             }
             }
+        }
+        if (DEEP) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (late_issue) {
+                k_young = 0;
+                if (s + 2 < nsteps) {
+                    issue_rows_dep(p2, iv2, boff2, U_a, rid_a, sl_n[0]);
+                    k_young = dma_count(U_a);
+                }
+                fetch_ids(p3, U_a, rid_a);
+            }
+            const int b0 = boff0;
+            boff0 = boff1; boff1 = boff2; boff2 = b0;
+            p1 = p2; iv1 = iv2;
+            p2 = p3; iv2 = iv3;
+            advance(p3, iv3);
         }
     }
 
@@ -668,6 +747,7 @@ static void launch_shared_one(dim3 grid, size_t lds, hipStream_t s, const GsArgs
         kern = k_gfstack_dma<WAVES, NROW, MODE, 32, 1>;   // 1024-chain groups exist as NT = 32 only
     } else {
         kern = (a.dma == 2 && a.nt == 32) ? k_gfstack_dma<WAVES, NROW, MODE, 32, 1>
+             : (a.dma == 2 && a.deep == 1) ? k_gfstack_dma<WAVES, NROW, MODE, 64, 1, 1>
              : (a.dma == 2) ? k_gfstack_dma<WAVES, NROW, MODE, 64, 1>
              : a.dma ? k_gfstack_dma<WAVES, NROW, MODE, 64, 0>
              : (a.nt == 48) ? k_gfstack_shared<WAVES, NROW, MODE, 48>
@@ -827,7 +907,16 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         if (a.nt == 32 && a.dma != 2) { a.nt = 64; a.ntile = (int)((L.N + 63) / 64); nblocks = ngroups * L.T * a.ntile;
                                         lds = (size_t)ucap * (a.nt + 2) * sizeof(double); a.dma = 0; }
         BA_CHECK(CG != 1024 || a.dma == 2, BEATAMD_EINVAL, "gfstack: 1024-chain groups need the LDS-DMA kernel");
-        if (a.dma) lds *= 2;
+        // three row buffers (rows requested two steps ahead) when they fit
+        const char *d = getenv("BEATAMD_GS_DEEP");
+        a.deep = 0;
+        if (a.dma == 2 && a.nt == 64 && CG <= 512 && 3 * lds <= 158 * 1024) {
+            a.deep = GS_DEEP_DEFAULT;
+            // (DEEP = 2, staggered issue by a run-time wavefront test, is not instantiated: hipcc
+            // spills there and reuses registers of in-flight asm loads -- tools/audit_hidden_loads.py)
+            if (d && atoi(d) >= 0 && atoi(d) <= 1) a.deep = atoi(d);
+        }
+        if (a.dma) lds *= (a.deep ? 3 : 2);
     }
     {
         // chain groups of one (target, tile) on one XCD (several groups only)
@@ -836,8 +925,12 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         if (e && atoi(e) == 1 && a.dma) a.xcd_order = 1;
         if (a.xcd_order) nblocks = ((L.T * a.ntile + 7) / 8) * 8 * ngroups;
     }
-    snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "%s<%d,%d,%d,%d,%d>",
-             a.dma ? "k_gfstack_dma" : "k_gfstack_shared", CG / 64, nrow, k.mode, a.nt, a.dma == 2 ? 1 : 0);
+    if (a.deep)
+        snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack_dma<%d,%d,%d,%d,1,%d>",
+                 CG / 64, nrow, k.mode, a.nt, a.deep);
+    else
+        snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "%s<%d,%d,%d,%d,%d>",
+                 a.dma ? "k_gfstack_dma" : "k_gfstack_shared", CG / 64, nrow, k.mode, a.nt, a.dma == 2 ? 1 : 0);
     ctx->gs_ngtp = GTP;
     ctx->gs_N = L.N;
     ctx->gs_cg = CG;

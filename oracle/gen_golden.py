@@ -90,6 +90,45 @@ def gen_sweep():
     save("sweep", **cases)
 
 
+def gen_sweep_ties():
+    """slowness fields whose rupture times land EXACTLY on k + 0.5 ties of the
+    start-time grid (t / dt = k + 0.5 with dt = 0.5, 0.25), where round-half-even decides the
+    int16 index.  Slowness x patch size are dyadic numbers (0.25, 0.125, 0.75 ...), so along rows
+    and columns through the hypocentre the one-sided updates are exact sums and every
+    implementation that keeps the reference's operation order reproduces the tie bit for bit; a
+    contracted or re-associated update would move it off the tie and flip the index."""
+    cases, names = {}, []
+    specs = []
+    specs.append(("tie_homog_quarter", np.full((9, 12), 0.25), 1.0, 4, 5))       # t = 0.25 k
+    specs.append(("tie_homog_075", np.full((8, 8), 0.375), 2.0, 0, 0))           # t = 0.75 k
+    het = np.full((10, 10), 0.25)
+    het[:, 5:] = 0.125                                                            # two media
+    het[3, :] = 0.75
+    specs.append(("tie_two_media", het, 1.0, 3, 2))
+    stripes = np.tile(np.array([0.125, 0.375, 0.25, 0.625]), (12, 5))             # 12 x 20
+    specs.append(("tie_stripes", stripes, 2.0, 6, 0))
+    specs.append(("tie_eighth", np.full((20, 20), 0.125), 1.0, 19, 0))            # t = 0.125 k
+    n_ties = 0
+    for name, slow, psz, hd, hs in specs:
+        nd, ns = slow.shape
+        c = fast_sweep_ext.fast_sweep(np.ascontiguousarray(slow).ravel(), psz, hd, hs, nd, ns)
+        cases[name + "_slow"] = slow
+        cases[name + "_meta"] = np.array([psz, hd, hs, nd, ns], dtype=np.float64)
+        cases[name + "_c"] = c
+        for dt in (0.5, 0.25):
+            x = c / dt
+            tie = (x - np.floor(x)) == 0.5
+            n_ties += int(tie.sum())
+            # the reference's index maps on the reference's times (ffi/base.py:506-517)
+            cases[name + "_idx_nn_%g" % dt] = np.round((c - 0.0) / dt).astype("int16")
+            cases[name + "_idx_ml_%g" % dt] = np.ceil((c - 0.0) / dt).astype("int16")
+            cases[name + "_ties_%g" % dt] = tie
+        names.append(name)
+    assert n_ties >= 50, n_ties
+    cases["names"] = np.array(names)
+    save("sweep_ties", **cases)
+
+
 # ---------------------------------------------------------------- positions2idxs
 def gen_positions():
     rng = np.random.default_rng(7)
@@ -288,7 +327,12 @@ def gen_laquila():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:          # regenerate selected fixtures only: gen_golden.py sweep_ties ...
+        for what in sys.argv[1:]:
+            globals()["gen_" + what]()
+        sys.exit(0)
     gen_sweep()
+    gen_sweep_ties()
     gen_positions()
     gen_stack()
     gen_cov()

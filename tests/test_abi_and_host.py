@@ -175,15 +175,22 @@ def test_isa_audit_of_hidden_asm_loads(tmp_path):
         "audit_hidden_loads", os.path.join(os.path.dirname(__file__), "..", "tools", "audit_hidden_loads.py"))
     aud = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(aud)
+    gather = ["ds_read_b64 v[40:41], v1 offset:%d" % (8 * i) for i in range(40)]   # marks the step loop
     bad = [".LBB0_1:", "s_waitcnt vmcnt(0)", "s_barrier", "global_load_ushort v9, v[2:3], off",
-           "global_load_dwordx2 v[4:5], v[6:7], off", "v_fma_f64 v[10:11], v[12:13], v[14:15], v[10:11]",
-           "s_cbranch_scc1 .LBB0_1", "s_endpgm"]
+           "global_load_dwordx2 v[4:5], v[6:7], off"] + gather + \
+          ["v_fma_f64 v[10:11], v[12:13], v[14:15], v[10:11]", "s_cbranch_scc1 .LBB0_1", "s_endpgm"]
     n, problems = aud.audit(bad)
     assert n == 2 and not problems
     bad.insert(0, "v_mov_b32_e32 v20, v9")          # before the loop: not on the path
     bad.insert(2, "v_mov_b64_e32 v[30:31], v[4:5]")  # at the loop header, before the wait
     n, problems = aud.audit(bad)
     assert len(problems) == 1 and "v[30:31]" in problems[0][3]
+    # three-buffer variants: a row request in front of the slot/weight loads of its step is flagged
+    deep = [".LBB0_1:", "s_waitcnt vmcnt(3)", "s_barrier", "global_load_lds_dwordx4 v1, s[4:5]",
+            "global_load_ushort v9, v[2:3], off"] + gather + ["s_cbranch_scc1 .LBB0_1", "s_endpgm"]
+    assert aud.audit_order(deep) == [2]
+    deep[3], deep[4] = deep[4], deep[3]
+    assert aud.audit_order(deep) == []
     if shutil.which("hipcc") is None:
         pytest.skip("hipcc not available")
     assert aud.main() == 0

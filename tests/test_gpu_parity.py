@@ -44,6 +44,47 @@ def test_sweep_golden_times_and_indices(ctx, orc):
                                   orc.time2idx(ref, 0.0, dt, "multilinear")[0])
 
 
+def test_sweep_tie_fixtures_indices_bit_exact(ctx, orc):
+    """slowness fields that put t / dt on exact k + 0.5 ties (dyadic slowness x patch
+    size): the device sweep must reproduce those times EXACTLY (any contraction or re-association
+    moves them off the tie) and the grid indices of the reference (round-half-even / ceil)"""
+    g = load_golden("sweep_ties")
+    n_ties = 0
+    for name in g["names"]:
+        slow = g[name + "_slow"]
+        psz, hd, hs, nd, ns = g[name + "_meta"]
+        nd, ns = int(nd), int(ns)
+        out = ctx.fast_sweep_batch(slow.reshape(1, -1), psz, [int(hd)], [int(hs)], nd, ns)[0]
+        ref = g[name + "_c"]
+        np.testing.assert_allclose(out, ref, rtol=0, atol=1e-12, err_msg=name)
+        for dt in (0.5, 0.25):
+            tie = g[name + "_ties_%g" % dt]
+            n_ties += int(tie.sum())
+            assert np.array_equal(out[tie], ref[tie]), name          # ties are exact sums
+            assert np.array_equal(orc.time2idx(out, 0.0, dt)[0], g[name + "_idx_nn_%g" % dt]), name
+            assert np.array_equal(orc.time2idx(out, 0.0, dt, "multilinear")[0], g[name + "_idx_ml_%g" % dt])
+    assert n_ties >= 50
+    # through the fused model: the index tables the stacking kernel builds from these times select
+    # the reference's rows -- one patch-wide library whose rows encode (duration, starttime) index
+    from beat_amd.ffi import SeismicGFLibrary, SeismicGFLibraryConfig
+    name = "tie_two_media"
+    slow = g[name + "_slow"]
+    psz, hd, hs, nd, ns = g[name + "_meta"]
+    P, S = slow.size, 64
+    gf = SeismicGFLibrary(SeismicGFLibraryConfig(dimensions=(1, P, 1, S, 2), starttime_sampling=0.5,
+                                                 duration_sampling=0.5, starttime_min=0.0, duration_min=0.5))
+    gf.setup(1, P, 1, S, 2, allocate=True)
+    gf._gfmatrix[0, :, 0, :, 0] = np.arange(S)[None, :]          # sample 0 of a row = its starttime index
+    gf._gfmatrix[0, :, 0, :, 1] = 1.0
+    gf.init_optimization(ctx)
+    t = ctx.fast_sweep_batch(slow.reshape(1, -1), psz, [int(hd)], [int(hs)], int(nd), int(ns))
+    for p in range(P):
+        sl = np.zeros((1, P))
+        sl[0, p] = 1.0
+        syn = gf.stack_all_batch(np.full((1, P), 0.5), t.reshape(1, 1, P), sl)
+        assert syn[0, 0, 0] == g[name + "_idx_nn_0.5"][p] and syn[0, 0, 1] == 1.0
+
+
 def test_sweep_batch_random_vs_oracle(ctx, orc):
     rng = np.random.default_rng(5)
     for nd, ns in [(20, 20), (7, 31), (64, 3), (70, 70), (1, 1), (2, 90)]:
@@ -168,11 +209,25 @@ def test_shared_row_kernel_equals_streaming_kernel(ctx, orc, monkeypatch, C, int
     for c in (0, C // 2, C - 1):
         ref = orc.stack_all(G, dur[c], st[c], sl[c], 0.5, 0.25, 0.0, 0.5, interp)
         assert np.abs(b[c] - ref).max() <= 1e-11 * np.abs(ref).max()
-    for cg in ("64", "128", "256", "512"):
+    seen = set()
+    for cg in ("64", "128", "256", "512", "1024"):
         monkeypatch.setenv("BEATAMD_GS_CG", cg)
-        for dma in ("2", "1", "0"):
+        for dma, deep, nt, order in (("2", "0", "64", "0"), ("2", "1", "64", "1"), ("2", "0", "32", "1"),
+                                     ("1", "0", "64", "0"), ("0", "0", "64", "0")):
+            if cg == "1024" and dma != "2":
+                continue   # 1024-chain groups exist for the LDS-DMA kernel only
             monkeypatch.setenv("BEATAMD_GS_DMA", dma)
-            assert np.array_equal(gf.stack_all_batch(dur, st, sl, interpolation=interp), a), (cg, dma)
+            monkeypatch.setenv("BEATAMD_GS_DEEP", deep)
+            monkeypatch.setenv("BEATAMD_GS_NT", nt)
+            monkeypatch.setenv("BEATAMD_GS_ORDER", order)
+            assert np.array_equal(gf.stack_all_batch(dur, st, sl, interpolation=interp), a), (cg, dma, deep, nt)
+            seen.add(ctx.last_kernel())
+    nrow, w = (4 if interp == "multilinear" else 1), {"64": 1, "128": 2, "256": 4, "512": 8, "1024": 16}
+    for cg in w:   # every variant really ran (names as beatamd_ctx_last_kernel reports them)
+        assert "k_gfstack_dma<%d,%d,0,32,1>" % (w[cg], nrow) in seen, seen
+        if cg != "1024":
+            assert "k_gfstack_dma<%d,%d,0,64,1,1>" % (w[cg], nrow) in seen, seen
+            assert "k_gfstack_shared<%d,%d,0,64,0>" % (w[cg], nrow) in seen, seen
 
 
 @pytest.mark.parametrize("name", ["seis_dense_ml_shifts", "joint_multifault", "all_nn_odd_N",

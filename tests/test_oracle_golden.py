@@ -110,3 +110,26 @@ def test_noise_covariance(golden):
         assert np.array_equal(orc.autocovariance(d), g["c%d_autocov" % k])
         assert np.array_equal(orc.running_window_rms(d, w, "same"), g["c%d_rms_same" % k])
         assert np.array_equal(orc.non_toeplitz_covariance(d, w), g["c%d_ntc" % k])
+
+
+def test_sweep_tie_fixtures_oracle_bit_exact():
+    """rupture times that sit exactly on k + 0.5 ties of the start-time grid
+    (tests/golden/sweep_ties.npz, times from the reference's C extension): the C restatement
+    reproduces them bit for bit and maps them to the reference's int16 indices (round-half-even)"""
+    g = load_golden("sweep_ties")
+    n_ties = 0
+    for name in g["names"]:
+        slow = g[name + "_slow"]
+        psz, hd, hs, nd, ns = g[name + "_meta"]
+        out = orc.fast_sweep(slow.ravel(), psz, int(hd), int(hs), int(nd), int(ns))
+        assert np.array_equal(out, g[name + "_c"]), name
+        for dt in (0.5, 0.25):
+            tie = g[name + "_ties_%g" % dt]
+            n_ties += int(tie.sum())
+            assert np.array_equal(orc.time2idx(out, 0.0, dt)[0], g[name + "_idx_nn_%g" % dt])
+            assert np.array_equal(orc.time2idx(out, 0.0, dt, "multilinear")[0], g[name + "_idx_ml_%g" % dt])
+            # half-even: a tie k + 0.5 goes to the even neighbour
+            k = np.floor(out[tie] / dt)
+            want = np.where(k % 2 == 0, k, k + 1)
+            assert np.array_equal(orc.time2idx(out, 0.0, dt)[0][tie], want.astype(np.int16))
+    assert n_ties >= 50

@@ -48,19 +48,40 @@ def functions(lines):
                 name = None
 
 
+def main_loop(body, labels):
+    """(index of the back-edge branch, index of the header label) of the step loop: the backward
+    branch whose span holds the most LDS reads (the gather).  Other backward branches (short DMA
+    loops, out-of-line blocks) are not loop back-edges of interest."""
+    best = None
+    for j, cur in enumerate(body):
+        m = re.match(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", cur)
+        if not m or labels.get(m.group(1), 1 << 30) >= j:
+            continue
+        h = labels[m.group(1)]
+        nds = sum(1 for ln in body[h:j] if ln.startswith("ds_read_b"))
+        if nds >= 32 and (best is None or nds > best[2]):
+            best = (j, h, nds)
+    return best
+
+
 def audit(body):
     labels = {ln[:-1]: i for i, ln in enumerate(body) if ln.endswith(":")}
+    loop = main_loop(body, labels)
     problems, nchecked = [], 0
     for i, ln in enumerate(body):
         if not (ln.startswith("global_load_ushort") or ln.startswith("global_load_dwordx2")):
             continue
+        if loop is None or i > loop[0]:
+            continue   # epilogue loads are ordinary, waited loads
         dest = vregs(ln.split(",")[0])
         nchecked += 1
         j, jumped, steps = i + 1, False, 0
         while j < len(body) and steps < 20000:
             cur = body[j]
             steps += 1
-            if cur.startswith("s_waitcnt vmcnt(0)"):
+            if re.match(r"s_waitcnt vmcnt\(\d+\)", cur):
+                # (the three-buffer variants wait with vmcnt(k), k = row requests issued AFTER the
+                # slot/weight loads: the loads themselves are covered by every arm of that switch)
                 break
             if not cur.endswith(":"):
                 # the partner load of the same statement group may use the register as address
@@ -68,17 +89,28 @@ def audit(body):
                 ops = cur.split(None, 1)[1] if " " in cur else ""
                 if vregs(ops) & dest and not cur.startswith("global_load_"):
                     problems.append((i, ln, j, cur))
-                m = re.match(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", cur)
-                if m and not jumped and labels.get(m.group(1), 1 << 30) < j and \
-                        labels[m.group(1)] < i:
-                    # the loop back-edge: continue at the loop header (once)
-                    nxt = j + 1
-                    # keep walking the fall-through first only if it is the loop exit: the wait
-                    # of interest is at the header
-                    j, jumped = labels[m.group(1)], True
+                if j == loop[0] and not jumped:
+                    j, jumped = loop[1], True   # the step loop's back-edge: on to the loop header
                     continue
             j += 1
     return nchecked, problems
+
+
+def audit_order(body):
+    """Three-buffer variants (any `s_waitcnt vmcnt(N)`, N > 0, in the kernel): the step-top wait
+    leaves the N youngest requests in flight, so inside a step the slot/weight loads must be
+    issued BEFORE the row requests (global_load_lds).  -> list of offending barrier positions."""
+    if not any(re.match(r"s_waitcnt vmcnt\([1-9]\d*\)", ln) for ln in body):
+        return []
+    bad = []
+    bars = [i for i, ln in enumerate(body) if ln.startswith("s_barrier")]
+    for a, b in zip(bars, bars[1:] + [len(body)]):
+        seg = body[a:b]
+        tab = [i for i, ln in enumerate(seg) if ln.startswith("global_load_ushort")]
+        dma = [i for i, ln in enumerate(seg) if ln.startswith("global_load_lds")]
+        if tab and dma and min(dma) < min(tab):
+            bad.append(a)
+    return bad
 
 
 def main(path=None):
@@ -99,6 +131,9 @@ def main(path=None):
         for (i, ln, j, cur) in problems:
             bad += 1
             print("%s: load `%s` (line %d) in flight, touched by `%s` (line %d)" % (name, ln, i, cur, j))
+        for a in audit_order(body):
+            bad += 1
+            print("%s: row requests issued before the slot/weight loads after the barrier at line %d" % (name, a))
     print("audited %d kernel instances, %d hidden loads, %d hazards" % (nfun, total, bad))
     return 1 if (bad or nfun == 0 or total == 0) else 0
 
