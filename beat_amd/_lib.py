@@ -92,6 +92,7 @@ _PROTOS = {
     "beatamd_gather_rows": [_vp, _i64, _i64, _vp, _i64, _vp, _vp],
     "beatamd_metropolis_tune": [_vp, _i64, _vp, _vp, _i32],
     "beatamd_whiten_rows": [_vp, _vp, _i64, _i64, _vp],
+    "beatamd_halfspace_displacements_batch": [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _f64, _vp],
 }
 
 EXPORTS = sorted(list(_PROTOS) + ["beatamd_last_error", "beatamd_version"])

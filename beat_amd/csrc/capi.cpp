@@ -1093,4 +1093,36 @@ int beatamd_whiten_rows(beatamd_ctx *ctx, double *rows, int64_t nrows, int64_t N
     return BEATAMD_OK;
 }
 
+// ------------------------------------------------------------------ half-space synthetics
+int beatamd_halfspace_displacements_batch(beatamd_ctx *ctx, int64_t C, int32_t nsrc,
+                                          const int32_t *kind, const double *params, int64_t nobs,
+                                          const double *east, const double *north, double nu,
+                                          double *out)
+{
+    ENTER(ctx);
+    BA_CHECK(kind && params && east && north && out && C >= 0 && nsrc > 0 && nobs > 0, BEATAMD_EINVAL,
+             "halfspace_displacements: bad argument");
+    BA_CHECK(nu > -1.0 && nu < 0.5, BEATAMD_EINVAL, "Poisson ratio outside (-1, 0.5)");
+    BA_CHECK(!is_device_ptr(kind), BEATAMD_EINVAL, "halfspace_displacements: kind must be a host array");
+    for (int i = 0; i < nsrc; i++)
+        BA_CHECK(kind[i] == 0 || kind[i] == 1, BEATAMD_EINVAL, "unknown source kind %d", kind[i]);
+    if (C == 0) return BEATAMD_OK;
+    std::vector<int64_t> poff((size_t)nsrc * 10);
+    for (size_t i = 0; i < poff.size(); i++) poff[i] = (int64_t)i;
+    const void *d_k, *d_o, *d_p, *d_e, *d_n;
+    void *d_out;
+    Arg rec;
+    BA_TRY(stage_in(ctx, SL_IN0, kind, (size_t)nsrc * 4, &d_k));
+    BA_TRY(stage_in(ctx, SL_IN1, poff.data(), poff.size() * 8, &d_o));
+    BA_TRY(stage_in(ctx, SL_IN2, params, (size_t)C * nsrc * 10 * 8, &d_p));
+    BA_TRY(stage_in(ctx, SL_IN3, east, (size_t)nobs * 8, &d_e));
+    BA_TRY(stage_in(ctx, SL_IN4, north, (size_t)nobs * 8, &d_n));
+    BA_TRY(stage_out(ctx, SL_OUT0, out, (size_t)C * nsrc * nobs * 3 * 8, &d_out, &rec));
+    BA_TRY(launch_geom_disp(ctx, nsrc, (const int32_t *)d_k, (const int64_t *)d_o, (const double *)d_p,
+                            C, nobs, (const double *)d_e, (const double *)d_n, nu, (double *)d_out));
+    BA_TRY(finish_out(ctx, &rec, 1));
+    BA_HIP(hipStreamSynchronize(ctx->stream));   // `poff` is a stack temporary
+    return BEATAMD_OK;
+}
+
 }  // extern "C"

@@ -43,6 +43,9 @@ struct GroupTabArgs {
     ChainVec slips[4];
     int ucap, ustride;
     uint32_t *urows;   // [(g*T+t)*P+p][ustride], padded with the last id
+    uint32_t *uslot;   // [(g*T+t)*P+p][ustride] LDS slot of each listed row
+    int windowed;      // slots chosen by LDS bank window (k_gfstack_dma / ds_read_b64), else dense
+    int depth;         // windowed: rows per window (LDS holds 32 * depth slots)
     uint32_t *ucount;  // [(g*T+t)*P+p]
     uint32_t *umax;    // max over ucount (atomicMax; zeroed by the launcher)
     uint16_t *slot;    // [((g*T+t)*P+p)*nrow + k][CG]
@@ -56,6 +59,9 @@ __global__ void k_gf_group_tables(GroupTabArgs a)
     extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
     uint32_t *flags = sm;                 // [DS] presence -> slot
     uint32_t *wsum = sm + a.DS;           // [CG] per-thread partial counts
+    uint32_t *gmask = wsum + a.CG + 1;    // [DS] windowed: 32-lane groups of the workgroup using the row
+    uint32_t *lst = gmask + a.DS;         // [128] windowed: local row index of list entry `pos`
+    uint32_t *slt = lst + 128;            // [128] windowed: LDS slot of list entry `pos`
     const int tid = threadIdx.x, CG = a.CG;
     const int64_t gtp = blockIdx.x;       // (g*T + t)*P + p
     const int64_t p = gtp % a.P;
@@ -66,13 +72,17 @@ __global__ void k_gf_group_tables(GroupTabArgs a)
     const bool live = c < a.C;
     const int64_t row0 = (t * a.P + p) * a.DS;
 
-    for (int64_t i = tid; i < a.DS; i += CG) flags[i] = 0;
+    for (int64_t i = tid; i < a.DS; i += CG) {
+        flags[i] = 0;
+        if (a.windowed) gmask[i] = 0;
+    }
     __syncthreads();
     uint32_t v[4] = {0, 0, 0, 0};
     if (live)
         for (int k = 0; k < a.nrow; k++) {
             v[k] = a.rowoff[((c * a.T + t) * a.P + p) * a.nrow + k] - (uint32_t)row0;
             flags[v[k]] = 1;  // benign race: every writer stores 1
+            if (a.windowed) atomicOr(&gmask[v[k]], 1u << (tid >> 5));
         }
     __syncthreads();
     // exclusive scan of flags in row order -> slot numbers (deterministic): chunks of CG flags,
@@ -96,6 +106,7 @@ __global__ void k_gf_group_tables(GroupTabArgs a)
                 const uint32_t pos = run + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                 a.urows[gtp * a.ustride + pos] = (uint32_t)(row0 + i);
                 flags[i] = pos;
+                if (a.windowed) lst[pos] = (uint32_t)i;
             }
             run += total;
             __syncthreads();
@@ -108,11 +119,56 @@ __global__ void k_gf_group_tables(GroupTabArgs a)
         }
     }
     __syncthreads();
+    const int total = (int)wsum[CG];
+    if (a.windowed && total > 32) {
+        // LDS slots by bank window.  k_gfstack_dma reads row `slot` of a lane at slot * (NT+1)
+        // doubles with ds_read_b64: the 32 lanes of a lane group hit the two-bank window
+        // (slot + sample) mod 32, so rows whose slots differ by 32 collide when ONE lane group reads
+        // both (measured with the population of SURVEY 8(d), 39 rows per step on dense slots:
+        // SQ_LDS_BANK_CONFLICT = 39 % of the LDS cycles).  Rows sharing a window are therefore
+        // chosen so that no 32-lane group uses two of them, as far as the masks allow: rows in
+        // order of decreasing number of lane groups using them, each into the window with the
+        // least overlap (then the emptiest, then the lowest).  Wavefront 0; lanes 0..31 are the
+        // windows.  Results do not depend on the slots, only the LDS read timing does.
+        if (tid < 64) {
+            const int r0 = tid, r1 = tid + 64;
+            const uint32_t m0 = r0 < total ? gmask[lst[r0]] : 0u, m1 = r1 < total ? gmask[lst[r1]] : 0u;
+            int key0 = r0 < total ? ((__popc(m0) << 8) | (255 - r0)) : -1;
+            int key1 = r1 < total ? ((__popc(m1) << 8) | (255 - r1)) : -1;
+            uint32_t wmask = 0;
+            int wcnt = 0;
+            for (int it = 0; it < total; it++) {
+                int best = max(key0, key1);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off, 64));
+                const int ridx = 255 - (best & 255);
+                const uint32_t mm = __shfl(ridx < 64 ? m0 : m1, ridx & 63, 64);
+                int cost = (tid < 32 && wcnt < a.depth)
+                    ? ((__popc(wmask & mm) << 12) | (wcnt << 6) | tid) : 0x7fffffff;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) cost = min(cost, __shfl_xor(cost, off, 64));
+                const int w = cost & 63;
+                if (tid == w) {
+                    slt[ridx] = (uint32_t)(w + 32 * wcnt);
+                    wmask |= mm;
+                    wcnt++;
+                }
+                if (tid == (ridx & 63)) {
+                    if (ridx < 64) key0 = -1; else key1 = -1;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < total; i += CG) flags[lst[i]] = slt[i];
+        __syncthreads();
+    }
     {
         // pad to the stride with the last id: the stacking kernel reads ids unclamped
-        const int total = (int)wsum[CG];
         const uint32_t last = total > 0 ? a.urows[gtp * a.ustride + total - 1] : (uint32_t)row0;
         for (int i = total + tid; i < a.ustride; i += CG) a.urows[gtp * a.ustride + i] = last;
+        // LDS slot of every listed row (dense numbering unless windows were assigned above)
+        for (int i = tid; i < a.ustride; i += CG)
+            a.uslot[gtp * a.ustride + i] = (i < total) ? flags[a.urows[gtp * a.ustride + i] - (uint32_t)row0] : 0u;
     }
     for (int k = 0; k < a.nrow; k++)
         a.slot[(gtp * a.nrow + k) * CG + tid] = live ? (uint16_t)flags[v[k]] : (uint16_t)0;
@@ -142,7 +198,7 @@ struct GsArgs {
     int deep;          // k_gfstack_dma: 0 two row buffers / 1 three buffers, rows two steps ahead / 2 + staggered issue
     int xcd_order;     // k_gfstack_dma: chain groups of a (target, tile) share an XCD
     int64_t ngroups;
-    const uint32_t *urows, *ucount;
+    const uint32_t *urows, *uslot, *ucount;
     const uint16_t *slot;
     const double *w;
     int64_t w_var_stride;
@@ -488,10 +544,10 @@ k_gfstack_dma(GsArgs a)
     const uint32_t rowbytes = (uint32_t)(N * 8);
     // `dep` is an ordering token only (not named in the text): a request that lists the destination
     // register of the step's slot load as input cannot be placed in front of that load
-    auto dma_row = [&](const double *Gv, uint32_t r, int j, int boff, uint32_t dep) {
+    auto dma_row = [&](const double *Gv, uint32_t r, uint32_t slotidx, int boff, uint32_t dep) {
         const uint64_t off = (uint64_t)r * (uint64_t)rowbytes;
         const char *rowp = reinterpret_cast<const char *>(Gv) + off;
-        const uint32_t dst = lds0 + (uint32_t)((boff + j * GS_PITCH) * 8);
+        const uint32_t dst = lds0 + (uint32_t)(boff * 8) + slotidx * (uint32_t)(GS_PITCH * 8);
         uint32_t tok;
         asm("s_mov_b32 m0, %3\n\t"
             "s_nop 0\n\t"
@@ -501,30 +557,37 @@ k_gfstack_dma(GsArgs a)
         keep |= tok;
     };
     // distinct-row count + this wavefront's first KPRE row ids of step s (wave-uniform)
-    auto fetch_ids = [&](int p, int &U, uint32_t (&rid)[KPRE]) {
+    auto fetch_ids = [&](int p, int &U, uint32_t (&rid)[KPRE], uint32_t (&rsl)[KPRE]) {
         const int64_t gtq = gt * a.P + p;
         U = __builtin_amdgcn_readfirstlane((int)a.ucount[gtq]);
         const uint32_t *uq = a.urows + gtq * a.ustride + wave;
+        const uint32_t *us = a.uslot + gtq * a.ustride + wave;
 #pragma unroll
-        for (int k = 0; k < KPRE; k++) rid[k] = uq[k * WAVES];   // padded: always in bounds
+        for (int k = 0; k < KPRE; k++) {   // padded: always in bounds
+            rid[k] = uq[k * WAVES];
+            rsl[k] = us[k * WAVES];
+        }
     };
     // (library base pointers in registers: indexing a.G[] by a run-time iv is a kernarg load with
     // its latency in front of every step's DMAs)
     const double *const G0 = a.G[0], *const G1 = a.G[1], *const G2 = a.G[2], *const G3 = a.G[3];
-    auto issue_rows_dep = [&](int p, int iv, int boff, int U, const uint32_t (&rid)[KPRE], uint32_t dep) {
+    auto issue_rows_dep = [&](int p, int iv, int boff, int U, const uint32_t (&rid)[KPRE],
+                              const uint32_t (&rsl)[KPRE], uint32_t dep) {
         const double *Gv = iv == 0 ? G0 : iv == 1 ? G1 : iv == 2 ? G2 : G3;
         if (dma_lane) {
 #pragma unroll
             for (int k = 0; k < KPRE; k++)
-                if (wave + k * WAVES < U) dma_row(Gv, rid[k], wave + k * WAVES, boff, dep);
+                if (wave + k * WAVES < U) dma_row(Gv, rid[k], rsl[k], boff, dep);
             if (U > KPRE * WAVES) {   // rare: more distinct rows than the prefetched ids cover
                 const uint32_t *uq = a.urows + (gt * a.P + p) * a.ustride;
-                for (int j = wave + KPRE * WAVES; j < U; j += WAVES) dma_row(Gv, uq[j], j, boff, dep);
+                const uint32_t *us = a.uslot + (gt * a.P + p) * a.ustride;
+                for (int j = wave + KPRE * WAVES; j < U; j += WAVES) dma_row(Gv, uq[j], us[j], boff, dep);
             }
         }
     };
-    auto issue_rows = [&](int p, int iv, int buf, int U, const uint32_t (&rid)[KPRE]) {
-        issue_rows_dep(p, iv, buf * bufsz, U, rid, 0u);
+    auto issue_rows = [&](int p, int iv, int buf, int U, const uint32_t (&rid)[KPRE],
+                          const uint32_t (&rsl)[KPRE]) {
+        issue_rows_dep(p, iv, buf * bufsz, U, rid, rsl, 0u);
     };
     // the lane's slot and weight of step s: asm loads (hipcc must not count them, see above);
     // valid after the step-top wait statement, which names them
@@ -552,19 +615,19 @@ k_gfstack_dma(GsArgs a)
     int p3 = p2, iv3 = iv2;       // step s+3 (DEEP)
     advance(p3, iv3);
     int U_a;
-    uint32_t rid_a[KPRE];
+    uint32_t rid_a[KPRE], rsl_a[KPRE];
     int k_young = 0;              // DEEP: row requests issued after the youngest slot/weight loads
     int boff0 = 0, boff1 = bufsz, boff2 = 2 * bufsz;   // DEEP: buffers of steps s, s+1, s+2 (doubles)
-    fetch_ids(0, U_a, rid_a);
-    issue_rows(0, 0, 0, U_a, rid_a);
+    fetch_ids(0, U_a, rid_a, rsl_a);
+    issue_rows(0, 0, 0, U_a, rid_a, rsl_a);
     fetch_tabs(0, 0);
-    fetch_ids(p1, U_a, rid_a);
+    fetch_ids(p1, U_a, rid_a, rsl_a);
     if (DEEP) {
         if (nsteps > 1) {
-            issue_rows_dep(p1, iv1, boff1, U_a, rid_a, sl_n[0]);
+            issue_rows_dep(p1, iv1, boff1, U_a, rid_a, rsl_a, sl_n[0]);
             k_young = dma_count(U_a);
         }
-        fetch_ids(p2, U_a, rid_a);
+        fetch_ids(p2, U_a, rid_a, rsl_a);
     }
     for (int s = 0; s < nsteps; s++) {
         // the tables of this step and (older) the DMA of this step's rows have landed
@@ -602,9 +665,9 @@ k_gfstack_dma(GsArgs a)
         __builtin_amdgcn_sched_barrier(0);
         const bool late_issue = (DEEP == 2) && (wave & 1);
         if (!DEEP) {
-            if (s + 1 < nsteps) issue_rows(p1, iv1, (s + 1) & 1, U_a, rid_a);   // -> other buffer
+            if (s + 1 < nsteps) issue_rows(p1, iv1, (s + 1) & 1, U_a, rid_a, rsl_a);   // -> other buffer
             fetch_tabs(p1, iv1);
-            fetch_ids(p2, U_a, rid_a);
+            fetch_ids(p2, U_a, rid_a, rsl_a);
             p1 = p2; iv1 = iv2;
             advance(p2, iv2);
         } else {
@@ -613,10 +676,10 @@ k_gfstack_dma(GsArgs a)
             if (!late_issue) {
                 k_young = 0;
                 if (s + 2 < nsteps) {
-                    issue_rows_dep(p2, iv2, boff2, U_a, rid_a, sl_n[0]);
+                    issue_rows_dep(p2, iv2, boff2, U_a, rid_a, rsl_a, sl_n[0]);
                     k_young = dma_count(U_a);
                 }
-                fetch_ids(p3, U_a, rid_a);
+                fetch_ids(p3, U_a, rid_a, rsl_a);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -684,10 +747,10 @@ k_gfstack_dma(GsArgs a)
             if (late_issue) {
                 k_young = 0;
                 if (s + 2 < nsteps) {
-                    issue_rows_dep(p2, iv2, boff2, U_a, rid_a, sl_n[0]);
+                    issue_rows_dep(p2, iv2, boff2, U_a, rid_a, rsl_a, sl_n[0]);
                     k_young = dma_count(U_a);
                 }
-                fetch_ids(p3, U_a, rid_a);
+                fetch_ids(p3, U_a, rid_a, rsl_a);
             }
             const int b0 = boff0;
             boff0 = boff1; boff1 = boff2; boff2 = b0;
@@ -815,7 +878,7 @@ bool gfstack_shared_applicable(const GfStackCall &k, int *cg_out, int *ucap_out)
         ucap = std::min<int64_t>((int64_t)cg * nrow, DS);
     }
     if (ucap * GS_PITCH * 8 > 150 * 1024) return false;
-    if (DS * 4 + cg * 4 > 60 * 1024) return false;  // presence map of k_gf_group_tables
+    if (2 * DS * 4 + cg * 4 + 2048 > 60 * 1024) return false;  // presence map + group masks of k_gf_group_tables
     *cg_out = cg;
     *ucap_out = (int)std::max<int64_t>(ucap, 2);
     return true;
@@ -840,6 +903,8 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     ga.ustride = (ucap + 63) / 64 * 64;   // covers the unclamped first-pass ids of 8 waves
     BA_TRY(ctx->get_scratch(SL_GS_UROWS, (size_t)GTP * ga.ustride * sizeof(uint32_t), &p));
     ga.urows = (uint32_t *)p;
+    BA_TRY(ctx->get_scratch(SL_GS_USLOT, (size_t)GTP * ga.ustride * sizeof(uint32_t), &p));
+    ga.uslot = (uint32_t *)p;
     BA_TRY(ctx->get_scratch(SL_GS_UCOUNT, (size_t)GTP * sizeof(uint32_t), &p));
     ga.ucount = (uint32_t *)p;
     BA_TRY(ctx->get_scratch(SL_GS_SLOT, (size_t)GTP * nrow * CG * sizeof(uint16_t), &p));
@@ -854,9 +919,21 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         ga.umax = (uint32_t *)p;
         BA_HIP(hipMemsetAsync(ga.umax, 0, sizeof(uint32_t), ctx->stream));
     }
+    // LDS slots by bank window for the ds_read_b64 LDS-DMA kernel with large chain groups (the
+    // small groups size their LDS by the measured row count and keep dense slots): the row
+    // buffers then hold 32 * depth slots
+    {
+        const char *ew = getenv("BEATAMD_GS_WIN"), *ed = getenv("BEATAMD_GS_DMA");
+        const int depth = (ucap + 31) / 32;
+        const bool dma2 = !(ed && (atoi(ed) == 0 || atoi(ed) == 1)) && L.N % 2 == 0;
+        ga.windowed = (CG >= 256 && dma2 && ucap > 32 && ucap <= 128 && !(ew && atoi(ew) == 0) &&
+                       (size_t)2 * 32 * depth * (GS_NT_MAX + 2) * 8 <= 158 * 1024) ? 1 : 0;
+        ga.depth = depth;
+        if (ga.windowed) ucap = 32 * depth;
+    }
     {
         ScopedTimer tm(ctx, "grouptables");
-        const size_t lds = (size_t)(ga.DS + CG + 1) * sizeof(uint32_t);
+        const size_t lds = (size_t)(2 * ga.DS + CG + 1 + 256) * sizeof(uint32_t);
         hipLaunchKernelGGL(k_gf_group_tables, dim3((unsigned)GTP), dim3(CG), lds, ctx->stream, ga);
     }
     BA_HIP(hipGetLastError());
@@ -875,7 +952,7 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     }
     a.ngroups = ngroups;
     a.ntile = (int)((L.N + a.nt - 1) / a.nt);
-    a.urows = ga.urows; a.ucount = ga.ucount; a.slot = ga.slot; a.w = ga.w;
+    a.urows = ga.urows; a.uslot = ga.uslot; a.ucount = ga.ucount; a.slot = ga.slot; a.w = ga.w;
     a.w_var_stride = ga.w_var_stride;
     a.data = k.data; a.wscalar = k.wscalar; a.out = k.out;
     if (k.mode == GF_RESID_SCALAR) {
@@ -907,6 +984,7 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         if (a.nt == 32 && a.dma != 2) { a.nt = 64; a.ntile = (int)((L.N + 63) / 64); nblocks = ngroups * L.T * a.ntile;
                                         lds = (size_t)ucap * (a.nt + 2) * sizeof(double); a.dma = 0; }
         BA_CHECK(CG != 1024 || a.dma == 2, BEATAMD_EINVAL, "gfstack: 1024-chain groups need the LDS-DMA kernel");
+        BA_CHECK(!ga.windowed || a.dma == 2, BEATAMD_EINVAL, "internal: window slots need the ds_read_b64 kernel");
         // three row buffers (rows requested two steps ahead) when they fit
         const char *d = getenv("BEATAMD_GS_DEEP");
         a.deep = 0;

@@ -118,6 +118,10 @@ int launch_accept(beatamd_ctx *ctx, int64_t C, int64_t nparams, int64_t nllk, do
 // geometry.hip: line-of-sight synthetics of rectangular / Mogi sources, mu [C, Nobs]
 int launch_geom_los(beatamd_ctx *ctx, const GeomSources &g, const double *Q, int64_t nparams,
                     int64_t C, double *mu);
+// displacement components (n, e, up) per (parameter set, source, point): out [C, nsrc, Nobs, 3]
+int launch_geom_disp(beatamd_ctx *ctx, int nsrc, const int32_t *kind, const int64_t *poff,
+                     const double *params, int64_t C, int64_t nobs, const double *east,
+                     const double *north, double nu, double *out);
 // covariance.py:716-771 on device
 int launch_autocovariance(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *data,
                           const double *mean, double *out);

@@ -443,6 +443,21 @@ class Context(object):
         check(self._lib.beatamd_metropolis_tune(self._h, int(scaling.shape[0]), ptr(scaling), ptr(accepted),
                                                 int(tune_interval)))
 
+    def halfspace_displacements_batch(self, kinds, params, east, north, nu=0.25):
+        """params (C, nsrc, 10) -> (C, nsrc, nobs, 3) = (north, east, up) [m]"""
+        kinds = np.ascontiguousarray(kinds, dtype=np.int32)
+        prm = f64(params)
+        self._adopt_stream(prm)
+        Cn, nsrc = int(prm.shape[0]), int(prm.shape[1])
+        if tuple(prm.shape[1:]) != (kinds.size, 10):
+            raise ValueError("params must be (C, %d, 10)" % kinds.size)
+        e, n = f64(east), f64(north)
+        nobs = int(e.numel()) if _is_dev(e) else int(e.size)
+        out = _empty_like(prm, (Cn, nsrc, nobs, 3))
+        check(self._lib.beatamd_halfspace_displacements_batch(self._h, Cn, nsrc, ptr(kinds), ptr(prm), nobs,
+                                                              ptr(e), ptr(n), float(nu), ptr(out)))
+        return out
+
     def whiten_rows(self, rows, W):
         """rows (R, N) device tensor, in place: rows <- rows . W^T"""
         self._adopt_stream(rows)

@@ -306,6 +306,23 @@ int beatamd_metropolis_tune(beatamd_ctx *ctx, int64_t C, double *scaling, int32_
  * an upper-triangular W (heart.py:233) skips its zero half. */
 int beatamd_whiten_rows(beatamd_ctx *ctx, double *rows, int64_t nrows, int64_t N, const double *W);
 
+/* ---------------------------------------------------------------- half-space synthetics ---
+ * replaces: heart.geo_synthetics(engine, targets, sources, outmode)   beat/heart.py:4158-4239
+ *           (what pytensorf.GeoSynthesizer.perform calls, pytensorf.py:88-123) for a HOMOGENEOUS
+ *           HALF SPACE: rectangular dislocations (Okada 1985; kind 0) and Mogi sources (kind 1).
+ *           The reference computes these displacements with pyrocko's layered GF-store engine
+ *           (not in its tree): parity with BEAT is unpinned for this entry, it is pinned to Okada's
+ *           published check values.
+ *   params [C, nsrc, 10]: east_shift north_shift depth [km] (top-edge centre), strike dip rake
+ *   [deg], length width [km], slip [m] (Mogi: volume change [m^3]), opening_fraction
+ *   east/north [nobs] observation points [km]
+ *   -> out [C, nsrc, nobs, 3] = (north, east, up) displacement [m] of every source at every point
+ *      (the reference's per-(source, target) arrays `[n, e, -d]`, heart.py:4218-4224) */
+int beatamd_halfspace_displacements_batch(beatamd_ctx *ctx, int64_t C, int32_t nsrc,
+                                          const int32_t *kind, const double *params, int64_t nobs,
+                                          const double *east, const double *north, double nu,
+                                          double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -230,6 +230,39 @@ def test_shared_row_kernel_equals_streaming_kernel(ctx, orc, monkeypatch, C, int
             assert "k_gfstack_shared<%d,%d,0,64,0>" % (w[cg], nrow) in seen, seen
 
 
+@pytest.mark.parametrize("interp", ["nearest_neighbor", "multilinear"])
+def test_window_slots_with_more_than_32_distinct_rows(ctx, orc, monkeypatch, interp):
+    """k_gfstack_dma places the staged rows in LDS by bank window when a chain group uses more than
+    32 distinct rows per patch (slots 32 apart share a two-bank window): 75-row library, 530 and
+    1100 chains with widely spread start times; bitwise equal to the streaming kernel and to the
+    dense-slot numbering, oracle on sampled chains"""
+    T, P, D, S, N = 2, 6, 3, 25, 128
+    rng = np.random.default_rng(12)
+    G = rng.standard_normal((T, P, D, S, N))
+    gf = _make_lib(ctx, G, 0.0, 0.5, 0.5, 0.5)
+    for C in (530, 1100):
+        dur = rng.uniform(0.5, 1.5, (C, P))
+        st = rng.uniform(0.0, 11.9, (C, T, P))
+        sl = rng.uniform(0, 5, (C, P))
+        monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
+        a = gf.stack_all_batch(dur, st, sl, interpolation=interp)
+        monkeypatch.setenv("BEATAMD_GF_KERNEL", "1")
+        for cg in ("256", "512", "1024"):
+            monkeypatch.setenv("BEATAMD_GS_CG", cg)
+            for win, deep in (("1", "0"), ("1", "1"), ("0", "0")):
+                if cg == "1024" and deep == "1":
+                    continue
+                monkeypatch.setenv("BEATAMD_GS_WIN", win)
+                monkeypatch.setenv("BEATAMD_GS_DEEP", deep)
+                b = gf.stack_all_batch(dur, st, sl, interpolation=interp)
+                assert ctx.last_kernel().startswith("k_gfstack_dma<"), ctx.last_kernel()
+                assert ctx.gf_group_stats()["max_rows"] > 32
+                assert np.array_equal(a, b), (C, cg, win, deep)
+        for c in (0, 529, C - 1):
+            ref = orc.stack_all(G, dur[c], st[c], sl[c], 0.5, 0.5, 0.0, 0.5, interp)
+            assert np.abs(a[c] - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("name", ["seis_dense_ml_shifts", "joint_multifault", "all_nn_odd_N",
                                   "seis_scalar_nn"])
 def test_fused_model_with_shared_row_kernel(ctx, monkeypatch, name):
