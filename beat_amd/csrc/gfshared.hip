@@ -43,7 +43,8 @@ struct GroupTabArgs {
     ChainVec slips[4];
     int ucap, ustride;
     uint32_t *urows;   // [(g*T+t)*P+p][ustride], padded with the last id
-    uint32_t *uslot;   // [(g*T+t)*P+p][ustride] LDS slot of each listed row
+    uint32_t *uent;    // k_gfstack_dma: [(g*T+t)*P+p][waves][ustride/waves][2] = (row id, LDS slot) of
+                       // list entry j = wave + k*waves: a wavefront's entries are contiguous
     int windowed;      // slots chosen by LDS bank window (k_gfstack_dma / ds_read_b64), else dense
     int depth;         // windowed: rows per window (LDS holds 32 * depth slots)
     uint32_t *ucount;  // [(g*T+t)*P+p]
@@ -52,6 +53,12 @@ struct GroupTabArgs {
     double *w;         // nn: [v][(g*P+p)][CG]   ml: [v][((g*T+t)*P+p)*4 + k][CG]
     int64_t w_var_stride;
 };
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    // the lanes of a wavefront run in lockstep: wait for its LDS operations, no barrier needed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
 
 // one workgroup of CG threads per (group, target, patch); thread <-> chain
 __global__ void k_gf_group_tables(GroupTabArgs a)
@@ -131,18 +138,35 @@ __global__ void k_gf_group_tables(GroupTabArgs a)
         // least overlap (then the emptiest, then the lowest).  Wavefront 0; lanes 0..31 are the
         // windows.  Results do not depend on the slots, only the LDS read timing does.
         if (tid < 64) {
+            // order = rank by (lane groups using the row, descending; list position): every lane
+            // ranks its (up to two) rows against all others -- no cross-lane traffic
             const int r0 = tid, r1 = tid + 64;
             const uint32_t m0 = r0 < total ? gmask[lst[r0]] : 0u, m1 = r1 < total ? gmask[lst[r1]] : 0u;
-            int key0 = r0 < total ? ((__popc(m0) << 8) | (255 - r0)) : -1;
-            int key1 = r1 < total ? ((__popc(m1) << 8) | (255 - r1)) : -1;
+            const int key0 = r0 < total ? ((__popc(m0) << 8) | (255 - r0)) : -1;
+            const int key1 = r1 < total ? ((__popc(m1) << 8) | (255 - r1)) : -1;
+            int rank0 = 0, rank1 = 0;
+            for (int j = 0; j < total; j++) {
+                const int kj = (__popc(gmask[lst[j]]) << 8) | (255 - j);
+                rank0 += kj > key0;
+                rank1 += kj > key1;
+            }
+            // the 32 most used rows: one window each
+            if (r0 < total && rank0 < 32) slt[r0] = (uint32_t)rank0;
+            if (r1 < total && rank1 < 32) slt[r1] = (uint32_t)rank1;
+            if (r0 < total) wsum[rank0] = (uint32_t)r0;   // rank -> list position (wsum is free here)
+            if (r1 < total) wsum[rank1] = (uint32_t)r1;
+            wave_lds_fence();
+            // window state in lanes 0..31
             uint32_t wmask = 0;
             int wcnt = 0;
-            for (int it = 0; it < total; it++) {
-                int best = max(key0, key1);
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off, 64));
-                const int ridx = 255 - (best & 255);
-                const uint32_t mm = __shfl(ridx < 64 ? m0 : m1, ridx & 63, 64);
+            if (tid < 32) {
+                wmask = gmask[lst[wsum[tid]]];
+                wcnt = 1;
+            }
+            // the others in rank order: window with the least overlap, then the emptiest, lowest
+            for (int rk = 32; rk < total; rk++) {
+                const int ridx = (int)wsum[rk];
+                const uint32_t mm = gmask[lst[ridx]];
                 int cost = (tid < 32 && wcnt < a.depth)
                     ? ((__popc(wmask & mm) << 12) | (wcnt << 6) | tid) : 0x7fffffff;
 #pragma unroll
@@ -152,9 +176,6 @@ __global__ void k_gf_group_tables(GroupTabArgs a)
                     slt[ridx] = (uint32_t)(w + 32 * wcnt);
                     wmask |= mm;
                     wcnt++;
-                }
-                if (tid == (ridx & 63)) {
-                    if (ridx < 64) key0 = -1; else key1 = -1;
                 }
             }
         }
@@ -166,9 +187,15 @@ __global__ void k_gf_group_tables(GroupTabArgs a)
         // pad to the stride with the last id: the stacking kernel reads ids unclamped
         const uint32_t last = total > 0 ? a.urows[gtp * a.ustride + total - 1] : (uint32_t)row0;
         for (int i = total + tid; i < a.ustride; i += CG) a.urows[gtp * a.ustride + i] = last;
-        // LDS slot of every listed row (dense numbering unless windows were assigned above)
-        for (int i = tid; i < a.ustride; i += CG)
-            a.uslot[gtp * a.ustride + i] = (i < total) ? flags[a.urows[gtp * a.ustride + i] - (uint32_t)row0] : 0u;
+        // (row id, LDS slot) of every list entry, grouped by the wavefront that stages it (dense
+        // slot numbering unless windows were assigned above)
+        const int nw = CG >> 6, kstr = a.ustride / nw;
+        for (int i = tid; i < a.ustride; i += CG) {
+            const uint32_t r = (i < total) ? a.urows[gtp * a.ustride + i] : last;
+            uint32_t *e = a.uent + ((gtp * nw + (i % nw)) * kstr + (i / nw)) * 2;
+            e[0] = r;
+            e[1] = (i < total) ? flags[r - (uint32_t)row0] : 0u;
+        }
     }
     for (int k = 0; k < a.nrow; k++)
         a.slot[(gtp * a.nrow + k) * CG + tid] = live ? (uint16_t)flags[v[k]] : (uint16_t)0;
@@ -198,7 +225,7 @@ struct GsArgs {
     int deep;          // k_gfstack_dma: 0 two row buffers / 1 three buffers, rows two steps ahead / 2 + staggered issue
     int xcd_order;     // k_gfstack_dma: chain groups of a (target, tile) share an XCD
     int64_t ngroups;
-    const uint32_t *urows, *uslot, *ucount;
+    const uint32_t *urows, *uent, *ucount;
     const uint16_t *slot;
     const double *w;
     int64_t w_var_stride;
@@ -557,15 +584,18 @@ k_gfstack_dma(GsArgs a)
         keep |= tok;
     };
     // distinct-row count + this wavefront's first KPRE row ids of step s (wave-uniform)
+    // (row id, LDS slot) of this wavefront's first KPRE list entries: contiguous in memory, one
+    // scalar load instruction (the gather's lgkmcnt waits count scalar loads too)
+    struct alignas(KPRE * 8) EntBlock { uint32_t v[2 * KPRE]; };
+    const int kstr = a.ustride / WAVES;
     auto fetch_ids = [&](int p, int &U, uint32_t (&rid)[KPRE], uint32_t (&rsl)[KPRE]) {
         const int64_t gtq = gt * a.P + p;
         U = __builtin_amdgcn_readfirstlane((int)a.ucount[gtq]);
-        const uint32_t *uq = a.urows + gtq * a.ustride + wave;
-        const uint32_t *us = a.uslot + gtq * a.ustride + wave;
+        const EntBlock eb = *reinterpret_cast<const EntBlock *>(a.uent + ((gtq * WAVES + wave) * kstr) * 2);
 #pragma unroll
         for (int k = 0; k < KPRE; k++) {   // padded: always in bounds
-            rid[k] = uq[k * WAVES];
-            rsl[k] = us[k * WAVES];
+            rid[k] = eb.v[2 * k];
+            rsl[k] = eb.v[2 * k + 1];
         }
     };
     // (library base pointers in registers: indexing a.G[] by a run-time iv is a kernarg load with
@@ -579,9 +609,8 @@ k_gfstack_dma(GsArgs a)
             for (int k = 0; k < KPRE; k++)
                 if (wave + k * WAVES < U) dma_row(Gv, rid[k], rsl[k], boff, dep);
             if (U > KPRE * WAVES) {   // rare: more distinct rows than the prefetched ids cover
-                const uint32_t *uq = a.urows + (gt * a.P + p) * a.ustride;
-                const uint32_t *us = a.uslot + (gt * a.P + p) * a.ustride;
-                for (int j = wave + KPRE * WAVES; j < U; j += WAVES) dma_row(Gv, uq[j], us[j], boff, dep);
+                const uint32_t *ue = a.uent + (((gt * a.P + p) * WAVES + wave) * kstr) * 2;
+                for (int k = KPRE; wave + k * WAVES < U; k++) dma_row(Gv, ue[2 * k], ue[2 * k + 1], boff, dep);
             }
         }
     };
@@ -903,8 +932,8 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     ga.ustride = (ucap + 63) / 64 * 64;   // covers the unclamped first-pass ids of 8 waves
     BA_TRY(ctx->get_scratch(SL_GS_UROWS, (size_t)GTP * ga.ustride * sizeof(uint32_t), &p));
     ga.urows = (uint32_t *)p;
-    BA_TRY(ctx->get_scratch(SL_GS_USLOT, (size_t)GTP * ga.ustride * sizeof(uint32_t), &p));
-    ga.uslot = (uint32_t *)p;
+    BA_TRY(ctx->get_scratch(SL_GS_USLOT, (size_t)GTP * ga.ustride * 2 * sizeof(uint32_t), &p));
+    ga.uent = (uint32_t *)p;
     BA_TRY(ctx->get_scratch(SL_GS_UCOUNT, (size_t)GTP * sizeof(uint32_t), &p));
     ga.ucount = (uint32_t *)p;
     BA_TRY(ctx->get_scratch(SL_GS_SLOT, (size_t)GTP * nrow * CG * sizeof(uint16_t), &p));
@@ -926,7 +955,9 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         const char *ew = getenv("BEATAMD_GS_WIN"), *ed = getenv("BEATAMD_GS_DMA");
         const int depth = (ucap + 31) / 32;
         const bool dma2 = !(ed && (atoi(ed) == 0 || atoi(ed) == 1)) && L.N % 2 == 0;
-        ga.windowed = (CG >= 256 && dma2 && ucap > 32 && ucap <= 128 && !(ew && atoi(ew) == 0) &&
+        // (8- and 16-wavefront workgroups are alone on their CU anyway; smaller groups would lose
+        // a resident workgroup to the larger row buffers -- measured: 256 chains 6.6 -> 11.2 ms)
+        ga.windowed = (CG >= 512 && dma2 && ucap > 32 && ucap <= 128 && !(ew && atoi(ew) == 0) &&
                        (size_t)2 * 32 * depth * (GS_NT_MAX + 2) * 8 <= 158 * 1024) ? 1 : 0;
         ga.depth = depth;
         if (ga.windowed) ucap = 32 * depth;
@@ -952,7 +983,7 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     }
     a.ngroups = ngroups;
     a.ntile = (int)((L.N + a.nt - 1) / a.nt);
-    a.urows = ga.urows; a.uslot = ga.uslot; a.ucount = ga.ucount; a.slot = ga.slot; a.w = ga.w;
+    a.urows = ga.urows; a.uent = ga.uent; a.ucount = ga.ucount; a.slot = ga.slot; a.w = ga.w;
     a.w_var_stride = ga.w_var_stride;
     a.data = k.data; a.wscalar = k.wscalar; a.out = k.out;
     if (k.mode == GF_RESID_SCALAR) {
