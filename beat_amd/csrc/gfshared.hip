@@ -33,6 +33,7 @@
 namespace beatamd {
 
 constexpr int GS_NT_MAX = 64;         // samples per tile (per lane: that many accumulators)
+constexpr int GS_INTL_DEFAULT = 0;    // row requests interleaved with the gather unless BEATAMD_GS_INTL says otherwise
 constexpr int GS_DEEP_DEFAULT = 0;    // DMA pipeline depth of k_gfstack_dma unless BEATAMD_GS_DEEP says otherwise
 
 struct GroupTabArgs {
@@ -222,6 +223,7 @@ struct GsArgs {
     int64_t C, T, P, N;
     int CG, ucap, ustride, ntile, nt;
     int dma;  // 1: k_gfstack_dma (two LDS row buffers filled by LDS-DMA)
+    int intl;          // k_gfstack_dma: row requests issued inside the gather, one list entry per group
     int deep;          // k_gfstack_dma: 0 two row buffers / 1 three buffers, rows two steps ahead / 2 + staggered issue
     int xcd_order;     // k_gfstack_dma: chain groups of a (target, tile) share an XCD
     int64_t ngroups;
@@ -507,12 +509,16 @@ __device__ __forceinline__ void lds_wait8_b64(double (&x)[8])
 // the number of row requests this wavefront issued (an over-wait is always safe).
 // DEEP = 2: the odd wavefronts issue their row requests after their gather instead of before it,
 // so that half of the workgroup feeds the LDS pipe while the other half is in its issue phase.
-template <int WAVES, int NROW, int MODE, int NT, int B64, int DEEP = 0>
+// INTL = 1: the row requests of the coming step are not issued in a block in front of the gather
+// (8 wavefronts doing scalar address work at the same time while the LDS pipe idles) but one list
+// entry per gather group, in the shadow of that group's LDS reads.
+template <int WAVES, int NROW, int MODE, int NT, int B64, int DEEP = 0, int INTL = 0>
 __global__ void __launch_bounds__(WAVES * 64)
     __attribute__((amdgpu_waves_per_eu(NT == 64 ? 2 : 4, NT == 64 ? 2 : 4)))
 k_gfstack_dma(GsArgs a)
 {
     static_assert(DEEP == 0 || B64 == 1, "the three-buffer pipeline exists for the ds_read_b64 layout");
+    static_assert(INTL == 0 || B64 == 1, "interleaved issue exists for the ds_read_b64 layout");
     constexpr int GS_NT = NT;
     constexpr int GS_PITCH = B64 ? NT + 1 : NT + 2;
     constexpr int LPR = NT / 2;         // lanes moving one row segment (16 B each)
@@ -584,6 +590,27 @@ k_gfstack_dma(GsArgs a)
         keep |= tok;
     };
     // distinct-row count + this wavefront's first KPRE row ids of step s (wave-uniform)
+    // the same request without control flow (INTL): lanes chosen through EXEC inside the statement;
+    // an invalid list entry runs with EXEC = 0 (no memory access, padded ids are valid addresses).
+    // The loop runs with all lanes active, so EXEC is restored to -1.
+    uint32_t keep_s = 0;
+    const uint64_t dma_mask = __ballot(dma_lane);
+    auto dma_row_masked = [&](const double *Gv, uint32_t r, uint32_t slotidx, int boff, bool valid,
+                              uint32_t dep) {
+        const uint64_t off = (uint64_t)r * (uint64_t)rowbytes;
+        const char *rowp = reinterpret_cast<const char *>(Gv) + off;
+        const uint32_t dst = lds0 + (uint32_t)(boff * 8) + slotidx * (uint32_t)(GS_PITCH * 8);
+        const uint64_t mk = valid ? dma_mask : 0ull;
+        uint32_t tok;
+        asm("s_mov_b64 exec, %4\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %2\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            "s_mov_b32 %0, 0"
+            : "=s"(tok) : "v"(voff), "s"(rowp), "s"(dst), "s"(mk), "v"(dep));
+        keep_s |= tok;
+    };
     // (row id, LDS slot) of this wavefront's first KPRE list entries: contiguous in memory, one
     // scalar load instruction (the gather's lgkmcnt waits count scalar loads too)
     struct alignas(KPRE * 8) EntBlock { uint32_t v[2 * KPRE]; };
@@ -693,8 +720,21 @@ k_gfstack_dma(GsArgs a)
         __syncthreads();  // rows of step s visible; everyone has left the FMA phase of step s-1
         __builtin_amdgcn_sched_barrier(0);
         const bool late_issue = (DEEP == 2) && (wave & 1);
-        if (!DEEP) {
-            if (s + 1 < nsteps) issue_rows(p1, iv1, (s + 1) & 1, U_a, rid_a, rsl_a);   // -> other buffer
+        // rows requested during this step: step s+1 -> the other buffer, or (DEEP) step s+2 -> the
+        // third buffer; (p_i, iv_i), target buffer and whether there is such a step
+        const int p_i = DEEP ? p2 : p1, iv_i = DEEP ? iv2 : iv1;
+        const int boff_i = DEEP ? boff2 : ((s + 1) & 1) * bufsz;
+        const bool have_i = DEEP ? (s + 2 < nsteps) : (s + 1 < nsteps);
+        const double *const Gv_i = iv_i == 0 ? G0 : iv_i == 1 ? G1 : iv_i == 2 ? G2 : G3;
+        if (INTL) {
+            fetch_tabs(p1, iv1);      // slot/weight of step s+1 first; requests follow in the gather
+            if (have_i && U_a > KPRE * WAVES && dma_lane) {   // rare: beyond the prefetched entries
+                const uint32_t *ue = a.uent + (((gt * a.P + p_i) * WAVES + wave) * kstr) * 2;
+                for (int e = KPRE; wave + e * WAVES < U_a; e++)
+                    dma_row(Gv_i, ue[2 * e], ue[2 * e + 1], boff_i, sl_n[0]);
+            }
+        } else if (!DEEP) {
+            if (have_i) issue_rows(p1, iv1, (s + 1) & 1, U_a, rid_a, rsl_a);   // -> other buffer
             fetch_tabs(p1, iv1);
             fetch_ids(p2, U_a, rid_a, rsl_a);
             p1 = p2; iv1 = iv2;
@@ -704,7 +744,7 @@ k_gfstack_dma(GsArgs a)
             fetch_tabs(p1, iv1);
             if (!late_issue) {
                 k_young = 0;
-                if (s + 2 < nsteps) {
+                if (have_i) {
                     issue_rows_dep(p2, iv2, boff2, U_a, rid_a, rsl_a, sl_n[0]);
                     k_young = dma_count(U_a);
                 }
@@ -745,6 +785,15 @@ k_gfstack_dma(GsArgs a)
                     default: break;
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    if (INTL && k == 0) {
+                        // list entries gq*SPG .. of this wavefront, behind the group's LDS reads
+                        constexpr int SPG = (KPRE + NG8 - 1) / NG8;
+#pragma unroll
+                        for (int e = gq * SPG; e < (gq + 1) * SPG && e < KPRE; e++)
+                            dma_row_masked(Gv_i, rid_a[e], rsl_a[e], boff_i,
+                                           have_i && wave + e * WAVES < U_a, sl_n[0]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             } else {
             constexpr int NG = GS_NT / 16;   // groups of 8 reads = 16 samples
@@ -771,6 +820,19 @@ k_gfstack_dma(GsArgs a)
             }
             }
         }
+        if (INTL) {
+            // (no control flow behind the gather: hipcc sinks the FMAs of the whole gather into a
+            // block that follows it, and with them 64 live LDS operands -> 256 VGPRs and spills)
+            __builtin_amdgcn_sched_barrier(0);
+            k_young = have_i ? dma_count(U_a) : 0;
+            if (!DEEP) {
+                fetch_ids(p2, U_a, rid_a, rsl_a);
+                p1 = p2; iv1 = iv2;
+                advance(p2, iv2);
+            } else {
+                fetch_ids(p3, U_a, rid_a, rsl_a);
+            }
+        }
         if (DEEP) {
             __builtin_amdgcn_sched_barrier(0);
             if (late_issue) {
@@ -790,7 +852,7 @@ k_gfstack_dma(GsArgs a)
     }
 
     // ---- epilogue: lane = chain c, acc[i] = synthetics[c, t, n0 + i]
-    const bool live = (c < a.C) && (keep == 0);
+    const bool live = (c < a.C) && (keep == 0) && (keep_s == 0);
     const int nvalid = (int)min((int64_t)GS_NT, N - n0);
     if (MODE == GF_STORE_SYN) {
         if (live) {
@@ -839,6 +901,8 @@ static void launch_shared_one(dim3 grid, size_t lds, hipStream_t s, const GsArgs
         kern = k_gfstack_dma<WAVES, NROW, MODE, 32, 1>;   // 1024-chain groups exist as NT = 32 only
     } else {
         kern = (a.dma == 2 && a.nt == 32) ? k_gfstack_dma<WAVES, NROW, MODE, 32, 1>
+             : (a.dma == 2 && a.deep == 1 && a.intl) ? k_gfstack_dma<WAVES, NROW, MODE, 64, 1, 1, 1>
+             : (a.dma == 2 && a.intl) ? k_gfstack_dma<WAVES, NROW, MODE, 64, 1, 0, 1>
              : (a.dma == 2 && a.deep == 1) ? k_gfstack_dma<WAVES, NROW, MODE, 64, 1, 1>
              : (a.dma == 2) ? k_gfstack_dma<WAVES, NROW, MODE, 64, 1>
              : a.dma ? k_gfstack_dma<WAVES, NROW, MODE, 64, 0>
@@ -957,7 +1021,9 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         const bool dma2 = !(ed && (atoi(ed) == 0 || atoi(ed) == 1)) && L.N % 2 == 0;
         // (8- and 16-wavefront workgroups are alone on their CU anyway; smaller groups would lose
         // a resident workgroup to the larger row buffers -- measured: 256 chains 6.6 -> 11.2 ms)
-        ga.windowed = (CG >= 512 && dma2 && ucap > 32 && ucap <= 128 && !(ew && atoi(ew) == 0) &&
+        // (multilinear: every chain reads four rows per patch, the lane-group masks are dense and
+        // the windows bring nothing: measured 21.1 vs 20.2 ms)
+        ga.windowed = (CG >= 512 && nrow == 1 && dma2 && ucap > 32 && ucap <= 128 && !(ew && atoi(ew) == 0) &&
                        (size_t)2 * 32 * depth * (GS_NT_MAX + 2) * 8 <= 158 * 1024) ? 1 : 0;
         ga.depth = depth;
         if (ga.windowed) ucap = 32 * depth;
@@ -1025,6 +1091,11 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
             // spills there and reuses registers of in-flight asm loads -- tools/audit_hidden_loads.py)
             if (d && atoi(d) >= 0 && atoi(d) <= 1) a.deep = atoi(d);
         }
+        {
+            const char *ei = getenv("BEATAMD_GS_INTL");
+            a.intl = (a.dma == 2 && a.nt == 64 && CG <= 512) ? GS_INTL_DEFAULT : 0;
+            if (ei && a.dma == 2 && a.nt == 64 && CG <= 512) a.intl = atoi(ei) ? 1 : 0;
+        }
         if (a.dma) lds *= (a.deep ? 3 : 2);
     }
     {
@@ -1034,9 +1105,9 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         if (e && atoi(e) == 1 && a.dma) a.xcd_order = 1;
         if (a.xcd_order) nblocks = ((L.T * a.ntile + 7) / 8) * 8 * ngroups;
     }
-    if (a.deep)
-        snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack_dma<%d,%d,%d,%d,1,%d>",
-                 CG / 64, nrow, k.mode, a.nt, a.deep);
+    if (a.deep || a.intl)
+        snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), a.intl ? "k_gfstack_dma<%d,%d,%d,%d,1,%d,1>"
+                 : "k_gfstack_dma<%d,%d,%d,%d,1,%d>", CG / 64, nrow, k.mode, a.nt, a.deep);
     else
         snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "%s<%d,%d,%d,%d,%d>",
                  a.dma ? "k_gfstack_dma" : "k_gfstack_shared", CG / 64, nrow, k.mode, a.nt, a.dma == 2 ? 1 : 0);

@@ -212,21 +212,26 @@ def test_shared_row_kernel_equals_streaming_kernel(ctx, orc, monkeypatch, C, int
     seen = set()
     for cg in ("64", "128", "256", "512", "1024"):
         monkeypatch.setenv("BEATAMD_GS_CG", cg)
-        for dma, deep, nt, order in (("2", "0", "64", "0"), ("2", "1", "64", "1"), ("2", "0", "32", "1"),
-                                     ("1", "0", "64", "0"), ("0", "0", "64", "0")):
+        for dma, deep, nt, order, intl in (("2", "0", "64", "0", "0"), ("2", "1", "64", "1", "0"),
+                                           ("2", "0", "32", "1", "0"), ("2", "0", "64", "1", "1"),
+                                           ("2", "1", "64", "0", "1"), ("1", "0", "64", "0", "0"),
+                                           ("0", "0", "64", "0", "0")):
             if cg == "1024" and dma != "2":
                 continue   # 1024-chain groups exist for the LDS-DMA kernel only
             monkeypatch.setenv("BEATAMD_GS_DMA", dma)
             monkeypatch.setenv("BEATAMD_GS_DEEP", deep)
             monkeypatch.setenv("BEATAMD_GS_NT", nt)
             monkeypatch.setenv("BEATAMD_GS_ORDER", order)
-            assert np.array_equal(gf.stack_all_batch(dur, st, sl, interpolation=interp), a), (cg, dma, deep, nt)
+            monkeypatch.setenv("BEATAMD_GS_INTL", intl)
+            assert np.array_equal(gf.stack_all_batch(dur, st, sl, interpolation=interp), a), (cg, dma, deep, nt, intl)
             seen.add(ctx.last_kernel())
     nrow, w = (4 if interp == "multilinear" else 1), {"64": 1, "128": 2, "256": 4, "512": 8, "1024": 16}
     for cg in w:   # every variant really ran (names as beatamd_ctx_last_kernel reports them)
         assert "k_gfstack_dma<%d,%d,0,32,1>" % (w[cg], nrow) in seen, seen
         if cg != "1024":
             assert "k_gfstack_dma<%d,%d,0,64,1,1>" % (w[cg], nrow) in seen, seen
+            assert "k_gfstack_dma<%d,%d,0,64,1,0,1>" % (w[cg], nrow) in seen, seen
+            assert "k_gfstack_dma<%d,%d,0,64,1,1,1>" % (w[cg], nrow) in seen, seen
             assert "k_gfstack_shared<%d,%d,0,64,0>" % (w[cg], nrow) in seen, seen
 
 
@@ -249,11 +254,13 @@ def test_window_slots_with_more_than_32_distinct_rows(ctx, orc, monkeypatch, int
         monkeypatch.setenv("BEATAMD_GF_KERNEL", "1")
         for cg in ("256", "512", "1024"):
             monkeypatch.setenv("BEATAMD_GS_CG", cg)
-            for win, deep in (("1", "0"), ("1", "1"), ("0", "0")):
+            for win, deep, intl in (("1", "0", "0"), ("1", "1", "0"), ("0", "0", "0"), ("1", "0", "1"),
+                                    ("1", "1", "1")):
                 if cg == "1024" and deep == "1":
                     continue
                 monkeypatch.setenv("BEATAMD_GS_WIN", win)
                 monkeypatch.setenv("BEATAMD_GS_DEEP", deep)
+                monkeypatch.setenv("BEATAMD_GS_INTL", intl)
                 b = gf.stack_all_batch(dur, st, sl, interpolation=interp)
                 assert ctx.last_kernel().startswith("k_gfstack_dma<"), ctx.last_kernel()
                 assert ctx.gf_group_stats()["max_rows"] > 32
