@@ -615,28 +615,37 @@ k_gfstack_dma(GsArgs a)
     // scalar load instruction (the gather's lgkmcnt waits count scalar loads too)
     struct alignas(KPRE * 8) EntBlock { uint32_t v[2 * KPRE]; };
     const int kstr = a.ustride / WAVES;
-    auto fetch_ids = [&](int p, int &U, uint32_t (&rid)[KPRE], uint32_t (&rsl)[KPRE]) {
-        const int64_t gtq = gt * a.P + p;
-        U = __builtin_amdgcn_readfirstlane((int)a.ucount[gtq]);
-        const EntBlock eb = *reinterpret_cast<const EntBlock *>(a.uent + ((gtq * WAVES + wave) * kstr) * 2);
+    // Table addresses: the (group, target) part is loop invariant and hoisted as 64-bit bases; the
+    // per-step part is a 32 x 32 bit product added as an unsigned byte offset (scalar loads take it
+    // as their offset operand).  Written out by hand: hipcc kept whole 64 x 64 bit index products
+    // inside the loop (about 60 scalar instructions per step).
+    const char *const cnt_base = reinterpret_cast<const char *>(a.ucount + gt * a.P);
+    const char *const ent_base = reinterpret_cast<const char *>(a.uent + ((gt * a.P) * WAVES + wave) * kstr * 2);
+    const uint32_t ent_step = (uint32_t)(a.ustride * 8);   // bytes per patch: WAVES * kstr entries of 8 B
+    const double *G_a = nullptr;   // library of the step whose list entries are in rid_a / rsl_a
+    auto fetch_ids = [&](int p, int iv, int &U, uint32_t (&rid)[KPRE], uint32_t (&rsl)[KPRE]) {
+        U = __builtin_amdgcn_readfirstlane(
+            (int)*reinterpret_cast<const uint32_t *>(cnt_base + (uint32_t)p * 4u));
+        const EntBlock eb = *reinterpret_cast<const EntBlock *>(ent_base + (uint32_t)p * ent_step);
 #pragma unroll
         for (int k = 0; k < KPRE; k++) {   // padded: always in bounds
             rid[k] = eb.v[2 * k];
             rsl[k] = eb.v[2 * k + 1];
         }
+        // library base pointer of that step: a scalar load from the kernel arguments, issued with
+        // the list entries one step before it is needed (selecting among four register pairs by a
+        // run-time index costs a branch maze of ~25 scalar instructions per step)
+        G_a = a.G[iv];
     };
-    // (library base pointers in registers: indexing a.G[] by a run-time iv is a kernarg load with
-    // its latency in front of every step's DMAs)
-    const double *const G0 = a.G[0], *const G1 = a.G[1], *const G2 = a.G[2], *const G3 = a.G[3];
     auto issue_rows_dep = [&](int p, int iv, int boff, int U, const uint32_t (&rid)[KPRE],
                               const uint32_t (&rsl)[KPRE], uint32_t dep) {
-        const double *Gv = iv == 0 ? G0 : iv == 1 ? G1 : iv == 2 ? G2 : G3;
+        const double *Gv = G_a;
         if (dma_lane) {
 #pragma unroll
             for (int k = 0; k < KPRE; k++)
                 if (wave + k * WAVES < U) dma_row(Gv, rid[k], rsl[k], boff, dep);
             if (U > KPRE * WAVES) {   // rare: more distinct rows than the prefetched ids cover
-                const uint32_t *ue = a.uent + (((gt * a.P + p) * WAVES + wave) * kstr) * 2;
+                const uint32_t *ue = reinterpret_cast<const uint32_t *>(ent_base + (uint32_t)p * ent_step);
                 for (int k = KPRE; wave + k * WAVES < U; k++) dma_row(Gv, ue[2 * k], ue[2 * k + 1], boff, dep);
             }
         }
@@ -649,14 +658,19 @@ k_gfstack_dma(GsArgs a)
     // valid after the step-top wait statement, which names them
     uint32_t sl_n[NROW];
     double wl_n[NROW];
+    const char *const slot_base = reinterpret_cast<const char *>(a.slot + (gt * a.P * NROW) * CG + tid);
+    const char *const w_base = reinterpret_cast<const char *>(
+        (NROW == 1) ? a.w + (g * a.P) * CG + tid : a.w + (gt * a.P * 4) * CG + tid);
+    const uint32_t slot_step = (uint32_t)(NROW * CG * 2);                    // bytes per patch
+    const uint32_t w_step = (uint32_t)((NROW == 1 ? 1 : 4) * CG * 8);
+    const int64_t w_var_bytes = a.w_var_stride * 8;
     auto fetch_tabs = [&](int p, int iv) {
-        const int64_t gtq = gt * a.P + p;
+        const char *sp = slot_base + (uint32_t)p * slot_step;
+        const char *wp = w_base + (uint32_t)p * w_step + (nvar == 1 ? (int64_t)0 : (int64_t)iv * w_var_bytes);
 #pragma unroll
         for (int k = 0; k < NROW; k++) {
-            const uint16_t *ps = a.slot + (gtq * NROW + k) * CG + tid;
-            const double *pw = (NROW == 1)
-                ? a.w + (int64_t)iv * a.w_var_stride + (g * a.P + p) * CG + tid
-                : a.w + (int64_t)iv * a.w_var_stride + (gtq * 4 + k) * CG + tid;
+            const uint16_t *ps = reinterpret_cast<const uint16_t *>(sp) + k * CG;
+            const double *pw = reinterpret_cast<const double *>(wp) + k * CG;
             asm("global_load_ushort %0, %1, off" : "=v"(sl_n[k]) : "v"(ps));
             asm("global_load_dwordx2 %0, %1, off" : "=v"(wl_n[k]) : "v"(pw));
         }
@@ -674,16 +688,16 @@ k_gfstack_dma(GsArgs a)
     uint32_t rid_a[KPRE], rsl_a[KPRE];
     int k_young = 0;              // DEEP: row requests issued after the youngest slot/weight loads
     int boff0 = 0, boff1 = bufsz, boff2 = 2 * bufsz;   // DEEP: buffers of steps s, s+1, s+2 (doubles)
-    fetch_ids(0, U_a, rid_a, rsl_a);
+    fetch_ids(0, 0, U_a, rid_a, rsl_a);
     issue_rows(0, 0, 0, U_a, rid_a, rsl_a);
     fetch_tabs(0, 0);
-    fetch_ids(p1, U_a, rid_a, rsl_a);
+    fetch_ids(p1, iv1, U_a, rid_a, rsl_a);
     if (DEEP) {
         if (nsteps > 1) {
             issue_rows_dep(p1, iv1, boff1, U_a, rid_a, rsl_a, sl_n[0]);
             k_young = dma_count(U_a);
         }
-        fetch_ids(p2, U_a, rid_a, rsl_a);
+        fetch_ids(p2, iv2, U_a, rid_a, rsl_a);
     }
     for (int s = 0; s < nsteps; s++) {
         // the tables of this step and (older) the DMA of this step's rows have landed
@@ -722,21 +736,21 @@ k_gfstack_dma(GsArgs a)
         const bool late_issue = (DEEP == 2) && (wave & 1);
         // rows requested during this step: step s+1 -> the other buffer, or (DEEP) step s+2 -> the
         // third buffer; (p_i, iv_i), target buffer and whether there is such a step
-        const int p_i = DEEP ? p2 : p1, iv_i = DEEP ? iv2 : iv1;
+        const int p_i = DEEP ? p2 : p1;
         const int boff_i = DEEP ? boff2 : ((s + 1) & 1) * bufsz;
         const bool have_i = DEEP ? (s + 2 < nsteps) : (s + 1 < nsteps);
-        const double *const Gv_i = iv_i == 0 ? G0 : iv_i == 1 ? G1 : iv_i == 2 ? G2 : G3;
+        const double *const Gv_i = G_a;
         if (INTL) {
             fetch_tabs(p1, iv1);      // slot/weight of step s+1 first; requests follow in the gather
             if (have_i && U_a > KPRE * WAVES && dma_lane) {   // rare: beyond the prefetched entries
-                const uint32_t *ue = a.uent + (((gt * a.P + p_i) * WAVES + wave) * kstr) * 2;
+                const uint32_t *ue = reinterpret_cast<const uint32_t *>(ent_base + (uint32_t)p_i * ent_step);
                 for (int e = KPRE; wave + e * WAVES < U_a; e++)
                     dma_row(Gv_i, ue[2 * e], ue[2 * e + 1], boff_i, sl_n[0]);
             }
         } else if (!DEEP) {
             if (have_i) issue_rows(p1, iv1, (s + 1) & 1, U_a, rid_a, rsl_a);   // -> other buffer
             fetch_tabs(p1, iv1);
-            fetch_ids(p2, U_a, rid_a, rsl_a);
+            fetch_ids(p2, iv2, U_a, rid_a, rsl_a);
             p1 = p2; iv1 = iv2;
             advance(p2, iv2);
         } else {
@@ -748,7 +762,7 @@ k_gfstack_dma(GsArgs a)
                     issue_rows_dep(p2, iv2, boff2, U_a, rid_a, rsl_a, sl_n[0]);
                     k_young = dma_count(U_a);
                 }
-                fetch_ids(p3, U_a, rid_a, rsl_a);
+                fetch_ids(p3, iv3, U_a, rid_a, rsl_a);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -826,11 +840,11 @@ k_gfstack_dma(GsArgs a)
             __builtin_amdgcn_sched_barrier(0);
             k_young = have_i ? dma_count(U_a) : 0;
             if (!DEEP) {
-                fetch_ids(p2, U_a, rid_a, rsl_a);
+                fetch_ids(p2, iv2, U_a, rid_a, rsl_a);
                 p1 = p2; iv1 = iv2;
                 advance(p2, iv2);
             } else {
-                fetch_ids(p3, U_a, rid_a, rsl_a);
+                fetch_ids(p3, iv3, U_a, rid_a, rsl_a);
             }
         }
         if (DEEP) {
@@ -841,7 +855,7 @@ k_gfstack_dma(GsArgs a)
                     issue_rows_dep(p2, iv2, boff2, U_a, rid_a, rsl_a, sl_n[0]);
                     k_young = dma_count(U_a);
                 }
-                fetch_ids(p3, U_a, rid_a, rsl_a);
+                fetch_ids(p3, iv3, U_a, rid_a, rsl_a);
             }
             const int b0 = boff0;
             boff0 = boff1; boff1 = boff2; boff2 = b0;
