@@ -577,17 +577,17 @@ k_gfstack_dma(GsArgs a)
     const uint32_t rowbytes = (uint32_t)(N * 8);
     // `dep` is an ordering token only (not named in the text): a request that lists the destination
     // register of the step's slot load as input cannot be placed in front of that load
-    auto dma_row = [&](const double *Gv, uint32_t r, uint32_t slotidx, int boff, uint32_t dep) {
+    // `tk` chains the requests of a step: every statement passes it through untouched (in/out
+    // operand, no instruction), its final value is folded into `keep` once per step -- the
+    // statements are not volatile (see above) and must not be dropped.
+    auto dma_row = [&](const double *Gv, uint32_t r, uint32_t slotidx, int boff, uint32_t dep, uint32_t &tk) {
         const uint64_t off = (uint64_t)r * (uint64_t)rowbytes;
         const char *rowp = reinterpret_cast<const char *>(Gv) + off;
         const uint32_t dst = lds0 + (uint32_t)(boff * 8) + slotidx * (uint32_t)(GS_PITCH * 8);
-        uint32_t tok;
         asm("s_mov_b32 m0, %3\n\t"
             "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, %2\n\t"
-            "s_mov_b32 %0, 0"
-            : "=s"(tok) : "v"(voff), "s"(rowp), "s"(dst), "v"(dep));
-        keep |= tok;
+            "global_load_lds_dwordx4 %1, %2"
+            : "+s"(tk) : "v"(voff), "s"(rowp), "s"(dst), "v"(dep));
     };
     // distinct-row count + this wavefront's first KPRE row ids of step s (wave-uniform)
     // the same request without control flow (INTL): lanes chosen through EXEC inside the statement;
@@ -641,18 +641,20 @@ k_gfstack_dma(GsArgs a)
                               const uint32_t (&rsl)[KPRE], uint32_t dep) {
         const double *Gv = G_a;
         if (dma_lane) {
+            uint32_t tk = 0;
 #pragma unroll
             for (int k = 0; k < KPRE; k++)
-                if (wave + k * WAVES < U) dma_row(Gv, rid[k], rsl[k], boff, dep);
+                if (wave + k * WAVES < U) dma_row(Gv, rid[k], rsl[k], boff, dep, tk);
             if (U > KPRE * WAVES) {   // rare: more distinct rows than the prefetched ids cover
                 const uint32_t *ue = reinterpret_cast<const uint32_t *>(ent_base + (uint32_t)p * ent_step);
-                for (int k = KPRE; wave + k * WAVES < U; k++) dma_row(Gv, ue[2 * k], ue[2 * k + 1], boff, dep);
+                for (int k = KPRE; wave + k * WAVES < U; k++) dma_row(Gv, ue[2 * k], ue[2 * k + 1], boff, dep, tk);
             }
+            keep |= tk;
         }
     };
     auto issue_rows = [&](int p, int iv, int buf, int U, const uint32_t (&rid)[KPRE],
                           const uint32_t (&rsl)[KPRE]) {
-        issue_rows_dep(p, iv, buf * bufsz, U, rid, rsl, 0u);
+        issue_rows_dep(p, iv, buf * bufsz, U, rid, rsl, voff);   // (any live VGPR: no ordering needed here)
     };
     // the lane's slot and weight of step s: asm loads (hipcc must not count them, see above);
     // valid after the step-top wait statement, which names them
@@ -744,8 +746,10 @@ k_gfstack_dma(GsArgs a)
             fetch_tabs(p1, iv1);      // slot/weight of step s+1 first; requests follow in the gather
             if (have_i && U_a > KPRE * WAVES && dma_lane) {   // rare: beyond the prefetched entries
                 const uint32_t *ue = reinterpret_cast<const uint32_t *>(ent_base + (uint32_t)p_i * ent_step);
+                uint32_t tk = 0;
                 for (int e = KPRE; wave + e * WAVES < U_a; e++)
-                    dma_row(Gv_i, ue[2 * e], ue[2 * e + 1], boff_i, sl_n[0]);
+                    dma_row(Gv_i, ue[2 * e], ue[2 * e + 1], boff_i, sl_n[0], tk);
+                keep |= tk;
             }
         } else if (!DEEP) {
             if (have_i) issue_rows(p1, iv1, (s + 1) & 1, U_a, rid_a, rsl_a);   // -> other buffer
