@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbeat_amd.so")
+# BEATAMD_LIB: another build of the library (kernel A/B experiments in one GPU session)
+LIB_PATH = os.environ.get("BEATAMD_LIB") or os.path.join(_HERE, "libbeat_amd.so")
 
 NEAREST_NEIGHBOR, MULTILINEAR = 0, 1
 W_SCALAR, W_DENSE = 0, 1

@@ -161,6 +161,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streaming-leg", action="store_true",
                     help="skip the reuse-free streaming-kernel leg (roofline_streaming)")
+    ap.add_argument("--no-batch-leg", action="store_true", help="skip the labelled 2048-chain batch leg")
     ap.add_argument("--no-narrow-leg", action="store_true",
                     help="skip the labelled round-1 narrow-prior leg")
     ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "r2_bench_c512_nn_gfstack_summary.json"),
@@ -370,6 +371,18 @@ def main():
             "stage_transition_ms": stage_ms,
             "setup_s": t_build,
         }
+        q_ms, q_n = main_leg["times"]["quadform"]
+        if q_n:
+            # dense-W misfit: chain-batched W.R on the FP64 matrix cores; W upper triangular -> half
+            qflops = 2.0 * spec.T * spec.N * spec.N / 2.0 * B
+            qa = qflops / (q_ms / q_n * 1e-3) / 1e12
+            out["roofline_quadform"] = {
+                "bound": "fp64_mfma", "kernel": "k_quadform<128>", "achieved": qa,
+                "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": qa / FP64_VALU_PEAK_TFLOPS,
+                "avg_launch_ms": q_ms / q_n, "launches": q_n, "flops_per_launch": qflops,
+                "mfma_loop_ceiling_TFLOPs": 49.4,
+                "note": "v_mfma_f64_16x16x4_f64; a register-resident MFMA loop reaches 49.4 TF on this "
+                        "part (tools/micro/mfma64.hip), nominal 78.6"}
         # HBM traffic of the dominant kernel from the PMC passes of the same command
         # (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streams, +WRITE_SIZE)
         default_cfg = (B == 512 and spec.interpolation == "nearest_neighbor" and spec.covariance == "scalar"
@@ -404,6 +417,14 @@ def main():
             "avg_launch_ms": ms / max(n, 1), "launches": n,
             "chain_steps_per_s": Bs * 4 / leg["dt"],
             "note": "no cross-chain row reuse: algorithmic bytes = HBM bytes (block order chain-major)"}
+    # ---- the same population in larger batches: chain groups of one (target, tile) share an XCD,
+    # rows common to several groups come from its L2 (labelled leg; `value` stays the 512-chain batch)
+    if world == 1 and not args.no_batch_leg and spec.covariance == "scalar" and B < 2048:
+        leg = run_leg(spec, f, 2048, max(K // 2, 3), 1, seed_offset=1000)
+        ms, n = leg["times"]["gfstack"]
+        out["batch_2048_leg"] = {"chains": 2048, "chain_steps_per_s": 2048 * max(K // 2, 3) / leg["dt"],
+                                 "gfstack_avg_launch_ms": ms / max(n, 1), "kernel": leg["kernel"],
+                                 "distinct_rows_per_patch_mean": leg["stats"]["mean_rows"]}
     # ---- round 1's narrow prior, labelled, for continuity with BENCH_r01
     if world == 1 and not args.no_narrow_leg and args.prior == "survey" and spec.covariance == "scalar":
         import copy

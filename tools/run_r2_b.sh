@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 for deep in 1 0; do
   export BEATAMD_GS_DEEP=$deep
   P=$O/pmc_deep$deep; mkdir -p $P
-  CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-streaming-leg --no-narrow-leg"
+  CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-streaming-leg --no-narrow-leg --no-batch-leg"
   run() { name=$1; shift; timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $P/$name -o p -- $CMD > $P/$name.log 2>&1; }
   run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
   run sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT
