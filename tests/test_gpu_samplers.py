@@ -330,3 +330,28 @@ def test_library_files_round_trip_through_hbm(ctx, tmp_path):
     np.testing.assert_array_equal(np.asarray(g4._gfmatrix), gf._gfmatrix)
     g4.init_optimization(ctx)
     assert np.array_equal(g4.stack_all_batch(dur, st, sl, interpolation="multilinear"), before)
+
+
+# ----------------------------------------------------------------------------- multi-GPU readiness
+def test_bench_two_ranks_over_rccl():
+    """bench.py --gpus 2 under torchrun (one rank per GPU, RCCL): skipped on 1-GPU boxes.  Checks
+    the line's contract fields and that the stage transition ran over both ranks."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--chains", "64", "--no-cpu-baseline",
+           "--targets", "4", "--samples", "256"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_chains"] == 128
+    assert d["stage_transition_ms"] > 0 and d["value"] > 0
