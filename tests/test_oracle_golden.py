@@ -4,6 +4,7 @@ exists).  CPU only."""
 import numpy as np
 import pytest
 
+from conftest import load_golden
 from oracle import oracle as orc
 
 
