@@ -33,6 +33,7 @@
 namespace beatamd {
 
 constexpr int GS_NT_MAX = 64;         // samples per tile (per lane: that many accumulators)
+constexpr int GS_WS_DEFAULT = 1;      // wave-specialised kernel for 512-chain groups unless BEATAMD_GS_WS says otherwise
 constexpr int GS_INTL_DEFAULT = 0;    // row requests interleaved with the gather unless BEATAMD_GS_INTL says otherwise
 constexpr int GS_DEEP_DEFAULT = 0;    // DMA pipeline depth of k_gfstack_dma unless BEATAMD_GS_DEEP says otherwise
 
@@ -46,6 +47,7 @@ struct GroupTabArgs {
     uint32_t *urows;   // [(g*T+t)*P+p][ustride], padded with the last id
     uint32_t *uent;    // k_gfstack_dma: [(g*T+t)*P+p][waves][ustride/waves][2] = (row id, LDS slot) of
                        // list entry j = wave + k*waves: a wavefront's entries are contiguous
+    int nissue;        // wavefronts that stage rows: CG/64 (k_gfstack_dma) or the loaders of k_gfstack_ws
     int windowed;      // slots chosen by LDS bank window (k_gfstack_dma / ds_read_b64), else dense
     int depth;         // windowed: rows per window (LDS holds 32 * depth slots)
     uint32_t *ucount;  // [(g*T+t)*P+p]
@@ -190,7 +192,7 @@ __global__ void k_gf_group_tables(GroupTabArgs a)
         for (int i = total + tid; i < a.ustride; i += CG) a.urows[gtp * a.ustride + i] = last;
         // (row id, LDS slot) of every list entry, grouped by the wavefront that stages it (dense
         // slot numbering unless windows were assigned above)
-        const int nw = CG >> 6, kstr = a.ustride / nw;
+        const int nw = a.nissue, kstr = a.ustride / nw;
         for (int i = tid; i < a.ustride; i += CG) {
             const uint32_t r = (i < total) ? a.urows[gtp * a.ustride + i] : last;
             uint32_t *e = a.uent + ((gtp * nw + (i % nw)) * kstr + (i / nw)) * 2;
@@ -223,6 +225,7 @@ struct GsArgs {
     int64_t C, T, P, N;
     int CG, ucap, ustride, ntile, nt;
     int dma;  // 1: k_gfstack_dma (two LDS row buffers filled by LDS-DMA)
+    int ws;            // k_gfstack_ws: 8 consumer + 4 loader wavefronts, three row buffers
     int intl;          // k_gfstack_dma: row requests issued inside the gather, one list entry per group
     int deep;          // k_gfstack_dma: 0 two row buffers / 1 three buffers, rows two steps ahead / 2 + staggered issue
     int xcd_order;     // k_gfstack_dma: chain groups of a (target, tile) share an XCD
@@ -911,6 +914,362 @@ k_gfstack_dma(GsArgs a)
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// k_gfstack_ws: wave-specialised form of k_gfstack_dma (512-chain groups).  Ablations of
+// k_gfstack_dma on the population of SURVEY 8(d) (same box, ms per launch; timing only): as shipped
+// 7.58; row requests replaced by s_nop 6.03; no request block at all 4.96; no LDS reads / FMAs at all
+// 6.74 -- a wavefront's step is the SERIAL sum of request issue and gather, and with only one
+// step of rows in flight the stream also waits for its own latency (rows two steps ahead without
+// the gather: 5.1 ms = the chip's LDS-DMA fill rate).  Here a workgroup is CW = 8 consumer wavefronts
+// (lane <-> chain, the accumulators, slot/weight loads, gather + FMA: nothing else) plus LW = 4
+// loader wavefronts that issue the row requests two steps ahead into a ring of three LDS row
+// buffers.  One s_barrier per step, executed by all twelve wavefronts:
+//   loader   : wait until at most its requests of step s+1 are in flight (vmcnt(k), k = what it
+//              issued last step, so its rows of step s have landed); barrier(s); issue its
+//              share of the rows of step s+2 into buffer (s+2) mod 3 (last read in step s-1)
+//   consumer : wait for its slot/weight of step s (hidden asm loads, one step ahead);
+//              barrier(s); issue the slot/weight loads of step s+1; gather + FMA from buffer s mod 3
+// 12 wavefronts per CU need <= 168 VGPRs (3 per SIMD): tables are addressed with scalar bases +
+// 32-bit lane offsets.  Same arithmetic, same order: bitwise equal to the other kernels.
+template <int NROW, int MODE, int NB>
+__global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3)))
+k_gfstack_ws(GsArgs a)
+{
+    constexpr int CW = 8, LW = 4;
+    constexpr int GS_NT = 64;
+    constexpr int GS_PITCH = GS_NT + 1;   // ds_read_b64 layout
+    constexpr int LPR = GS_NT / 2;        // lanes moving one row segment (16 B each)
+    constexpr int KPRE = 16;              // list entries per loader fetched ahead (64 rows per step)
+    extern __shared__ __attribute__((aligned(16))) double xbuf[];  // [3][slots][GS_PITCH]
+    constexpr int CG = CW * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile;
+    int64_t t, g;
+    if (a.xcd_order) {
+        const int64_t b = blockIdx.x;
+        const int64_t x = b & 7, q = b >> 3;
+        g = q % a.ngroups;
+        const int64_t tt = (q / a.ngroups) * 8 + x;
+        if (tt >= a.T * a.ntile) return;
+        tile = (int)(tt % a.ntile);
+        t = tt / a.ntile;
+    } else {
+        tile = blockIdx.x % a.ntile;
+        const int64_t gt0 = blockIdx.x / a.ntile;
+        t = gt0 % a.T;
+        g = gt0 / a.T;
+    }
+    const int64_t gt = g * a.T + t;
+    const int64_t N = a.N;
+    const int64_t n0 = (int64_t)tile * GS_NT;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)xbuf;
+    const int bufsz = a.ucap * GS_PITCH;                          // doubles per buffer
+    const int P = (int)a.P, nvar = a.nvar;
+    const int nsteps = P * nvar;
+    auto advance = [&](int &p, int &iv) {
+        if (++iv == nvar) { iv = 0; ++p; }
+        if (p >= P) { p = P - 1; iv = nvar - 1; }
+    };
+
+    if (wave >= CW) {
+        // ==================================== loader ====================================
+        const int lw = wave - CW;
+        const bool dma_lane = (lane < LPR) && (n0 + lane * 2 < N);   // N even (launcher)
+        const uint32_t voff = (uint32_t)((n0 + lane * 2) * 8);      // byte offset inside a row
+        const uint32_t rowbytes = (uint32_t)(N * 8);
+        uint32_t keep = 0;
+        auto dma_row = [&](const double *Gv, uint32_t r, uint32_t slotidx, int boff, uint32_t &tk) {
+            const uint64_t off = (uint64_t)r * (uint64_t)rowbytes;
+            const char *rowp = reinterpret_cast<const char *>(Gv) + off;
+            const uint32_t dst = lds0 + (uint32_t)(boff * 8) + slotidx * (uint32_t)(GS_PITCH * 8);
+            asm("s_mov_b32 m0, %3\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, %2"
+                : "+s"(tk) : "v"(voff), "s"(rowp), "s"(dst));
+        };
+        const int kstr = a.ustride / LW;
+        const char *const cnt_base = reinterpret_cast<const char *>(a.ucount + gt * a.P);
+        const char *const ent_base = reinterpret_cast<const char *>(a.uent + ((gt * a.P) * LW + lw) * kstr * 2);
+        const uint32_t ent_step = (uint32_t)(a.ustride * 8);
+        int U_a;
+        uint32_t rid[KPRE], rsl[KPRE];
+        const double *G_a = nullptr;
+        auto fetch_ids = [&](int p, int iv) {
+            // constant address space: the tables are written by k_gf_group_tables before this
+            // launch, never here, and must come in through scalar loads -- a vector load would be
+            // counted in this wavefront's vmcnt together with its row requests
+            typedef const __attribute__((address_space(4))) uint32_t *cu32;
+            typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+            typedef const __attribute__((address_space(4))) u32x16 *cent;
+            U_a = (int)*(cu32)(uintptr_t)(cnt_base + (uint32_t)p * 4u);
+            const char *e = ent_base + (uint32_t)p * ent_step;
+            const u32x16 e0 = *(cent)(uintptr_t)e;
+            const u32x16 e1 = *(cent)(uintptr_t)(e + 64);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                rid[k] = e0[2 * k];      rsl[k] = e0[2 * k + 1];
+                rid[8 + k] = e1[2 * k];  rsl[8 + k] = e1[2 * k + 1];
+            }
+            G_a = a.G[iv];
+        };
+        auto dma_count = [&](int U) { return U > lw ? (U - lw + LW - 1) / LW : 0; };
+        // rows lw, lw + LW, ... of the list whose entries are in rid / rsl -> buffer at boff
+        auto issue_rows = [&](int p, int boff) {
+            if (dma_lane) {
+                uint32_t tk = 0;
+#pragma unroll
+                for (int k = 0; k < KPRE; k++)
+                    if (lw + k * LW < U_a) dma_row(G_a, rid[k], rsl[k], boff, tk);
+                if (U_a > KPRE * LW) {   // rare: more than 64 distinct rows
+                    typedef const __attribute__((address_space(4))) uint32_t *cu32;
+                    cu32 ue = (cu32)(uintptr_t)(ent_base + (uint32_t)p * ent_step);
+                    for (int k = KPRE; lw + k * LW < U_a; k++) dma_row(G_a, ue[2 * k], ue[2 * k + 1], boff, tk);
+                }
+                keep |= tk;
+            }
+        };
+        // steps 0 .. NB-2 go out before the loop, then step s+NB-1 behind the barrier of step s
+        int boff[NB];
+#pragma unroll
+        for (int j = 0; j < NB; j++) boff[j] = j * bufsz;   // boff[j]: buffer of step s+j
+        int cnt[NB];                                          // cnt[j]: this loader's requests of step s+j
+#pragma unroll
+        for (int j = 0; j < NB; j++) cnt[j] = 0;
+        int pn = 0, ivn = 0;                                  // next step to fetch ids for
+        fetch_ids(pn, ivn);
+#pragma unroll
+        for (int j = 0; j < NB - 1; j++) {
+            if (j < nsteps) {
+                issue_rows(pn, boff[j]);
+                cnt[j] = dma_count(U_a);
+            }
+            advance(pn, ivn);
+            fetch_ids(pn, ivn);                               // ids of step j+1
+        }
+        int p_i = pn;                                         // step whose ids are in rid / rsl (s+NB-1)
+        for (int s = 0; s < nsteps; s++) {
+            __builtin_amdgcn_sched_barrier(0);
+            // this loader's rows of step s have landed when at most its requests of the NB-2
+            // younger steps stay in flight (s_waitcnt takes an immediate; an over-wait is safe)
+            {
+                int young = 0;
+#pragma unroll
+                for (int j = 1; j < NB - 1; j++) young += cnt[j];
+                uint32_t tk = 0;
+#define BA_LWAIT(NOUT) asm("s_waitcnt vmcnt(" #NOUT ")" : "+s"(tk) : "s"(s))
+                switch (young) {
+                case 0: BA_LWAIT(0); break;   case 1: BA_LWAIT(1); break;   case 2: BA_LWAIT(2); break;
+                case 3: BA_LWAIT(3); break;   case 4: BA_LWAIT(4); break;   case 5: BA_LWAIT(5); break;
+                case 6: BA_LWAIT(6); break;   case 7: BA_LWAIT(7); break;   case 8: BA_LWAIT(8); break;
+                case 9: BA_LWAIT(9); break;   case 10: BA_LWAIT(10); break; case 11: BA_LWAIT(11); break;
+                case 12: BA_LWAIT(12); break; case 13: BA_LWAIT(13); break; case 14: BA_LWAIT(14); break;
+                case 15: BA_LWAIT(15); break; case 16: BA_LWAIT(16); break; case 17: BA_LWAIT(17); break;
+                case 18: BA_LWAIT(18); break; case 19: BA_LWAIT(19); break; case 20: BA_LWAIT(20); break;
+                case 21: BA_LWAIT(21); break; case 22: BA_LWAIT(22); break; case 23: BA_LWAIT(23); break;
+                case 24: BA_LWAIT(24); break; case 25: BA_LWAIT(25); break; case 26: BA_LWAIT(26); break;
+                case 27: BA_LWAIT(27); break; case 28: BA_LWAIT(28); break; case 29: BA_LWAIT(29); break;
+                case 30: BA_LWAIT(30); break; case 31: BA_LWAIT(31); break; default: BA_LWAIT(32); break;
+                }
+#undef BA_LWAIT
+                keep |= tk;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();   // rows of step s published; buffer of step s-1 is free
+            __builtin_amdgcn_sched_barrier(0);
+            int k_new = 0;
+            if (s + NB - 1 < nsteps) {
+                issue_rows(p_i, boff[NB - 1]);
+                k_new = dma_count(U_a);
+            }
+            advance(pn, ivn);
+            p_i = pn;
+            fetch_ids(pn, ivn);
+            const int b0 = boff[0];
+#pragma unroll
+            for (int j = 0; j < NB - 1; j++) { boff[j] = boff[j + 1]; cnt[j] = cnt[j + 1]; }
+            boff[NB - 1] = b0;
+            cnt[NB - 1] = 0;
+            cnt[NB - 2] = k_new;
+        }
+        __builtin_amdgcn_s_barrier();   // the consumers' barrier "of step nsteps" (their pipelined loop)
+        // the consumers' epilogue passes the data tile through LDS behind two barriers
+        if (MODE != GF_STORE_SYN) {
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
+        }
+        if (keep != 0) a.out[0] = 0.0;   // never true: keeps the request statements alive
+        return;
+    }
+
+    // ==================================== consumer ====================================
+    static_assert(NROW == 1, "the loader / consumer kernel exists for single-row interpolation");
+    const int64_t c = g * CG + tid;
+    double acc[GS_NT];
+#pragma unroll
+    for (int i = 0; i < GS_NT; i++) acc[i] = 0.0;
+    // the lane's slot and weight, fetched one step ahead by asm loads hipcc does not count
+    uint32_t sl_n;
+    double wl_n;
+    // scalar base + 32-bit lane offset: no 64-bit pointers in VGPRs
+    const uint32_t voff_s = (uint32_t)tid * 2u;   // (the weight's offset is rebuilt from it per load: one
+                                                   // register less is what keeps the step loop free of spills)
+    const char *const slot_base = reinterpret_cast<const char *>(a.slot + (gt * a.P) * CG);
+    const char *const w_base = reinterpret_cast<const char *>(a.w + (g * a.P) * CG);
+    const uint32_t slot_step = (uint32_t)(CG * 2);
+    const uint32_t w_step = (uint32_t)(CG * 8);
+    const int64_t w_var_bytes = a.w_var_stride * 8;
+    auto tab_slot = [&](int p) { return slot_base + (uint32_t)p * slot_step; };
+    auto tab_w = [&](int p, int iv) {
+        return w_base + (uint32_t)p * w_step + (nvar == 1 ? (int64_t)0 : (int64_t)iv * w_var_bytes);
+    };
+    auto fetch_tabs = [&](const char *ps, const char *pw) {
+        asm("global_load_ushort %0, %1, %2" : "=v"(sl_n) : "v"(voff_s), "s"(ps));
+        uint32_t voff_w;
+        asm("v_lshlrev_b32 %1, 2, %2\n\t"
+            "global_load_dwordx2 %0, %1, %3" : "=v"(wl_n), "=&v"(voff_w) : "v"(voff_s), "s"(pw));
+    };
+    // The landed slot / weight are consumed INSIDE asm statements placed behind the wait: a tied
+    // ("+v") wait statement lets hipcc copy the still-in-flight register in front of it.
+    // xs = LDS byte address of the lane's row = base + slot * (GS_PITCH * 8), GS_PITCH = 65
+    auto row_address = [&](uint32_t base) {
+        uint32_t x;
+        asm("s_waitcnt vmcnt(0)\n\t"
+            "v_lshl_add_u32 %0, %1, 6, %1\n\t"
+            "v_lshl_add_u32 %0, %0, 3, %2" : "=&v"(x) : "v"(sl_n), "s"(base), "v"(wl_n));
+        return x;
+    };
+    auto landed_weight = [&](uint32_t after) {   // `after`: the row address, i.e. behind the wait
+        double x;
+        asm("v_mov_b64 %0, %1" : "=v"(x) : "v"(wl_n), "v"(after));
+        return x;
+    };
+    static_assert(GS_PITCH == 65, "row_address multiplies by 65");
+    constexpr int NG8 = GS_NT / 8;
+    static_assert(NG8 == 8, "the read schedule below is written for 64-sample tiles");
+    double ya[8], yb[8];
+    int p1 = 0, iv1 = 0;          // position of the step whose slot/weight are fetched next
+    advance(p1, iv1);
+    int gbuf = 0;                 // row buffer of the step being gathered
+    const int ring = NB * bufsz;
+    // The gather of a step is 8 groups of 8 ds_read_b64 + 8 FMA, two groups in flight.  It is
+    // pipelined across the step boundary: once the reads of step s are all back (before the FMAs
+    // of its last group) the wavefront passes the barrier of step s+1 and has that step's first
+    // group in flight while it finishes step s -- the LDS pipe does not drain at every barrier.
+    double w;
+    uint32_t xs;
+    fetch_tabs(tab_slot(0), tab_w(0, 0));
+    xs = row_address(lds0);
+    w = landed_weight(xs);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();     // rows of step 0 visible
+    __builtin_amdgcn_sched_barrier(0);
+    lds_rd8_b64<0>(ya, xs, -1);
+    lds_rd8_b64<64>(yb, xs, -1);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_tabs(tab_slot(p1), tab_w(p1, iv1));
+    advance(p1, iv1);
+#pragma clang loop unroll(disable)
+    for (int s = 0; s < nsteps; s++) {
+        // all scalar bookkeeping of the step first: hipcc sinks FMAs into any block that follows the
+        // gather, so nothing below may branch
+        int gnext = gbuf + bufsz;
+        if (gnext == ring) gnext = 0;
+        const char *const ps2 = tab_slot(p1), *const pw2 = tab_w(p1, iv1);   // tables of step s+2
+        advance(p1, iv1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int gq = 0; gq < NG8 - 2; gq++) {
+            double(&cur)[8] = (gq & 1) ? yb : ya;
+            lds_wait8_b64<8>(cur);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 8; q++) acc[gq * 8 + q] = fma(cur[q], w, acc[gq * 8 + q]);
+            __builtin_amdgcn_sched_barrier(0);
+            switch (gq + 2) {
+            case 2: lds_rd8_b64<128>(cur, xs, s); break;
+            case 3: lds_rd8_b64<192>(cur, xs, s); break;
+            case 4: lds_rd8_b64<256>(cur, xs, s); break;
+            case 5: lds_rd8_b64<320>(cur, xs, s); break;
+            case 6: lds_rd8_b64<384>(cur, xs, s); break;
+            default: lds_rd8_b64<448>(cur, xs, s); break;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // group 6: every read of this step is back once both groups have landed
+        lds_wait8_b64<0>(ya);
+        lds_wait8_b64<0>(yb);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; q++) acc[48 + q] = fma(ya[q], w, acc[48 + q]);
+        __builtin_amdgcn_sched_barrier(0);
+        gbuf = gnext;
+        xs = row_address(lds0 + (uint32_t)(gbuf * 8));   // slot / weight of step s+1 have landed
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();   // rows of step s+1 visible; this wavefront is done with buffer s
+        __builtin_amdgcn_sched_barrier(0);
+        lds_rd8_b64<0>(ya, xs, s);      // first group of step s+1 (after the last step: unused rows)
+        __builtin_amdgcn_sched_barrier(0);
+        // group 7 with the weight of step s, then the weight of step s+1
+#pragma unroll
+        for (int q = 0; q < 8; q++) acc[56 + q] = fma(yb[q], w, acc[56 + q]);
+        __builtin_amdgcn_sched_barrier(0);
+        w = landed_weight(xs);
+        lds_rd8_b64<64>(yb, xs, s);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_tabs(ps2, pw2);           // slot / weight of step s+2
+    }
+    // drain the reads issued for the step after the last (their registers stay reserved until here)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : "+v"(ya[0]), "+v"(ya[1]), "+v"(ya[2]), "+v"(ya[3]), "+v"(ya[4]), "+v"(ya[5]), "+v"(ya[6]),
+                   "+v"(ya[7]), "+v"(yb[0]), "+v"(yb[1]), "+v"(yb[2]), "+v"(yb[3]), "+v"(yb[4]), "+v"(yb[5]),
+                   "+v"(yb[6]), "+v"(yb[7]), "+v"(sl_n), "+v"(wl_n));
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue: lane = chain c, acc[i] = synthetics[c, t, n0 + i]
+    const bool live = (c < a.C);
+    const int nvalid = (int)min((int64_t)GS_NT, N - n0);
+    if (MODE == GF_STORE_SYN) {
+        if (live) {
+            double *o = a.out + (c * a.T + t) * N + n0;
+#pragma unroll
+            for (int i = 0; i < GS_NT; i++)
+                if (i < nvalid) o[i] = acc[i];
+        }
+        return;
+    }
+    __builtin_amdgcn_s_barrier();
+    if (tid < GS_NT) xbuf[tid] = (tid < nvalid) ? a.data[t * N + n0 + tid] : 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (MODE == GF_RESID_STORE) {
+        double *o = a.out + (c * a.T + t) * N + n0;
+#pragma unroll
+        for (int i0 = 0; i0 < GS_NT; i0 += 8) {
+#pragma unroll
+            for (int i = i0; i < i0 + 8; i++)
+                if (live && i < nvalid) o[i] = xbuf[i] - acc[i];  // seismic.py:1332
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        const double w = a.wscalar[t];
+        double q = 0.0;
+#pragma unroll
+        for (int i0 = 0; i0 < GS_NT; i0 += 8) {
+#pragma unroll
+            for (int i = i0; i < i0 + 8; i++)
+                if (i < nvalid) {
+                    const double tt = w * (xbuf[i] - acc[i]);
+                    q = fma(tt, tt, q);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (live) a.partial[(c * a.T + t) * a.ntile + tile] = q;
+    }
+}
+
+
 template <int WAVES, int NROW, int MODE>
 static void launch_shared_one(dim3 grid, size_t lds, hipStream_t s, const GsArgs &a)
 {
@@ -947,6 +1306,17 @@ static void launch_shared_nrow(int nrow, int mode, dim3 grid, size_t lds, hipStr
 {
     if (nrow == 1) launch_shared_mode<WAVES, 1>(mode, grid, lds, s, a);
     else launch_shared_mode<WAVES, 4>(mode, grid, lds, s, a);
+}
+
+// (single-row interpolation only: with four rows per chain the consumers run out of registers and
+// hipcc spills the not-yet-landed results of the hidden table loads)
+static void launch_ws(int mode, dim3 grid, size_t lds, hipStream_t s, const GsArgs &a)
+{
+    void (*kern)(GsArgs) = mode == GF_STORE_SYN ? k_gfstack_ws<1, GF_STORE_SYN, 3>
+                           : mode == GF_RESID_SCALAR ? k_gfstack_ws<1, GF_RESID_SCALAR, 3>
+                                                     : k_gfstack_ws<1, GF_RESID_STORE, 3>;
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(768), lds, s, a);
 }
 
 // chains per group for a batch of C chains: the group size that minimises
@@ -1030,6 +1400,17 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         ga.umax = (uint32_t *)p;
         BA_HIP(hipMemsetAsync(ga.umax, 0, sizeof(uint32_t), ctx->stream));
     }
+    // wave-specialised kernel: 512-chain groups whose three row buffers fit LDS
+    bool use_ws = false;
+    const int ws_nb = 3;   // row buffers (four of 64 slots measured the same as three of 96)
+    {
+        const char *e = getenv("BEATAMD_GS_WS"), *ed = getenv("BEATAMD_GS_DMA"), *en = getenv("BEATAMD_GS_NT");
+        const int depth = (ucap + 31) / 32;
+        const bool want = e ? atoi(e) != 0 : (GS_WS_DEFAULT != 0);
+        use_ws = want && CG == 512 && nrow == 1 && L.N % 2 == 0 && !(ed && atoi(ed) != 2) && !(en && atoi(en) != 64) &&
+                 ucap <= 128 && (size_t)3 * 32 * depth * (GS_NT_MAX + 1) * 8 <= 158 * 1024;
+    }
+    ga.nissue = use_ws ? 4 : CG / 64;
     // LDS slots by bank window for the ds_read_b64 LDS-DMA kernel with large chain groups (the
     // small groups size their LDS by the measured row count and keep dense slots): the row
     // buffers then hold 32 * depth slots
@@ -1044,7 +1425,7 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         ga.windowed = (CG >= 512 && nrow == 1 && dma2 && ucap > 32 && ucap <= 128 && !(ew && atoi(ew) == 0) &&
                        (size_t)2 * 32 * depth * (GS_NT_MAX + 2) * 8 <= 158 * 1024) ? 1 : 0;
         ga.depth = depth;
-        if (ga.windowed) ucap = 32 * depth;
+        if (ga.windowed || use_ws) ucap = 32 * depth;
     }
     {
         ScopedTimer tm(ctx, "grouptables");
@@ -1114,7 +1495,9 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
             a.intl = (a.dma == 2 && a.nt == 64 && CG <= 512) ? GS_INTL_DEFAULT : 0;
             if (ei && a.dma == 2 && a.nt == 64 && CG <= 512) a.intl = atoi(ei) ? 1 : 0;
         }
-        if (a.dma) lds *= (a.deep ? 3 : 2);
+        a.ws = (use_ws && a.dma == 2) ? ws_nb : 0;
+        if (a.ws) { a.deep = 0; a.intl = 0; lds = (size_t)ucap * (a.nt + 1) * sizeof(double) * a.ws; }
+        else if (a.dma) lds *= (a.deep ? 3 : 2);
     }
     {
         // chain groups of one (target, tile) on one XCD (several groups only)
@@ -1123,7 +1506,9 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         if (e && atoi(e) == 1 && a.dma) a.xcd_order = 1;
         if (a.xcd_order) nblocks = ((L.T * a.ntile + 7) / 8) * 8 * ngroups;
     }
-    if (a.deep || a.intl)
+    if (a.ws)
+        snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack_ws<%d,%d,%d>", nrow, k.mode, a.ws);
+    else if (a.deep || a.intl)
         snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), a.intl ? "k_gfstack_dma<%d,%d,%d,%d,1,%d,1>"
                  : "k_gfstack_dma<%d,%d,%d,%d,1,%d>", CG / 64, nrow, k.mode, a.nt, a.deep);
     else
@@ -1135,7 +1520,8 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     {
         ScopedTimer tm(ctx, "gfstack");
         dim3 grid((unsigned)nblocks);
-        if (CG == 1024) launch_shared_nrow<16>(nrow, k.mode, grid, lds, ctx->stream, a);
+        if (a.ws) launch_ws(k.mode, grid, lds, ctx->stream, a);
+        else if (CG == 1024) launch_shared_nrow<16>(nrow, k.mode, grid, lds, ctx->stream, a);
         else if (CG == 512) launch_shared_nrow<8>(nrow, k.mode, grid, lds, ctx->stream, a);
         else if (CG == 256) launch_shared_nrow<4>(nrow, k.mode, grid, lds, ctx->stream, a);
         else if (CG == 128) launch_shared_nrow<2>(nrow, k.mode, grid, lds, ctx->stream, a);

@@ -192,6 +192,7 @@ def test_fullsize_shipped_dma_kernel_at_bench_shape(full, monkeypatch, C):
     monkeypatch.setenv("BEATAMD_GS_CG", "512")
     for interp, nrow in (("nearest_neighbor", 1), ("multilinear", 4)):
         monkeypatch.delenv("BEATAMD_GF_KERNEL", raising=False)
+        monkeypatch.setenv("BEATAMD_GS_WS", "0")
         out = gf.stack_all_batch(dur_d, st_d, sl_d, interpolation=interp)
         name = ctx.last_kernel()
         assert name.startswith("k_gfstack_dma<8,%d,0,64," % nrow), name
@@ -204,6 +205,12 @@ def test_fullsize_shipped_dma_kernel_at_bench_shape(full, monkeypatch, C):
         monkeypatch.delenv("BEATAMD_GF_KERNEL")
         assert torch.equal(out, ref), "k_gfstack_dma differs from the streaming kernel (%s)" % interp
         del ref
+        if nrow == 1:   # the loader / consumer kernel on the same tables
+            monkeypatch.setenv("BEATAMD_GS_WS", "1")
+            out2 = gf.stack_all_batch(dur_d, st_d, sl_d, interpolation=interp)
+            assert ctx.last_kernel() == "k_gfstack_ws<1,0,3>", ctx.last_kernel()
+            assert torch.equal(out, out2), "k_gfstack_ws differs from k_gfstack_dma"
+            del out2
         for c, t in pairs:
             want = _stack_reference(full, dur[c], st[c, t], sl[c], t, interp)
             got = out[c, t].cpu().numpy()
@@ -223,8 +230,13 @@ def test_fullsize_fused_logp_through_dma_kernel(full, monkeypatch, C):
     Qd = torch.from_numpy(Q).to("cuda:0")
     monkeypatch.delenv("BEATAMD_GF_KERNEL", raising=False)
     monkeypatch.setenv("BEATAMD_GS_CG", "512")
+    monkeypatch.setenv("BEATAMD_GS_WS", "1")
+    LW = f.batch(Qd).cpu().numpy()
+    assert ctx.last_kernel() == "k_gfstack_ws<1,1,3>", ctx.last_kernel()
+    monkeypatch.setenv("BEATAMD_GS_WS", "0")
     LL = f.batch(Qd).cpu().numpy()
     assert ctx.last_kernel().startswith("k_gfstack_dma<8,1,1,64,"), ctx.last_kernel()
+    assert np.array_equal(LL, LW)
     monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
     LS = f.batch(Qd).cpu().numpy()
     monkeypatch.delenv("BEATAMD_GF_KERNEL")

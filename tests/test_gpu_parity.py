@@ -223,8 +223,17 @@ def test_shared_row_kernel_equals_streaming_kernel(ctx, orc, monkeypatch, C, int
             monkeypatch.setenv("BEATAMD_GS_NT", nt)
             monkeypatch.setenv("BEATAMD_GS_ORDER", order)
             monkeypatch.setenv("BEATAMD_GS_INTL", intl)
+            monkeypatch.setenv("BEATAMD_GS_WS", "0")
             assert np.array_equal(gf.stack_all_batch(dur, st, sl, interpolation=interp), a), (cg, dma, deep, nt, intl)
             seen.add(ctx.last_kernel())
+        if cg == "512":   # loader / consumer wavefronts (single-row interpolation only)
+            for order in ("0", "1"):
+                monkeypatch.setenv("BEATAMD_GS_WS", "1")
+                monkeypatch.setenv("BEATAMD_GS_ORDER", order)
+                monkeypatch.setenv("BEATAMD_GS_DMA", "2")
+                monkeypatch.setenv("BEATAMD_GS_NT", "64")
+                assert np.array_equal(gf.stack_all_batch(dur, st, sl, interpolation=interp), a), (cg, "ws", order)
+                seen.add(ctx.last_kernel())
     nrow, w = (4 if interp == "multilinear" else 1), {"64": 1, "128": 2, "256": 4, "512": 8, "1024": 16}
     for cg in w:   # every variant really ran (names as beatamd_ctx_last_kernel reports them)
         assert "k_gfstack_dma<%d,%d,0,32,1>" % (w[cg], nrow) in seen, seen
@@ -233,6 +242,8 @@ def test_shared_row_kernel_equals_streaming_kernel(ctx, orc, monkeypatch, C, int
             assert "k_gfstack_dma<%d,%d,0,64,1,0,1>" % (w[cg], nrow) in seen, seen
             assert "k_gfstack_dma<%d,%d,0,64,1,1,1>" % (w[cg], nrow) in seen, seen
             assert "k_gfstack_shared<%d,%d,0,64,0>" % (w[cg], nrow) in seen, seen
+    if nrow == 1 and C > 0:
+        assert "k_gfstack_ws<1,0,3>" in seen, seen
 
 
 @pytest.mark.parametrize("interp", ["nearest_neighbor", "multilinear"])
@@ -261,10 +272,18 @@ def test_window_slots_with_more_than_32_distinct_rows(ctx, orc, monkeypatch, int
                 monkeypatch.setenv("BEATAMD_GS_WIN", win)
                 monkeypatch.setenv("BEATAMD_GS_DEEP", deep)
                 monkeypatch.setenv("BEATAMD_GS_INTL", intl)
+                monkeypatch.setenv("BEATAMD_GS_WS", "0")
                 b = gf.stack_all_batch(dur, st, sl, interpolation=interp)
                 assert ctx.last_kernel().startswith("k_gfstack_dma<"), ctx.last_kernel()
                 assert ctx.gf_group_stats()["max_rows"] > 32
                 assert np.array_equal(a, b), (C, cg, win, deep)
+            if cg == "512" and interp == "nearest_neighbor":
+                for win in ("1", "0"):   # three row buffers of 96 slots, four loader wavefronts
+                    monkeypatch.setenv("BEATAMD_GS_WIN", win)
+                    monkeypatch.setenv("BEATAMD_GS_WS", "1")
+                    b = gf.stack_all_batch(dur, st, sl, interpolation=interp)
+                    assert ctx.last_kernel() == "k_gfstack_ws<1,0,3>", ctx.last_kernel()
+                    assert np.array_equal(a, b), (C, cg, "ws", win)
         for c in (0, 529, C - 1):
             ref = orc.stack_all(G, dur[c], st[c], sl[c], 0.5, 0.5, 0.0, 0.5, interp)
             assert np.abs(a[c] - ref).max() <= 1e-11 * np.abs(ref).max()
@@ -306,8 +325,14 @@ def test_fused_model_512_chain_groups(ctx, monkeypatch, name):
     A = f.batch(Q)
     monkeypatch.setenv("BEATAMD_GF_KERNEL", "1")
     monkeypatch.setenv("BEATAMD_GS_CG", "512")
+    monkeypatch.setenv("BEATAMD_GS_WS", "0")
     B = f.batch(Q)
     np.testing.assert_allclose(A, B, rtol=1e-11, atol=1e-9)
+    monkeypatch.setenv("BEATAMD_GS_WS", "1")   # loader / consumer wavefronts where they apply
+    B2 = f.batch(Q)
+    if "nn" in name:
+        assert ctx.last_kernel().startswith("k_gfstack_ws<1,"), ctx.last_kernel()
+    assert np.array_equal(B, B2)
     for c in (0, 511, 512, 529):
         ref, _ = problem_oracle.forward(host, Q[c])
         np.testing.assert_allclose(B[c], ref, rtol=RTOL)
