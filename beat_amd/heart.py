@@ -223,6 +223,12 @@ class HalfspaceEngine(object):
     def close_cashed_stores(self):   # the reference's Ops call this before pickling
         pass
 
+    def __getstate__(self):
+        return {"nu": self.nu}       # the device context is per process: looked up again on use
+
+    def __setstate__(self, state):
+        self.nu, self._ctx = state["nu"], None
+
     def static_displacements(self, sources, targets):
         """-> list, index i_t + i_s * n_targets (heart.py:4213-4216), of (n_points, 3) arrays
         [north, east, up] = [n, e, -d] (heart.py:4218-4224)"""

@@ -1,6 +1,6 @@
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r2h
+O=$R/gpurun_out/${RUN_TAG:-r2h}
 mkdir -p $O
 cd $R
 timeout 1500 python -m pytest tests -m gpu -q --tb=short -rf > $O/pytest.log 2>&1
