@@ -908,7 +908,7 @@ int beatamd_ctx_gf_group_stats(beatamd_ctx *ctx, int64_t *chains_per_group, doub
     }
     *mean_rows = (double)tot / (double)uc.size();
     *max_rows = mx;
-    *row_bytes = tot * ctx->gs_N * 8;   // every distinct row is staged once per (group, target)
+    *row_bytes = tot * ctx->gs_trep * ctx->gs_N * 8;   // every distinct row is staged once per (group, target)
     return BEATAMD_OK;
 }
 

@@ -151,7 +151,7 @@ struct beatamd_ctx {
     // name of the stacking kernel of the most recent launch (tests assert which kernel ran)
     char last_gf_kernel[96] = "";
     // distinct-row statistics of the most recent chain-shared launch (bench.py roofline leg)
-    int64_t gs_ngtp = 0, gs_N = 0;
+    int64_t gs_ngtp = 0, gs_N = 0, gs_trep = 1;   // trep: targets served by one table cell
     int gs_cg = 0;
 
     // grow-only scratch slot

@@ -230,6 +230,10 @@ struct GsArgs {
     int deep;          // k_gfstack_dma: 0 two row buffers / 1 three buffers, rows two steps ahead / 2 + staggered issue
     int xcd_order;     // k_gfstack_dma: chain groups of a (target, tile) share an XCD
     int64_t ngroups;
+    // tables per (group, target, patch), or per (group, patch) when the start times do not depend
+    // on the target (no station shifts): Ttab = T or 1; the row ids are then those of target 0 and
+    // target t reads rows_per_target * t further on
+    int64_t Ttab, rows_per_target;
     const uint32_t *urows, *uent, *ucount;
     const uint16_t *slot;
     const double *w;
@@ -263,9 +267,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_gfstack_shared(GsArgs a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row ids via s_load
     const int tile = blockIdx.x % a.ntile;
-    const int64_t gt = blockIdx.x / a.ntile;  // g*T + t
-    const int64_t t = gt % a.T;
-    const int64_t g = gt / a.T;
+    const int64_t gt0 = blockIdx.x / a.ntile;  // g*T + t
+    const int64_t t = gt0 % a.T;
+    const int64_t g = gt0 / a.T;
+    const int64_t gt = g * a.Ttab + (a.Ttab == 1 ? 0 : t);                       // table cell
+    const int64_t tbase = (a.Ttab == 1) ? t * a.rows_per_target * a.N : 0;      // doubles
     const int64_t c = g * CG + tid;
     const int64_t N = a.N;
     const int64_t n0 = (int64_t)tile * GS_NT;
@@ -322,7 +328,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_gfstack_shared(GsArgs a)
             uint32_t ra[4], rb[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) { ra[u] = ra_n[u]; rb[u] = rb_n[u]; }
-            const double *Gv = a.G[iv];
+            const double *Gv = a.G[iv] + tbase;
             __syncthreads();  // everyone finished reading the previous rows
             // ---- stage the distinct rows of this (group, target, patch) in LDS
             {
@@ -553,7 +559,8 @@ k_gfstack_dma(GsArgs a)
         t = gt0 % a.T;
         g = gt0 / a.T;
     }
-    const int64_t gt = g * a.T + t;
+    const int64_t gt = g * a.Ttab + (a.Ttab == 1 ? 0 : t);                       // table cell
+    const int64_t tbase = (a.Ttab == 1) ? t * a.rows_per_target * a.N : 0;      // doubles
     const int64_t c = g * CG + tid;
     const int64_t N = a.N;
     const int64_t n0 = (int64_t)tile * GS_NT;
@@ -638,7 +645,7 @@ k_gfstack_dma(GsArgs a)
         // library base pointer of that step: a scalar load from the kernel arguments, issued with
         // the list entries one step before it is needed (selecting among four register pairs by a
         // run-time index costs a branch maze of ~25 scalar instructions per step)
-        G_a = a.G[iv];
+        G_a = a.G[iv] + tbase;
     };
     auto issue_rows_dep = [&](int p, int iv, int boff, int U, const uint32_t (&rid)[KPRE],
                               const uint32_t (&rsl)[KPRE], uint32_t dep) {
@@ -960,7 +967,8 @@ k_gfstack_ws(GsArgs a)
         t = gt0 % a.T;
         g = gt0 / a.T;
     }
-    const int64_t gt = g * a.T + t;
+    const int64_t gt = g * a.Ttab + (a.Ttab == 1 ? 0 : t);                       // table cell
+    const int64_t tbase = (a.Ttab == 1) ? t * a.rows_per_target * a.N : 0;      // doubles
     const int64_t N = a.N;
     const int64_t n0 = (int64_t)tile * GS_NT;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)xbuf;
@@ -1011,7 +1019,7 @@ k_gfstack_ws(GsArgs a)
                 rid[k] = e0[2 * k];      rsl[k] = e0[2 * k + 1];
                 rid[8 + k] = e1[2 * k];  rsl[8 + k] = e1[2 * k + 1];
             }
-            G_a = a.G[iv];
+            G_a = a.G[iv] + tbase;
         };
         auto dma_count = [&](int U) { return U > lw ? (U - lw + LW - 1) / LW : 0; };
         // rows lw, lw + LW, ... of the list whose entries are in rid / rsl -> buffer at boff
@@ -1366,18 +1374,18 @@ bool gfstack_shared_applicable(const GfStackCall &k, int *cg_out, int *ucap_out)
 }
 
 int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *rowoff,
-                          const double *fac, int CG, int ucap)
+                          const double *fac, int CG, int ucap, int64_t Ttab)
 {
     const SeisLib &L = *k.libs[0];
     const int nrow = k.interp == BEATAMD_MULTILINEAR ? 4 : 1;
     const int64_t ngroups = (k.C + CG - 1) / CG;
-    const int64_t GTP = ngroups * L.T * L.P;
+    const int64_t GTP = ngroups * Ttab * L.P;
     void *p = nullptr;
 
     GroupTabArgs ga;
     memset(&ga, 0, sizeof(ga));
     ga.nrow = nrow; ga.nvar = k.nvar; ga.CG = CG;
-    ga.C = k.C; ga.T = L.T; ga.P = L.P; ga.DS = L.D * L.S;
+    ga.C = k.C; ga.T = Ttab; ga.P = L.P; ga.DS = L.D * L.S;
     ga.rowoff = rowoff; ga.fac = fac;
     for (int v = 0; v < k.nvar; v++) ga.slips[v] = k.slips[v];
     ga.ucap = ucap;
@@ -1439,6 +1447,7 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     for (int v = 0; v < k.nvar; v++) a.G[v] = k.libs[v]->g;
     a.nvar = k.nvar; a.nrow = nrow;
     a.C = k.C; a.T = L.T; a.P = L.P; a.N = L.N;
+    a.Ttab = Ttab; a.rows_per_target = L.P * L.D * L.S;
     a.CG = CG; a.ucap = ucap; a.ustride = ga.ustride;
     a.nt = 64;
     {
@@ -1515,6 +1524,7 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "%s<%d,%d,%d,%d,%d>",
                  a.dma ? "k_gfstack_dma" : "k_gfstack_shared", CG / 64, nrow, k.mode, a.nt, a.dma == 2 ? 1 : 0);
     ctx->gs_ngtp = GTP;
+    ctx->gs_trep = L.T / Ttab;
     ctx->gs_N = L.N;
     ctx->gs_cg = CG;
     {

@@ -48,6 +48,8 @@ __device__ __forceinline__ bool wrap_index(int &i, int n)
 __global__ void __launch_bounds__(256) k_gf_tables(TabArgs a)
 {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // a.T = number of targets the tables are built for: all of them, or 1 when the start times do
+    // not depend on the target (row ids of target 0; the stacking kernels add the target's base)
     const int64_t total = a.C * a.T * a.P;
     if (idx >= total) return;
     const int64_t p = idx % a.P;
@@ -119,6 +121,7 @@ struct GfArgs {
     int order;        // 0: blocks ordered (chain, target, tile); 1: (group, target, chain, tile)
     int64_t C;
     int cgroup;       // order 1: chains per group
+    int64_t Ttab, rows_per_target;   // tables per (chain, target, patch) or, Ttab = 1, per (chain, patch)
 };
 
 template <int W> struct VecT;
@@ -168,6 +171,8 @@ __global__ void __launch_bounds__(256) k_gfstack(GfArgs a)
         c = c0 + (r - t * gsz);
     }
     const int64_t ct = c * a.T + t;
+    const int64_t ctt = c * a.Ttab + (a.Ttab == 1 ? 0 : t);                   // table cell
+    const int64_t tbase = (a.Ttab == 1) ? t * a.rows_per_target : 0;         // rows
     const int64_t N = a.N;
     const int P = (int)a.P;
 
@@ -179,8 +184,8 @@ __global__ void __launch_bounds__(256) k_gfstack(GfArgs a)
         inb[v] = nn < N;  // N even when W == 2 -> a pair is never split
         n[v] = inb[v] ? nn : 0;  // out-of-range lanes re-read sample 0 (discarded)
     }
-    const uint32_t *ro = a.rowoff + ct * a.P * NROW;
-    const double *fa = INTERP ? (a.fac + ct * a.P * NROW) : nullptr;
+    const uint32_t *ro = a.rowoff + ctt * a.P * NROW;
+    const double *fa = INTERP ? (a.fac + ctt * a.P * NROW) : nullptr;
     const double *sl[NVAR];
 #pragma unroll
     for (int iv = 0; iv < NVAR; iv++)
@@ -197,7 +202,7 @@ __global__ void __launch_bounds__(256) k_gfstack(GfArgs a)
         for (int u = 0; u < U; u++)
 #pragma unroll
             for (int k = 0; k < NROW; k++) {
-                const int64_t roff = (int64_t)ro[(p + u) * NROW + k] * N;  // wave-uniform (SGPR)
+                const int64_t roff = ((int64_t)ro[(p + u) * NROW + k] + tbase) * N;  // wave-uniform (SGPR)
 #pragma unroll
                 for (int iv = 0; iv < NVAR; iv++) {
                     const double *row = a.G[iv] + roff;
@@ -220,7 +225,7 @@ __global__ void __launch_bounds__(256) k_gfstack(GfArgs a)
     for (; p < P; p++) {
 #pragma unroll
         for (int k = 0; k < NROW; k++) {
-            const int64_t roff = (int64_t)ro[p * NROW + k] * N;
+            const int64_t roff = ((int64_t)ro[p * NROW + k] + tbase) * N;
 #pragma unroll
             for (int iv = 0; iv < NVAR; iv++) {
                 double w = sl[iv][p];
@@ -325,12 +330,18 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &k)
     BA_CHECK(L.T * L.P * L.D * L.S < (int64_t)0xffffffffLL, BEATAMD_EINVAL,
              "gfstack: library has more than 2^32 rows");
     if (k.C == 0) return BEATAMD_OK;
-    const int64_t CTP = k.C * L.T * L.P;
+    // Without explicit start times and without station shifts the start-time and duration
+    // indices of a chain are the same for every target (seismic.py:1283-1296 tiles starttimes0
+    // over the targets): the tables are then built once per (chain, patch) instead of T times.
+    const bool tinv = !k.st.explicit_st && !k.st.shift_off &&
+                      !(getenv("BEATAMD_GF_TINV") && atoi(getenv("BEATAMD_GF_TINV")) == 0);
+    const int64_t Ttab = tinv ? 1 : L.T;
+    const int64_t CTP = k.C * Ttab * L.P;
     const int nrow = k.interp == BEATAMD_MULTILINEAR ? 4 : 1;
 
     TabArgs ta;
     ta.interp = k.interp;
-    ta.C = k.C; ta.T = L.T; ta.P = L.P; ta.D = L.D; ta.S = L.S;
+    ta.C = k.C; ta.T = Ttab; ta.P = L.P; ta.D = L.D; ta.S = L.S;
     ta.st_min = L.st_min; ta.st_dt = L.st_dt; ta.du_min = L.du_min; ta.du_dt = L.du_dt;
     ta.durations = k.durations;
     ta.st = k.st;
@@ -353,7 +364,7 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &k)
     {
         int cg = 0, ucap = 0;
         if (gfstack_shared_applicable(k, &cg, &ucap))
-            return launch_gfstack_shared(ctx, k, ta.rowoff, ta.fac, cg, ucap);
+            return launch_gfstack_shared(ctx, k, ta.rowoff, ta.fac, cg, ucap, Ttab);
     }
 
     GfArgs a;
@@ -363,6 +374,7 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &k)
         a.slips[v] = k.slips[v];
     }
     a.T = L.T; a.P = L.P; a.N = L.N;
+    a.Ttab = Ttab; a.rows_per_target = L.P * L.D * L.S;
     a.C = k.C;
     {
         const char *e = getenv("BEATAMD_GF_ORDER");

@@ -58,7 +58,7 @@ int launch_sum_tiles(beatamd_ctx *ctx, const double *partial, int64_t n, int nti
 // gfshared.hip: chain-shared variant (distinct rows staged once per chain group)
 bool gfstack_shared_applicable(const GfStackCall &call, int *cg, int *ucap);
 int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &call, const uint32_t *rowoff,
-                          const double *fac, int CG, int ucap);
+                          const double *fac, int CG, int ucap, int64_t Ttab);
 
 // ---- quadform.hip ----------------------------------------------------------------
 // quad[c,d] = || A_d x_{c,d} ||^2 ; A [nd or 1, M, M] row-major ; x(c,d,k) = X[c*xs_c + d*xs_d + k]

@@ -333,6 +333,14 @@ def test_fused_model_512_chain_groups(ctx, monkeypatch, name):
     if "nn" in name:
         assert ctx.last_kernel().startswith("k_gfstack_ws<1,"), ctx.last_kernel()
     assert np.array_equal(B, B2)
+    # without station shifts the index tables are built once per (chain, patch) and shared by the
+    # targets; BEATAMD_GF_TINV=0 builds them per target as with shifts: same numbers either way
+    monkeypatch.setenv("BEATAMD_GF_TINV", "0")
+    for ws, kern in (("1", "1"), ("0", "1"), ("0", "0")):
+        monkeypatch.setenv("BEATAMD_GS_WS", ws)
+        monkeypatch.setenv("BEATAMD_GF_KERNEL", kern)
+        B3 = f.batch(Q)
+        assert np.array_equal(B3, B if kern == "1" else A), (ws, kern)
     for c in (0, 511, 512, 529):
         ref, _ = problem_oracle.forward(host, Q[c])
         np.testing.assert_allclose(B[c], ref, rtol=RTOL)
