@@ -289,6 +289,33 @@ def test_window_slots_with_more_than_32_distinct_rows(ctx, orc, monkeypatch, int
             assert np.abs(a[c] - ref).max() <= 1e-11 * np.abs(ref).max()
 
 
+def test_more_than_64_distinct_rows_per_step(ctx, orc, monkeypatch):
+    """96-row library, 600 chains spread over all of it: a 512-chain group uses > 64 distinct rows
+    per patch, beyond the row ids the loader wavefronts (k_gfstack_ws) / the issue block
+    (k_gfstack_dma) prefetch into scalar registers -- the overflow loops; bitwise vs streaming"""
+    T, P, D, S, N = 2, 5, 3, 32, 128
+    rng = np.random.default_rng(5)
+    G = rng.standard_normal((T, P, D, S, N))
+    gf = _make_lib(ctx, G, 0.0, 0.5, 0.5, 0.5)
+    C = 600
+    dur = rng.uniform(0.5, 1.5, (C, P))
+    st = rng.uniform(0.0, 15.4, (C, T, P))
+    sl = rng.uniform(0, 5, (C, P))
+    monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
+    a = gf.stack_all_batch(dur, st, sl)
+    monkeypatch.setenv("BEATAMD_GF_KERNEL", "1")
+    monkeypatch.setenv("BEATAMD_GS_CG", "512")
+    for ws, name in (("1", "k_gfstack_ws<1,0,3>"), ("0", "k_gfstack_dma<8,1,0,64,1>")):
+        monkeypatch.setenv("BEATAMD_GS_WS", ws)
+        b = gf.stack_all_batch(dur, st, sl)
+        assert ctx.last_kernel() == name, ctx.last_kernel()
+        assert ctx.gf_group_stats()["max_rows"] > 64
+        assert np.array_equal(a, b), ws
+    for c in (0, 511, 599):
+        ref = orc.stack_all(G, dur[c], st[c], sl[c], 0.5, 0.5, 0.0, 0.5)
+        assert np.abs(a[c] - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("name", ["seis_dense_ml_shifts", "joint_multifault", "all_nn_odd_N",
                                   "seis_scalar_nn"])
 def test_fused_model_with_shared_row_kernel(ctx, monkeypatch, name):
