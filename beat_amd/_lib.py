@@ -17,7 +17,7 @@ NEAREST_NEIGHBOR, MULTILINEAR = 0, 1
 W_SCALAR, W_DENSE = 0, 1
 INTERPOLATIONS = {"nearest_neighbor": NEAREST_NEIGHBOR, "multilinear": MULTILINEAR}
 
-OK, EINVAL, EHIP, EINDEX, ENOMEM, ENAN = 0, -1, -2, -3, -4, -5
+OK, EINVAL, EHIP, EINDEX, ENOMEM, ENAN, ENOTPSD = 0, -1, -2, -3, -4, -5, -6
 
 
 class BeatAmdError(RuntimeError):
@@ -93,6 +93,7 @@ _PROTOS = {
     "beatamd_gather_rows": [_vp, _i64, _i64, _vp, _i64, _vp, _vp],
     "beatamd_metropolis_tune": [_vp, _i64, _vp, _vp, _i32],
     "beatamd_whiten_rows": [_vp, _vp, _i64, _i64, _vp],
+    "beatamd_chol_inverse_batch": [_vp, _i64, _i64, _vp, _vp, _vp],
     "beatamd_halfspace_displacements_batch": [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _f64, _vp],
 }
 
@@ -140,6 +141,8 @@ def check(rc):
         raise IndexError(msg)
     if rc == ENOMEM:
         raise MemoryError(msg)
+    if rc == ENOTPSD:
+        raise np.linalg.LinAlgError(msg)
     raise BeatAmdError(msg)
 
 

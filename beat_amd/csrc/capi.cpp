@@ -1058,6 +1058,24 @@ int beatamd_metropolis_tune(beatamd_ctx *ctx, int64_t C, double *scaling, int32_
     return finish_out(ctx, recs, 2);
 }
 
+// ------------------------------------------------------------------ whitening operator
+int beatamd_chol_inverse_batch(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *covs, double *W,
+                               double *log_pdet)
+{
+    ENTER(ctx);
+    BA_CHECK(covs && W && log_pdet && nd >= 0 && n > 0, BEATAMD_EINVAL, "chol_inverse_batch: bad argument");
+    if (nd == 0) return BEATAMD_OK;
+    const void *d_c;
+    void *d_w, *d_l;
+    Arg recs[2];
+    BA_TRY(stage_in(ctx, SL_IN0, covs, (size_t)nd * n * n * 8, &d_c));
+    BA_TRY(stage_out(ctx, SL_OUT0, W, (size_t)nd * n * n * 8, &d_w, &recs[0]));
+    BA_TRY(stage_out(ctx, SL_OUT1, log_pdet, (size_t)nd * 8, &d_l, &recs[1]));
+    BA_TRY(launch_chol_inverse(ctx, nd, n, (const double *)d_c, (double *)d_w, (double *)d_l));
+    BA_TRY(ctx->check_status());
+    return finish_out(ctx, recs, 2);
+}
+
 // ------------------------------------------------------------------ library whitening
 int beatamd_whiten_rows(beatamd_ctx *ctx, double *rows, int64_t nrows, int64_t N, const double *W)
 {

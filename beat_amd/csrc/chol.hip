@@ -1,0 +1,201 @@
+// chol.hip -- the whitening operator of a batch of covariance matrices on the device:
+//
+//     W = cholesky(inv(C)).T   (upper triangular),   log_pdet = log det C
+//
+// what heart.Covariance.chol_inverse / .log_pdet hand to the likelihood (reference
+// beat/heart.py:216-253; per SMC stage for every dataset of a wavemap, seismic.py:1509-1534).
+// The reference inverts C and factors the inverse.  With J the exchange matrix,
+// chol(J C J) =: M gives  J C J = M M^T  =>  inv(C) = (J M^-T J)(J M^-1 J)  and J M^-T J is LOWER
+// triangular with positive diagonal, i.e. it IS the Cholesky factor of inv(C) (uniqueness):
+//
+//     W = J . inv(M) . J ,   log det C = 2 sum log diag(M)
+//
+// one factorisation + one triangular inverse (2/3 n^3 flops) instead of factor, invert, multiply,
+// factor (4/3 n^3 and more), and no explicit inv(C).  Blocked with 64 x 64 diagonal blocks:
+//   k_chol_flip_pad   A = J C J, padded to a multiple of 64 with an identity block
+//   k_chol_diag       factor the diagonal block in LDS (unblocked), its inverse beside it
+//   panel             A[i,k] <- A[i,k] . inv(L_kk)^T           k_gemm_f64 NT, in place
+//   trailing update   A[i,j] -= A[i,k] . A[j,k]^T  (i >= j > k) k_gemm_f64 NT, lower tiles only
+//   inverse by row blocks   X[k,k] = inv(L_kk);  X[k,<k] = -inv(L_kk) . (M[k,<k] . X[<k,<k])
+//                                                              two k_gemm_f64 NN (b_lower)
+//   k_chol_unflip     W[i,j] = X[n-1-i, n-1-j]
+// All GEMMs run batched over the matrices of the stack (grid.y), on the FP64 matrix cores.
+#include "kernels.hpp"
+
+namespace beatamd {
+
+constexpr int CH_NB = 64;
+
+// A[b][i][j] = C[b][n-1-i][n-1-j] inside n x n, identity in the padding
+__global__ void __launch_bounds__(256) k_chol_flip_pad(const double *C, int64_t n, int64_t np, double *A)
+{
+    const int64_t b = blockIdx.y;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= np * np) return;
+    const int64_t i = idx / np, j = idx % np;
+    double v;
+    if (i < n && j < n) v = C[(b * n + (n - 1 - i)) * n + (n - 1 - j)];
+    else v = (i == j) ? 1.0 : 0.0;
+    A[b * np * np + idx] = v;
+}
+
+// W[b][i][j] = X[b][n-1-i][n-1-j]
+__global__ void __launch_bounds__(256) k_chol_unflip(const double *X, int64_t n, int64_t np, double *W)
+{
+    const int64_t b = blockIdx.y;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * n) return;
+    const int64_t i = idx / n, j = idx % n;
+    W[b * n * n + idx] = X[(b * np + (n - 1 - i)) * np + (n - 1 - j)];
+}
+
+// One workgroup per matrix: factor the 64 x 64 diagonal block kb (lower triangle of A, already
+// carrying the updates of the block columns to its left) in LDS, write L back, its inverse to
+// Dinv[b][kb] (full 64 x 64, zeros above the diagonal) and into X's diagonal block, and
+// sum_j log L_jj to logd[b][kb].  A pivot <= 0 or NaN raises ST_NOT_PSD.
+__global__ void __launch_bounds__(256) k_chol_diag(double *A, int64_t np, int kb, double *Dinv, double *X,
+                                                   double *logd, int nblk, int *status)
+{
+    constexpr int NB = CH_NB, PITCH = NB + 1;
+    __shared__ double L[NB * PITCH];
+    __shared__ double Li[NB * PITCH];
+    __shared__ int bad;
+    const int64_t b = blockIdx.x;
+    const int tid = threadIdx.x;
+    double *Ab = A + b * np * np + ((int64_t)kb * NB) * np + (int64_t)kb * NB;
+    if (tid == 0) bad = 0;
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e / NB, j = e % NB;
+        L[i * PITCH + j] = (j <= i) ? Ab[(int64_t)i * np + j] : 0.0;
+    }
+    __syncthreads();
+    // right-looking, one column per round: pivot, scale the column, rank-1 update of the rest
+    for (int j = 0; j < NB; j++) {
+        const double d = L[j * PITCH + j];
+        if (!(d > 0.0)) {   // also NaN
+            if (tid == 0) bad = 1;
+        }
+        const double r = sqrt(d);
+        __syncthreads();
+        if (tid == 0) L[j * PITCH + j] = r;
+        for (int i = j + 1 + tid; i < NB; i += 256) L[i * PITCH + j] /= r;
+        __syncthreads();
+        // A[i][l] -= L[i][j] * L[l][j] for j < l <= i
+        for (int e = tid; e < NB * NB; e += 256) {
+            const int i = e / NB, l = e % NB;
+            if (l > j && l <= i) L[i * PITCH + l] = fma(-L[i * PITCH + j], L[l * PITCH + j], L[i * PITCH + l]);
+        }
+        __syncthreads();
+    }
+    // inverse by forward substitution, one column per thread: L . x = e_c
+    for (int e = tid; e < NB * PITCH; e += 256) Li[e] = 0.0;
+    __syncthreads();
+    if (tid < NB) {
+        const int c = tid;
+        for (int i = c; i < NB; i++) {
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int q = c; q < i; q++) s = fma(-L[i * PITCH + q], Li[q * PITCH + c], s);
+            Li[i * PITCH + c] = s / L[i * PITCH + i];
+        }
+    }
+    __syncthreads();
+    double *Db = Dinv + (b * nblk + kb) * NB * NB;
+    double *Xb = X + b * np * np + ((int64_t)kb * NB) * np + (int64_t)kb * NB;
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e / NB, j = e % NB;
+        if (j <= i) Ab[(int64_t)i * np + j] = L[i * PITCH + j];
+        Db[e] = Li[i * PITCH + j];
+        Xb[(int64_t)i * np + j] = Li[i * PITCH + j];
+    }
+    if (tid == 0) {
+        double s = 0.0;
+        for (int j = 0; j < NB; j++) s += log(L[j * PITCH + j]);
+        logd[b * nblk + kb] = s;
+        if (bad) atomicOr(status, ST_NOT_PSD);
+    }
+}
+
+// log_pdet[b] = 2 * sum_k logd[b][k], summed in block order
+__global__ void k_chol_logdet(const double *logd, int nblk, int64_t nbatch, double *out)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbatch) return;
+    double s = 0.0;
+    for (int k = 0; k < nblk; k++) s += logd[b * nblk + k];
+    out[b] = 2.0 * s;
+}
+
+int launch_chol_inverse(beatamd_ctx *ctx, int64_t nbatch, int64_t n, const double *C, double *W, double *log_pdet)
+{
+    if (nbatch == 0 || n == 0) return BEATAMD_OK;
+    BA_CHECK(C && W && log_pdet && nbatch > 0 && n > 0 && nbatch <= 65535, BEATAMD_EINVAL,
+             "chol_inverse: bad argument");
+    const int64_t np = (n + CH_NB - 1) / CH_NB * CH_NB;
+    const int nblk = (int)(np / CH_NB);
+    void *p = nullptr;
+    BA_TRY(ctx->get_scratch(SL_CHOL_A, (size_t)nbatch * np * np * 8, &p));
+    double *A = (double *)p;
+    BA_TRY(ctx->get_scratch(SL_CHOL_X, (size_t)nbatch * np * np * 8, &p));
+    double *X = (double *)p;
+    BA_TRY(ctx->get_scratch(SL_CHOL_D, (size_t)nbatch * nblk * CH_NB * CH_NB * 8, &p));
+    double *Dinv = (double *)p;
+    BA_TRY(ctx->get_scratch(SL_CHOL_T, (size_t)nbatch * CH_NB * np * 8, &p));
+    double *T = (double *)p;
+    BA_TRY(ctx->get_scratch(SL_CHOL_L, (size_t)nbatch * nblk * 8, &p));
+    double *logd = (double *)p;
+    ScopedTimer tm(ctx, "chol_inverse");
+    BA_HIP(hipMemsetAsync(X, 0, (size_t)nbatch * np * np * 8, ctx->stream));
+    {
+        const dim3 grid((unsigned)((np * np + 255) / 256), (unsigned)nbatch);
+        hipLaunchKernelGGL(k_chol_flip_pad, grid, dim3(256), 0, ctx->stream, C, n, np, A);
+    }
+    const int64_t sM = np * np;
+    for (int kb = 0; kb < nblk; kb++) {
+        hipLaunchKernelGGL(k_chol_diag, dim3((unsigned)nbatch), dim3(256), 0, ctx->stream, A, np, kb, Dinv, X,
+                           logd, nblk, ctx->d_status);
+        const int64_t r0 = (int64_t)(kb + 1) * CH_NB, below = np - r0;
+        if (below == 0) break;
+        GemmCall g;
+        // panel: A[r0:, kb] <- A[r0:, kb] . inv(L_kk)^T
+        g.A = A + r0 * np + (int64_t)kb * CH_NB; g.lda = np; g.sA = sM;
+        g.B = Dinv + (int64_t)kb * CH_NB * CH_NB; g.ldb = CH_NB; g.sB = (int64_t)nblk * CH_NB * CH_NB;
+        g.O = A + r0 * np + (int64_t)kb * CH_NB; g.ldo = np; g.sO = sM;
+        g.M = below; g.N = CH_NB; g.K = CH_NB; g.b_kn = 0; g.nbatch = (int)nbatch;
+        g.timer = nullptr;
+        BA_TRY(launch_gemm_f64(ctx, g));
+        // trailing update of the lower triangle: A[r0:, r0:] -= P . P^T with P = A[r0:, kb]
+        GemmCall u;
+        u.A = A + r0 * np + (int64_t)kb * CH_NB; u.lda = np; u.sA = sM;
+        u.B = u.A; u.ldb = np; u.sB = sM;
+        u.O = A + r0 * np + r0; u.ldo = np; u.sO = sM;
+        u.M = below; u.N = below; u.K = CH_NB; u.b_kn = 0; u.nbatch = (int)nbatch;
+        u.alpha = -1.0; u.accumulate = 1; u.lower_only = 1;
+        BA_TRY(launch_gemm_f64(ctx, u));
+    }
+    // X = inv(M) by row blocks (X's diagonal blocks are in place already)
+    for (int kb = 1; kb < nblk; kb++) {
+        const int64_t kc = (int64_t)kb * CH_NB;
+        GemmCall g;   // T = -M[kb, :kc] . X[:kc, :kc]
+        g.A = A + kc * np; g.lda = np; g.sA = sM;
+        g.B = X; g.ldb = np; g.sB = sM;
+        g.O = T; g.ldo = np; g.sO = (int64_t)CH_NB * np;
+        g.M = CH_NB; g.N = kc; g.K = kc; g.b_kn = 1; g.b_lower = 1; g.alpha = -1.0; g.nbatch = (int)nbatch;
+        BA_TRY(launch_gemm_f64(ctx, g));
+        GemmCall h;   // X[kb, :kc] = inv(L_kk) . T
+        h.A = Dinv + (int64_t)kb * CH_NB * CH_NB; h.lda = CH_NB; h.sA = (int64_t)nblk * CH_NB * CH_NB;
+        h.B = T; h.ldb = np; h.sB = (int64_t)CH_NB * np;
+        h.O = X + kc * np; h.ldo = np; h.sO = sM;
+        h.M = CH_NB; h.N = kc; h.K = CH_NB; h.b_kn = 1; h.nbatch = (int)nbatch;
+        BA_TRY(launch_gemm_f64(ctx, h));
+    }
+    {
+        const dim3 grid((unsigned)((n * n + 255) / 256), (unsigned)nbatch);
+        hipLaunchKernelGGL(k_chol_unflip, grid, dim3(256), 0, ctx->stream, (const double *)X, n, np, W);
+        hipLaunchKernelGGL(k_chol_logdet, dim3((unsigned)((nbatch + 63) / 64)), dim3(64), 0, ctx->stream,
+                           (const double *)logd, nblk, nbatch, log_pdet);
+    }
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
+}  // namespace beatamd

@@ -176,6 +176,10 @@ int beatamd_ctx::check_status()
             set_error("nucleation index outside the patch grid");
             return BEATAMD_EINVAL;
         }
+        if (st & ST_NOT_PSD) {
+            set_error("Matrix is not positive definite");   // numpy.linalg.LinAlgError's text
+            return BEATAMD_ENOTPSD;
+        }
     }
     return BEATAMD_OK;
 }

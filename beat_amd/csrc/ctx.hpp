@@ -43,7 +43,7 @@ void set_error(const char *fmt, ...);
     } while (0)
 
 // device status bits set by kernels (checked at synchronisation points)
-enum : int { ST_INDEX_OOB = 1, ST_BAD_HYPO = 2 };
+enum : int { ST_INDEX_OOB = 1, ST_BAD_HYPO = 2, ST_NOT_PSD = 4 };
 
 struct DevBuf {
     void *p = nullptr;
@@ -195,7 +195,8 @@ enum Slot : int {
     SL_OUT0, SL_OUT1, SL_OUT2,
     SL_ROWOFF, SL_WEIGHTS, SL_ST0, SL_RESID, SL_PARTIAL, SL_QUAD, SL_MU, SL_SLIPS,
     SL_QPROP, SL_LPROP, SL_MISC, SL_GS_UROWS, SL_GS_UCOUNT, SL_GS_SLOT, SL_GS_W, SL_GS_UMAX, SL_GS_USLOT,
-    SL_CHAINBAD, SL_Z, SL_ROWSCALE, SL_CUM, SL_STAGE2, SL_WHITEN, SL_COUNT
+    SL_CHAINBAD, SL_Z, SL_ROWSCALE, SL_CUM, SL_STAGE2, SL_WHITEN,
+    SL_CHOL_A, SL_CHOL_X, SL_CHOL_D, SL_CHOL_T, SL_CHOL_L, SL_COUNT
 };
 
 }  // namespace beatamd

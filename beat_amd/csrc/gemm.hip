@@ -31,6 +31,12 @@ struct GemmArgs {
     int64_t lda, ldb, ldo, M, N, K;
     int b_kn, b_upper, vec_ok;
     int ncb;
+    // batched / accumulating form used by the blocked factorisations (chol.hip)
+    int64_t sA, sB, sO;   // element strides between the matrices of a batch (blockIdx.y)
+    double alpha;         // O = alpha * (A . Bop) [+ O when accumulate]
+    int accumulate;
+    int lower_only;       // M x N output with M == N: tiles strictly above the diagonal are skipped
+    int b_lower;          // NN only: Bop[k, n] == 0 for k < n (lower-triangular B)
 };
 
 __device__ __forceinline__ void gm_load4(const double *p, int64_t k, int64_t K, bool ok, int vec_ok,
@@ -58,6 +64,10 @@ __global__ void __launch_bounds__(256) k_gemm_f64(GemmArgs a)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t i0 = rb * GM_BM, n0 = (int64_t)cb * GM_BN;
     const int64_t K = a.K;
+    if (a.lower_only && n0 > i0 + GM_BM - 1) return;
+    a.A += (int64_t)blockIdx.y * a.sA;
+    a.B += (int64_t)blockIdx.y * a.sB;
+    a.O += (int64_t)blockIdx.y * a.sO;
 
     // A tile [64 x 16]: thread -> row lr, 4 consecutive k
     const int lr = tid >> 2, lk = (tid & 3) * 4;
@@ -81,6 +91,7 @@ __global__ void __launch_bounds__(256) k_gemm_f64(GemmArgs a)
 
     int64_t kstart = 0;
     if (!B_KN && a.b_upper) kstart = (n0 / GM_KB) * GM_KB;
+    if (B_KN && a.b_lower) kstart = min((n0 / GM_KB) * GM_KB, ((K - 1) / GM_KB) * GM_KB);
     double av[4], bv[8];
     auto load_tile = [&](int64_t k0) {
         gm_load4(Ap, k0 + lk, K, a_ok, a.vec_ok, av);
@@ -135,7 +146,11 @@ __global__ void __launch_bounds__(256) k_gemm_f64(GemmArgs a)
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
             const int64_t col = n0 + j * 16 + (lane & 15);
-            if (col < a.N) a.O[row * a.ldo + col] = a.row_scale ? acc[j][r] * sc : acc[j][r];
+            if (col >= a.N) continue;
+            double o = a.row_scale ? acc[j][r] * sc : acc[j][r];
+            if (a.alpha != 1.0) o *= a.alpha;   // (alpha = +-1 in every caller: exact)
+            if (a.accumulate) o += a.O[row * a.ldo + col];
+            a.O[row * a.ldo + col] = o;
         }
     }
 }
@@ -151,15 +166,23 @@ int launch_gemm_f64(beatamd_ctx *ctx, const GemmCall &k)
     a.b_kn = k.b_kn;
     a.b_upper = k.b_kn ? 0 : k.b_upper;
     a.vec_ok = (k.lda % 2 == 0) && (k.ldb % 2 == 0) && (((uintptr_t)k.A | (uintptr_t)k.B) % 16 == 0);
+    a.sA = k.sA; a.sB = k.sB; a.sO = k.sO;
+    a.alpha = k.alpha; a.accumulate = k.accumulate;
+    a.lower_only = k.lower_only;
+    a.b_lower = k.b_kn ? k.b_lower : 0;
+    if (k.nbatch > 1)
+        a.vec_ok = a.vec_ok && (k.sA % 2 == 0) && (k.sB % 2 == 0);
     a.ncb = (int)((k.N + GM_BN - 1) / GM_BN);
     const int64_t nrb = (k.M + GM_BM - 1) / GM_BM;
     const int64_t nblocks = nrb * a.ncb;
     BA_CHECK(nblocks < (int64_t)0x7fffffff, BEATAMD_EINVAL, "gemm: too many tiles");
+    BA_CHECK(k.nbatch >= 1 && k.nbatch <= 65535, BEATAMD_EINVAL, "gemm: batch of %d", k.nbatch);
     ScopedTimer tm(ctx, k.timer ? k.timer : "gemm");
+    const dim3 grid((unsigned)nblocks, (unsigned)k.nbatch);
     if (k.b_kn)
-        hipLaunchKernelGGL(k_gemm_f64<1>, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(k_gemm_f64<1>, grid, dim3(256), 0, ctx->stream, a);
     else
-        hipLaunchKernelGGL(k_gemm_f64<0>, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(k_gemm_f64<0>, grid, dim3(256), 0, ctx->stream, a);
     BA_HIP(hipGetLastError());
     return BEATAMD_OK;
 }

@@ -137,8 +137,17 @@ struct GemmCall {
     int b_kn = 0;     // 0: Bop[k,n] = B[n*ldb + k] ("NT")   1: Bop[k,n] = B[k*ldb + n] ("NN")
     int b_upper = 0;  // NT only: B[n,k] == 0 for k < n
     const char *timer = nullptr;
+    // batched / accumulating form (chol.hip): O = alpha * A.Bop (+ O); matrices sA/sB/sO apart
+    int nbatch = 1;
+    int64_t sA = 0, sB = 0, sO = 0;
+    double alpha = 1.0;
+    int accumulate = 0;
+    int lower_only = 0;   // M == N: tiles strictly above the diagonal are skipped
+    int b_lower = 0;      // NN only: Bop[k,n] == 0 for k < n
 };
 int launch_gemm_f64(beatamd_ctx *ctx, const GemmCall &call);
+// chol.hip: W = cholesky(inv(C)).T and log det C of a stack of matrices (device pointers)
+int launch_chol_inverse(beatamd_ctx *ctx, int64_t nbatch, int64_t n, const double *C, double *W, double *log_pdet);
 
 // ---- smc.hip: sampler steps on the device
 int launch_smc_calc_beta(beatamd_ctx *ctx, int64_t n, const double *lik, int64_t stride, double beta,

@@ -458,6 +458,18 @@ class Context(object):
                                                               ptr(e), ptr(n), float(nu), ptr(out)))
         return out
 
+    def chol_inverse_batch(self, covs):
+        """covs (nd, n, n) -> (W (nd, n, n) upper triangular = cholesky(inv(C)).T, log_pdet (nd,));
+        numpy or torch-cuda in, same kind out; numpy.linalg.LinAlgError if not positive definite"""
+        if _is_dev(covs):
+            self._adopt_stream(covs)
+        C = f64(covs)
+        nd, n = int(C.shape[0]), int(C.shape[1])
+        W = _empty_like(C, (nd, n, n))
+        lp = _empty_like(C, (nd,))
+        check(self._lib.beatamd_chol_inverse_batch(self._h, nd, n, ptr(C), ptr(W), ptr(lp)))
+        return W, lp
+
     def whiten_rows(self, rows, W):
         """rows (R, N) device tensor, in place: rows <- rows . W^T"""
         self._adopt_stream(rows)

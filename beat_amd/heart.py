@@ -143,14 +143,12 @@ class Covariance(object):
 def chol_inverse_batch(covs, device=None):
     """(W (nd,n,n), log_pdet (nd,)) of a stack of covariances at once on the GPU -- what
     ``update_weights`` needs per stage for every dataset of a wavemap (seismic.py:1509-1534).
-    Library factorisations (torch.linalg = rocSOLVER) as per-stage set-up; results as numpy."""
-    import torch
-    dev = device if device is not None else torch.device("cuda", 0)
-    C = torch.as_tensor(np.ascontiguousarray(covs), dtype=torch.float64, device=dev)
-    L = torch.linalg.cholesky(C)
-    log_pdet = 2.0 * torch.log(torch.diagonal(L, dim1=1, dim2=2)).sum(1)
-    K = torch.linalg.cholesky(torch.cholesky_inverse(L))   # K K^T = inv(C); W = K^T
-    return K.transpose(1, 2).contiguous().cpu().numpy(), log_pdet.cpu().numpy()
+    ``beatamd_chol_inverse_batch`` (csrc/chol.hip): blocked factorisation of the exchange-flipped
+    matrices on the FP64 matrix cores; numpy in, numpy out."""
+    from .engine import get_context
+    dev_index = None if device is None else getattr(device, "index", device)
+    W, log_pdet = get_context(dev_index).chol_inverse_batch(np.ascontiguousarray(covs, dtype=np.float64))
+    return W, log_pdet
 
 
 # ------------------------------------------------------------------------------------------------

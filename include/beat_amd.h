@@ -35,6 +35,7 @@ extern "C" {
 #define BEATAMD_EINDEX (-3)   /* index outside the GF library (reference: numpy IndexError) */
 #define BEATAMD_ENOMEM (-4)
 #define BEATAMD_ENAN (-5)     /* non-finite likelihood at stage 0 (metropolis.py:279-284)  */
+#define BEATAMD_ENOTPSD (-6)  /* covariance not positive definite (numpy.linalg.LinAlgError) */
 
 #define BEATAMD_NEAREST_NEIGHBOR 0 /* interpolation="nearest_neighbor" */
 #define BEATAMD_MULTILINEAR 1      /* interpolation="multilinear"      */
@@ -305,6 +306,17 @@ int beatamd_metropolis_tune(beatamd_ctx *ctx, int64_t C, double *scaling, int32_
  * of the dataset instead of once per chain step (SeismicWavemap.prewhitened).  FP64 MFMA GEMM;
  * an upper-triangular W (heart.py:233) skips its zero half. */
 int beatamd_whiten_rows(beatamd_ctx *ctx, double *rows, int64_t nrows, int64_t N, const double *W);
+
+/* ---------------------------------------------------------------- whitening operator ------
+ * replaces: heart.Covariance.chol_inverse / .log_pdet                beat/heart.py:216-253
+ *           (numpy.linalg.inv + cholesky, + slogdet) for a stack of nd covariance matrices, as
+ *           update_weights needs them per stage for every dataset (seismic.py:1509-1534)
+ *   covs [nd,n,n] symmetric positive definite -> W [nd,n,n] = cholesky(inv(C)).T (upper
+ *   triangular), log_pdet [nd] = log det C.  Blocked factorisation of the exchange-flipped matrix
+ *   on the FP64 matrix cores (no explicit inverse of C).  A matrix that is not positive definite
+ *   is BEATAMD_ENOTPSD (numpy raises LinAlgError). */
+int beatamd_chol_inverse_batch(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *covs, double *W,
+                               double *log_pdet);
 
 /* ---------------------------------------------------------------- half-space synthetics ---
  * replaces: heart.geo_synthetics(engine, targets, sources, outmode)   beat/heart.py:4158-4239

@@ -707,6 +707,38 @@ def test_noise_covariance_estimators_vs_reference_golden(ctx):
         np.testing.assert_allclose(out[i], orc.non_toeplitz_covariance(data[i], 30), rtol=1e-12, atol=1e-14)
 
 
+@pytest.mark.parametrize("n", [1, 10, 64, 65, 130, 200, 520])
+def test_chol_inverse_batch_kernel(ctx, n):
+    """beatamd_chol_inverse_batch (blocked factorisation of the exchange-flipped matrix, FP64 MFMA
+    GEMMs) against numpy's route of the reference, heart.py:216-253: W = cholesky(inv(C)).T and
+    log_pdet; exponential (Toeplitz) and random covariances, sizes around the 64-blocking"""
+    rng = np.random.default_rng(n)
+    t = np.arange(n)
+    Cs = [np.exp(-np.abs(t[:, None] - t[None, :]) / 5.0) * 0.7 + 1e-3 * np.eye(n)]
+    A = rng.standard_normal((n, n + 3))
+    Cs.append(A @ A.T / (n + 3) + 0.1 * np.eye(n))
+    Cs.append(np.diag(rng.uniform(0.5, 2.0, n)))
+    Cs = np.stack(Cs)
+    W, lp = ctx.chol_inverse_batch(Cs)
+    for i in range(3):
+        ref = np.linalg.cholesky(np.linalg.inv(Cs[i])).T
+        assert np.array_equal(np.tril(W[i], -1), np.zeros((n, n)))          # upper triangular
+        np.testing.assert_allclose(W[i], ref, rtol=0, atol=1e-9 * np.abs(ref).max())
+        np.testing.assert_allclose(W[i].T @ W[i] @ Cs[i], np.eye(n), rtol=0, atol=1e-8)
+        np.testing.assert_allclose(lp[i], np.linalg.slogdet(Cs[i])[1], rtol=1e-11, atol=1e-10)
+    # device tensors in -> device tensors out
+    import torch
+    Wd, lpd = ctx.chol_inverse_batch(torch.from_numpy(Cs).to("cuda:0"))
+    assert Wd.is_cuda and np.array_equal(Wd.cpu().numpy(), W) and np.array_equal(lpd.cpu().numpy(), lp)
+    # not positive definite: numpy raises LinAlgError, so does the device path; the context stays usable
+    bad = Cs.copy()
+    bad[1, n // 2, n // 2] = -1.0
+    with pytest.raises(np.linalg.LinAlgError):
+        ctx.chol_inverse_batch(bad)
+    W2, _ = ctx.chol_inverse_batch(Cs)
+    assert np.array_equal(W2, W)
+
+
 def test_covariance_class_and_mvn_adaptor(ctx):
     """heart.Covariance interface + multivariate_normal_chol(datasets, weights, hyperparams,
     residuals) adaptor against the reference golden / scipy (test_models.py:149-222)"""
