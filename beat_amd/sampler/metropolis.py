@@ -83,7 +83,7 @@ class BatchedMetropolis(object):
     # -- resume support
     def state_dict(self):
         return dict(scaling=self.scaling.cpu().numpy(), n_steps_total=self.n_steps_total,
-                    steps_until_tune=self.steps_until_tune,
+                    steps_until_tune=self.steps_until_tune, seed=self.seed,
                     accepted_since_tune=self.accepted_since_tune.cpu().numpy())
 
     def load_state_dict(self, st, block=None):
@@ -94,3 +94,5 @@ class BatchedMetropolis(object):
             self.torch.from_numpy(np.asarray(st["accepted_since_tune"], dtype=np.int32)[sl]))
         self.n_steps_total = int(st["n_steps_total"])
         self.steps_until_tune = int(st["steps_until_tune"])
+        if "seed" in st:   # the proposal stream is keyed by (seed, step counter, chain)
+            self.seed = int(st["seed"])

@@ -179,7 +179,7 @@ def _dump_stage(step, homepath, layout, out_names, backend):
     rs = step.rng.get_state()
     np.savez(os.path.join(path, "sampler_state.npz"), beta=step.beta, old_beta=step.old_beta,
              stage=step.stage, population=pop, lpoints=lp, scaling=sc, accepted_since_tune=ac,
-             n_steps_total=st["n_steps_total"], steps_until_tune=st["steps_until_tune"],
+             n_steps_total=st["n_steps_total"], steps_until_tune=st["steps_until_tune"], seed=st["seed"],
              rng_keys=rs[1], rng_pos=rs[2], rng_has_gauss=rs[3], rng_cached=rs[4])
 
 
@@ -196,7 +196,9 @@ def load_stage(step, homepath, stage):
     if "scaling" in z.files and z["scaling"].size == step.n_chains:
         step.stepper.load_state_dict(dict(scaling=z["scaling"], accepted_since_tune=z["accepted_since_tune"],
                                           n_steps_total=z["n_steps_total"],
-                                          steps_until_tune=z["steps_until_tune"]), block=step.block)
+                                          steps_until_tune=z["steps_until_tune"],
+                                          **({"seed": z["seed"]} if "seed" in z.files else {})),
+                                     block=step.block)
     if "rng_keys" in z.files:
         step.rng.set_state(("MT19937", z["rng_keys"], int(z["rng_pos"]), int(z["rng_has_gauss"]),
                             float(z["rng_cached"])))

@@ -128,13 +128,15 @@ def test_smc_stage_traces_and_resume(tmp_path):
     ch = NumpyChain.load(os.path.join(stage_path(str(tmp_path), -1), "chain-5.bin"))
     np.testing.assert_array_equal(ch.get_values("x")[0], pop[5])
     assert ch.get_values("like")[0] == lp[5, 0]
-    # resume after stage 1: same remaining stage count (deterministic shared RNG differs, so only
-    # structure is compared)
+    # resume after stage 1 with a sampler seeded differently: the stage state (population, beta,
+    # per-chain step sizes and tuning counters, the shared random stream) is restored, so the
+    # resumed run repeats the uninterrupted one bit for bit
     step2 = SMC(HostTarget(f, n), -2 * np.ones(n), 2 * np.ones(n), n_chains=64, tune_interval=10,
                 random_seed=4)
     pop2, lp2, betas2 = smc_sample(20, step2, homepath=str(tmp_path), layout=None, resume_stage=1)
-    assert betas2[0] == betas[1] and betas2[-1] == 1.0 and pop2.shape == pop.shape
     assert nstage >= 2
+    assert betas2 == betas[1:]
+    assert np.array_equal(pop2, pop) and np.array_equal(lp2, lp)
 
 
 def test_host_proposal_draws_normal_and_cauchy_statistics():
