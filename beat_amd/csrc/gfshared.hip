@@ -1186,45 +1186,53 @@ k_gfstack_ws(GsArgs a)
         const char *const ps2 = tab_slot(p1), *const pw2 = tab_w(p1, iv1);   // tables of step s+2
         advance(p1, iv1);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int gq = 0; gq < NG8 - 2; gq++) {
-            double(&cur)[8] = (gq & 1) ? yb : ya;
-            lds_wait8_b64<8>(cur);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < 8; q++) acc[gq * 8 + q] = fma(cur[q], w, acc[gq * 8 + q]);
-            __builtin_amdgcn_sched_barrier(0);
-            switch (gq + 2) {
-            case 2: lds_rd8_b64<128>(cur, xs, s); break;
-            case 3: lds_rd8_b64<192>(cur, xs, s); break;
-            case 4: lds_rd8_b64<256>(cur, xs, s); break;
-            case 5: lds_rd8_b64<320>(cur, xs, s); break;
-            case 6: lds_rd8_b64<384>(cur, xs, s); break;
-            default: lds_rd8_b64<448>(cur, xs, s); break;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // group 6: every read of this step is back once both groups have landed
-        lds_wait8_b64<0>(ya);
-        lds_wait8_b64<0>(yb);
+        // One asm statement per gather group: wait for the group's reads, its 8 FMAs, and the reads
+        // of the group after next into the registers just consumed (v_fmac_f64 d, x, w = fma(x, w, d)).
+#define BA_FMA8 \
+    "v_fmac_f64 %0, %8, %16\n\tv_fmac_f64 %1, %9, %16\n\tv_fmac_f64 %2, %10, %16\n\tv_fmac_f64 %3, %11, %16\n\t" \
+    "v_fmac_f64 %4, %12, %16\n\tv_fmac_f64 %5, %13, %16\n\tv_fmac_f64 %6, %14, %16\n\tv_fmac_f64 %7, %15, %16\n\t"
+#define BA_RD8(OFF) \
+    "ds_read_b64 %8, %17 offset:" #OFF "\n\tds_read_b64 %9, %17 offset:" #OFF "+8\n\t" \
+    "ds_read_b64 %10, %17 offset:" #OFF "+16\n\tds_read_b64 %11, %17 offset:" #OFF "+24\n\t" \
+    "ds_read_b64 %12, %17 offset:" #OFF "+32\n\tds_read_b64 %13, %17 offset:" #OFF "+40\n\t" \
+    "ds_read_b64 %14, %17 offset:" #OFF "+48\n\tds_read_b64 %15, %17 offset:" #OFF "+56"
+#define BA_ACC8(G) \
+    "+v"(acc[G * 8]), "+v"(acc[G * 8 + 1]), "+v"(acc[G * 8 + 2]), "+v"(acc[G * 8 + 3]), "+v"(acc[G * 8 + 4]), \
+        "+v"(acc[G * 8 + 5]), "+v"(acc[G * 8 + 6]), "+v"(acc[G * 8 + 7])
+#define BA_Y8(Y) "+v"(Y[0]), "+v"(Y[1]), "+v"(Y[2]), "+v"(Y[3]), "+v"(Y[4]), "+v"(Y[5]), "+v"(Y[6]), "+v"(Y[7])
+#define BA_GROUP(G, Y, OFFNEXT) \
+    asm("s_waitcnt lgkmcnt(8)\n\t" BA_FMA8 BA_RD8(OFFNEXT) : BA_ACC8(G), BA_Y8(Y) : "v"(w), "v"(xs))
+        BA_GROUP(0, ya, 128);
+        BA_GROUP(1, yb, 192);
+        BA_GROUP(2, ya, 256);
+        BA_GROUP(3, yb, 320);
+        BA_GROUP(4, ya, 384);
+        BA_GROUP(5, yb, 448);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 8; q++) acc[48 + q] = fma(ya[q], w, acc[48 + q]);
+        // group 6: every read of this step is back once both groups in flight have landed
+        // (yb is named so that group 7 stays behind this wait)
+        asm("s_waitcnt lgkmcnt(0)\n\t" BA_FMA8
+            : BA_ACC8(6), BA_Y8(ya) : "v"(w), "v"(xs), "v"(yb[0]), "v"(yb[1]), "v"(yb[2]), "v"(yb[3]),
+              "v"(yb[4]), "v"(yb[5]), "v"(yb[6]), "v"(yb[7]));
         __builtin_amdgcn_sched_barrier(0);
         gbuf = gnext;
-        xs = row_address(lds0 + (uint32_t)(gbuf * 8));   // slot / weight of step s+1 have landed
+        const uint32_t xs_n = row_address(lds0 + (uint32_t)(gbuf * 8));   // slot / weight of step s+1 have landed
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();   // rows of step s+1 visible; this wavefront is done with buffer s
         __builtin_amdgcn_sched_barrier(0);
-        lds_rd8_b64<0>(ya, xs, s);      // first group of step s+1 (after the last step: unused rows)
+        lds_rd8_b64<0>(ya, xs_n, s);    // first group of step s+1 (after the last step: unused rows)
         __builtin_amdgcn_sched_barrier(0);
-        // group 7 with the weight of step s, then the weight of step s+1
-#pragma unroll
-        for (int q = 0; q < 8; q++) acc[56 + q] = fma(yb[q], w, acc[56 + q]);
+        // group 7 with the weight of step s, then the weight of step s+1 and that step's second group
+        asm(BA_FMA8
+            "v_mov_b64 %16, %18\n\t" BA_RD8(64)
+            : BA_ACC8(7), BA_Y8(yb), "+v"(w) : "v"(xs_n), "v"(wl_n));
+        xs = xs_n;
         __builtin_amdgcn_sched_barrier(0);
-        w = landed_weight(xs);
-        lds_rd8_b64<64>(yb, xs, s);
-        __builtin_amdgcn_sched_barrier(0);
+#undef BA_GROUP
+#undef BA_Y8
+#undef BA_ACC8
+#undef BA_RD8
+#undef BA_FMA8
         fetch_tabs(ps2, pw2);           // slot / weight of step s+2
     }
     // drain the reads issued for the step after the last (their registers stay reserved until here)
