@@ -152,6 +152,8 @@ struct beatamd_ctx {
     char last_gf_kernel[96] = "";
     // distinct-row statistics of the most recent chain-shared launch (bench.py roofline leg)
     int64_t gs_ngtp = 0, gs_N = 0, gs_trep = 1;   // trep: targets served by one table cell
+    // measured chains-per-workgroup choice per problem shape: key -> (group size, row bound)
+    std::map<std::vector<int64_t>, std::pair<int, int>> gs_tuned;
     int gs_cg = 0;
 
     // grow-only scratch slot

@@ -34,8 +34,6 @@ namespace beatamd {
 
 constexpr int GS_NT_MAX = 64;         // samples per tile (per lane: that many accumulators)
 constexpr int GS_WS_DEFAULT = 1;      // wave-specialised kernel for 512-chain groups unless BEATAMD_GS_WS says otherwise
-constexpr int GS_INTL_DEFAULT = 0;    // row requests interleaved with the gather unless BEATAMD_GS_INTL says otherwise
-constexpr int GS_DEEP_DEFAULT = 0;    // DMA pipeline depth of k_gfstack_dma unless BEATAMD_GS_DEEP says otherwise
 
 struct GroupTabArgs {
     int nrow, nvar, CG;
@@ -226,8 +224,6 @@ struct GsArgs {
     int CG, ucap, ustride, ntile, nt;
     int dma;  // 1: k_gfstack_dma (two LDS row buffers filled by LDS-DMA)
     int ws;            // k_gfstack_ws: 8 consumer + 4 loader wavefronts, three row buffers
-    int intl;          // k_gfstack_dma: row requests issued inside the gather, one list entry per group
-    int deep;          // k_gfstack_dma: 0 two row buffers / 1 three buffers, rows two steps ahead / 2 + staggered issue
     int xcd_order;     // k_gfstack_dma: chain groups of a (target, tile) share an XCD
     int64_t ngroups;
     // tables per (group, target, patch), or per (group, patch) when the start times do not depend
@@ -508,26 +504,14 @@ __device__ __forceinline__ void lds_wait8_b64(double (&x)[8])
 // while the other sits in its barrier / DMA-issue phase) or one 16-wavefront workgroup = 1024-chain
 // groups (every distinct row staged once for twice the chains).
 //
-// DEEP = 1, 2: three LDS row buffers, the rows of step s+2 are requested during step s.  With the
-// population of SURVEY 8(d) a 512-chain group stages ~39 distinct rows (20 KB) per step; a CU's
-// share of the HBM stream (~11 B/clk) needs longer than one gather phase for that, so with one step
-// of run-ahead every step ended waiting for its own row requests (8.1 ms per launch, measured).
-// Two steps of run-ahead keep requests in flight all the time.  The step-top wait must then leave
-// the youngest requests (step s+2's, a per-step VARIABLE number) outstanding while covering the
-// slot/weight loads issued just before them: s_waitcnt takes an immediate, hence the switch over
-// the number of row requests this wavefront issued (an over-wait is always safe).
-// DEEP = 2: the odd wavefronts issue their row requests after their gather instead of before it,
-// so that half of the workgroup feeds the LDS pipe while the other half is in its issue phase.
-// INTL = 1: the row requests of the coming step are not issued in a block in front of the gather
-// (8 wavefronts doing scalar address work at the same time while the LDS pipe idles) but one list
-// entry per gather group, in the shadow of that group's LDS reads.
-template <int WAVES, int NROW, int MODE, int NT, int B64, int DEEP = 0, int INTL = 0>
+// (Three row buffers with requests two steps ahead, and requests issued inside the gather, were
+// tried in this kernel and measured slower -- profiles/r2_variants.md; the deeper pipeline lives
+// in k_gfstack_ws, where other wavefronts do the issue work.)
+template <int WAVES, int NROW, int MODE, int NT, int B64>
 __global__ void __launch_bounds__(WAVES * 64)
     __attribute__((amdgpu_waves_per_eu(NT == 64 ? 2 : 4, NT == 64 ? 2 : 4)))
 k_gfstack_dma(GsArgs a)
 {
-    static_assert(DEEP == 0 || B64 == 1, "the three-buffer pipeline exists for the ds_read_b64 layout");
-    static_assert(INTL == 0 || B64 == 1, "interleaved issue exists for the ds_read_b64 layout");
     constexpr int GS_NT = NT;
     constexpr int GS_PITCH = B64 ? NT + 1 : NT + 2;
     constexpr int LPR = NT / 2;         // lanes moving one row segment (16 B each)
@@ -599,28 +583,6 @@ k_gfstack_dma(GsArgs a)
             "global_load_lds_dwordx4 %1, %2"
             : "+s"(tk) : "v"(voff), "s"(rowp), "s"(dst), "v"(dep));
     };
-    // distinct-row count + this wavefront's first KPRE row ids of step s (wave-uniform)
-    // the same request without control flow (INTL): lanes chosen through EXEC inside the statement;
-    // an invalid list entry runs with EXEC = 0 (no memory access, padded ids are valid addresses).
-    // The loop runs with all lanes active, so EXEC is restored to -1.
-    uint32_t keep_s = 0;
-    const uint64_t dma_mask = __ballot(dma_lane);
-    auto dma_row_masked = [&](const double *Gv, uint32_t r, uint32_t slotidx, int boff, bool valid,
-                              uint32_t dep) {
-        const uint64_t off = (uint64_t)r * (uint64_t)rowbytes;
-        const char *rowp = reinterpret_cast<const char *>(Gv) + off;
-        const uint32_t dst = lds0 + (uint32_t)(boff * 8) + slotidx * (uint32_t)(GS_PITCH * 8);
-        const uint64_t mk = valid ? dma_mask : 0ull;
-        uint32_t tok;
-        asm("s_mov_b64 exec, %4\n\t"
-            "s_mov_b32 m0, %3\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, %2\n\t"
-            "s_mov_b64 exec, -1\n\t"
-            "s_mov_b32 %0, 0"
-            : "=s"(tok) : "v"(voff), "s"(rowp), "s"(dst), "s"(mk), "v"(dep));
-        keep_s |= tok;
-    };
     // (row id, LDS slot) of this wavefront's first KPRE list entries: contiguous in memory, one
     // scalar load instruction (the gather's lgkmcnt waits count scalar loads too)
     struct alignas(KPRE * 8) EntBlock { uint32_t v[2 * KPRE]; };
@@ -688,29 +650,16 @@ k_gfstack_dma(GsArgs a)
         }
     };
 
-    // number of row requests wavefront `wave` issues for a step with U distinct rows
-    auto dma_count = [&](int U) { return U > wave ? (U - wave + WAVES - 1) / WAVES : 0; };
     int p1 = 0, iv1 = 0;          // step s+1
     advance(p1, iv1);
     int p2 = p1, iv2 = iv1;       // step s+2
     advance(p2, iv2);
-    int p3 = p2, iv3 = iv2;       // step s+3 (DEEP)
-    advance(p3, iv3);
     int U_a;
     uint32_t rid_a[KPRE], rsl_a[KPRE];
-    int k_young = 0;              // DEEP: row requests issued after the youngest slot/weight loads
-    int boff0 = 0, boff1 = bufsz, boff2 = 2 * bufsz;   // DEEP: buffers of steps s, s+1, s+2 (doubles)
     fetch_ids(0, 0, U_a, rid_a, rsl_a);
     issue_rows(0, 0, 0, U_a, rid_a, rsl_a);
     fetch_tabs(0, 0);
     fetch_ids(p1, iv1, U_a, rid_a, rsl_a);
-    if (DEEP) {
-        if (nsteps > 1) {
-            issue_rows_dep(p1, iv1, boff1, U_a, rid_a, rsl_a, sl_n[0]);
-            k_young = dma_count(U_a);
-        }
-        fetch_ids(p2, iv2, U_a, rid_a, rsl_a);
-    }
     for (int s = 0; s < nsteps; s++) {
         // the tables of this step and (older) the DMA of this step's rows have landed
         __builtin_amdgcn_sched_barrier(0);
@@ -724,63 +673,19 @@ k_gfstack_dma(GsArgs a)
                 "v_mov_b32 %0, %2\n\t"                                                          \
                 "v_mov_b64 %1, %3"                                                              \
                 : "=&v"(sl[k]), "=&v"(wl[k]) : "v"(sl_n[k]), "v"(wl_n[k]))
-        if (DEEP) {
-            // at most k_young row requests (the ones of step s+1, issued after this step's
-            // slot/weight loads) may stay in flight
-            switch (k_young) {
-            case 0: BA_WAIT_COPY(0); break;
-            case 1: BA_WAIT_COPY(1); break;
-            case 2: BA_WAIT_COPY(2); break;
-            case 3: BA_WAIT_COPY(3); break;
-            case 4: BA_WAIT_COPY(4); break;
-            case 5: BA_WAIT_COPY(5); break;
-            case 6: BA_WAIT_COPY(6); break;
-            case 7: BA_WAIT_COPY(7); break;
-            default: BA_WAIT_COPY(8); break;
-            }
-        } else {
-            BA_WAIT_COPY(0);
-        }
+        BA_WAIT_COPY(0);
 #undef BA_WAIT_COPY
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();  // rows of step s visible; everyone has left the FMA phase of step s-1
         __builtin_amdgcn_sched_barrier(0);
-        const bool late_issue = (DEEP == 2) && (wave & 1);
-        // rows requested during this step: step s+1 -> the other buffer, or (DEEP) step s+2 -> the
-        // third buffer; (p_i, iv_i), target buffer and whether there is such a step
-        const int p_i = DEEP ? p2 : p1;
-        const int boff_i = DEEP ? boff2 : ((s + 1) & 1) * bufsz;
-        const bool have_i = DEEP ? (s + 2 < nsteps) : (s + 1 < nsteps);
-        const double *const Gv_i = G_a;
-        if (INTL) {
-            fetch_tabs(p1, iv1);      // slot/weight of step s+1 first; requests follow in the gather
-            if (have_i && U_a > KPRE * WAVES && dma_lane) {   // rare: beyond the prefetched entries
-                const uint32_t *ue = reinterpret_cast<const uint32_t *>(ent_base + (uint32_t)p_i * ent_step);
-                uint32_t tk = 0;
-                for (int e = KPRE; wave + e * WAVES < U_a; e++)
-                    dma_row(Gv_i, ue[2 * e], ue[2 * e + 1], boff_i, sl_n[0], tk);
-                keep |= tk;
-            }
-        } else if (!DEEP) {
-            if (have_i) issue_rows(p1, iv1, (s + 1) & 1, U_a, rid_a, rsl_a);   // -> other buffer
-            fetch_tabs(p1, iv1);
-            fetch_ids(p2, iv2, U_a, rid_a, rsl_a);
-            p1 = p2; iv1 = iv2;
-            advance(p2, iv2);
-        } else {
-            // slot/weight of step s+1 FIRST, then the rows of step s+2 -> third buffer
-            fetch_tabs(p1, iv1);
-            if (!late_issue) {
-                k_young = 0;
-                if (have_i) {
-                    issue_rows_dep(p2, iv2, boff2, U_a, rid_a, rsl_a, sl_n[0]);
-                    k_young = dma_count(U_a);
-                }
-                fetch_ids(p3, iv3, U_a, rid_a, rsl_a);
-            }
-        }
+        // rows of step s+1 -> the other buffer, then that step's slot/weight and the ids of step s+2
+        if (s + 1 < nsteps) issue_rows(p1, iv1, (s + 1) & 1, U_a, rid_a, rsl_a);
+        fetch_tabs(p1, iv1);
+        fetch_ids(p2, iv2, U_a, rid_a, rsl_a);
+        p1 = p2; iv1 = iv2;
+        advance(p2, iv2);
         __builtin_amdgcn_sched_barrier(0);
-        const int gbuf = DEEP ? boff0 : (s & 1) * bufsz;   // doubles: the buffer of step s
+        const int gbuf = (s & 1) * bufsz;   // doubles: the buffer of step s
         // ---- every lane applies ITS rows with ITS weights.  The 2*NT/4 ds_read_b128 of a row
         // are issued by hand in groups of 8, two groups in flight (hipcc keeps 3-4 reads in
         // flight, which leaves the phase bound by LDS latency instead of LDS throughput); the
@@ -813,15 +718,6 @@ k_gfstack_dma(GsArgs a)
                     default: break;
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (INTL && k == 0) {
-                        // list entries gq*SPG .. of this wavefront, behind the group's LDS reads
-                        constexpr int SPG = (KPRE + NG8 - 1) / NG8;
-#pragma unroll
-                        for (int e = gq * SPG; e < (gq + 1) * SPG && e < KPRE; e++)
-                            dma_row_masked(Gv_i, rid_a[e], rsl_a[e], boff_i,
-                                           have_i && wave + e * WAVES < U_a, sl_n[0]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
                 }
             } else {
             constexpr int NG = GS_NT / 16;   // groups of 8 reads = 16 samples
@@ -848,39 +744,18 @@ k_gfstack_dma(GsArgs a)
             }
             }
         }
-        if (INTL) {
-            // (no control flow behind the gather: hipcc sinks the FMAs of the whole gather into a
-            // block that follows it, and with them 64 live LDS operands -> 256 VGPRs and spills)
-            __builtin_amdgcn_sched_barrier(0);
-            k_young = have_i ? dma_count(U_a) : 0;
-            if (!DEEP) {
-                fetch_ids(p2, iv2, U_a, rid_a, rsl_a);
-                p1 = p2; iv1 = iv2;
-                advance(p2, iv2);
-            } else {
-                fetch_ids(p3, iv3, U_a, rid_a, rsl_a);
-            }
-        }
-        if (DEEP) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (late_issue) {
-                k_young = 0;
-                if (s + 2 < nsteps) {
-                    issue_rows_dep(p2, iv2, boff2, U_a, rid_a, rsl_a, sl_n[0]);
-                    k_young = dma_count(U_a);
-                }
-                fetch_ids(p3, iv3, U_a, rid_a, rsl_a);
-            }
-            const int b0 = boff0;
-            boff0 = boff1; boff1 = boff2; boff2 = b0;
-            p1 = p2; iv1 = iv2;
-            p2 = p3; iv2 = iv3;
-            advance(p3, iv3);
-        }
     }
+    // The slot/weight loads issued in the last step (for the step after the last) are still in
+    // flight: wait for them before their registers can be given to anything else.  Without this the
+    // epilogue's store addresses were built in those registers and overwritten by the late data
+    // (observed as a memory fault with RESID_STORE and >= 29 groups; tools/audit_hidden_loads.py
+    // now follows the loop's exit paths as well).
+#pragma unroll
+    for (int k = 0; k < NROW; k++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(sl_n[k]), "+v"(wl_n[k]));
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- epilogue: lane = chain c, acc[i] = synthetics[c, t, n0 + i]
-    const bool live = (c < a.C) && (keep == 0) && (keep_s == 0);
+    const bool live = (c < a.C) && (keep == 0);
     const int nvalid = (int)min((int64_t)GS_NT, N - n0);
     if (MODE == GF_STORE_SYN) {
         if (live) {
@@ -1294,9 +1169,6 @@ static void launch_shared_one(dim3 grid, size_t lds, hipStream_t s, const GsArgs
         kern = k_gfstack_dma<WAVES, NROW, MODE, 32, 1>;   // 1024-chain groups exist as NT = 32 only
     } else {
         kern = (a.dma == 2 && a.nt == 32) ? k_gfstack_dma<WAVES, NROW, MODE, 32, 1>
-             : (a.dma == 2 && a.deep == 1 && a.intl) ? k_gfstack_dma<WAVES, NROW, MODE, 64, 1, 1, 1>
-             : (a.dma == 2 && a.intl) ? k_gfstack_dma<WAVES, NROW, MODE, 64, 1, 0, 1>
-             : (a.dma == 2 && a.deep == 1) ? k_gfstack_dma<WAVES, NROW, MODE, 64, 1, 1>
              : (a.dma == 2) ? k_gfstack_dma<WAVES, NROW, MODE, 64, 1>
              : a.dma ? k_gfstack_dma<WAVES, NROW, MODE, 64, 0>
              : (a.nt == 48) ? k_gfstack_shared<WAVES, NROW, MODE, 48>
@@ -1351,6 +1223,34 @@ static int pick_group(int64_t C)
         if (c < bestc - 1e-12) { bestc = c; best = cand[i]; }
     }
     return best;
+}
+
+// the distinct-row bound of chain groups of `cg`, or false when their row buffers or the table
+// kernel's maps do not fit LDS
+static bool shared_fit(const GfStackCall &k, int cg, int *ucap_out)
+{
+    const SeisLib &L = *k.libs[0];
+    const int nrow = k.interp == BEATAMD_MULTILINEAR ? 4 : 1;
+    const int64_t DS = L.D * L.S;
+    const int64_t ucap = std::min<int64_t>((int64_t)cg * nrow, DS);
+    if (ucap * (GS_NT_MAX + 2) * 8 > 150 * 1024) return false;
+    if (2 * DS * 4 + cg * 4 + 2048 > 60 * 1024) return false;
+    *ucap_out = (int)std::max<int64_t>(ucap, 2);
+    return true;
+}
+
+// group sizes worth timing for this call (gfstack.hip tunes the choice once per problem shape)
+int gfstack_shared_candidates(const GfStackCall &k, int *cgs, int *ucaps)
+{
+    int n = 0;
+    const int cand[4] = {512, 256, 128, 64};
+    for (int i = 0; i < 4; i++) {
+        // a group size that would leave more than half of its lanes without a chain only pads
+        if (cand[i] > 64 && (int64_t)cand[i] / 2 >= k.C) continue;
+        int u = 0;
+        if (shared_fit(k, cand[i], &u)) { cgs[n] = cand[i]; ucaps[n] = u; n++; }
+    }
+    return n;
 }
 
 bool gfstack_shared_applicable(const GfStackCall &k, int *cg_out, int *ucap_out)
@@ -1498,23 +1398,9 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
                                         lds = (size_t)ucap * (a.nt + 2) * sizeof(double); a.dma = 0; }
         BA_CHECK(CG != 1024 || a.dma == 2, BEATAMD_EINVAL, "gfstack: 1024-chain groups need the LDS-DMA kernel");
         BA_CHECK(!ga.windowed || a.dma == 2, BEATAMD_EINVAL, "internal: window slots need the ds_read_b64 kernel");
-        // three row buffers (rows requested two steps ahead) when they fit
-        const char *d = getenv("BEATAMD_GS_DEEP");
-        a.deep = 0;
-        if (a.dma == 2 && a.nt == 64 && CG <= 512 && 3 * lds <= 158 * 1024) {
-            a.deep = GS_DEEP_DEFAULT;
-            // (DEEP = 2, staggered issue by a run-time wavefront test, is not instantiated: hipcc
-            // spills there and reuses registers of in-flight asm loads -- tools/audit_hidden_loads.py)
-            if (d && atoi(d) >= 0 && atoi(d) <= 1) a.deep = atoi(d);
-        }
-        {
-            const char *ei = getenv("BEATAMD_GS_INTL");
-            a.intl = (a.dma == 2 && a.nt == 64 && CG <= 512) ? GS_INTL_DEFAULT : 0;
-            if (ei && a.dma == 2 && a.nt == 64 && CG <= 512) a.intl = atoi(ei) ? 1 : 0;
-        }
         a.ws = (use_ws && a.dma == 2) ? ws_nb : 0;
-        if (a.ws) { a.deep = 0; a.intl = 0; lds = (size_t)ucap * (a.nt + 1) * sizeof(double) * a.ws; }
-        else if (a.dma) lds *= (a.deep ? 3 : 2);
+        if (a.ws) lds = (size_t)ucap * (a.nt + 1) * sizeof(double) * a.ws;
+        else if (a.dma) lds *= 2;
     }
     {
         // chain groups of one (target, tile) on one XCD (several groups only)
@@ -1525,9 +1411,6 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     }
     if (a.ws)
         snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack_ws<%d,%d,%d>", nrow, k.mode, a.ws);
-    else if (a.deep || a.intl)
-        snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), a.intl ? "k_gfstack_dma<%d,%d,%d,%d,1,%d,1>"
-                 : "k_gfstack_dma<%d,%d,%d,%d,1,%d>", CG / 64, nrow, k.mode, a.nt, a.deep);
     else
         snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "%s<%d,%d,%d,%d,%d>",
                  a.dma ? "k_gfstack_dma" : "k_gfstack_shared", CG / 64, nrow, k.mode, a.nt, a.dma == 2 ? 1 : 0);

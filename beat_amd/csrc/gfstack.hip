@@ -363,8 +363,48 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &k)
 
     {
         int cg = 0, ucap = 0;
-        if (gfstack_shared_applicable(k, &cg, &ucap))
+        if (gfstack_shared_applicable(k, &cg, &ucap)) {
+            // Chains per workgroup: which size is fastest depends on the library (distinct rows a
+            // group can share, D*S), the batch and the population, so it is MEASURED once per
+            // problem shape -- every candidate is launched on the real inputs (the kernels are
+            // bitwise equal for every group size, the outputs are simply rewritten) and the
+            // fastest is kept.  BEATAMD_GS_CG fixes the size, BEATAMD_GS_TUNE=0 uses the static
+            // table of pick_group (measured on config 3).
+            const bool tune = !getenv("BEATAMD_GS_CG") &&
+                              !(getenv("BEATAMD_GS_TUNE") && atoi(getenv("BEATAMD_GS_TUNE")) == 0);
+            if (tune) {
+                const std::vector<int64_t> key = {k.C, nrow, k.nvar, k.mode, L.T, L.P, L.D, L.S, L.N, Ttab};
+                auto it = ctx->gs_tuned.find(key);
+                if (it == ctx->gs_tuned.end()) {
+                    int cgs[4], ucaps[4];
+                    const int nc = gfstack_shared_candidates(k, cgs, ucaps);
+                    int best = -1;
+                    float best_ms = 0.f;
+                    hipEvent_t e0, e1;
+                    BA_HIP(hipEventCreate(&e0));
+                    BA_HIP(hipEventCreate(&e1));
+                    for (int i = 0; i < nc && nc > 1; i++) {
+                        float ms_min = 0.f;
+                        for (int rep = 0; rep < 3; rep++) {   // first launch of a size: warm-up
+                            BA_HIP(hipEventRecord(e0, ctx->stream));
+                            BA_TRY(launch_gfstack_shared(ctx, k, ta.rowoff, ta.fac, cgs[i], ucaps[i], Ttab));
+                            BA_HIP(hipEventRecord(e1, ctx->stream));
+                            BA_HIP(hipEventSynchronize(e1));
+                            float ms = 0.f;
+                            BA_HIP(hipEventElapsedTime(&ms, e0, e1));
+                            if (rep == 1 || (rep == 2 && ms < ms_min)) ms_min = ms;
+                        }
+                        if (best < 0 || ms_min < best_ms) { best = i; best_ms = ms_min; }
+                    }
+                    (void)hipEventDestroy(e0);
+                    (void)hipEventDestroy(e1);
+                    if (nc == 1) best = 0;
+                    if (best >= 0) it = ctx->gs_tuned.emplace(key, std::make_pair(cgs[best], ucaps[best])).first;
+                }
+                if (it != ctx->gs_tuned.end()) { cg = it->second.first; ucap = it->second.second; }
+            }
             return launch_gfstack_shared(ctx, k, ta.rowoff, ta.fac, cg, ucap, Ttab);
+        }
     }
 
     GfArgs a;

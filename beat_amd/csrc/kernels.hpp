@@ -57,6 +57,7 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &call);
 int launch_sum_tiles(beatamd_ctx *ctx, const double *partial, int64_t n, int ntile, double *quad);
 // gfshared.hip: chain-shared variant (distinct rows staged once per chain group)
 bool gfstack_shared_applicable(const GfStackCall &call, int *cg, int *ucap);
+int gfstack_shared_candidates(const GfStackCall &call, int *cgs, int *ucaps);
 int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &call, const uint32_t *rowoff,
                           const double *fac, int CG, int ucap, int64_t Ttab);
 

@@ -175,17 +175,34 @@ def test_isa_audit_of_hidden_asm_loads(tmp_path):
         "audit_hidden_loads", os.path.join(os.path.dirname(__file__), "..", "tools", "audit_hidden_loads.py"))
     aud = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(aud)
-    gather = ["ds_read_b64 v[40:41], v1 offset:%d" % (8 * i) for i in range(40)]   # marks the step loop
-    bad = [".LBB0_1:", "s_waitcnt vmcnt(0)", "s_barrier", "global_load_ushort v9, v[2:3], off",
-           "global_load_dwordx2 v[4:5], v[6:7], off"] + gather + \
-          ["v_fma_f64 v[10:11], v[12:13], v[14:15], v[10:11]", "s_cbranch_scc1 .LBB0_1", "s_endpgm"]
-    n, problems = aud.audit(bad)
+    gather = ["ds_read_b64 v[40:41], v1 offset:%d" % (8 * i) for i in range(40)]
+    loop = [".LBB0_1:", "s_waitcnt vmcnt(0)", "s_barrier", "global_load_ushort v9, v[2:3], off",
+            "global_load_dwordx2 v[4:5], v[6:7], off"] + gather + \
+           ["v_fma_f64 v[10:11], v[12:13], v[14:15], v[10:11]", "s_cbranch_scc1 .LBB0_1"]
+    hidden = lambda body: [ln.startswith("global_load_") for ln in body]   # the asm-statement lines
+    ok = loop + ["s_waitcnt vmcnt(0)", "v_mov_b32_e32 v9, v1", "s_endpgm"]
+    n, problems = aud.audit(ok, hidden(ok))
     assert n == 2 and not problems
+    bad = list(ok)
     bad.insert(0, "v_mov_b32_e32 v20, v9")          # before the loop: not on the path
     bad.insert(2, "v_mov_b64_e32 v[30:31], v[4:5]")  # at the loop header, before the wait
-    n, problems = aud.audit(bad)
+    n, problems = aud.audit(bad, hidden(bad))
     assert len(problems) == 1 and "v[30:31]" in problems[0][3]
-    # three-buffer variants: a row request in front of the slot/weight loads of its step is flagged
+    # the way OUT of the loop: the loads of the step after the last are in flight behind the loop
+    # (the round-2 fault of k_gfstack_dma: store addresses built in those registers)
+    leak = loop + ["v_lshl_add_u64 v[4:5], v[60:61], 0, s[2:3]", "global_store_dwordx2 v[4:5], v[10:11], off",
+                   "s_endpgm"]
+    n, problems = aud.audit(leak, hidden(leak))
+    assert len(problems) == 1 and "v_lshl_add_u64" in problems[0][3]
+    # a conditional skip around the only wait is followed too
+    skip = loop + ["s_cbranch_execz .LBB0_2", "s_waitcnt vmcnt(0)", ".LBB0_2:", "v_mov_b32_e32 v9, v1", "s_endpgm"]
+    n, problems = aud.audit(skip, hidden(skip))
+    assert len(problems) == 1 and "v_mov_b32_e32 v9" in problems[0][3]
+    # a compiler-generated load (outside asm statements) is not a hidden load
+    plain = [".LBB0_1:", "global_load_dwordx2 v[4:5], v[6:7], off", "v_mov_b32_e32 v8, v4", "s_endpgm"]
+    assert aud.audit(plain, [False] * len(plain)) == (0, [])
+    # a row request in front of the slot/weight loads of its step is flagged (k_gfstack_ws loaders
+    # wait with vmcnt(k) > 0)
     deep = [".LBB0_1:", "s_waitcnt vmcnt(3)", "s_barrier", "global_load_lds_dwordx4 v1, s[4:5]",
             "global_load_ushort v9, v[2:3], off"] + gather + ["s_cbranch_scc1 .LBB0_1", "s_endpgm"]
     assert aud.audit_order(deep) == [2]

@@ -1,12 +1,15 @@
 #!/usr/bin/env python
 """ISA audit of k_gfstack_dma / k_gfstack_ws (beat_amd/csrc/gfshared.hip).
 
-The kernel hides its slot/weight loads from hipcc (asm `global_load_ushort` / `global_load_dwordx2`
-whose completion is awaited by a hand-placed `s_waitcnt vmcnt(0)` one step later).  hipcc treats
+The kernels hide their slot/weight loads from hipcc (asm `global_load_ushort` / `global_load_dwordx2`
+whose completion is awaited by a hand-placed `s_waitcnt vmcnt` one step later).  hipcc treats
 the destination registers as written when the asm statement ends, so nothing guarantees that it
 does not copy, reuse or spill them while the load is in flight.  This script compiles the file
-to assembly and checks, for every instance of the kernel, that no instruction between such a load
-and the wait that covers it (following the loop back-edge) names the destination registers.
+to assembly and walks, for every such load of every instance, the control-flow graph forward --
+fall-through, both arms of every conditional branch, the loop back-edge AND the ways out of the
+loop -- until a vmcnt wait: no instruction on the way may name the destination registers.
+(Round 2: the first version followed the back-edge only; the loads of the step after the last were
+in flight behind the loop of k_gfstack_dma while its epilogue reused their registers.)
 
 usage: audit_hidden_loads.py [path/to/gfshared.s]   (without an argument it runs hipcc -S)
 exit status 0 = clean."""
@@ -31,68 +34,70 @@ def vregs(text):
 
 
 def functions(lines):
-    name, body = None, []
+    """-> (name, body, in_asm): instructions and labels of every kernel instance; in_asm[i] tells
+    whether body[i] comes from an inline-asm statement (between ;;#ASMSTART and ;;#ASMEND)"""
+    name, body, in_asm, asm = None, [], [], False
     for ln in lines:
         m = re.match(r"^(_ZN7beatamd1[23]k_gfstack_(?:dma|ws)\w+):", ln)
         if m:
-            name, body = m.group(1), []
+            name, body, in_asm, asm = m.group(1), [], [], False
             continue
         if name is not None:
             s = ln.strip()
-            if s and not s.startswith(";") and not s.startswith("."):
+            if s.startswith(";;#ASMSTART"):
+                asm = True
+            elif s.startswith(";;#ASMEND"):
+                asm = False
+            elif s and not s.startswith(";") and not s.startswith("."):
                 body.append(s.split(";")[0].strip())
+                in_asm.append(asm)
             elif re.match(r"^\.LBB\d+_\d+:", s):
                 body.append(s.split(";")[0].strip())
+                in_asm.append(False)
             if s.startswith("s_endpgm"):
-                yield name, body
+                yield name, body, in_asm
                 name = None
 
 
-def main_loop(body, labels):
-    """(index of the back-edge branch, index of the header label) of the step loop: the backward
-    branch whose span holds the most LDS reads (the gather).  Other backward branches (short DMA
-    loops, out-of-line blocks) are not loop back-edges of interest."""
-    best = None
-    for j, cur in enumerate(body):
-        m = re.match(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", cur)
-        if not m or labels.get(m.group(1), 1 << 30) >= j:
-            continue
-        h = labels[m.group(1)]
-        nds = sum(1 for ln in body[h:j] if ln.startswith("ds_read_b"))
-        if nds >= 32 and (best is None or nds > best[2]):
-            best = (j, h, nds)
-    return best
-
-
-def audit(body):
+def audit(body, in_asm):
+    """every hidden load (a global load written in an asm statement): walk the control-flow graph
+    forward from it -- fall-through, both arms of conditional branches, loop back-edges and loop
+    exits alike -- until a vmcnt wait; any instruction on the way that names the destination
+    registers (other than a hidden load using them as its address) is a hazard, and so is
+    reaching the end of a path that re-issues the same load (no wait in a whole loop round)"""
     labels = {ln[:-1]: i for i, ln in enumerate(body) if ln.endswith(":")}
-    loop = main_loop(body, labels)
     problems, nchecked = [], 0
     for i, ln in enumerate(body):
-        if not (ln.startswith("global_load_ushort") or ln.startswith("global_load_dwordx2")):
+        if not in_asm[i] or not (ln.startswith("global_load_ushort") or ln.startswith("global_load_dwordx2")):
             continue
-        if loop is None or i > loop[0]:
-            continue   # epilogue loads are ordinary, waited loads
         dest = vregs(ln.split(",")[0])
         nchecked += 1
-        j, jumped, steps = i + 1, False, 0
-        while j < len(body) and steps < 20000:
-            cur = body[j]
-            steps += 1
-            if re.match(r"s_waitcnt vmcnt\(\d+\)", cur):
-                # (the three-buffer variants wait with vmcnt(k), k = row requests issued AFTER the
-                # slot/weight loads: the loads themselves are covered by every arm of that switch)
-                break
-            if not cur.endswith(":"):
-                # the partner load of the same statement group may use the register as address
-                # BEFORE overwriting it; any other mention is a hazard
-                ops = cur.split(None, 1)[1] if " " in cur else ""
-                if vregs(ops) & dest and not cur.startswith("global_load_"):
-                    problems.append((i, ln, j, cur))
-                if j == loop[0] and not jumped:
-                    j, jumped = loop[1], True   # the step loop's back-edge: on to the loop header
-                    continue
-            j += 1
+        seen, todo = set(), [i + 1]
+        while todo:
+            j = todo.pop()
+            while j < len(body) and j not in seen:
+                seen.add(j)
+                cur = body[j]
+                if re.match(r"s_waitcnt vmcnt\(\d+\)", cur) or cur.startswith("s_endpgm"):
+                    # (the three-buffer variants wait with vmcnt(k), k = row requests issued AFTER
+                    # the slot/weight loads: the loads themselves are covered by every arm)
+                    break
+                if not cur.endswith(":"):
+                    ops = cur.split(None, 1)[1] if " " in cur else ""
+                    if j == i:
+                        problems.append((i, ln, j, "the same load again: a loop round without a wait"))
+                        break
+                    # the partner load of the same statement group may use the register as its
+                    # address BEFORE overwriting it; any other mention is a hazard
+                    if vregs(ops) & dest and not (in_asm[j] and cur.startswith("global_load_")):
+                        problems.append((i, ln, j, cur))
+                        break
+                    m = re.match(r"s_(c?)branch\w*\s+(\.LBB\d+_\d+)", cur)
+                    if m and m.group(2) in labels:
+                        todo.append(labels[m.group(2)])
+                        if not m.group(1):
+                            break            # unconditional: no fall-through
+                j += 1
     return nchecked, problems
 
 
@@ -124,11 +129,11 @@ def main(path=None):
                                    "-o", out], stderr=subprocess.DEVNULL)
             text = open(out).read()
     total, bad, nfun = 0, 0, 0
-    for name, body in functions(text.splitlines()):
-        n, problems = audit(body)
+    for name, body, in_asm in functions(text.splitlines()):
+        n, problems = audit(body, in_asm)
         nfun += 1
         total += n
-        for (i, ln, j, cur) in problems:
+        for (i, ln, j, cur) in sorted(set(problems)):
             bad += 1
             print("%s: load `%s` (line %d) in flight, touched by `%s` (line %d)" % (name, ln, i, cur, j))
         for a in audit_order(body):
