@@ -44,6 +44,14 @@ def main(src, dst, tag, *kernels):
         if not disp:
             print("no dispatch of", kn)
             continue
+        # several kernels may match (the stacking path times every chain-group size once per
+        # problem shape before settling): the summary is of the instance launched most often
+        by_name = {}
+        for d in disp:
+            by_name.setdefault(d[0], []).append(d)
+        exact = max(by_name, key=lambda k: len(by_name[k]))
+        others = {k.replace("void ", ""): len(v) for k, v in by_name.items() if k != exact}
+        disp = by_name[exact]
         durs = [d[1] for d in disp]
         summary = dict(kernel=disp[0][0].replace("void ", ""), dispatches=len(disp),
                        avg_us=sum(durs) / len(durs) / 1e3, min_us=min(durs) / 1e3, max_us=max(durs) / 1e3,
@@ -54,14 +62,20 @@ def main(src, dst, tag, *kernels):
             if not p:
                 continue
             d2 = sqlite3.connect(p)
-            vals = [r[0] for r in d2.execute("select value from counters_collection where kernel_name like ? "
-                                             "and counter_name like ?", ("%" + kn + "%", key))]
+            vals = [r[0] for r in d2.execute("select value from counters_collection where kernel_name = ? "
+                                             "and counter_name like ?", (exact, key))]
+            if not vals:   # (kernel names of the counter table may carry a different decoration)
+                vals = [r[0] for r in d2.execute("select value from counters_collection where kernel_name like ? "
+                                                 "and counter_name like ?",
+                                                 ("%" + exact.replace("void ", "").split("(")[0] + "%", key))]
             if vals:
                 summary[key + "_KB_per_launch_raw"] = sum(vals) / len(vals)
         if "FETCH_SIZE_KB_per_launch_raw" in summary:
             summary["hbm_read_bytes_per_launch_corrected"] = summary["FETCH_SIZE_KB_per_launch_raw"] * 1024 * 2
         if "WRITE_SIZE_KB_per_launch_raw" in summary:
             summary["hbm_write_bytes_per_launch"] = summary["WRITE_SIZE_KB_per_launch_raw"] * 1024
+        if others:
+            summary["other_matching_kernels_not_summarised"] = others
         name = kn.replace("k_", "").replace("<", "").replace(">", "").replace(",", "_")
         with open(os.path.join(dst, "%s_%s_summary.json" % (tag, name)), "w") as fh:
             json.dump(summary, fh, indent=1)
