@@ -262,6 +262,8 @@ int beatamd_ctx_destroy(beatamd_ctx *c)
         }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->d_status) (void)hipFree(c->d_status);
+    if (c->h_umax) (void)hipHostFree(c->h_umax);
+    if (c->umax_event) (void)hipEventDestroy(c->umax_event);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return BEATAMD_OK;

@@ -152,6 +152,12 @@ struct beatamd_ctx {
     char last_gf_kernel[96] = "";
     // distinct-row statistics of the most recent chain-shared launch (bench.py roofline leg)
     int64_t gs_ngtp = 0, gs_N = 0, gs_trep = 1;   // trep: targets served by one table cell
+    // largest distinct-row count of the previous small-group launch, read back asynchronously
+    // (pinned mailbox + event; never waited for): sizes the next launch's row buffers
+    uint32_t *h_umax = nullptr;
+    hipEvent_t umax_event = nullptr;
+    bool umax_pending = false;
+    int umax_hist = -1, umax_hist_cg = 0;
     // measured chains-per-workgroup choice per problem shape: key -> (group size, row bound)
     std::map<std::vector<int64_t>, std::pair<int, int>> gs_tuned;
     int gs_cg = 0;

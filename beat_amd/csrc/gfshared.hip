@@ -230,6 +230,10 @@ struct GsArgs {
     // on the target (no station shifts): Ttab = T or 1; the row ids are then those of target 0 and
     // target t reads rows_per_target * t further on
     int64_t Ttab, rows_per_target;
+    // twin launches of small groups (launcher): run only if the batch's largest distinct-row count
+    // *guard_umax is <= guard_fit (mode 1) / > guard_fit (mode 2); mode 0: always
+    const uint32_t *guard_umax;
+    int guard_mode, guard_fit;
     const uint32_t *urows, *uent, *ucount;
     const uint16_t *slot;
     const double *w;
@@ -263,6 +267,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_gfstack_shared(GsArgs a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row ids via s_load
     const int tile = blockIdx.x % a.ntile;
+    if (a.guard_mode && ((a.guard_mode == 1) == (*a.guard_umax > (uint32_t)a.guard_fit))) return;
     const int64_t gt0 = blockIdx.x / a.ntile;  // g*T + t
     const int64_t t = gt0 % a.T;
     const int64_t g = gt0 / a.T;
@@ -522,6 +527,7 @@ k_gfstack_dma(GsArgs a)
     constexpr int CG = WAVES * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (a.guard_mode && ((a.guard_mode == 1) == (*a.guard_umax > (uint32_t)a.guard_fit))) return;
     int tile;
     int64_t t, g;
     if (a.xcd_order) {
@@ -1375,19 +1381,50 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     int64_t nblocks = ngroups * L.T * a.ntile;
     BA_CHECK(nblocks < (int64_t)0x7fffffff, BEATAMD_EINVAL, "gfstack: batch too large");
     // Small chain groups (1-2 wavefronts per workgroup) reach the 2 waves/SIMD the kernels are
-    // built for only if several workgroups fit a CU's LDS: size the row buffers by the largest
-    // distinct-row count that actually occurs in this batch instead of the bound min(chains*rows,
-    // D*S).  Costs one 4-byte read-back (a stream synchronisation) per launch; skipped for the
-    // large groups, whose occupancy is register-bound anyway.
+    // built for only if several workgroups fit a CU's LDS: their row buffers are sized by the
+    // largest distinct-row count that actually occurs instead of the bound min(chains*rows, D*S).
+    // No host synchronisation: the count of THIS batch stays on the device (ga.umax); the launcher
+    // sizes the buffers from the count of the PREVIOUS launch (asynchronous read-back into a pinned
+    // mailbox, used when it has arrived) plus a margin, launches that kernel guarded by "count <=
+    // slots" and the full-size kernel guarded by the opposite -- exactly one of the twins works.
+    int ucap_fit = 0;
     if (fit_lds) {
-        uint32_t umax = 0;
-        BA_HIP(hipMemcpyAsync(&umax, ga.umax, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        BA_HIP(hipStreamSynchronize(ctx->stream));
-        BA_CHECK((int)umax <= ucap, BEATAMD_EINVAL, "gfstack: distinct-row count %u exceeds its bound %d",
-                 umax, ucap);
-        ucap = std::max<int>((int)umax, 2);
-        a.ucap = ucap;
+        if (!ctx->h_umax) {
+            BA_HIP(hipHostMalloc((void **)&ctx->h_umax, sizeof(uint32_t), hipHostMallocDefault));
+            BA_HIP(hipEventCreateWithFlags(&ctx->umax_event, hipEventDisableTiming));
+        }
+        if (ctx->umax_pending && hipEventQuery(ctx->umax_event) == hipSuccess) {
+            ctx->umax_hist = (int)*ctx->h_umax;
+            ctx->umax_pending = false;
+        }
+        (void)hipGetLastError();   // (hipErrorNotReady of the query is not an error)
+        // (BEATAMD_GS_NT=32 may fall back to 64-sample tiles per buffer size: one twin only then)
+        if (ctx->umax_hist >= 0 && ctx->umax_hist_cg == CG && a.nt == 64) {
+            // (a tight fit: whole workgroups per CU are at stake -- 3 instead of 2 at 128 chains and
+            // 45 rows -- and a batch that exceeds it only costs that step the full-size twin)
+            const int want = ctx->umax_hist + 1;
+            if (want < ucap) ucap_fit = std::max(want, 2);
+        }
+        if (!ctx->umax_pending) {
+            BA_HIP(hipMemcpyAsync(ctx->h_umax, ga.umax, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            BA_HIP(hipEventRecord(ctx->umax_event, ctx->stream));
+            ctx->umax_pending = true;
+            ctx->umax_hist_cg = CG;
+        }
     }
+    // (fitted twin first, then the full-size twin; a single unguarded launch otherwise)
+    const int full_ucap = ucap;
+    const int64_t nblocks0 = nblocks;
+    const int nt0 = a.nt, ntile0 = a.ntile;
+    ScopedTimer tm(ctx, "gfstack");   // (both twins: one timing)
+    for (int twin = (ucap_fit ? 1 : 0); twin <= (ucap_fit ? 2 : 0); twin++) {
+    ucap = (twin == 1) ? ucap_fit : full_ucap;
+    nblocks = nblocks0;
+    a.nt = nt0; a.ntile = ntile0;
+    a.ucap = ucap;
+    a.guard_mode = twin;
+    a.guard_fit = ucap_fit;
+    a.guard_umax = ga.umax;
     size_t lds = (size_t)ucap * (a.nt + 2) * sizeof(double);
     {
         // two row buffers when they fit (BEATAMD_GS_DMA=0 forces the single-buffer kernel)
@@ -1419,7 +1456,6 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     ctx->gs_N = L.N;
     ctx->gs_cg = CG;
     {
-        ScopedTimer tm(ctx, "gfstack");
         dim3 grid((unsigned)nblocks);
         if (a.ws) launch_ws(k.mode, grid, lds, ctx->stream, a);
         else if (CG == 1024) launch_shared_nrow<16>(nrow, k.mode, grid, lds, ctx->stream, a);
@@ -1427,6 +1463,8 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         else if (CG == 256) launch_shared_nrow<4>(nrow, k.mode, grid, lds, ctx->stream, a);
         else if (CG == 128) launch_shared_nrow<2>(nrow, k.mode, grid, lds, ctx->stream, a);
         else launch_shared_nrow<1>(nrow, k.mode, grid, lds, ctx->stream, a);
+    }
+    BA_HIP(hipGetLastError());
     }
     BA_HIP(hipGetLastError());
     if (k.mode == GF_RESID_SCALAR) BA_TRY(launch_sum_tiles(ctx, a.partial, k.C * L.T, a.ntile, k.quad));
