@@ -33,6 +33,7 @@
 namespace beatamd {
 
 constexpr int GS_NT_MAX = 64;         // samples per tile (per lane: that many accumulators)
+constexpr int GS_NTHINT_DEFAULT = 1;  // non-temporal row requests of single-group batches unless BEATAMD_GS_NTHINT says otherwise
 constexpr int GS_WS_DEFAULT = 1;      // wave-specialised kernel for 512-chain groups unless BEATAMD_GS_WS says otherwise
 
 struct GroupTabArgs {
@@ -224,6 +225,7 @@ struct GsArgs {
     int CG, ucap, ustride, ntile, nt;
     int dma;  // 1: k_gfstack_dma (two LDS row buffers filled by LDS-DMA)
     int ws;            // k_gfstack_ws: 8 consumer + 4 loader wavefronts, three row buffers
+    int nthint;        // k_gfstack_ws / k_gfstack_dma: non-temporal row requests
     int xcd_order;     // k_gfstack_dma: chain groups of a (target, tile) share an XCD
     int64_t ngroups;
     // tables per (group, target, patch), or per (group, patch) when the start times do not depend
@@ -584,10 +586,16 @@ k_gfstack_dma(GsArgs a)
         const uint64_t off = (uint64_t)r * (uint64_t)rowbytes;
         const char *rowp = reinterpret_cast<const char *>(Gv) + off;
         const uint32_t dst = lds0 + (uint32_t)(boff * 8) + slotidx * (uint32_t)(GS_PITCH * 8);
-        asm("s_mov_b32 m0, %3\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, %2"
-            : "+s"(tk) : "v"(voff), "s"(rowp), "s"(dst), "v"(dep));
+        if (a.nthint)   // non-temporal: single-group batches read every row segment exactly once
+            asm("s_mov_b32 m0, %3\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, %2 nt"
+                : "+s"(tk) : "v"(voff), "s"(rowp), "s"(dst), "v"(dep));
+        else
+            asm("s_mov_b32 m0, %3\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, %2"
+                : "+s"(tk) : "v"(voff), "s"(rowp), "s"(dst), "v"(dep));
     };
     // (row id, LDS slot) of this wavefront's first KPRE list entries: contiguous in memory, one
     // scalar load instruction (the gather's lgkmcnt waits count scalar loads too)
@@ -819,7 +827,7 @@ k_gfstack_dma(GsArgs a)
 //              barrier(s); issue the slot/weight loads of step s+1; gather + FMA from buffer s mod 3
 // 12 wavefronts per CU need <= 168 VGPRs (3 per SIMD): tables are addressed with scalar bases +
 // 32-bit lane offsets.  Same arithmetic, same order: bitwise equal to the other kernels.
-template <int NROW, int MODE, int NB>
+template <int NROW, int MODE, int NB, int NTH>
 __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_gfstack_ws(GsArgs a)
 {
@@ -872,10 +880,18 @@ k_gfstack_ws(GsArgs a)
             const uint64_t off = (uint64_t)r * (uint64_t)rowbytes;
             const char *rowp = reinterpret_cast<const char *>(Gv) + off;
             const uint32_t dst = lds0 + (uint32_t)(boff * 8) + slotidx * (uint32_t)(GS_PITCH * 8);
-            asm("s_mov_b32 m0, %3\n\t"
-                "s_nop 0\n\t"
-                "global_load_lds_dwordx4 %1, %2"
-                : "+s"(tk) : "v"(voff), "s"(rowp), "s"(dst));
+            // NTH: non-temporal requests -- a row segment is read by this CU once and by no other
+            // workgroup when the batch is a single chain group (several groups share rows through L2)
+            if (NTH)
+                asm("s_mov_b32 m0, %3\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %1, %2 nt"
+                    : "+s"(tk) : "v"(voff), "s"(rowp), "s"(dst));
+            else
+                asm("s_mov_b32 m0, %3\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %1, %2"
+                    : "+s"(tk) : "v"(voff), "s"(rowp), "s"(dst));
         };
         const int kstr = a.ustride / LW;
         const char *const cnt_base = reinterpret_cast<const char *>(a.ucount + gt * a.P);
@@ -1206,9 +1222,13 @@ static void launch_shared_nrow(int nrow, int mode, dim3 grid, size_t lds, hipStr
 // hipcc spills the not-yet-landed results of the hidden table loads)
 static void launch_ws(int mode, dim3 grid, size_t lds, hipStream_t s, const GsArgs &a)
 {
-    void (*kern)(GsArgs) = mode == GF_STORE_SYN ? k_gfstack_ws<1, GF_STORE_SYN, 3>
-                           : mode == GF_RESID_SCALAR ? k_gfstack_ws<1, GF_RESID_SCALAR, 3>
-                                                     : k_gfstack_ws<1, GF_RESID_STORE, 3>;
+    void (*kern)(GsArgs);
+    if (a.nthint)
+        kern = mode == GF_STORE_SYN ? k_gfstack_ws<1, GF_STORE_SYN, 3, 1>
+               : mode == GF_RESID_SCALAR ? k_gfstack_ws<1, GF_RESID_SCALAR, 3, 1> : k_gfstack_ws<1, GF_RESID_STORE, 3, 1>;
+    else
+        kern = mode == GF_STORE_SYN ? k_gfstack_ws<1, GF_STORE_SYN, 3, 0>
+               : mode == GF_RESID_SCALAR ? k_gfstack_ws<1, GF_RESID_SCALAR, 3, 0> : k_gfstack_ws<1, GF_RESID_STORE, 3, 0>;
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(768), lds, s, a);
 }
@@ -1436,6 +1456,10 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         BA_CHECK(CG != 1024 || a.dma == 2, BEATAMD_EINVAL, "gfstack: 1024-chain groups need the LDS-DMA kernel");
         BA_CHECK(!ga.windowed || a.dma == 2, BEATAMD_EINVAL, "internal: window slots need the ds_read_b64 kernel");
         a.ws = (use_ws && a.dma == 2) ? ws_nb : 0;
+        {
+            const char *e = getenv("BEATAMD_GS_NTHINT");
+            a.nthint = e ? (atoi(e) != 0) : (GS_NTHINT_DEFAULT && ngroups == 1);
+        }
         if (a.ws) lds = (size_t)ucap * (a.nt + 1) * sizeof(double) * a.ws;
         else if (a.dma) lds *= 2;
     }
@@ -1447,7 +1471,7 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         if (a.xcd_order) nblocks = ((L.T * a.ntile + 7) / 8) * 8 * ngroups;
     }
     if (a.ws)
-        snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack_ws<%d,%d,%d>", nrow, k.mode, a.ws);
+        snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack_ws<%d,%d,%d,%d>", nrow, k.mode, a.ws, a.nthint);
     else
         snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "%s<%d,%d,%d,%d,%d>",
                  a.dma ? "k_gfstack_dma" : "k_gfstack_shared", CG / 64, nrow, k.mode, a.nt, a.dma == 2 ? 1 : 0);

@@ -208,7 +208,7 @@ def test_fullsize_shipped_dma_kernel_at_bench_shape(full, monkeypatch, C):
         if nrow == 1:   # the loader / consumer kernel on the same tables
             monkeypatch.setenv("BEATAMD_GS_WS", "1")
             out2 = gf.stack_all_batch(dur_d, st_d, sl_d, interpolation=interp)
-            assert ctx.last_kernel() == "k_gfstack_ws<1,0,3>", ctx.last_kernel()
+            assert ctx.last_kernel().startswith("k_gfstack_ws<1,0,3,"), ctx.last_kernel()
             assert torch.equal(out, out2), "k_gfstack_ws differs from k_gfstack_dma"
             del out2
         for c, t in pairs:
@@ -232,7 +232,7 @@ def test_fullsize_fused_logp_through_dma_kernel(full, monkeypatch, C):
     monkeypatch.setenv("BEATAMD_GS_CG", "512")
     monkeypatch.setenv("BEATAMD_GS_WS", "1")
     LW = f.batch(Qd).cpu().numpy()
-    assert ctx.last_kernel() == "k_gfstack_ws<1,1,3>", ctx.last_kernel()
+    assert ctx.last_kernel().startswith("k_gfstack_ws<1,1,3,"), ctx.last_kernel()
     monkeypatch.setenv("BEATAMD_GS_WS", "0")
     LL = f.batch(Qd).cpu().numpy()
     assert ctx.last_kernel().startswith("k_gfstack_dma<8,1,1,64,"), ctx.last_kernel()

@@ -34,7 +34,7 @@ def test_fullsize_two_slip_variables_dma_vs_streaming_vs_rows(monkeypatch):
     monkeypatch.delenv("BEATAMD_GF_KERNEL", raising=False)
     monkeypatch.setenv("BEATAMD_GS_CG", "512")
     LL = f.batch(Qd).cpu().numpy()
-    assert ctx.last_kernel() == "k_gfstack_ws<1,1,3>", ctx.last_kernel()   # the default for 512-chain groups
+    assert ctx.last_kernel().startswith("k_gfstack_ws<1,1,3,"), ctx.last_kernel()   # the default for 512-chain groups
     monkeypatch.setenv("BEATAMD_GS_WS", "0")
     LD = f.batch(Qd).cpu().numpy()
     assert ctx.last_kernel().startswith("k_gfstack_dma<8,1,1,64,"), ctx.last_kernel()

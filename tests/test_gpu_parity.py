@@ -226,6 +226,7 @@ def test_shared_row_kernel_equals_streaming_kernel(ctx, orc, monkeypatch, C, int
             for order in ("0", "1"):
                 monkeypatch.setenv("BEATAMD_GS_WS", "1")
                 monkeypatch.setenv("BEATAMD_GS_ORDER", order)
+                monkeypatch.setenv("BEATAMD_GS_NTHINT", order)   # (non-temporal row requests: off / on)
                 monkeypatch.setenv("BEATAMD_GS_DMA", "2")
                 monkeypatch.setenv("BEATAMD_GS_NT", "64")
                 assert np.array_equal(gf.stack_all_batch(dur, st, sl, interpolation=interp), a), (cg, "ws", order)
@@ -238,7 +239,7 @@ def test_shared_row_kernel_equals_streaming_kernel(ctx, orc, monkeypatch, C, int
             assert "k_gfstack_dma<%d,%d,0,64,0>" % (w[cg], nrow) in seen, seen
             assert "k_gfstack_shared<%d,%d,0,64,0>" % (w[cg], nrow) in seen, seen
     if nrow == 1 and C > 0:
-        assert "k_gfstack_ws<1,0,3>" in seen, seen
+        assert "k_gfstack_ws<1,0,3,0>" in seen and "k_gfstack_ws<1,0,3,1>" in seen, seen
 
 
 @pytest.mark.parametrize("interp", ["nearest_neighbor", "multilinear"])
@@ -272,7 +273,7 @@ def test_window_slots_with_more_than_32_distinct_rows(ctx, orc, monkeypatch, int
                     monkeypatch.setenv("BEATAMD_GS_WIN", win)
                     monkeypatch.setenv("BEATAMD_GS_WS", "1")
                     b = gf.stack_all_batch(dur, st, sl, interpolation=interp)
-                    assert ctx.last_kernel() == "k_gfstack_ws<1,0,3>", ctx.last_kernel()
+                    assert ctx.last_kernel().startswith("k_gfstack_ws<1,0,3,"), ctx.last_kernel()
                     assert np.array_equal(a, b), (C, cg, "ws", win)
         for c in (0, 529, C - 1):
             ref = orc.stack_all(G, dur[c], st[c], sl[c], 0.5, 0.5, 0.0, 0.5, interp)
@@ -318,7 +319,7 @@ def test_more_than_64_distinct_rows_per_step(ctx, orc, monkeypatch):
     a = gf.stack_all_batch(dur, st, sl)
     monkeypatch.setenv("BEATAMD_GF_KERNEL", "1")
     monkeypatch.setenv("BEATAMD_GS_CG", "512")
-    for ws, name in (("1", "k_gfstack_ws<1,0,3>"), ("0", "k_gfstack_dma<8,1,0,64,1>")):
+    for ws, name in (("1", "k_gfstack_ws<1,0,3,0>"), ("0", "k_gfstack_dma<8,1,0,64,1>")):
         monkeypatch.setenv("BEATAMD_GS_WS", ws)
         b = gf.stack_all_batch(dur, st, sl)
         assert ctx.last_kernel() == name, ctx.last_kernel()
