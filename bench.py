@@ -142,8 +142,8 @@ def make_spec(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--chains", type=int, default=512, help="chains per GPU per step")
     ap.add_argument("--interp", default="nearest_neighbor",
                     choices=["nearest_neighbor", "multilinear"])
