@@ -1097,8 +1097,21 @@ k_gfstack_ws(GsArgs a)
     "+v"(acc[G * 8]), "+v"(acc[G * 8 + 1]), "+v"(acc[G * 8 + 2]), "+v"(acc[G * 8 + 3]), "+v"(acc[G * 8 + 4]), \
         "+v"(acc[G * 8 + 5]), "+v"(acc[G * 8 + 6]), "+v"(acc[G * 8 + 7])
 #define BA_Y8(Y) "+v"(Y[0]), "+v"(Y[1]), "+v"(Y[2]), "+v"(Y[3]), "+v"(Y[4]), "+v"(Y[5]), "+v"(Y[6]), "+v"(Y[7])
+#define BA_FMA4A \
+    "v_fmac_f64 %0, %8, %16\n\tv_fmac_f64 %1, %9, %16\n\tv_fmac_f64 %2, %10, %16\n\tv_fmac_f64 %3, %11, %16\n\t"
+#define BA_FMA4B \
+    "v_fmac_f64 %4, %12, %16\n\tv_fmac_f64 %5, %13, %16\n\tv_fmac_f64 %6, %14, %16\n\tv_fmac_f64 %7, %15, %16\n\t"
+#define BA_RD4A(OFF) \
+    "ds_read_b64 %8, %17 offset:" #OFF "\n\tds_read_b64 %9, %17 offset:" #OFF "+8\n\t" \
+    "ds_read_b64 %10, %17 offset:" #OFF "+16\n\tds_read_b64 %11, %17 offset:" #OFF "+24\n\t"
+#define BA_RD4B(OFF) \
+    "ds_read_b64 %12, %17 offset:" #OFF "+32\n\tds_read_b64 %13, %17 offset:" #OFF "+40\n\t" \
+    "ds_read_b64 %14, %17 offset:" #OFF "+48\n\tds_read_b64 %15, %17 offset:" #OFF "+56"
+// in half groups of 4 (LDS operations return in order): 12..16 reads stay in flight instead of
+// 8..16 -- measured 0.5 % (39 rows per step) to 1.3 % (21 rows) per launch
 #define BA_GROUP(G, Y, OFFNEXT) \
-    asm("s_waitcnt lgkmcnt(8)\n\t" BA_FMA8 BA_RD8(OFFNEXT) : BA_ACC8(G), BA_Y8(Y) : "v"(w), "v"(xs))
+    asm("s_waitcnt lgkmcnt(12)\n\t" BA_FMA4A BA_RD4A(OFFNEXT) "s_waitcnt lgkmcnt(12)\n\t" BA_FMA4B BA_RD4B(OFFNEXT) \
+        : BA_ACC8(G), BA_Y8(Y) : "v"(w), "v"(xs))
         BA_GROUP(0, ya, 128);
         BA_GROUP(1, yb, 192);
         BA_GROUP(2, ya, 256);
@@ -1126,6 +1139,10 @@ k_gfstack_ws(GsArgs a)
         xs = xs_n;
         __builtin_amdgcn_sched_barrier(0);
 #undef BA_GROUP
+#undef BA_RD4B
+#undef BA_RD4A
+#undef BA_FMA4B
+#undef BA_FMA4A
 #undef BA_Y8
 #undef BA_ACC8
 #undef BA_RD8
