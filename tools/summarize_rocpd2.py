@@ -54,7 +54,8 @@ def main(src, dst, tag, *kernels):
         disp = by_name[exact]
         durs = [d[1] for d in disp]
         summary = dict(kernel=disp[0][0].replace("void ", ""), dispatches=len(disp),
-                       avg_us=sum(durs) / len(durs) / 1e3, min_us=min(durs) / 1e3, max_us=max(durs) / 1e3,
+                       avg_us=sum(durs) / len(durs) / 1e3, median_us=sorted(durs)[len(durs) // 2] / 1e3,
+                       min_us=min(durs) / 1e3, max_us=max(durs) / 1e3,
                        grid=disp[0][2], workgroup=disp[0][3], vgpr=disp[0][4], agpr=disp[0][5],
                        sgpr=disp[0][6], lds=disp[0][7])
         for sub, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
