@@ -1076,6 +1076,36 @@ int beatamd_chol_inverse_batch(beatamd_ctx *ctx, int64_t nd, int64_t n, const do
     return finish_out(ctx, recs, 2);
 }
 
+int beatamd_whitening_ratio_batch(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *W_new,
+                                  const double *W_old, double *M)
+{
+    ENTER(ctx);
+    BA_CHECK(W_new && W_old && M && nd >= 0 && n > 0, BEATAMD_EINVAL, "whitening_ratio_batch: bad argument");
+    if (nd == 0) return BEATAMD_OK;
+    const void *d_n, *d_o;
+    void *d_m;
+    Arg rec;
+    BA_TRY(stage_in(ctx, SL_IN0, W_new, (size_t)nd * n * n * 8, &d_n));
+    BA_TRY(stage_in(ctx, SL_IN1, W_old, (size_t)nd * n * n * 8, &d_o));
+    BA_TRY(stage_out(ctx, SL_OUT0, M, (size_t)nd * n * n * 8, &d_m, &rec));
+    BA_TRY(launch_triu_ratio(ctx, nd, n, (const double *)d_n, (const double *)d_o, (double *)d_m));
+    BA_TRY(ctx->check_status());
+    return finish_out(ctx, &rec, 1);
+}
+
+int beatamd_ffi_model_update_data(beatamd_ctx *ctx, int32_t model_id, int32_t wavemap_index, const double *data)
+{
+    ENTER(ctx);
+    FfiModel *m = get_obj(ctx->models, model_id);
+    BA_CHECK(m, BEATAMD_EINVAL, "unknown model %d", model_id);
+    BA_CHECK(data && wavemap_index >= 0 && (size_t)wavemap_index < m->wavemaps.size(), BEATAMD_EINVAL,
+             "model_update_data: bad argument");
+    Wavemap &w = m->wavemaps[wavemap_index];
+    BA_HIP(hipMemcpyAsync(w.data, data, (size_t)w.T * w.N * 8, hipMemcpyDefault, ctx->stream));
+    BA_HIP(hipStreamSynchronize(ctx->stream));
+    return BEATAMD_OK;
+}
+
 // ------------------------------------------------------------------ library whitening
 int beatamd_whiten_rows(beatamd_ctx *ctx, double *rows, int64_t nrows, int64_t N, const double *W)
 {

@@ -199,3 +199,113 @@ int launch_chol_inverse(beatamd_ctx *ctx, int64_t nbatch, int64_t n, const doubl
 }
 
 }  // namespace beatamd
+
+// ---------------------------------------------------------------------------------------------
+// M = Wn . inv(Wo) for stacks of UPPER-triangular matrices (both are whitening operators
+// cholesky(inv(C)).T): the operator that takes rows whitened with Wo to rows whitened with Wn,
+//     rows . Wn^T = (rows . Wo^T) . M^T ,
+// so a pre-whitened library follows a covariance update in place, without a copy of the
+// unwhitened library (seismic.py:1509-1534 update_weights).  Right-side
+// triangular solve M . Wo = Wn by 64-wide block columns, M upper triangular:
+//     M[:, k] = (Wn[:, k] - M[:, <k] . Wo[<k, k]) . inv(Wo[k, k])
+// with the diagonal blocks of Wo inverted in LDS (back substitution, one column per thread) and
+// the block products on the FP64 matrix cores (batched k_gemm_f64).
+namespace beatamd {
+
+// Dinv[b][kb] = inv(U_kk) of the upper-triangular diagonal block kb of U [np x np]; a zero or
+// non-finite pivot raises ST_NOT_PSD
+__global__ void __launch_bounds__(256) k_triu_diag_inv(const double *U, int64_t np, int nblk, double *Dinv, int *status)
+{
+    constexpr int NB = CH_NB, PITCH = NB + 1;
+    __shared__ double A[NB * PITCH];
+    __shared__ double X[NB * PITCH];
+    const int64_t b = blockIdx.y;
+    const int kb = blockIdx.x, tid = threadIdx.x;
+    const double *Ub = U + b * np * np + ((int64_t)kb * NB) * np + (int64_t)kb * NB;
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e / NB, j = e % NB;
+        A[i * PITCH + j] = (j >= i) ? Ub[(int64_t)i * np + j] : 0.0;
+        X[i * PITCH + j] = 0.0;
+    }
+    __syncthreads();
+    if (tid < NB) {
+        // column c of the inverse: U x = e_c, x_i = 0 for i > c, back substitution upwards
+        const int c = tid;
+        bool bad = false;
+        for (int i = c; i >= 0; i--) {
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int q = i + 1; q <= c; q++) s = fma(-A[i * PITCH + q], X[q * PITCH + c], s);
+            const double d = A[i * PITCH + i];
+            if (!(fabs(d) > 0.0) || !(fabs(d) < __builtin_inf())) bad = true;
+            X[i * PITCH + c] = s / d;
+        }
+        if (bad) atomicOr(status, ST_NOT_PSD);
+    }
+    __syncthreads();
+    double *Db = Dinv + (b * nblk + kb) * NB * NB;
+    for (int e = tid; e < NB * NB; e += 256) Db[e] = X[(e / NB) * PITCH + (e % NB)];
+}
+
+// P[b][i][j] = (i < n && j < n) ? S[b][i][j] : (i == j)  (identity padding to a multiple of 64)
+__global__ void __launch_bounds__(256) k_pad_identity(const double *S, int64_t n, int64_t np, double *P)
+{
+    const int64_t b = blockIdx.y;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= np * np) return;
+    const int64_t i = idx / np, j = idx % np;
+    P[b * np * np + idx] = (i < n && j < n) ? S[(b * n + i) * n + j] : ((i == j) ? 1.0 : 0.0);
+}
+
+__global__ void __launch_bounds__(256) k_unpad(const double *P, int64_t n, int64_t np, double *S)
+{
+    const int64_t b = blockIdx.y;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * n) return;
+    const int64_t i = idx / n, j = idx % n;
+    S[b * n * n + idx] = (j >= i) ? P[(b * np + i) * np + j] : 0.0;
+}
+
+int launch_triu_ratio(beatamd_ctx *ctx, int64_t nbatch, int64_t n, const double *Wn, const double *Wo, double *M)
+{
+    if (nbatch == 0 || n == 0) return BEATAMD_OK;
+    BA_CHECK(Wn && Wo && M && nbatch > 0 && n > 0 && nbatch <= 65535, BEATAMD_EINVAL, "triu_ratio: bad argument");
+    const int64_t np = (n + CH_NB - 1) / CH_NB * CH_NB;
+    const int nblk = (int)(np / CH_NB);
+    void *p = nullptr;
+    BA_TRY(ctx->get_scratch(SL_CHOL_A, (size_t)nbatch * np * np * 8, &p));
+    double *A = (double *)p;      // padded Wo
+    BA_TRY(ctx->get_scratch(SL_CHOL_X, (size_t)nbatch * np * np * 8, &p));
+    double *X = (double *)p;      // padded Wn, overwritten by M block column by block column
+    BA_TRY(ctx->get_scratch(SL_CHOL_D, (size_t)nbatch * nblk * CH_NB * CH_NB * 8, &p));
+    double *Dinv = (double *)p;
+    ScopedTimer tm(ctx, "triu_ratio");
+    const dim3 gp((unsigned)((np * np + 255) / 256), (unsigned)nbatch);
+    hipLaunchKernelGGL(k_pad_identity, gp, dim3(256), 0, ctx->stream, Wo, n, np, A);
+    hipLaunchKernelGGL(k_pad_identity, gp, dim3(256), 0, ctx->stream, Wn, n, np, X);
+    hipLaunchKernelGGL(k_triu_diag_inv, dim3((unsigned)nblk, (unsigned)nbatch), dim3(256), 0, ctx->stream,
+                       (const double *)A, np, nblk, Dinv, ctx->d_status);
+    const int64_t sM = np * np;
+    for (int kb = 0; kb < nblk; kb++) {
+        const int64_t kc = (int64_t)kb * CH_NB, rows = kc + CH_NB;   // M[:, kb] is nonzero in rows < rows
+        if (kb > 0) {
+            GemmCall g;   // X[:rows, kb] -= M[:rows, :kc] . Wo[:kc, kb]
+            g.A = X; g.lda = np; g.sA = sM;
+            g.B = A + kc; g.ldb = np; g.sB = sM;
+            g.O = X + kc; g.ldo = np; g.sO = sM;
+            g.M = rows; g.N = CH_NB; g.K = kc; g.b_kn = 1; g.alpha = -1.0; g.accumulate = 1; g.nbatch = (int)nbatch;
+            BA_TRY(launch_gemm_f64(ctx, g));
+        }
+        GemmCall h;       // M[:rows, kb] = X[:rows, kb] . inv(Wo[kb, kb])   (in place: one column block)
+        h.A = X + kc; h.lda = np; h.sA = sM;
+        h.B = Dinv + (int64_t)kb * CH_NB * CH_NB; h.ldb = CH_NB; h.sB = (int64_t)nblk * CH_NB * CH_NB;
+        h.O = X + kc; h.ldo = np; h.sO = sM;
+        h.M = rows; h.N = CH_NB; h.K = CH_NB; h.b_kn = 1; h.nbatch = (int)nbatch;
+        BA_TRY(launch_gemm_f64(ctx, h));
+    }
+    const dim3 gu((unsigned)((n * n + 255) / 256), (unsigned)nbatch);
+    hipLaunchKernelGGL(k_unpad, gu, dim3(256), 0, ctx->stream, (const double *)X, n, np, M);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
+}  // namespace beatamd

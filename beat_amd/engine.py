@@ -470,6 +470,20 @@ class Context(object):
         check(self._lib.beatamd_chol_inverse_batch(self._h, nd, n, ptr(C), ptr(W), ptr(lp)))
         return W, lp
 
+    def whitening_ratio_batch(self, W_new, W_old):
+        """M (nd, n, n) = W_new . inv(W_old) for upper-triangular whitening operators"""
+        Wn, Wo = f64(W_new), f64(W_old)
+        if Wn.shape != Wo.shape or Wn.ndim != 3:
+            raise ValueError("W_new and W_old must both be (nd, n, n)")
+        M = _empty_like(Wn, tuple(Wn.shape))
+        check(self._lib.beatamd_whitening_ratio_batch(self._h, int(Wn.shape[0]), int(Wn.shape[1]), ptr(Wn),
+                                                      ptr(Wo), ptr(M)))
+        return M
+
+    def ffi_model_update_data(self, model_id, wavemap_index, data):
+        d = f64(data)
+        check(self._lib.beatamd_ffi_model_update_data(self._h, int(model_id), int(wavemap_index), ptr(d)))
+
     def whiten_rows(self, rows, W):
         """rows (R, N) device tensor, in place: rows <- rows . W^T"""
         self._adopt_stream(rows)

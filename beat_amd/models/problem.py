@@ -103,8 +103,8 @@ class SeismicWavemap(object):
         agree with the unwhitened path to rounding.  The row products run on the FP64 matrix
         cores (``beatamd_whiten_rows``: rows . W_t^T, the zero half of the upper-triangular W_t
         skipped), in place on the HBM-resident library, chunked so that no second library copy is
-        needed when ``inplace``.  After a weight update (seismic.py:1509-1534) the wavemap has to
-        be whitened again from the unwhitened library (``LogpForwFunc.update_weights`` refuses)."""
+        needed when ``inplace``.  A weight update (seismic.py:1509-1534) re-whitens rows and data in
+        place with ``M_t = W_new,t . inv(W_old,t)`` (``LogpForwFunc.update_weights``)."""
         import torch
 
         from ..engine import get_context
@@ -139,6 +139,7 @@ class SeismicWavemap(object):
         wm = SeismicWavemap(gfs, d.cpu().numpy(), np.ones(T), self.slog_pdet, self.hypers,
                             self.time_shifts, self.interpolation, self.name)
         wm.is_prewhitened = True
+        wm._whitened_with = w      # the operator folded into rows and data (for update_weights)
         return wm
 
 
@@ -376,14 +377,32 @@ class LogpForwFunc(object):
         """seismic.py:1509-1534 update_weights: new chol_inverse + slog_pdet per dataset.  Kind
         and size must match the uploaded set (checked by the library)."""
         wm = self.problem.wavemaps[wavemap_index]
-        if getattr(wm, "is_prewhitened", False):
-            raise NotImplementedError(
-                "wavemap %s was compiled with a pre-whitened library: its weights are folded into "
-                "the library rows and the data.  Whiten the unwhitened library with the new "
-                "weights and compile again (FFIProblem.compile(prewhiten=True))." % wm.name)
         w = np.ascontiguousarray(weights, dtype=np.float64)
         sl = np.ascontiguousarray(slog_pdet, dtype=np.float64).ravel()
         T, N = wm.data.shape
+        if getattr(wm, "is_prewhitened", False):
+            # The old operator is folded into the library rows and the data: rows . W_new^T =
+            # (rows . W_old^T) . M^T with M = W_new . inv(W_old) (upper triangular, solved on the
+            # device), applied in place -- no copy of the unwhitened library is needed.
+            import torch
+            if w.shape != (T, N, N) or sl.shape != (T,):
+                raise ValueError("a pre-whitened wavemap takes dense weights (%d,%d,%d) and slog_pdet (%d,)"
+                                 % (T, N, N, T))
+            dev = torch.device("cuda", self.ctx.device)
+            M = self.ctx.whitening_ratio_batch(torch.from_numpy(w).to(dev),
+                                               torch.from_numpy(np.ascontiguousarray(wm._whitened_with)).to(dev))
+            for gf in wm.gfs.values():
+                rows = gf._device_tensor.view(T, -1, N)
+                for t in range(T):
+                    self.ctx.whiten_rows(rows[t], M[t])
+            d = torch.from_numpy(np.ascontiguousarray(wm.data)).to(dev)
+            for t in range(T):
+                self.ctx.whiten_rows(d[t:t + 1], M[t])
+            self.ctx.ffi_model_update_data(self.model_id, wavemap_index, d)
+            self.ctx.weights_update(wm._wset, np.ones(T), sl)
+            self.ctx.synchronize()
+            wm.data, wm.slog_pdet, wm._whitened_with = d.cpu().numpy(), sl, w
+            return
         if w.shape not in ((T,), (T, N, N)) or sl.shape != (T,):
             raise ValueError("weights must be (%d,) or (%d,%d,%d) and slog_pdet (%d,)" % (T, T, N, N, T))
         self.ctx.weights_update(wm._wset, w, sl)

@@ -318,6 +318,17 @@ int beatamd_whiten_rows(beatamd_ctx *ctx, double *rows, int64_t nrows, int64_t N
 int beatamd_chol_inverse_batch(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *covs, double *W,
                                double *log_pdet);
 
+/* replaces: nothing in the reference (it keeps W and multiplies per step); companion of
+ *           beatamd_whiten_rows for update_weights (seismic.py:1509-1534) on a pre-whitened library:
+ *   M [nd,n,n] = W_new . inv(W_old) for upper-triangular whitening operators, so that
+ *   rows . W_new^T = (rows . W_old^T) . M^T -- the library and the data follow a covariance update in
+ *   place.  A singular W_old is BEATAMD_ENOTPSD. */
+int beatamd_whitening_ratio_batch(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *W_new,
+                                  const double *W_old, double *M);
+/* replaces: the data half of update_weights on a pre-whitened wavemap: new observed data
+ *   [T,N] (already whitened) of wavemap `wavemap_index` of a compiled model */
+int beatamd_ffi_model_update_data(beatamd_ctx *ctx, int32_t model_id, int32_t wavemap_index, const double *data);
+
 /* ---------------------------------------------------------------- half-space synthetics ---
  * replaces: heart.geo_synthetics(engine, targets, sources, outmode)   beat/heart.py:4158-4239
  *           (what pytensorf.GeoSynthesizer.perform calls, pytensorf.py:88-123) for a HOMOGENEOUS

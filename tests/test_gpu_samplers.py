@@ -234,10 +234,60 @@ def test_update_weights_validation(ctx):
         ctx.weights_update(prob.wavemaps[0]._wset, np.ones(3), sl)   # scalar into a dense set
     prob2, _ = build_problem(spec)
     f2 = prob2.compile(ctx, prewhiten=True)
-    with pytest.raises(NotImplementedError):
-        f2.update_weights(0, W, sl)
     with pytest.raises(ValueError):
-        ctx.weights_update(prob2.wavemaps[0]._wset, W, sl)  # the library refuses as well
+        f2.update_weights(0, np.ones(3), sl)                # a pre-whitened wavemap takes dense operators
+    with pytest.raises(ValueError):
+        ctx.weights_update(prob2.wavemaps[0]._wset, W, sl)  # the library refuses a dense set for a scalar one
+
+
+@pytest.mark.parametrize("n", [5, 64, 100, 200])
+def test_whitening_ratio_kernel(ctx, n):
+    """M = W_new . inv(W_old) for upper-triangular whitening operators (blocked right-side triangular
+    solve on the FP64 matrix cores) against numpy"""
+    rng = np.random.default_rng(n)
+    t = np.arange(n)
+    def op(scale, corr):
+        Cm = scale * np.exp(-np.abs(t[:, None] - t[None, :]) / corr) + 1e-3 * np.eye(n)
+        return np.linalg.cholesky(np.linalg.inv(Cm)).T
+    Wo = np.stack([op(0.7, 5.0), op(1.3, 2.0), np.triu(rng.standard_normal((n, n))) + 4.0 * np.eye(n)])
+    Wn = np.stack([op(0.9, 4.0), op(0.4, 7.0), np.triu(rng.standard_normal((n, n))) + 3.0 * np.eye(n)])
+    M = ctx.whitening_ratio_batch(Wn, Wo)
+    for i in range(3):
+        ref = Wn[i] @ np.linalg.inv(Wo[i])
+        assert np.array_equal(np.tril(M[i], -1), np.zeros((n, n)))
+        np.testing.assert_allclose(M[i], ref, rtol=0, atol=1e-10 * np.abs(ref).max())
+        np.testing.assert_allclose(M[i] @ Wo[i], Wn[i], rtol=0, atol=1e-11 * np.abs(Wn[i]).max())
+    bad = Wo.copy()
+    bad[1, n // 2, n // 2] = 0.0
+    with pytest.raises(np.linalg.LinAlgError):
+        ctx.whitening_ratio_batch(Wn, bad)
+
+
+@pytest.mark.parametrize("name", ["seis_dense_ml_shifts", "joint_multifault"])
+def test_update_weights_on_prewhitened_library(ctx, name):
+    """SURVEY 8(f) row 2, "re-whiten on update_weights": a wavemap compiled with a pre-whitened
+    library follows a covariance update in place (rows and data times M = W_new . inv(W_old)) and
+    gives the likelihoods of a model built with the new weights from scratch; twice in a row"""
+    from test_gpu_parity import _specs
+    from beat_amd.heart import chol_inverse_batch
+    from beat_amd.synthetic import build_problem, draw_population
+    spec = _specs()[name]
+    prob, host = build_problem(spec)
+    fp = prob.compile(ctx, prewhiten=True)
+    probd, _ = build_problem(spec)
+    fd = probd.compile(ctx)                                  # dense-weight twin
+    Q = draw_population(spec, host["layout"], host["lower"], host["upper"], 70)
+    np.testing.assert_allclose(fp.batch(Q), fd.batch(Q), rtol=1e-9, atol=1e-7)
+    T, N = prob.wavemaps[0].data.shape
+    t = np.arange(N)
+    rng = np.random.default_rng(3)
+    for rep in range(2):
+        covs = np.stack([rng.uniform(0.2, 2.0) * np.exp(-np.abs(t[:, None] - t[None, :]) / rng.uniform(1.0, 6.0))
+                         + 1e-3 * np.eye(N) for _ in range(T)])
+        W, sl = chol_inverse_batch(covs)
+        fp.update_weights(0, W, sl)
+        fd.update_weights(0, W, sl)
+        np.testing.assert_allclose(fp.batch(Q), fd.batch(Q), rtol=1e-9, atol=1e-7)
 
 
 # ----------------------------------------------------------------------------- seams
