@@ -95,6 +95,7 @@ _PROTOS = {
     "beatamd_whiten_rows": [_vp, _vp, _i64, _i64, _vp],
     "beatamd_chol_inverse_batch": [_vp, _i64, _i64, _vp, _vp, _vp],
     "beatamd_whitening_ratio_batch": [_vp, _i64, _i64, _vp, _vp, _vp],
+    "beatamd_factor_compact": [_vp, _i64, _i64, _vp, _vp],
     "beatamd_ffi_model_update_data": [_vp, _i32, _i32, _vp],
     "beatamd_halfspace_displacements_batch": [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _f64, _vp],
 }

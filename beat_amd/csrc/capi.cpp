@@ -1076,6 +1076,20 @@ int beatamd_chol_inverse_batch(beatamd_ctx *ctx, int64_t nd, int64_t n, const do
     return finish_out(ctx, recs, 2);
 }
 
+int beatamd_factor_compact(beatamd_ctx *ctx, int64_t K, int64_t n, const double *factor, double *R)
+{
+    ENTER(ctx);
+    BA_CHECK(factor && R && K > 0 && n > 0, BEATAMD_EINVAL, "factor_compact: bad argument");
+    const void *d_f;
+    void *d_r;
+    Arg rec;
+    BA_TRY(stage_in(ctx, SL_IN0, factor, (size_t)K * n * 8, &d_f));
+    BA_TRY(stage_out(ctx, SL_OUT0, R, (size_t)n * n * 8, &d_r, &rec));
+    BA_TRY(launch_gram_cholesky(ctx, K, n, (const double *)d_f, (double *)d_r));
+    BA_TRY(ctx->check_status());
+    return finish_out(ctx, &rec, 1);
+}
+
 int beatamd_whitening_ratio_batch(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *W_new,
                                   const double *W_old, double *M)
 {

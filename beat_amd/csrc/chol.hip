@@ -125,6 +125,38 @@ __global__ void k_chol_logdet(const double *logd, int nblk, int64_t nbatch, doub
     out[b] = 2.0 * s;
 }
 
+// blocked right-looking Cholesky of the lower triangles of A [nbatch][np][np] in place (np a multiple
+// of 64): diagonal blocks by k_chol_diag (their inverses to Dinv and to X's diagonal blocks, their
+// log-determinants to logd), panels and trailing updates as batched GEMMs
+static int potrf_lower(beatamd_ctx *ctx, int64_t nbatch, int64_t np, double *A, double *Dinv, double *X, double *logd)
+{
+    const int nblk = (int)(np / CH_NB);
+    const int64_t sM = np * np;
+    for (int kb = 0; kb < nblk; kb++) {
+        hipLaunchKernelGGL(k_chol_diag, dim3((unsigned)nbatch), dim3(256), 0, ctx->stream, A, np, kb, Dinv, X,
+                           logd, nblk, ctx->d_status);
+        const int64_t r0 = (int64_t)(kb + 1) * CH_NB, below = np - r0;
+        if (below == 0) break;
+        GemmCall g;
+        // panel: A[r0:, kb] <- A[r0:, kb] . inv(L_kk)^T
+        g.A = A + r0 * np + (int64_t)kb * CH_NB; g.lda = np; g.sA = sM;
+        g.B = Dinv + (int64_t)kb * CH_NB * CH_NB; g.ldb = CH_NB; g.sB = (int64_t)nblk * CH_NB * CH_NB;
+        g.O = A + r0 * np + (int64_t)kb * CH_NB; g.ldo = np; g.sO = sM;
+        g.M = below; g.N = CH_NB; g.K = CH_NB; g.b_kn = 0; g.nbatch = (int)nbatch;
+        g.timer = nullptr;
+        BA_TRY(launch_gemm_f64(ctx, g));
+        // trailing update of the lower triangle: A[r0:, r0:] -= P . P^T with P = A[r0:, kb]
+        GemmCall u;
+        u.A = A + r0 * np + (int64_t)kb * CH_NB; u.lda = np; u.sA = sM;
+        u.B = u.A; u.ldb = np; u.sB = sM;
+        u.O = A + r0 * np + r0; u.ldo = np; u.sO = sM;
+        u.M = below; u.N = below; u.K = CH_NB; u.b_kn = 0; u.nbatch = (int)nbatch;
+        u.alpha = -1.0; u.accumulate = 1; u.lower_only = 1;
+        BA_TRY(launch_gemm_f64(ctx, u));
+    }
+    return BEATAMD_OK;
+}
+
 int launch_chol_inverse(beatamd_ctx *ctx, int64_t nbatch, int64_t n, const double *C, double *W, double *log_pdet)
 {
     if (nbatch == 0 || n == 0) return BEATAMD_OK;
@@ -150,28 +182,7 @@ int launch_chol_inverse(beatamd_ctx *ctx, int64_t nbatch, int64_t n, const doubl
         hipLaunchKernelGGL(k_chol_flip_pad, grid, dim3(256), 0, ctx->stream, C, n, np, A);
     }
     const int64_t sM = np * np;
-    for (int kb = 0; kb < nblk; kb++) {
-        hipLaunchKernelGGL(k_chol_diag, dim3((unsigned)nbatch), dim3(256), 0, ctx->stream, A, np, kb, Dinv, X,
-                           logd, nblk, ctx->d_status);
-        const int64_t r0 = (int64_t)(kb + 1) * CH_NB, below = np - r0;
-        if (below == 0) break;
-        GemmCall g;
-        // panel: A[r0:, kb] <- A[r0:, kb] . inv(L_kk)^T
-        g.A = A + r0 * np + (int64_t)kb * CH_NB; g.lda = np; g.sA = sM;
-        g.B = Dinv + (int64_t)kb * CH_NB * CH_NB; g.ldb = CH_NB; g.sB = (int64_t)nblk * CH_NB * CH_NB;
-        g.O = A + r0 * np + (int64_t)kb * CH_NB; g.ldo = np; g.sO = sM;
-        g.M = below; g.N = CH_NB; g.K = CH_NB; g.b_kn = 0; g.nbatch = (int)nbatch;
-        g.timer = nullptr;
-        BA_TRY(launch_gemm_f64(ctx, g));
-        // trailing update of the lower triangle: A[r0:, r0:] -= P . P^T with P = A[r0:, kb]
-        GemmCall u;
-        u.A = A + r0 * np + (int64_t)kb * CH_NB; u.lda = np; u.sA = sM;
-        u.B = u.A; u.ldb = np; u.sB = sM;
-        u.O = A + r0 * np + r0; u.ldo = np; u.sO = sM;
-        u.M = below; u.N = below; u.K = CH_NB; u.b_kn = 0; u.nbatch = (int)nbatch;
-        u.alpha = -1.0; u.accumulate = 1; u.lower_only = 1;
-        BA_TRY(launch_gemm_f64(ctx, u));
-    }
+    BA_TRY(potrf_lower(ctx, nbatch, np, A, Dinv, X, logd));
     // X = inv(M) by row blocks (X's diagonal blocks are in place already)
     for (int kb = 1; kb < nblk; kb++) {
         const int64_t kc = (int64_t)kb * CH_NB;
@@ -304,6 +315,76 @@ int launch_triu_ratio(beatamd_ctx *ctx, int64_t nbatch, int64_t n, const double 
     }
     const dim3 gu((unsigned)((n * n + 255) / 256), (unsigned)nbatch);
     hipLaunchKernelGGL(k_unpad, gu, dim3(256), 0, ctx->stream, (const double *)X, n, np, M);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
+}  // namespace beatamd
+
+// ---------------------------------------------------------------------------------------------
+// R [n x n] upper triangular with R^T R = F^T F for a tall factor F [K x n] (K >> n): the compact
+// form of a proposal factor.  SMC draws its stage proposals as z . F with F the weighted, centred
+// population (K = number of chains), which needs K normals per proposal row; with many more chains
+// than parameters the n x n Cholesky factor of the same covariance gives the same distribution
+// from n normals per row (base.py:163-186 factors the covariance the same way).  Gram matrix and
+// factorisation on the FP64 matrix cores; a Gram matrix that is not numerically positive definite
+// (collapsed population) is BEATAMD_ENOTPSD and the caller keeps the tall factor.
+namespace beatamd {
+
+__global__ void __launch_bounds__(256) k_transpose(const double *F, int64_t K, int64_t n, double *Ft)
+{
+    __shared__ double tile[16][17];
+    const int64_t k0 = (int64_t)blockIdx.x * 16, j0 = (int64_t)blockIdx.y * 16;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    if (k0 + ty < K && j0 + tx < n) tile[ty][tx] = F[(k0 + ty) * n + j0 + tx];
+    __syncthreads();
+    if (j0 + ty < n && k0 + tx < K) Ft[(j0 + ty) * K + k0 + tx] = tile[tx][ty];
+}
+
+// R[i][j] = (j >= i) ? L[j][i] : 0  from the padded lower factor
+__global__ void __launch_bounds__(256) k_lower_to_upper(const double *L, int64_t n, int64_t np, double *R)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * n) return;
+    const int64_t i = idx / n, j = idx % n;
+    R[idx] = (j >= i) ? L[j * np + i] : 0.0;
+}
+
+__global__ void __launch_bounds__(256) k_identity_pad(double *A, int64_t n, int64_t np)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= np * np) return;
+    const int64_t i = idx / np, j = idx % np;
+    if (i >= n || j >= n) A[idx] = (i == j) ? 1.0 : 0.0;
+}
+
+int launch_gram_cholesky(beatamd_ctx *ctx, int64_t K, int64_t n, const double *F, double *R)
+{
+    BA_CHECK(F && R && K > 0 && n > 0, BEATAMD_EINVAL, "gram_cholesky: bad argument");
+    const int64_t np = (n + CH_NB - 1) / CH_NB * CH_NB;
+    const int nblk = (int)(np / CH_NB);
+    void *p = nullptr;
+    BA_TRY(ctx->get_scratch(SL_CHOL_A, (size_t)np * np * 8, &p));
+    double *A = (double *)p;
+    BA_TRY(ctx->get_scratch(SL_CHOL_X, (size_t)np * np * 8, &p));
+    double *X = (double *)p;
+    BA_TRY(ctx->get_scratch(SL_CHOL_D, (size_t)nblk * CH_NB * CH_NB * 8, &p));
+    double *Dinv = (double *)p;
+    BA_TRY(ctx->get_scratch(SL_CHOL_T, (size_t)n * K * 8, &p));
+    double *Ft = (double *)p;
+    BA_TRY(ctx->get_scratch(SL_CHOL_L, (size_t)nblk * 8, &p));
+    double *logd = (double *)p;
+    ScopedTimer tm(ctx, "gram_cholesky");
+    hipLaunchKernelGGL(k_transpose, dim3((unsigned)((K + 15) / 16), (unsigned)((n + 15) / 16)), dim3(256), 0,
+                       ctx->stream, F, K, n, Ft);
+    GemmCall g;   // A[:n, :n] = Ft . Ft^T
+    g.A = Ft; g.lda = K; g.B = Ft; g.ldb = K; g.O = A; g.ldo = np;
+    g.M = n; g.N = n; g.K = K; g.b_kn = 0;
+    BA_TRY(launch_gemm_f64(ctx, g));
+    hipLaunchKernelGGL(k_identity_pad, dim3((unsigned)((np * np + 255) / 256)), dim3(256), 0, ctx->stream, A, n, np);
+    BA_TRY(potrf_lower(ctx, 1, np, A, Dinv, X, logd));
+    hipLaunchKernelGGL(k_lower_to_upper, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const double *)A, n, np, R);
     BA_HIP(hipGetLastError());
     return BEATAMD_OK;
 }

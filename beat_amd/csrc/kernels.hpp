@@ -149,6 +149,8 @@ struct GemmCall {
 int launch_gemm_f64(beatamd_ctx *ctx, const GemmCall &call);
 // chol.hip: W = cholesky(inv(C)).T and log det C of a stack of matrices (device pointers)
 int launch_chol_inverse(beatamd_ctx *ctx, int64_t nbatch, int64_t n, const double *C, double *W, double *log_pdet);
+// R [n,n] upper triangular with R^T R = F^T F for a tall F [K,n] (device pointers)
+int launch_gram_cholesky(beatamd_ctx *ctx, int64_t K, int64_t n, const double *F, double *R);
 // M = Wn . inv(Wo) for stacks of upper-triangular matrices (device pointers)
 int launch_triu_ratio(beatamd_ctx *ctx, int64_t nbatch, int64_t n, const double *Wn, const double *Wo, double *M);
 

@@ -470,6 +470,20 @@ class Context(object):
         check(self._lib.beatamd_chol_inverse_batch(self._h, nd, n, ptr(C), ptr(W), ptr(lp)))
         return W, lp
 
+    def factor_compact(self, factor):
+        """tall proposal factor (K, n) -> upper-triangular R (n, n) with R^T R = factor^T factor, or
+        None when the Gram matrix is not numerically positive definite"""
+        if _is_dev(factor):
+            self._adopt_stream(factor)
+        F = f64(factor)
+        K, n = int(F.shape[0]), int(F.shape[1])
+        R = _empty_like(F, (n, n))
+        try:
+            check(self._lib.beatamd_factor_compact(self._h, K, n, ptr(F), ptr(R)))
+        except np.linalg.LinAlgError:
+            return None
+        return R
+
     def whitening_ratio_batch(self, W_new, W_old):
         """M (nd, n, n) = W_new . inv(W_old) for upper-triangular whitening operators"""
         Wn, Wo = f64(W_new), f64(W_old)

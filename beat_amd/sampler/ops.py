@@ -116,7 +116,16 @@ class DeviceOps(object):
         return self.ctx.smc_resample(weights, aux)
 
     def population_factor(self, population, weights):
-        return self.ctx.smc_population_factor(population, weights)
+        """tall factor F (chains, nparams) of the weighted sample covariance; with (many) more chains
+        than parameters its compact Cholesky form R (nparams, nparams), R^T R = F^T F -- nparams
+        instead of `chains` normals per proposal row.  A population whose covariance is not
+        numerically positive definite keeps the tall factor."""
+        F = self.ctx.smc_population_factor(population, weights)
+        if F.shape[0] >= 2 * F.shape[1]:
+            R = self.ctx.factor_compact(F)
+            if R is not None:
+                return R
+        return F
 
     def draw(self, factor, n_chains, seed, step, first_chain=0, df=0):
         return self.ctx.proposal_draw(factor, n_chains, seed, step, first_chain=first_chain, df=df)

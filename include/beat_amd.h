@@ -318,6 +318,15 @@ int beatamd_whiten_rows(beatamd_ctx *ctx, double *rows, int64_t nrows, int64_t N
 int beatamd_chol_inverse_batch(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *covs, double *W,
                                double *log_pdet);
 
+/* replaces: the Cholesky factor inside pymc's MultivariateNormalProposal (base.py:163-186,
+ *           numpy.linalg.cholesky of the proposal covariance) for the stage proposals of SMC:
+ *   factor [K,n] (beatamd_smc_population_factor, K = number of chains) -> R [n,n] upper triangular
+ *   with R^T R = factor^T factor, so that z[n] . R has the distribution of z[K] . factor.  Used when
+ *   the population is larger than the number of parameters (n normals per proposal row instead
+ *   of K).  A Gram matrix that is not numerically positive definite is BEATAMD_ENOTPSD: the caller
+ *   keeps the tall factor (a collapsed or too small population). */
+int beatamd_factor_compact(beatamd_ctx *ctx, int64_t K, int64_t n, const double *factor, double *R);
+
 /* replaces: nothing in the reference (it keeps W and multiplies per step); companion of
  *           beatamd_whiten_rows for update_weights (seismic.py:1509-1534) on a pre-whitened library:
  *   M [nd,n,n] = W_new . inv(W_old) for upper-triangular whitening operators, so that

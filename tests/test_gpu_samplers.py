@@ -76,7 +76,11 @@ def test_stage_ops_large_population_vs_host_ops(ctx):
         X = torch.from_numpy(rng.standard_normal((n, 37)))
         Fh = hops.population_factor(X, wh).numpy()
         Fd = dops.population_factor(X.to(dev), wh.to(dev)).cpu().numpy()
-        np.testing.assert_allclose(Fd, Fh, rtol=1e-10, atol=1e-13)
+        if Fd.shape == Fh.shape:
+            np.testing.assert_allclose(Fd, Fh, rtol=1e-10, atol=1e-13)
+        else:   # many more chains than parameters: the compact Cholesky form of the same covariance
+            assert Fd.shape == (37, 37)
+            np.testing.assert_allclose(Fd.T @ Fd, Fh.T @ Fh, rtol=1e-9, atol=1e-12)
         sel = torch.from_numpy(rng.integers(0, n, 100).astype(np.int32))
         assert torch.equal(dops.gather(X.to(dev), sel.to(dev)).cpu(), X[sel.long()])
     ctx.synchronize()
@@ -238,6 +242,37 @@ def test_update_weights_validation(ctx):
         f2.update_weights(0, np.ones(3), sl)                # a pre-whitened wavemap takes dense operators
     with pytest.raises(ValueError):
         ctx.weights_update(prob2.wavemaps[0]._wset, W, sl)  # the library refuses a dense set for a scalar one
+
+
+@pytest.mark.parametrize("K,n", [(40, 7), (1024, 12), (700, 130), (300, 200)])
+def test_compact_proposal_factor(ctx, K, n):
+    """R (n, n) upper triangular with R^T R = F^T F for a tall population factor (Gram matrix and
+    blocked Cholesky on the device); DeviceOps uses it when chains >= 2 x parameters; a collapsed
+    population (singular Gram matrix) keeps the tall factor"""
+    import torch
+    from beat_amd.sampler.ops import DeviceOps
+    rng = np.random.default_rng(K + n)
+    X = rng.standard_normal((K, n)) * (1.0 + np.arange(n))[None, :] + rng.standard_normal(n)
+    w = rng.random(K)
+    dev = torch.device("cuda", 0)
+    F = ctx.smc_population_factor(torch.from_numpy(X).to(dev), torch.from_numpy(w).to(dev))
+    R = ctx.factor_compact(F)
+    cov = np.cov(X, aweights=w, bias=False, rowvar=0)
+    Rn = R.cpu().numpy()
+    assert np.array_equal(np.tril(Rn, -1), np.zeros((n, n))) and (np.diag(Rn) > 0).all()
+    np.testing.assert_allclose(Rn.T @ Rn, cov, rtol=1e-10, atol=1e-12 * np.abs(cov).max())
+    np.testing.assert_allclose(Rn, np.linalg.cholesky(cov).T, rtol=1e-8, atol=1e-10 * np.abs(Rn).max())
+    ops = DeviceOps(ctx)
+    P = ops.population_factor(torch.from_numpy(X).to(dev), torch.from_numpy(w).to(dev))
+    assert tuple(P.shape) == ((n, n) if K >= 2 * n else (K, n))
+    Pn = P.cpu().numpy()
+    np.testing.assert_allclose(Pn.T @ Pn, cov, rtol=1e-10, atol=1e-12 * np.abs(cov).max())
+    # collapsed population: two distinct points only -> rank 1 -> the tall factor stays
+    Xc = np.repeat(X[:2], K // 2, axis=0)
+    Pc = ops.population_factor(torch.from_numpy(Xc).to(dev), torch.from_numpy(np.ones(len(Xc))).to(dev))
+    assert tuple(Pc.shape) == ((len(Xc), n) if n > 1 else (n, n))
+    Pcn = Pc.cpu().numpy()
+    np.testing.assert_allclose(Pcn.T @ Pcn, np.cov(Xc, rowvar=0), rtol=1e-9, atol=1e-9 * np.abs(cov).max())
 
 
 @pytest.mark.parametrize("n", [5, 64, 100, 200])
