@@ -211,6 +211,18 @@ def test_fullsize_shipped_dma_kernel_at_bench_shape(full, monkeypatch, C):
             assert ctx.last_kernel().startswith("k_gfstack_ws<1,0,3,"), ctx.last_kernel()
             assert torch.equal(out, out2), "k_gfstack_ws differs from k_gfstack_dma"
             del out2
+            # size-independent properties of the stack at the full size: scaling the
+            # slips by a power of two scales every synthetic exactly; slips a + b stack to the sum
+            # of the stacks (rounding of the 400-term sums only)
+            out4 = gf.stack_all_batch(dur_d, st_d, 4.0 * sl_d, interpolation=interp)
+            assert torch.equal(out4, 4.0 * out), "stack is not homogeneous in the slips"
+            del out4
+            sl_a = sl_d * torch.rand_like(sl_d)
+            oa = gf.stack_all_batch(dur_d, st_d, sl_a, interpolation=interp)
+            ob = gf.stack_all_batch(dur_d, st_d, sl_d - sl_a, interpolation=interp)
+            scale = float(out.abs().max())
+            assert float((oa + ob - out).abs().max()) <= 1e-11 * scale, "stack is not additive in the slips"
+            del oa, ob
         for c, t in pairs:
             want = _stack_reference(full, dur[c], st[c, t], sl[c], t, interp)
             got = out[c, t].cpu().numpy()
