@@ -361,6 +361,7 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &k)
     }
     BA_HIP(hipGetLastError());
 
+    if (gfstack_cell_applicable(k)) return launch_gfstack_cell(ctx, k, ta.rowoff, ta.fac, Ttab);
     {
         int cg = 0, ucap = 0;
         if (gfstack_shared_applicable(k, &cg, &ucap)) {

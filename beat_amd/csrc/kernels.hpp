@@ -61,6 +61,11 @@ int gfstack_shared_candidates(const GfStackCall &call, int *cgs, int *ucaps);
 int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &call, const uint32_t *rowoff,
                           const double *fac, int CG, int ucap, int64_t Ttab);
 
+// gfcell.hip: multilinear stacking with the rows of a cell in registers (512-chain groups)
+bool gfstack_cell_applicable(const GfStackCall &call);
+int launch_gfstack_cell(beatamd_ctx *ctx, const GfStackCall &call, const uint32_t *rowoff,
+                        const double *fac, int64_t Ttab);
+
 // ---- quadform.hip ----------------------------------------------------------------
 // quad[c,d] = || A_d x_{c,d} ||^2 ; A [nd or 1, M, M] row-major ; x(c,d,k) = X[c*xs_c + d*xs_d + k]
 struct QuadformCall {

@@ -1,0 +1,130 @@
+"""CPU check of the k_gfstack_cell wavefront program (beat_amd/csrc/gfcell_asm.inc).
+
+tools/gfcell_emu.py interprets the instruction list that tools/gen_gfcell_asm.py emits -- all 16
+wavefronts of a workgroup with their barriers, the ring of LDS row buffers, the command stream --
+and a numpy twin of the table builder; the result is compared with a direct multilinear stack
+(reference beat/ffi/base.py:663-704).  Timing / hazards are not modelled; the -m gpu tests run the
+real kernel against k_gfstack and the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import gen_gfcell_asm as gen  # noqa: E402
+import gfcell_emu as emu  # noqa: E402
+
+
+def _reference(G, ro, fa, sl, T, P, N):
+    """acc = a*b + c in the kernel's order: patches ascending, rows k = 0..3"""
+    C = sl.shape[0]
+    Gr = G.reshape(-1, N)
+    out = np.zeros((C, T, N))
+    for c in range(C):
+        for t in range(T):
+            acc = np.zeros(N)
+            for p in range(P):
+                for k in range(4):
+                    acc = Gr[ro[c, t, p, k]] * (fa[c, t, p, k] * sl[c, p]) + acc
+            out[c, t] = acc
+    return out
+
+
+def _run(T, P, D, S, N, C, Ttab_is_one, mode, sort, nth, seed):
+    rng = np.random.default_rng(seed)
+    G = rng.standard_normal((T, P, D, S, N))
+    du = rng.uniform(0.5, 0.5 + 0.5 * (D - 1), (C, P))
+    st = rng.uniform(0.0, 0.5 * (S - 1) - 0.01, (C, 1 if Ttab_is_one else T, P))
+    st[0, 0, 0] = 0.0        # exactly on node 0: the floor node wraps to the last one with factor 0
+    du[min(1, C - 1), P - 1] = 0.5
+    sl = rng.uniform(0, 5, (C, P))
+    Ttab = 1 if Ttab_is_one else T
+    ro, fa = emu.gf_tables_ml(st, du, 0.0, 0.5, 0.5, 0.5, D, S, Ttab, P)
+    DS = D * S
+    order = emu.gc_order(ro, C, Ttab, P, S, sort)
+    assert sorted(order[order != emu.DEAD].tolist()) == list(range(C))
+    stream, hdr, ucount = emu.gc_tables(ro, fa, [sl], order, C, Ttab, P, DS)
+    data = rng.standard_normal((T, N))
+    wsc = rng.uniform(0.5, 2.0, T)
+    ntile = (N + 63) // 64
+    mem = emu.Memory()
+    a = dict(T=T, P=P, N=N, DS=DS, Ttab=Ttab, rows_per_target=P * DS, nsteps=P, mode=mode, ntile=ntile,
+             wscalar=wsc)
+    a["G"] = mem.alloc(G.nbytes, G)
+    a["stream"] = mem.alloc(stream.nbytes, stream)
+    a["hdr"] = mem.alloc(hdr.nbytes, hdr)
+    a["order"] = mem.alloc(order.nbytes, order)
+    a["data"] = mem.alloc(data.nbytes, data)
+    a["out"] = mem.alloc(C * T * N * 8)
+    a["partial"] = mem.alloc(C * T * ntile * 8)
+    ngroups = order.size // emu.CG
+    stats = []
+    for g in range(ngroups):
+        for t in range(T):
+            for tile in range(ntile):
+                params = [emu.wave_params(w, g, t, tile, a) for w in range(emu.WAVES)]
+                wg = emu.Workgroup(mem, nth, emu.lds_bytes(DS), params).run()
+                assert all(w.done and not w.idx_en and w.exec == emu.MASK64 for w in wg.waves)
+                assert {w.nbarrier for w in wg.waves} == {P + 1}
+                stats.append(wg)
+    # full rows for the reference: with tables per patch the row ids are those of target 0
+    rof = ro if Ttab == T else np.stack([ro[:, 0] + t * P * DS for t in range(T)], 1)
+    faf = fa if Ttab == T else np.repeat(fa, T, axis=1)
+    ref = _reference(G, rof, faf, sl, T, P, N)
+    out = mem.array(a["out"], np.float64, C * T * N).reshape(C, T, N)
+    if mode == 0:
+        assert np.array_equal(out, ref)
+    elif mode == 2:
+        assert np.array_equal(out, data[None] - ref)
+    else:
+        part = mem.array(a["partial"], np.float64, C * T * ntile).reshape(C, T, ntile)
+        exp = np.zeros_like(part)
+        for c in range(C):
+            for t in range(T):
+                for tl in range(ntile):
+                    q = 0.0
+                    for i in range(tl * 64, min(N, tl * 64 + 64)):
+                        tt = wsc[t] * (data[t, i] - ref[c, t, i])
+                        q = tt * tt + q
+                    exp[c, t, tl] = q
+        assert np.array_equal(part, exp)
+    return stats, ucount
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_program_one_group(mode):
+    """40 chains (one full wavefront, one partly filled, fourteen empty), two tiles (64 + 6 samples),
+    tables per target, node-0 wrap and exact-grid durations included"""
+    _run(T=2, P=4, D=3, S=6, N=70, C=40, Ttab_is_one=False, mode=mode, sort=True, nth=mode & 1, seed=5 + mode)
+
+
+def test_program_tables_per_patch_and_order():
+    """tables built once per (chain, patch); results do not depend on the chain order"""
+    for sort in (True, False):
+        stats, _ = _run(T=2, P=3, D=2, S=5, N=64, C=70, Ttab_is_one=True, mode=0, sort=sort, nth=0, seed=11)
+    # every chain of a step costs exactly four indexed FMAs, whatever the batching
+    assert sum(w.fma_count for w in stats[0].waves) == 70 * 3 * 4
+
+
+def test_program_two_groups():
+    """513 chains: a full group and a group of one chain"""
+    stats, ucount = _run(T=1, P=2, D=2, S=4, N=64, C=513, Ttab_is_one=True, mode=1, sort=True, nth=1, seed=3)
+    # LDS-DMA moved every distinct row segment of the group once (plus the three-step prologue overlap)
+    assert stats[0].dma_bytes == int(ucount[:2].sum()) * 512
+
+
+def test_register_budget():
+    """the program stays inside the registers the kernel may use: 128 VGPRs (16 wavefronts per
+    workgroup = 4 per SIMD) and user SGPRs below s96 (VCC, FLAT_SCRATCH, XNACK_MASK above)"""
+    import re
+    assert gen.V_LAST < 128
+    for nth in (0, 1):
+        for ln in gen.program(nth):
+            for m in re.finditer(r"\bs\[(\d+):(\d+)\]|\bs(\d+)\b", ln):
+                hi = int(m.group(2) or m.group(3))
+                assert hi <= 95, ln
+            for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", ln):
+                hi = int(m.group(2) or m.group(3))
+                assert hi <= gen.V_LAST, ln

@@ -204,6 +204,13 @@ def test_fullsize_shipped_dma_kernel_at_bench_shape(full, monkeypatch, C):
         assert ctx.last_kernel().startswith("k_gfstack<"), ctx.last_kernel()
         monkeypatch.delenv("BEATAMD_GF_KERNEL")
         assert torch.equal(out, ref), "k_gfstack_dma differs from the streaming kernel (%s)" % interp
+        if nrow == 4:   # the shipped multilinear kernel (rows of a cell in registers, gfcell.hip)
+            monkeypatch.delenv("BEATAMD_GS_CG")
+            out2 = gf.stack_all_batch(dur_d, st_d, sl_d, interpolation=interp)
+            assert ctx.last_kernel().startswith("k_gfstack_cell<0,"), ctx.last_kernel()
+            assert torch.equal(out2, ref), "k_gfstack_cell differs from the streaming kernel"
+            del out2
+            monkeypatch.setenv("BEATAMD_GS_CG", "512")
         del ref
         if nrow == 1:   # the loader / consumer kernel on the same tables
             monkeypatch.setenv("BEATAMD_GS_WS", "1")

@@ -209,6 +209,19 @@ def test_shared_row_kernel_equals_streaming_kernel(ctx, orc, monkeypatch, C, int
     for c in (0, C // 2, C - 1):
         ref = orc.stack_all(G, dur[c], st[c], sl[c], 0.5, 0.25, 0.0, 0.5, interp)
         assert np.abs(b[c] - ref).max() <= 1e-11 * np.abs(ref).max()
+    if interp == "multilinear":
+        # rows of a cell in registers, accumulators through the VGPR index (gfcell.hip): the default
+        # from 192 chains on, forced below; chain order and non-temporal requests are scheduling only
+        if C >= 192:
+            assert ctx.last_kernel().startswith("k_gfstack_cell<0,"), ctx.last_kernel()
+        for srt, nth in (("1", "1"), ("0", "0")):
+            monkeypatch.setenv("BEATAMD_GS_CELL", "1")
+            monkeypatch.setenv("BEATAMD_GC_SORT", srt)
+            monkeypatch.setenv("BEATAMD_GS_NTHINT", nth)
+            assert np.array_equal(gf.stack_all_batch(dur, st, sl, interpolation=interp), a), (C, srt, nth)
+            assert ctx.last_kernel() == "k_gfstack_cell<0,%s>" % nth, ctx.last_kernel()
+        for name in ("BEATAMD_GS_CELL", "BEATAMD_GC_SORT", "BEATAMD_GS_NTHINT"):
+            monkeypatch.delenv(name)
     seen = set()
     for cg in ("64", "128", "256", "512", "1024"):
         monkeypatch.setenv("BEATAMD_GS_CG", cg)

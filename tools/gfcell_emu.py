@@ -1,0 +1,592 @@
+#!/usr/bin/env python
+"""
+gfcell_emu.py -- functional model of the k_gfstack_cell wavefront program (gfcell_asm.inc) and a
+numpy twin of its command-stream builder (k_gc_order / k_gc_tables in beat_amd/csrc/gfcell.hip).
+
+The wavefront program is register-allocated by hand and runs from tables; its control flow
+(buffer-set alternation, ring of three row buffers, barrier count per wavefront, pointer
+arithmetic) is checked here on the CPU -- tests/test_gfcell_program.py interprets the very
+instruction list tools/gen_gfcell_asm.py emits, for all 16 wavefronts of a workgroup, against a
+direct evaluation of the multilinear stack (reference beat/ffi/base.py:663-704).  Timing, hazards
+and wait counts are NOT modelled (the GPU tests cover the real thing); fma is evaluated as a*b+c
+on both sides.
+
+Test infrastructure only: nothing in the product imports this module.
+"""
+import os
+import re
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import gen_gfcell_asm as gen  # noqa: E402
+
+U32 = np.uint32
+MASK64 = (1 << 64) - 1
+DEAD = 0xFFFFFFFF
+CG, WAVES, NCH = 512, 16, gen.NCHAIN
+BLOCK = gen.BLOCK
+MAXBLK = NCH + 2
+STEP_STRIDE = MAXBLK * BLOCK
+TPITCH = 65 * 8
+PARAM_BYTES = WAVES * 128
+
+
+# =============================================================================== memory
+class Memory(object):
+    def __init__(self):
+        self.regions = []
+        self.next = 0x100000000
+
+    def alloc(self, nbytes, init=None):
+        base = self.next
+        buf = np.zeros(nbytes + 64, dtype=np.uint8)
+        if init is not None:
+            raw = np.ascontiguousarray(init).view(np.uint8).ravel()
+            buf[:raw.size] = raw
+        self.regions.append((base, buf))
+        self.next += ((nbytes + 64 + 0xFFFF) // 0x10000 + 1) * 0x10000
+        return base
+
+    def _find(self, addr, n):
+        for base, buf in self.regions:
+            if base <= addr and addr + n <= base + buf.size:
+                return buf, addr - base
+        raise IndexError("global access outside any allocation: 0x%x (+%d)" % (addr, n))
+
+    def read(self, addr, n):
+        buf, o = self._find(addr, n)
+        return buf[o:o + n]
+
+    def write(self, addr, data):
+        buf, o = self._find(addr, len(data))
+        buf[o:o + len(data)] = data
+
+    def array(self, base, dtype, count):
+        buf, o = self._find(base, count * np.dtype(dtype).itemsize)
+        return buf[o:o + count * np.dtype(dtype).itemsize].view(dtype)
+
+
+# =============================================================================== tables (numpy twin)
+def gf_tables_ml(st, du, st_min, st_dt, du_min, du_dt, D, S, T, P):
+    """k_gf_tables, multilinear branch (gfstack.hip): row ids [C,T,P,4] and factors [C,T,P,4]"""
+    C = st.shape[0]
+    ds = (st - st_min) / st_dt                       # [C,T,P]
+    dd = ((du - du_min) / du_dt)[:, None, :]         # [C,1,P]
+    sc = np.ceil(ds).astype(np.int64)
+    dc = np.ceil(dd).astype(np.int64) + np.zeros_like(sc)
+    stf, rtf = sc - ds, dc - dd
+    sf, df = sc - 1, dc - 1
+    sc, sf = np.where(sc < 0, sc + S, sc), np.where(sf < 0, sf + S, sf)
+    dc, df = np.where(dc < 0, dc + D, dc), np.where(df < 0, df + D, df)
+    row0 = (np.arange(T)[None, :, None] * P + np.arange(P)[None, None, :]) * D
+    ro = np.stack([(row0 + dc) * S + sc, (row0 + dc) * S + sf, (row0 + df) * S + sc, (row0 + df) * S + sf], -1)
+    fa = np.stack([(1 - stf) * (1 - rtf), stf * (1.0 - rtf), (1 - stf) * rtf, stf * rtf], -1)
+    return ro.astype(np.uint32), fa
+
+
+def gc_order(rowoff, C, T, P, S, sort=True):
+    ngroups = (C + CG - 1) // CG
+    order = np.full(ngroups * CG, DEAD, dtype=np.uint32)
+    for g in range(ngroups):
+        cs = np.arange(g * CG, min(C, (g + 1) * CG))
+        if not sort:
+            order[g * CG:g * CG + cs.size] = cs
+            continue
+        tid = cs - g * CG
+        s0 = rowoff[cs, 0, 0, 3] % S
+        s1 = rowoff[cs, 0, P // 2, 3] % S
+        r0 = np.argsort(np.argsort((s0.astype(np.int64) << 10) | tid))
+        band = r0 * 8 // cs.size
+        kb = (band.astype(np.int64) << 28) | (s1.astype(np.int64) << 10) | tid
+        r1 = np.argsort(np.argsort(kb))
+        order[g * CG + r1] = cs
+    return order
+
+
+def gc_tables(rowoff, fac, slips, order, C, T, P, DS, nvar=1):
+    """-> stream bytes, hdr dwords, ucount; layouts as k_gc_tables writes them"""
+    ngroups = order.size // CG
+    nsteps = P * nvar
+    GT = ngroups * T
+    stream = np.zeros(GT * WAVES * (nsteps + 1) * STEP_STRIDE + 256, dtype=np.uint8)
+    hdr = np.zeros(GT * (nsteps + 3) * WAVES * 8, dtype=np.uint32)
+    ucount = np.zeros(GT * P, dtype=np.uint32)
+    for g in range(ngroups):
+        for t in range(T):
+            gt = g * T + t
+            for p in range(P):
+                row0 = (t * P + p) * DS
+                ids = order[g * CG:(g + 1) * CG]
+                live = ids != DEAD
+                rel = np.zeros((CG, 4), dtype=np.int64)
+                rel[live] = rowoff[ids[live], t, p].astype(np.int64) - row0
+                distinct = np.unique(rel[live])
+                slot = {int(r): i for i, r in enumerate(distinct)}
+                U = distinct.size
+                ucount[gt * P + p] = U
+                for iv in range(nvar):
+                    s = p * nvar + iv
+                    ring = (s % 3) * DS
+                    for ww in range(WAVES):
+                        h = hdr[((gt * (nsteps + 3) + s) * WAVES + ww) * 8:][:8]
+                        h[0] = (U - ww + WAVES - 1) // WAVES if U > ww else 0
+                        for d in range(1, 8):
+                            idx = ww + WAVES * (d - 1)
+                            h[d] = (int(distinct[idx]) | (slot[int(distinct[idx])] << 16)) if idx < U else 0
+                    for w in range(WAVES):
+                        base = ((gt * WAVES + w) * (nsteps + 1) + s) * STEP_STRIDE
+                        js = [j for j in range(NCH) if live[w * NCH + j]]
+                        key = lambda j: (tuple(rel[w * NCH + j]), j)   # noqa: E731
+                        js.sort(key=key)
+                        batches = []
+                        for j in js:
+                            k4 = tuple(rel[w * NCH + j])
+                            if batches and batches[-1][0] == k4 and len(batches[-1][1]) < 4:
+                                batches[-1][1].append(j)
+                            else:
+                                batches.append((k4, [j]))
+                        nb = len(batches)
+                        nbe = max(nb, 1)
+                        gap = STEP_STRIDE - (nbe + 1) * BLOCK
+
+                        def info(i):
+                            return stream[base + i * BLOCK + 128:base + i * BLOCK + 144].view(np.uint32)
+                        lead = info(0)
+                        lead[2] = 0
+                        lead[3] = (gap if nbe == 1 else 0) << 8
+                        if nb == 0:
+                            lead[0] = ring * 64
+                            lead[1] = ring * 64
+                            e = info(1)
+                            e[:] = (0, 0, 0, 8)
+                        for b, (k4, chains) in enumerate(batches):
+                            i = 1 + b
+                            wq = stream[base + i * BLOCK:base + i * BLOCK + 128].view(np.float64)
+                            accb = 0
+                            for q, j in enumerate(chains):
+                                c = int(ids[w * NCH + j])
+                                sl = slips[iv][c, p]
+                                wq[4 * q:4 * q + 4] = fac[c, t, p] * sl
+                                accb |= (2 * j) << (8 * q)
+                            me = info(i)
+                            me[2] = accb
+                            me[3] = len(chains) | (8 if i == nb else 0) | ((gap if i == nb - 1 else 0) << 8)
+                            x = [(ring + slot[int(r)]) * 64 for r in k4]
+                            pv = info(i - 1)
+                            pv[0] = x[0] | (x[1] << 16)
+                            pv[1] = x[2] | (x[3] << 16)
+    return stream, hdr, ucount
+
+
+# =============================================================================== interpreter
+class Barrier(Exception):
+    pass
+
+
+def _parse_program(nth):
+    lines = gen.program(nth)
+    labels, prog = {}, []
+    for ln in lines:
+        m = re.match(r"^(\w+)_%=:$", ln)
+        if m:
+            labels[m.group(1)] = len(prog)
+        else:
+            prog.append(ln.replace("_%=", ""))
+    return prog, labels
+
+
+def _split_ops(rest):
+    out, depth, cur = [], 0, ""
+    for ch in rest:
+        if ch == "[":
+            depth += 1
+        if ch == "]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+class Wave(object):
+    def __init__(self, wg, wave_id, param_vgpr_value):
+        self.wg = wg
+        self.id = wave_id
+        self.s = np.zeros(128, dtype=np.uint64)       # SGPR file (32-bit values)
+        self.v = np.zeros((256, 64), dtype=np.uint32)
+        self.v[0, :] = param_vgpr_value               # the "%0" input lives in v0
+        self.exec = MASK64
+        self.vcc = 0
+        self.scc = 0
+        self.m0 = 0
+        self.idx_en = False
+        self.pc = 0
+        self.done = False
+        self.nbarrier = 0
+        self.ninstr = 0
+        self.fma_count = 0
+
+    # ---- operand access
+    def sreg(self, name):
+        if name == "vcc":
+            return ("special", "vcc")
+        if name == "exec":
+            return ("special", "exec")
+        if name == "m0":
+            return ("special", "m0")
+        m = re.match(r"^s\[(\d+):(\d+)\]$", name)
+        if m:
+            return ("s", int(m.group(1)), int(m.group(2)) - int(m.group(1)) + 1)
+        m = re.match(r"^s(\d+)$", name)
+        if m:
+            return ("s", int(m.group(1)), 1)
+        return None
+
+    def get_s32(self, op):
+        r = self.sreg(op)
+        if r is None:
+            return int(op, 0) & 0xFFFFFFFF
+        if r[0] == "special":
+            return getattr(self, r[1]) & 0xFFFFFFFF
+        return int(self.s[r[1]]) & 0xFFFFFFFF
+
+    def get_s64(self, op):
+        r = self.sreg(op)
+        if r is None:
+            return int(op, 0) & MASK64
+        if r[0] == "special":
+            return getattr(self, r[1]) & MASK64
+        return (int(self.s[r[1]]) & 0xFFFFFFFF) | ((int(self.s[r[1] + 1]) & 0xFFFFFFFF) << 32)
+
+    def set_s32(self, op, val):
+        r = self.sreg(op)
+        val &= 0xFFFFFFFF
+        if r[0] == "special":
+            setattr(self, r[1], val if r[1] == "m0" else (getattr(self, r[1]) & ~0xFFFFFFFF) | val)
+        else:
+            self.s[r[1]] = val
+
+    def set_s64(self, op, val):
+        r = self.sreg(op)
+        val &= MASK64
+        if r[0] == "special":
+            setattr(self, r[1], val)
+        else:
+            self.s[r[1]] = val & 0xFFFFFFFF
+            self.s[r[1] + 1] = val >> 32
+
+    @staticmethod
+    def vreg(name):
+        m = re.match(r"^-?v\[(\d+):(\d+)\]$", name)
+        if m:
+            return int(m.group(1))
+        m = re.match(r"^-?v(\d+)$", name)
+        if m:
+            return int(m.group(1))
+        return None
+
+    def src32(self, op):
+        """-> uint32[64]"""
+        if op == "%0":
+            return self.v[0]
+        r = self.vreg(op)
+        if r is not None:
+            return self.v[r]
+        return np.full(64, self.get_s32(op), dtype=np.uint32)
+
+    def src_f64(self, op, rel=0):
+        neg = op.startswith("-")
+        r = self.vreg(op)
+        if r is not None:
+            r += rel
+            x = (self.v[r].astype(np.uint64) | (self.v[r + 1].astype(np.uint64) << np.uint64(32))).view(np.float64)
+        else:
+            x = np.full(64, self.get_s64(op), dtype=np.uint64).view(np.float64)
+        return -x if neg else x
+
+    def lanes(self):
+        return np.array([(self.exec >> i) & 1 for i in range(64)], dtype=bool)
+
+    def wr32(self, r, val):
+        m = self.lanes()
+        x = (np.broadcast_to(np.asarray(val), (64,)).astype(np.uint64) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        self.v[r][m] = x[m]
+
+    def wr_f64(self, r, x):
+        m = self.lanes()
+        u = np.asarray(x, dtype=np.float64).view(np.uint64)
+        self.v[r][m] = (u & np.uint64(0xFFFFFFFF)).astype(np.uint32)[m]
+        self.v[r + 1][m] = (u >> np.uint64(32)).astype(np.uint32)[m]
+
+    # ---- execution
+    def run(self):
+        prog, labels = self.wg.prog, self.wg.labels
+        lds, mem = self.wg.lds, self.wg.mem
+        while self.pc < len(prog):
+            ln = prog[self.pc]
+            self.pc += 1
+            self.ninstr += 1
+            if self.ninstr > self.wg.max_instr:
+                raise RuntimeError("wavefront %d: instruction budget exceeded (runaway loop?)" % self.id)
+            parts = ln.split(None, 1)
+            op = parts[0]
+            rest = parts[1] if len(parts) > 1 else ""
+            imm_off = 0
+            mo = re.search(r"\soffset:(\w+)", rest)
+            if mo:
+                imm_off = int(mo.group(1), 0)
+                rest = rest.replace(mo.group(0), "")
+            ops = _split_ops(rest)
+            if self.idx_en and op.startswith("v_") and op != "v_fma_f64":
+                raise RuntimeError("VALU %s executed with VGPR indexing on" % op)
+            if self.idx_en and (op.startswith("ds_") or op.startswith("global_")):
+                raise RuntimeError("memory instruction with VGPR indexing on")
+            # ------------------------------------------------ scalar
+            if op in ("s_nop", "s_waitcnt"):
+                continue
+            if op == "s_barrier":
+                self.nbarrier += 1
+                yield "barrier"
+                continue
+            if op == "s_mov_b32":
+                self.set_s32(ops[0], self.get_s32(ops[1]))
+            elif op == "s_mov_b64":
+                val = int(ops[1], 0) if self.sreg(ops[1]) is None else self.get_s64(ops[1])
+                self.set_s64(ops[0], val)
+            elif op in ("s_add_u32", "s_addc_u32", "s_sub_u32"):
+                a, b = self.get_s32(ops[1]), self.get_s32(ops[2])
+                if op == "s_add_u32":
+                    r = a + b
+                    self.scc = int(r > 0xFFFFFFFF)
+                elif op == "s_addc_u32":
+                    r = a + b + self.scc
+                    self.scc = int(r > 0xFFFFFFFF)
+                else:
+                    r = a - b
+                    self.scc = int(b > a)
+                self.set_s32(ops[0], r)
+            elif op == "s_mul_i32":
+                self.set_s32(ops[0], self.get_s32(ops[1]) * self.get_s32(ops[2]))
+            elif op == "s_mul_hi_u32":
+                self.set_s32(ops[0], (self.get_s32(ops[1]) * self.get_s32(ops[2])) >> 32)
+            elif op in ("s_and_b32", "s_or_b32", "s_lshr_b32", "s_lshl_b32"):
+                a, b = self.get_s32(ops[1]), self.get_s32(ops[2])
+                r = {"s_and_b32": a & b, "s_or_b32": a | b, "s_lshr_b32": a >> (b & 31),
+                     "s_lshl_b32": (a << (b & 31))}[op] & 0xFFFFFFFF
+                self.set_s32(ops[0], r)
+                self.scc = int(r != 0)
+            elif op == "s_and_b64":
+                r = self.get_s64(ops[1]) & self.get_s64(ops[2])
+                self.set_s64(ops[0], r)
+                self.scc = int(r != 0)
+            elif op.startswith("s_cmp_"):
+                a, b = self.get_s32(ops[0]), self.get_s32(ops[1])
+                self.scc = int({"eq": a == b, "le": a <= b, "lt": a < b, "ge": a >= b}[op.split("_")[2]])
+            elif op == "s_bitcmp1_b32":
+                self.scc = (self.get_s32(ops[0]) >> (self.get_s32(ops[1]) & 31)) & 1
+            elif op == "s_bfm_b64":
+                n, sh = self.get_s32(ops[1]) & 63, self.get_s32(ops[2]) & 63
+                self.set_s64(ops[0], ((1 << n) - 1) << sh)
+            elif op == "s_cselect_b32":
+                self.set_s32(ops[0], self.get_s32(ops[1]) if self.scc else self.get_s32(ops[2]))
+            elif op in ("s_cbranch_scc1", "s_cbranch_scc0", "s_branch"):
+                if op == "s_branch" or self.scc == int(op.endswith("1")):
+                    self.pc = labels[ops[0]]
+            elif op == "s_set_gpr_idx_on":
+                self.idx_en = True
+                self.m0 = (self.m0 & ~0xF0FF) | (self.get_s32(ops[0]) & 0xFF) | ((int(ops[1], 0) & 0xF) << 12)
+            elif op == "s_set_gpr_idx_off":
+                self.idx_en = False
+            elif op.startswith("s_load_dwordx"):
+                n = int(op[len("s_load_dwordx"):])
+                r = self.sreg(ops[0])
+                assert r[2] == n and r[1] % min(n, 4) == 0, ln
+                base = self.sreg(ops[1])
+                assert base[1] % 2 == 0, ln
+                addr = self.get_s64(ops[1]) + int(ops[2], 0)
+                self.s[r[1]:r[1] + n] = mem.read(addr, 4 * n).view(np.uint32)
+            # ------------------------------------------------ vector
+            elif op == "v_mbcnt_lo_u32_b32":
+                self.wr32(self.vreg(ops[0]), np.minimum(np.arange(64), 32) + self.src32(ops[2]))
+            elif op == "v_mbcnt_hi_u32_b32":
+                self.wr32(self.vreg(ops[0]), np.maximum(np.arange(64) - 32, 0) + self.src32(ops[2]))
+            elif op == "v_lshlrev_b32":
+                self.wr32(self.vreg(ops[0]), self.src32(ops[2]).astype(np.uint64) << np.uint64(self.get_s32(ops[1])))
+            elif op == "v_lshrrev_b32":
+                self.wr32(self.vreg(ops[0]), self.src32(ops[2]).astype(np.uint64) >> np.uint64(self.get_s32(ops[1])))
+            elif op == "v_add_u32":
+                self.wr32(self.vreg(ops[0]), self.src32(ops[1]).astype(np.uint64) + self.src32(ops[2]))
+            elif op == "v_lshl_add_u32":
+                self.wr32(self.vreg(ops[0]), (self.src32(ops[1]).astype(np.uint64) << np.uint64(self.get_s32(ops[2])))
+                          + self.src32(ops[3]))
+            elif op == "v_mul_u32_u24":
+                self.wr32(self.vreg(ops[0]), (self.src32(ops[1]).astype(np.uint64) & np.uint64(0xFFFFFF))
+                          * (self.src32(ops[2]).astype(np.uint64) & np.uint64(0xFFFFFF)))
+            elif op == "v_mov_b32":
+                self.wr32(self.vreg(ops[0]), self.src32(ops[1]).astype(np.uint64))
+            elif op == "v_cndmask_b32":
+                assert ops[3] == "vcc"
+                sel = np.array([(self.vcc >> i) & 1 for i in range(64)], dtype=bool)
+                self.wr32(self.vreg(ops[0]), np.where(sel, self.src32(ops[2]), self.src32(ops[1])).astype(np.uint64))
+            elif op == "v_readlane_b32":
+                self.set_s32(ops[0], int(self.v[self.vreg(ops[1])][int(ops[2])]))
+            elif op == "v_writelane_b32":
+                self.v[self.vreg(ops[0])][int(ops[2])] = U32(self.get_s32(ops[1]))
+            elif op == "v_fma_f64":
+                rel = (self.m0 & 0xFF) if self.idx_en else 0
+                mode = (self.m0 >> 12) & 0xF if self.idx_en else 0
+                a = self.src_f64(ops[1], rel if mode & 1 else 0)
+                b = self.src_f64(ops[2], rel if mode & 2 else 0)
+                c = self.src_f64(ops[3], rel if mode & 4 else 0)
+                d = self.vreg(ops[0]) + (rel if mode & 8 else 0)
+                if self.idx_en:
+                    assert mode == 0xC and gen.ACC <= d <= gen.V_LAST - 1 and (d - gen.ACC) % 2 == 0, (ln, d)
+                    self.fma_count += 1
+                with np.errstate(all="ignore"):
+                    self.wr_f64(d, a * b + c)
+            elif op == "v_add_f64":
+                with np.errstate(all="ignore"):
+                    self.wr_f64(self.vreg(ops[0]), self.src_f64(ops[1]) + self.src_f64(ops[2]))
+            elif op == "v_mul_f64":
+                with np.errstate(all="ignore"):
+                    self.wr_f64(self.vreg(ops[0]), self.src_f64(ops[1]) * self.src_f64(ops[2]))
+            elif op == "v_mad_u64_u32":
+                r = self.vreg(ops[0])
+                c = self.v[self.vreg(ops[4])].astype(np.uint64) | (self.v[self.vreg(ops[4]) + 1].astype(np.uint64) << np.uint64(32))
+                prod = self.src32(ops[2]).astype(np.uint64) * self.src32(ops[3]).astype(np.uint64) + c
+                m = self.lanes()
+                self.v[r][m] = (prod & np.uint64(0xFFFFFFFF)).astype(np.uint32)[m]
+                self.v[r + 1][m] = (prod >> np.uint64(32)).astype(np.uint32)[m]
+            elif op == "v_cmp_ne_u32":
+                ne = self.src32(ops[1]) != self.src32(ops[2])
+                val = 0
+                for i in range(64):
+                    if ne[i] and (self.exec >> i) & 1:
+                        val |= 1 << i
+                self.set_s64(ops[0], val)
+            # ------------------------------------------------ LDS
+            elif op in ("ds_read_b32", "ds_read_b64", "ds_write_b64"):
+                off = imm_off
+                m = self.lanes()
+                if op == "ds_write_b64":
+                    addr = self.v[self.vreg(ops[0])].astype(np.int64) + off
+                    d = self.vreg(ops[1])
+                    for i in np.nonzero(m)[0]:
+                        assert 0 <= addr[i] and addr[i] + 8 <= lds.size, ("LDS write out of range", ln, addr[i])
+                        lds[addr[i]:addr[i] + 8].view(np.uint32)[:] = (self.v[d][i], self.v[d + 1][i])
+                else:
+                    n = 4 if op == "ds_read_b32" else 8
+                    addr = self.v[self.vreg(ops[1])].astype(np.int64) + off
+                    d = self.vreg(ops[0])
+                    for i in np.nonzero(m)[0]:
+                        if not (0 <= addr[i] and addr[i] + n <= lds.size):
+                            raise IndexError("LDS read out of range: %s lane %d addr %d" % (ln, i, addr[i]))
+                        w = lds[addr[i]:addr[i] + n].view(np.uint32)
+                        self.v[d][i] = w[0]
+                        if n == 8:
+                            self.v[d + 1][i] = w[1]
+            # ------------------------------------------------ global
+            elif op == "global_load_lds_dwordx4":
+                base = self.get_s64(ops[1].replace(" nt", ""))
+                voff = self.v[self.vreg(ops[0])].astype(np.int64)
+                for i in np.nonzero(self.lanes())[0]:
+                    dst = self.m0 + 16 * i
+                    assert PARAM_BYTES <= dst and dst + 16 <= lds.size, ("LDS-DMA destination", ln, dst)
+                    lds[dst:dst + 16] = mem.read(base + int(voff[i]), 16)
+                self.wg.dma_bytes += 16 * int(self.lanes().sum())
+            elif op in ("global_load_dwordx2", "global_load_dword"):
+                n = 8 if op.endswith("x2") else 4
+                off = imm_off
+                last = ops[2].split()[0]
+                base = self.get_s64(last)
+                voff = self.v[self.vreg(ops[1])].astype(np.int64)
+                d = self.vreg(ops[0])
+                for i in np.nonzero(self.lanes())[0]:
+                    w = mem.read(base + int(voff[i]) + off, n).view(np.uint32)
+                    self.v[d][i] = w[0]
+                    if n == 8:
+                        self.v[d + 1][i] = w[1]
+            elif op == "global_store_dwordx2":
+                d = self.vreg(ops[1])
+                if ops[2] == "off":
+                    a0 = self.vreg(ops[0])
+                    addr = self.v[a0].astype(np.uint64) | (self.v[a0 + 1].astype(np.uint64) << np.uint64(32))
+                else:
+                    addr = np.uint64(self.get_s64(ops[2])) + self.v[self.vreg(ops[0])].astype(np.uint64)
+                for i in np.nonzero(self.lanes())[0]:
+                    mem.write(int(addr[i]), np.array([self.v[d][i], self.v[d + 1][i]], dtype=np.uint32).view(np.uint8))
+            else:
+                raise NotImplementedError(ln)
+        self.done = True
+
+
+class Workgroup(object):
+    """one (group g, target t, tile) workgroup of k_gfstack_cell"""
+
+    def __init__(self, mem, nth, lds_bytes, params, max_instr=5000000):
+        self.mem = mem
+        self.prog, self.labels = _parse_program(nth)
+        self.lds = np.zeros(lds_bytes, dtype=np.uint8)
+        self.max_instr = max_instr
+        self.dma_bytes = 0
+        self.waves = []
+        for w in range(WAVES):
+            self.lds[w * 128:(w + 1) * 128].view(np.uint32)[:] = params[w]
+            self.waves.append(Wave(self, w, w * 128))
+
+    def run(self):
+        gens = [w.run() for w in self.waves]
+        alive = list(range(WAVES))
+        while alive:
+            arrived = []
+            for i in list(alive):
+                try:
+                    next(gens[i])
+                    arrived.append(i)
+                except StopIteration:
+                    alive.remove(i)
+            assert not arrived or len(arrived) == len(alive), "wavefronts disagree on the number of barriers"
+        nb = {w.nbarrier for w in self.waves}
+        assert len(nb) == 1, nb
+        return self
+
+
+def wave_params(w, g, t, tile, a):
+    """the parameter block the C++ prologue of k_gfstack_cell writes (dict a: the kernel arguments)"""
+    P = np.zeros(32, dtype=np.uint32)
+
+    def put64(k, x):
+        P[k], P[k + 1] = x & 0xFFFFFFFF, x >> 32
+    gt = g * a["Ttab"] + (0 if a["Ttab"] == 1 else t)
+    n0 = tile * 64
+    N, T = a["N"], a["T"]
+    put64(gen.P_ST, a["stream"] + ((gt * WAVES + w) * (a["nsteps"] + 1)) * STEP_STRIDE)
+    put64(gen.P_HD, a["hdr"] + (((gt * (a["nsteps"] + 3)) * WAVES + w) * 8) * 4)
+    put64(gen.P_GROW, a["G"] + ((t * a["rows_per_target"]) * N + n0) * 8)
+    P[gen.P_DSRB] = a["DS"] * N * 8
+    P[gen.P_ROWB] = N * 8
+    P[gen.P_RB0] = PARAM_BYTES
+    P[gen.P_BUFB] = a["DS"] * 512
+    P[gen.P_NSTEP] = a["nsteps"]
+    P[gen.P_NLANES] = min(32, (N - n0 + 1) // 2)
+    put64(gen.P_OUT, a["out"] + (t * N + n0) * 8)
+    P[gen.P_CTN] = T * N * 8
+    P[gen.P_MODE] = a["mode"]
+    put64(gen.P_DATA, a["data"] + (t * N + n0) * 8)
+    put64(gen.P_W, int(np.float64(a["wscalar"][t]).view(np.uint64)))
+    put64(gen.P_CID, a["order"] + (g * CG + w * NCH) * 4)
+    put64(gen.P_PART, a["partial"] + (t * a["ntile"] + tile) * 8)
+    P[gen.P_PCS] = T * a["ntile"] * 8
+    P[gen.P_NVALID] = min(64, N - n0)
+    P[gen.P_TRB] = PARAM_BYTES + w * 16 * TPITCH
+    return P
+
+
+def lds_bytes(DS):
+    return PARAM_BYTES + max(3 * DS * 512, WAVES * 16 * TPITCH)
