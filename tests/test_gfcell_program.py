@@ -45,7 +45,7 @@ def _run(T, P, D, S, N, C, Ttab_is_one, mode, sort, nth, seed):
     DS = D * S
     order = emu.gc_order(ro, C, Ttab, P, S, sort)
     assert sorted(order[order != emu.DEAD].tolist()) == list(range(C))
-    stream, hdr, ucount = emu.gc_tables(ro, fa, [sl], order, C, Ttab, P, DS)
+    wtab, ltab, ucount = emu.gc_tables(ro, fa, [sl], order, C, Ttab, P, DS)
     data = rng.standard_normal((T, N))
     wsc = rng.uniform(0.5, 2.0, T)
     ntile = (N + 63) // 64
@@ -53,9 +53,9 @@ def _run(T, P, D, S, N, C, Ttab_is_one, mode, sort, nth, seed):
     a = dict(T=T, P=P, N=N, DS=DS, Ttab=Ttab, rows_per_target=P * DS, nsteps=P, mode=mode, ntile=ntile,
              wscalar=wsc)
     a["G"] = mem.alloc(G.nbytes, G)
-    a["stream"] = mem.alloc(stream.nbytes, stream)
-    a["hdr"] = mem.alloc(hdr.nbytes, hdr)
-    a["order"] = mem.alloc(order.nbytes, order)
+    a["wtab"] = mem.alloc(wtab.nbytes, wtab)
+    a["ltab"] = mem.alloc(ltab.nbytes, ltab)
+    a["order"] = mem.alloc(order.nbytes + 256, order)
     a["data"] = mem.alloc(data.nbytes, data)
     a["out"] = mem.alloc(C * T * N * 8)
     a["partial"] = mem.alloc(C * T * ntile * 8)
@@ -95,33 +95,36 @@ def _run(T, P, D, S, N, C, Ttab_is_one, mode, sort, nth, seed):
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_program_one_group(mode):
-    """40 chains (one full wavefront, one partly filled, fourteen empty), two tiles (64 + 6 samples),
-    tables per target, node-0 wrap and exact-grid durations included"""
-    _run(T=2, P=4, D=3, S=6, N=70, C=40, Ttab_is_one=False, mode=mode, sort=True, nth=mode & 1, seed=5 + mode)
+    """45 chains (one full consumer wavefront, one partly filled, twelve empty), two tiles (64 + 6
+    samples), tables per target, node-0 wrap and exact-grid durations included"""
+    _run(T=2, P=4, D=3, S=6, N=70, C=45, Ttab_is_one=False, mode=mode, sort=True, nth=mode & 1, seed=5 + mode)
 
 
 def test_program_tables_per_patch_and_order():
     """tables built once per (chain, patch); results do not depend on the chain order"""
     for sort in (True, False):
-        stats, _ = _run(T=2, P=3, D=2, S=5, N=64, C=70, Ttab_is_one=True, mode=0, sort=sort, nth=0, seed=11)
+        stats, _ = _run(T=2, P=3, D=2, S=5, N=64, C=80, Ttab_is_one=True, mode=0, sort=sort, nth=0, seed=11)
     # every chain of a step costs exactly four indexed FMAs, whatever the batching
-    assert sum(w.fma_count for w in stats[0].waves) == 70 * 3 * 4
+    assert sum(w.fma_count for w in stats[0].waves) == 80 * 3 * 4
 
 
 def test_program_two_groups():
-    """513 chains: a full group and a group of one chain"""
-    stats, ucount = _run(T=1, P=2, D=2, S=4, N=64, C=513, Ttab_is_one=True, mode=1, sort=True, nth=1, seed=3)
+    """519 chains: a full group and a group of one chain"""
+    stats, ucount = _run(T=1, P=2, D=2, S=4, N=64, C=519, Ttab_is_one=True, mode=1, sort=True, nth=1, seed=3)
     # LDS-DMA moved every distinct row segment of the group once (plus the three-step prologue overlap)
     assert stats[0].dma_bytes == int(ucount[:2].sum()) * 512
 
 
 def test_register_budget():
-    """the program stays inside the registers the kernel may use: 128 VGPRs (16 wavefronts per
-    workgroup = 4 per SIMD) and user SGPRs below s96 (VCC, FLAT_SCRATCH, XNACK_MASK above)"""
+    """the programs stay inside the registers the kernel may use: 128 VGPRs (16 wavefronts per
+    workgroup = 4 per SIMD) and user SGPRs below s96 (VCC, FLAT_SCRATCH, XNACK_MASK above); SGPR
+    pairs used as addresses are even-aligned"""
     import re
-    assert gen.V_LAST < 128
-    for nth in (0, 1):
-        for ln in gen.program(nth):
+    assert gen.V_LAST < 128 and gen.NCONS + gen.NLOAD == 16 and gen.NQMIN >= 3
+    for prog in (gen.consumer(), gen.loader(0), gen.loader(1)):
+        for ln in prog:
+            for m in re.finditer(r"\bs\[(\d+):(\d+)\]", ln):
+                assert int(m.group(1)) % 2 == 0, ln
             for m in re.finditer(r"\bs\[(\d+):(\d+)\]|\bs(\d+)\b", ln):
                 hi = int(m.group(2) or m.group(3))
                 assert hi <= 95, ln

@@ -25,10 +25,9 @@ import gen_gfcell_asm as gen  # noqa: E402
 U32 = np.uint32
 MASK64 = (1 << 64) - 1
 DEAD = 0xFFFFFFFF
-CG, WAVES, NCH = 512, 16, gen.NCHAIN
-BLOCK = gen.BLOCK
-MAXBLK = NCH + 2
-STEP_STRIDE = MAXBLK * BLOCK
+NCH, NCONS, NLOAD = gen.NCHAIN, gen.NCONS, gen.NLOAD
+CG, WAVES = NCONS * NCH, NCONS + NLOAD
+QREC, QUAD, WSTRIDE, NQMIN, LTAB, BOUNCE = gen.QREC, gen.QUAD, gen.WSTRIDE, gen.NQMIN, gen.LTAB, gen.BOUNCE
 TPITCH = 65 * 8
 PARAM_BYTES = WAVES * 128
 
@@ -106,12 +105,12 @@ def gc_order(rowoff, C, T, P, S, sort=True):
 
 
 def gc_tables(rowoff, fac, slips, order, C, T, P, DS, nvar=1):
-    """-> stream bytes, hdr dwords, ucount; layouts as k_gc_tables writes them"""
+    """-> wtab bytes, ltab dwords, ucount; layouts as k_gc_tables writes them"""
     ngroups = order.size // CG
     nsteps = P * nvar
     GT = ngroups * T
-    stream = np.zeros(GT * WAVES * (nsteps + 1) * STEP_STRIDE + 256, dtype=np.uint8)
-    hdr = np.zeros(GT * (nsteps + 3) * WAVES * 8, dtype=np.uint32)
+    wtab = np.zeros(GT * NCONS * (nsteps + 1) * WSTRIDE + 4096, dtype=np.uint8)
+    ltab = np.zeros(GT * (nsteps + 3) * NLOAD * 32, dtype=np.uint32)
     ucount = np.zeros(GT * P, dtype=np.uint32)
     for g in range(ngroups):
         for t in range(T):
@@ -129,17 +128,29 @@ def gc_tables(rowoff, fac, slips, order, C, T, P, DS, nvar=1):
                 for iv in range(nvar):
                     s = p * nvar + iv
                     ring = (s % 3) * DS
-                    for ww in range(WAVES):
-                        h = hdr[((gt * (nsteps + 3) + s) * WAVES + ww) * 8:][:8]
-                        h[0] = (U - ww + WAVES - 1) // WAVES if U > ww else 0
-                        for d in range(1, 8):
-                            idx = ww + WAVES * (d - 1)
-                            h[d] = (int(distinct[idx]) | (slot[int(distinct[idx])] << 16)) if idx < U else 0
-                    for w in range(WAVES):
-                        base = ((gt * WAVES + w) * (nsteps + 1) + s) * STEP_STRIDE
+                    npair = (U + 1) // 2
+                    for ll in range(NLOAD):
+                        h = ltab[((gt * (nsteps + 3) + s) * NLOAD + ll) * 32:][:32]
+                        h[0] = (npair - ll + NLOAD - 1) // NLOAD if npair > ll else 0
+                        for d in range(1, 32):
+                            pr = ll + NLOAD * (d - 1)
+                            if pr < npair:
+                                ra = int(distinct[2 * pr])
+                                single = 2 * pr + 1 >= U
+                                rb = ra if single else int(distinct[2 * pr + 1])
+                                h[d] = ra | ((rb - ra) << 8) | ((2 * pr) << 16) | ((1 << 24) if single else 0)
+                            else:
+                                h[d] = 0
+                    for w in range(NCONS):
+                        wb = ((gt * NCONS + w) * (nsteps + 1) + s) * WSTRIDE
+
+                        def rec(bb):
+                            return wb + (bb // 4) * QUAD + (bb % 4) * QREC
+
+                        def aux(bb):
+                            return wtab[rec(bb) + 128:rec(bb) + 192].view(np.uint32)
                         js = [j for j in range(NCH) if live[w * NCH + j]]
-                        key = lambda j: (tuple(rel[w * NCH + j]), j)   # noqa: E731
-                        js.sort(key=key)
+                        js.sort(key=lambda j: (tuple(rel[w * NCH + j]), j))
                         batches = []
                         for j in js:
                             k4 = tuple(rel[w * NCH + j])
@@ -148,36 +159,37 @@ def gc_tables(rowoff, fac, slips, order, C, T, P, DS, nvar=1):
                             else:
                                 batches.append((k4, [j]))
                         nb = len(batches)
-                        nbe = max(nb, 1)
-                        gap = STEP_STRIDE - (nbe + 1) * BLOCK
+                        nbe = max(((nb + 3) // 4) * 4, 4 * NQMIN)
+                        nq = nbe // 4
+                        xe = ring * 512
 
-                        def info(i):
-                            return stream[base + i * BLOCK + 128:base + i * BLOCK + 144].view(np.uint32)
-                        lead = info(0)
-                        lead[2] = 0
-                        lead[3] = (gap if nbe == 1 else 0) << 8
-                        if nb == 0:
-                            lead[0] = ring * 64
-                            lead[1] = ring * 64
-                            e = info(1)
-                            e[:] = (0, 0, 0, 8)
+                        def cf(bb, cnt):
+                            return cnt | ((1 << gen.CF_LAST) if bb == nbe - 1 else 0) | \
+                                ((1 << gen.CF_CROSS) if (bb % 4 == 0 and bb // 4 + 2 == nq - 1) else 0)
+                        for e in range(nb, nbe):
+                            me = aux(e)
+                            me[gen.A_ACC01] = me[gen.A_ACC23] = 0x80008000
+                            me[gen.A_CF] = cf(e, 0)
+                            me[gen.A_XO:gen.A_XO + 4] = xe
+                            if e >= 1:
+                                aux(e - 1)[gen.A_XN:gen.A_XN + 4] = xe
+                        aux(nbe - 1)[gen.A_XN:gen.A_XN + 4] = xe
                         for b, (k4, chains) in enumerate(batches):
-                            i = 1 + b
-                            wq = stream[base + i * BLOCK:base + i * BLOCK + 128].view(np.float64)
-                            accb = 0
+                            wq = wtab[rec(b):rec(b) + 128].view(np.float64)
+                            m = [0x8000] * 4
                             for q, j in enumerate(chains):
                                 c = int(ids[w * NCH + j])
-                                sl = slips[iv][c, p]
-                                wq[4 * q:4 * q + 4] = fac[c, t, p] * sl
-                                accb |= (2 * j) << (8 * q)
-                            me = info(i)
-                            me[2] = accb
-                            me[3] = len(chains) | (8 if i == nb else 0) | ((gap if i == nb - 1 else 0) << 8)
-                            x = [(ring + slot[int(r)]) * 64 for r in k4]
-                            pv = info(i - 1)
-                            pv[0] = x[0] | (x[1] << 16)
-                            pv[1] = x[2] | (x[3] << 16)
-    return stream, hdr, ucount
+                                wq[4 * q:4 * q + 4] = fac[c, t, p] * slips[iv][c, p]
+                                m[q] = 0x8000 | (2 * j)
+                            me = aux(b)
+                            me[gen.A_ACC01] = m[0] | (m[1] << 16)
+                            me[gen.A_ACC23] = m[2] | (m[3] << 16)
+                            me[gen.A_CF] = cf(b, len(chains))
+                            x = [(ring + slot[int(r)]) * 512 for r in k4]
+                            me[gen.A_XO:gen.A_XO + 4] = x
+                            if b >= 1:
+                                aux(b - 1)[gen.A_XN:gen.A_XN + 4] = x
+    return wtab, ltab, ucount
 
 
 # =============================================================================== interpreter
@@ -185,8 +197,8 @@ class Barrier(Exception):
     pass
 
 
-def _parse_program(nth):
-    lines = gen.program(nth)
+def _parse_program(kind, nth):
+    lines = gen.consumer() if kind == "consumer" else gen.loader(nth)
     labels, prog = {}, []
     for ln in lines:
         m = re.match(r"^(\w+)_%=:$", ln)
@@ -326,7 +338,7 @@ class Wave(object):
 
     # ---- execution
     def run(self):
-        prog, labels = self.wg.prog, self.wg.labels
+        prog, labels = self.prog, self.labels
         lds, mem = self.wg.lds, self.wg.mem
         while self.pc < len(prog):
             ln = prog[self.pc]
@@ -343,10 +355,9 @@ class Wave(object):
                 imm_off = int(mo.group(1), 0)
                 rest = rest.replace(mo.group(0), "")
             ops = _split_ops(rest)
-            if self.idx_en and op.startswith("v_") and op != "v_fma_f64":
-                raise RuntimeError("VALU %s executed with VGPR indexing on" % op)
-            if self.idx_en and (op.startswith("ds_") or op.startswith("global_")):
-                raise RuntimeError("memory instruction with VGPR indexing on")
+            if self.idx_en and (self.m0 & 0xFF) and (op.startswith("v_") and op != "v_fmac_f64_dpp"
+                                                      or op.startswith("ds_") or op.startswith("global_")):
+                raise RuntimeError("%s executed with a non-zero VGPR index" % op)
             # ------------------------------------------------ scalar
             if op in ("s_nop", "s_waitcnt"):
                 continue
@@ -390,6 +401,21 @@ class Wave(object):
                 self.scc = int({"eq": a == b, "le": a <= b, "lt": a < b, "ge": a >= b}[op.split("_")[2]])
             elif op == "s_bitcmp1_b32":
                 self.scc = (self.get_s32(ops[0]) >> (self.get_s32(ops[1]) & 31)) & 1
+            elif op == "s_bfe_u32":
+                a_, f = self.get_s32(ops[1]), self.get_s32(ops[2])
+                r = (a_ >> (f & 31)) & ((1 << ((f >> 16) & 0x7F)) - 1)
+                self.set_s32(ops[0], r)
+                self.scc = int(r != 0)
+            elif op == "s_lshl_b64":
+                r = (self.get_s64(ops[1]) << (self.get_s32(ops[2]) & 63)) & MASK64
+                self.set_s64(ops[0], r)
+                self.scc = int(r != 0)
+            elif op == "s_or_b64":
+                r = self.get_s64(ops[1]) | self.get_s64(ops[2])
+                self.set_s64(ops[0], r)
+                self.scc = int(r != 0)
+            elif op == "s_cselect_b64":
+                self.set_s64(ops[0], self.get_s64(ops[1]) if self.scc else self.get_s64(ops[2]))
             elif op == "s_bfm_b64":
                 n, sh = self.get_s32(ops[1]) & 63, self.get_s32(ops[2]) & 63
                 self.set_s64(ops[0], ((1 << n) - 1) << sh)
@@ -425,6 +451,9 @@ class Wave(object):
             elif op == "v_lshl_add_u32":
                 self.wr32(self.vreg(ops[0]), (self.src32(ops[1]).astype(np.uint64) << np.uint64(self.get_s32(ops[2])))
                           + self.src32(ops[3]))
+            elif op == "v_mad_u32_u24":
+                self.wr32(self.vreg(ops[0]), (self.src32(ops[1]).astype(np.uint64) & np.uint64(0xFFFFFF))
+                          * (self.src32(ops[2]).astype(np.uint64) & np.uint64(0xFFFFFF)) + self.src32(ops[3]))
             elif op == "v_mul_u32_u24":
                 self.wr32(self.vreg(ops[0]), (self.src32(ops[1]).astype(np.uint64) & np.uint64(0xFFFFFF))
                           * (self.src32(ops[2]).astype(np.uint64) & np.uint64(0xFFFFFF)))
@@ -435,7 +464,28 @@ class Wave(object):
                 sel = np.array([(self.vcc >> i) & 1 for i in range(64)], dtype=bool)
                 self.wr32(self.vreg(ops[0]), np.where(sel, self.src32(ops[2]), self.src32(ops[1])).astype(np.uint64))
             elif op == "v_readlane_b32":
-                self.set_s32(ops[0], int(self.v[self.vreg(ops[1])][int(ops[2])]))
+                lane_sel = self.get_s32(ops[2]) & 63
+                self.set_s32(ops[0], int(self.v[self.vreg(ops[1])][lane_sel]))
+            elif op == "v_and_b32":
+                self.wr32(self.vreg(ops[0]), self.src32(ops[1]) & self.src32(ops[2]))
+            elif op == "v_add_u32_dpp":
+                k = int(re.search(r"row_newbcast:(\d+)", ln).group(1))
+                ops = [o.split()[0] for o in ops]
+                a_ = self.src32(ops[1])[(np.arange(64) // 16) * 16 + k]
+                self.wr32(self.vreg(ops[0]), a_.astype(np.uint64) + self.src32(ops[2]))
+            elif op == "v_fmac_f64_dpp":
+                # D = dpp(S0) * S1 + D ; row_newbcast:k: lane k of the lane's own 16-lane row
+                assert self.idx_en and ((self.m0 >> 12) & 0xF) == 0x8, ln
+                k = int(re.search(r"row_newbcast:(\d+)", ln).group(1))
+                ops = [o.split()[0] for o in ops]
+                d = self.vreg(ops[0]) + (self.m0 & 0xFF)
+                assert gen.ACC <= d <= gen.V_LAST - 1 and (d - gen.ACC) % 2 == 0, (ln, d)
+                a_ = self.src_f64(ops[1])[(np.arange(64) // 16) * 16 + k]
+                b_ = self.src_f64(ops[2])
+                c_ = (self.v[d].astype(np.uint64) | (self.v[d + 1].astype(np.uint64) << np.uint64(32))).view(np.float64)
+                self.fma_count += 1
+                with np.errstate(all="ignore"):
+                    self.wr_f64(d, a_ * b_ + c_)
             elif op == "v_writelane_b32":
                 self.v[self.vreg(ops[0])][int(ops[2])] = U32(self.get_s32(ops[1]))
             elif op == "v_fma_f64":
@@ -445,9 +495,7 @@ class Wave(object):
                 b = self.src_f64(ops[2], rel if mode & 2 else 0)
                 c = self.src_f64(ops[3], rel if mode & 4 else 0)
                 d = self.vreg(ops[0]) + (rel if mode & 8 else 0)
-                if self.idx_en:
-                    assert mode == 0xC and gen.ACC <= d <= gen.V_LAST - 1 and (d - gen.ACC) % 2 == 0, (ln, d)
-                    self.fma_count += 1
+                assert not self.idx_en
                 with np.errstate(all="ignore"):
                     self.wr_f64(d, a * b + c)
             elif op == "v_add_f64":
@@ -471,6 +519,12 @@ class Wave(object):
                         val |= 1 << i
                 self.set_s64(ops[0], val)
             # ------------------------------------------------ LDS
+            elif op == "ds_write_b128":
+                addr = self.v[self.vreg(ops[0])].astype(np.int64) + imm_off
+                d = int(re.match(r"v\[(\d+):", ops[1]).group(1))
+                for i in np.nonzero(self.lanes())[0]:
+                    assert 0 <= addr[i] and addr[i] + 16 <= lds.size and addr[i] % 16 == 0, ("LDS write", ln, addr[i])
+                    lds[addr[i]:addr[i] + 16].view(np.uint32)[:] = [self.v[d + kk][i] for kk in range(4)]
             elif op in ("ds_read_b32", "ds_read_b64", "ds_write_b64"):
                 off = imm_off
                 m = self.lanes()
@@ -500,8 +554,8 @@ class Wave(object):
                     assert PARAM_BYTES <= dst and dst + 16 <= lds.size, ("LDS-DMA destination", ln, dst)
                     lds[dst:dst + 16] = mem.read(base + int(voff[i]), 16)
                 self.wg.dma_bytes += 16 * int(self.lanes().sum())
-            elif op in ("global_load_dwordx2", "global_load_dword"):
-                n = 8 if op.endswith("x2") else 4
+            elif op in ("global_load_dwordx2", "global_load_dword", "global_load_dwordx4"):
+                n = 16 if op.endswith("x4") else 8 if op.endswith("x2") else 4
                 off = imm_off
                 last = ops[2].split()[0]
                 base = self.get_s64(last)
@@ -509,9 +563,8 @@ class Wave(object):
                 d = self.vreg(ops[0])
                 for i in np.nonzero(self.lanes())[0]:
                     w = mem.read(base + int(voff[i]) + off, n).view(np.uint32)
-                    self.v[d][i] = w[0]
-                    if n == 8:
-                        self.v[d + 1][i] = w[1]
+                    for kk in range(n // 4):
+                        self.v[d + kk][i] = w[kk]
             elif op == "global_store_dwordx2":
                 d = self.vreg(ops[1])
                 if ops[2] == "off":
@@ -527,18 +580,20 @@ class Wave(object):
 
 
 class Workgroup(object):
-    """one (group g, target t, tile) workgroup of k_gfstack_cell"""
+    """one (group g, target t, tile) workgroup of k_gfstack_cell: 14 consumers + 2 loaders"""
 
     def __init__(self, mem, nth, lds_bytes, params, max_instr=5000000):
         self.mem = mem
-        self.prog, self.labels = _parse_program(nth)
         self.lds = np.zeros(lds_bytes, dtype=np.uint8)
         self.max_instr = max_instr
         self.dma_bytes = 0
+        self.programs = {"consumer": _parse_program("consumer", nth), "loader": _parse_program("loader", nth)}
         self.waves = []
         for w in range(WAVES):
             self.lds[w * 128:(w + 1) * 128].view(np.uint32)[:] = params[w]
-            self.waves.append(Wave(self, w, w * 128))
+            wave = Wave(self, w, w * 128)
+            wave.prog, wave.labels = self.programs["consumer" if w < NCONS else "loader"]
+            self.waves.append(wave)
 
     def run(self):
         gens = [w.run() for w in self.waves]
@@ -566,27 +621,33 @@ def wave_params(w, g, t, tile, a):
     gt = g * a["Ttab"] + (0 if a["Ttab"] == 1 else t)
     n0 = tile * 64
     N, T = a["N"], a["T"]
-    put64(gen.P_ST, a["stream"] + ((gt * WAVES + w) * (a["nsteps"] + 1)) * STEP_STRIDE)
-    put64(gen.P_HD, a["hdr"] + (((gt * (a["nsteps"] + 3)) * WAVES + w) * 8) * 4)
-    put64(gen.P_GROW, a["G"] + ((t * a["rows_per_target"]) * N + n0) * 8)
-    P[gen.P_DSRB] = a["DS"] * N * 8
-    P[gen.P_ROWB] = N * 8
-    P[gen.P_RB0] = PARAM_BYTES
-    P[gen.P_BUFB] = a["DS"] * 512
-    P[gen.P_NSTEP] = a["nsteps"]
-    P[gen.P_NLANES] = min(32, (N - n0 + 1) // 2)
-    put64(gen.P_OUT, a["out"] + (t * N + n0) * 8)
-    P[gen.P_CTN] = T * N * 8
-    P[gen.P_MODE] = a["mode"]
-    put64(gen.P_DATA, a["data"] + (t * N + n0) * 8)
-    put64(gen.P_W, int(np.float64(a["wscalar"][t]).view(np.uint64)))
-    put64(gen.P_CID, a["order"] + (g * CG + w * NCH) * 4)
-    put64(gen.P_PART, a["partial"] + (t * a["ntile"] + tile) * 8)
-    P[gen.P_PCS] = T * a["ntile"] * 8
-    P[gen.P_NVALID] = min(64, N - n0)
-    P[gen.P_TRB] = PARAM_BYTES + w * 16 * TPITCH
+    if w < NCONS:
+        put64(gen.P_WP, a["wtab"] + ((gt * NCONS + w) * (a["nsteps"] + 1)) * WSTRIDE)
+        P[gen.P_RB0] = PARAM_BYTES
+        P[gen.P_NSTEP] = a["nsteps"]
+        P[gen.P_BNC] = PARAM_BYTES + 3 * a["DS"] * 512 + w * BOUNCE
+        put64(gen.P_OUT, a["out"] + (t * N + n0) * 8)
+        P[gen.P_CTN] = T * N * 8
+        P[gen.P_MODE] = a["mode"]
+        put64(gen.P_DATA, a["data"] + (t * N + n0) * 8)
+        put64(gen.P_W, int(np.float64(a["wscalar"][t]).view(np.uint64)))
+        put64(gen.P_CID, a["order"] + (g * CG + w * NCH) * 4)
+        put64(gen.P_PART, a["partial"] + (t * a["ntile"] + tile) * 8)
+        P[gen.P_PCS] = T * a["ntile"] * 8
+        P[gen.P_NVALID] = min(64, N - n0)
+        P[gen.P_TRB] = PARAM_BYTES + w * 16 * TPITCH
+    else:
+        ll = w - NCONS
+        put64(gen.PL_LT, a["ltab"] + (((gt * (a["nsteps"] + 3)) * NLOAD + ll) * 32) * 4)
+        put64(gen.PL_GROW, a["G"] + ((t * a["rows_per_target"]) * N + n0) * 8)
+        P[gen.PL_DSRB] = a["DS"] * N * 8
+        P[gen.PL_ROWB] = N * 8
+        P[gen.PL_RB0] = PARAM_BYTES
+        P[gen.PL_BUFB] = a["DS"] * 512
+        P[gen.PL_NSTEP] = a["nsteps"]
+        P[gen.PL_NLANES] = min(32, (N - n0 + 1) // 2)
     return P
 
 
 def lds_bytes(DS):
-    return PARAM_BYTES + max(3 * DS * 512, WAVES * 16 * TPITCH)
+    return PARAM_BYTES + max(3 * DS * 512 + NCONS * BOUNCE, NCONS * 16 * TPITCH)
