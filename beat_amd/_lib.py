@@ -17,7 +17,8 @@ NEAREST_NEIGHBOR, MULTILINEAR = 0, 1
 W_SCALAR, W_DENSE = 0, 1
 INTERPOLATIONS = {"nearest_neighbor": NEAREST_NEIGHBOR, "multilinear": MULTILINEAR}
 
-OK, EINVAL, EHIP, EINDEX, ENOMEM, ENAN, ENOTPSD = 0, -1, -2, -3, -4, -5, -6
+OK, EINVAL, EHIP, EINDEX, ENOMEM, ENAN, ENOTPSD, EBADCOV = 0, -1, -2, -3, -4, -5, -6, -7
+ABI_VERSION = 110   # include/beat_amd.h BEATAMD_VERSION this module was written against
 
 
 class BeatAmdError(RuntimeError):
@@ -90,6 +91,7 @@ _PROTOS = {
     "beatamd_smc_resample": [_vp, _i64, _vp, _f64, _vp],
     "beatamd_smc_population_factor": [_vp, _i64, _i64, _vp, _vp, _vp],
     "beatamd_proposal_draw": [_vp, _i64, _i64, _i64, _vp, C.c_uint64, C.c_uint32, _i64, _i32, _vp, _vp],
+    "beatamd_proposal_draw_univariate": [_vp, _i64, _i64, _i32, _vp, C.c_uint64, C.c_uint32, _i64, _vp, _vp],
     "beatamd_gather_rows": [_vp, _i64, _i64, _vp, _i64, _vp, _vp],
     "beatamd_metropolis_tune": [_vp, _i64, _vp, _vp, _i32],
     "beatamd_whiten_rows": [_vp, _vp, _i64, _i64, _vp],
@@ -129,6 +131,9 @@ def load():
         lib.beatamd_last_error.restype = C.c_char_p
         lib.beatamd_last_error.argtypes = []
         lib.beatamd_version.restype = C.c_int
+        if lib.beatamd_version() != ABI_VERSION:
+            raise BeatAmdError("libbeat_amd.so has ABI revision %d, beat_amd expects %d: rebuild with "
+                               "`make -C beat_amd/csrc`" % (lib.beatamd_version(), ABI_VERSION))
         _lib = lib
     return _lib
 
@@ -138,7 +143,7 @@ def check(rc):
     if rc == OK:
         return
     msg = load().beatamd_last_error().decode("utf-8", "replace")
-    if rc == EINVAL:
+    if rc in (EINVAL, EBADCOV):
         raise ValueError(msg)
     if rc == EINDEX:
         raise IndexError(msg)

@@ -1024,6 +1024,32 @@ int beatamd_proposal_draw(beatamd_ctx *ctx, int64_t C, int64_t K, int64_t nparam
     return finish_out(ctx, recs, nrec);
 }
 
+int beatamd_proposal_draw_univariate(beatamd_ctx *ctx, int64_t C, int64_t nparams, int32_t kind,
+                                     const double *scale, uint64_t seed, uint32_t step, int64_t first_chain,
+                                     double *delta, double *log_u)
+{
+    ENTER(ctx);
+    BA_CHECK(scale && delta && C >= 0 && nparams > 0 && first_chain >= 0, BEATAMD_EINVAL,
+             "proposal_draw_univariate: bad argument");
+    BA_CHECK(kind >= BEATAMD_PROPOSAL_NORMAL && kind <= BEATAMD_PROPOSAL_LAPLACE, BEATAMD_EINVAL,
+             "proposal_draw_univariate: kind must be Normal (0), Cauchy (1) or Laplace (2)");
+    if (C == 0) return BEATAMD_OK;
+    const void *d_s;
+    void *d_d, *d_u = nullptr;
+    Arg recs[2];
+    int nrec = 1;
+    BA_TRY(stage_in(ctx, SL_IN0, scale, (size_t)nparams * 8, &d_s));
+    BA_TRY(stage_out(ctx, SL_OUT0, delta, (size_t)C * nparams * 8, &d_d, &recs[0]));
+    if (log_u) {
+        BA_TRY(stage_out(ctx, SL_OUT1, log_u, (size_t)C * 8, &d_u, &recs[1]));
+        nrec = 2;
+    }
+    BA_TRY(launch_philox_univariate(ctx, (double *)d_d, C, nparams, kind, (const double *)d_s, seed, step,
+                                    (uint64_t)first_chain));
+    if (d_u) BA_TRY(launch_philox_chain(ctx, C, seed, step, (uint64_t)first_chain, 0, (double *)d_u, nullptr));
+    return finish_out(ctx, recs, nrec);
+}
+
 int beatamd_gather_rows(beatamd_ctx *ctx, int64_t nout, int64_t ncols, const double *src,
                         int64_t nrows_src, const int32_t *indexes, double *out)
 {

@@ -176,6 +176,12 @@ int beatamd_ctx::check_status()
             set_error("nucleation index outside the patch grid");
             return BEATAMD_EINVAL;
         }
+        if (st & ST_BAD_COV) {
+            // smc.py:167-186: the text of the reference's ValueError
+            set_error("Sample covariances contains Inf or NaN! Please try reducing the upper and lower bounds "
+                      "of hyper parameters!");
+            return BEATAMD_EBADCOV;
+        }
         if (st & ST_NOT_PSD) {
             set_error("Matrix is not positive definite");   // numpy.linalg.LinAlgError's text
             return BEATAMD_ENOTPSD;
@@ -188,7 +194,7 @@ extern "C" {
 
 const char *beatamd_last_error(void) { return g_err; }
 
-int beatamd_version(void) { return 100; }
+int beatamd_version(void) { return BEATAMD_VERSION; }
 
 int beatamd_ctx_create(int device, beatamd_ctx **out)
 {

@@ -172,6 +172,8 @@ int launch_tune_scaling(beatamd_ctx *ctx, int64_t C, double *scaling, int32_t *a
 int launch_accumulate_i32(beatamd_ctx *ctx, int64_t C, const int32_t *a, int32_t *acc);
 int launch_philox_normal(beatamd_ctx *ctx, double *z, int64_t C, int64_t K, uint64_t seed,
                          uint32_t step, uint64_t first_chain);
+int launch_philox_univariate(beatamd_ctx *ctx, double *delta, int64_t C, int64_t np, int kind,
+                             const double *scale, uint64_t seed, uint32_t step, uint64_t first_chain);
 int launch_philox_chain(beatamd_ctx *ctx, int64_t C, uint64_t seed, uint32_t step, uint64_t first_chain,
                         int df, double *log_u, double *row_scale);
 

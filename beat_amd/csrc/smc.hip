@@ -156,7 +156,7 @@ int launch_smc_resample(beatamd_ctx *ctx, int64_t n, const double *weights, doub
 // forming or factoring an (often singular) nparams x nparams matrix.  One workgroup per 64
 // parameter columns: 64 columns x 4 row groups, fixed-order sums.
 __global__ void __launch_bounds__(256) k_pop_factor(const double *X, int64_t ldx, const double *w,
-                                                   int64_t n, int64_t np, double *F)
+                                                   int64_t n, int64_t np, double *F, int *status)
 {
     __shared__ double sh[4][64];
     __shared__ double shw[8];
@@ -184,9 +184,17 @@ __global__ void __launch_bounds__(256) k_pop_factor(const double *X, int64_t ldx
     __syncthreads();
     const double mean = (((sh[0][col] + sh[1][col]) + sh[2][col]) + sh[3][col]) / v1;
     const double fact = 1.0 / (v1 - v2 / v1);
+    // degenerate weights (one chain carries everything: v1 - v2/v1 = 0) or a non-finite population:
+    // the reference's calc_covariance raises (smc.py:181-185); here the status word carries it to the
+    // next synchronisation
+    bool bad = !(v1 - v2 / v1 > 0.0);
     if (j < np)
-        for (int64_t i = rg; i < n; i += 4)
-            F[i * np + j] = sqrt(w[i] * fact) * (X[i * ldx + j] - mean);
+        for (int64_t i = rg; i < n; i += 4) {
+            const double f = sqrt(w[i] * fact) * (X[i * ldx + j] - mean);
+            bad = bad || !isfinite(f);
+            F[i * np + j] = f;
+        }
+    if (__any(bad) && (tid & 63) == 0) atomicOr(status, ST_BAD_COV);
 }
 
 int launch_pop_factor(beatamd_ctx *ctx, int64_t n, int64_t np, const double *X, int64_t ldx,
@@ -195,7 +203,7 @@ int launch_pop_factor(beatamd_ctx *ctx, int64_t n, int64_t np, const double *X, 
     if (n == 0 || np == 0) return BEATAMD_OK;
     ScopedTimer tm(ctx, "stage");
     hipLaunchKernelGGL(k_pop_factor, dim3((unsigned)((np + 63) / 64)), dim3(256), 0, ctx->stream, X,
-                       ldx, w, n, np, F);
+                       ldx, w, n, np, F, ctx->d_status);
     BA_HIP(hipGetLastError());
     return BEATAMD_OK;
 }
@@ -346,6 +354,55 @@ __global__ void __launch_bounds__(256) k_philox_chain(int64_t C, uint64_t seed, 
         }
         row_scale[c] = 1.0 / sqrt(x / (double)df);
     }
+}
+
+// per-parameter proposal families (reference beat/sampler/base.py:129-160): every component of a row is an
+// independent draw times the parameter's scale.  Streams 3 / 4 of the same counter layout; one thread
+// per (chain, pair of parameters).
+//   kind 0  NormalProposal   normal(scale)                                  (Box-Muller pair)
+//   kind 1  CauchyProposal   standard_cauchy() * scale = tan(pi (u - 1/2)) * scale
+//   kind 2  LaplaceProposal  (standard_exponential() - standard_exponential()) * scale
+__global__ void __launch_bounds__(256) k_philox_univariate(double *delta, int64_t C, int64_t np, int kind,
+                                                          const double *scale, uint64_t seed, uint32_t step,
+                                                          uint64_t first_chain)
+{
+    const int64_t npair = (np + 1) / 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= C * npair) return;
+    const int64_t c = i / npair, j = i - c * npair;
+    const uint64_t gc = first_chain + (uint64_t)c;
+    uint32_t r[4];
+    philox4x32_10((uint32_t)j, (uint32_t)gc, step, 3u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const double u1 = u53(r[0], r[1]), u2 = u53(r[2], r[3]);
+    double a, b;
+    if (kind == 0) {
+        const double rad = sqrt(-2.0 * log(u1));
+        const double th = 6.283185307179586476925286766559 * u2;
+        a = rad * cos(th);
+        b = rad * sin(th);
+    } else if (kind == 1) {
+        a = tan(3.14159265358979323846 * (u1 - 0.5));
+        b = tan(3.14159265358979323846 * (u2 - 0.5));
+    } else {
+        uint32_t q[4];
+        philox4x32_10((uint32_t)j, (uint32_t)gc, step, 4u, (uint32_t)seed, (uint32_t)(seed >> 32), q);
+        a = log(u53(q[0], q[1])) - log(u1);     // E1 - E2 with E = -log u
+        b = log(u53(q[2], q[3])) - log(u2);
+    }
+    delta[c * np + 2 * j] = a * scale[2 * j];
+    if (2 * j + 1 < np) delta[c * np + 2 * j + 1] = b * scale[2 * j + 1];
+}
+
+int launch_philox_univariate(beatamd_ctx *ctx, double *delta, int64_t C, int64_t np, int kind,
+                             const double *scale, uint64_t seed, uint32_t step, uint64_t first_chain)
+{
+    const int64_t n = C * ((np + 1) / 2);
+    if (n == 0) return BEATAMD_OK;
+    ScopedTimer tm(ctx, "proposal");
+    hipLaunchKernelGGL(k_philox_univariate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       delta, C, np, kind, scale, seed, step, first_chain);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
 }
 
 int launch_philox_normal(beatamd_ctx *ctx, double *z, int64_t C, int64_t K, uint64_t seed,

@@ -426,6 +426,22 @@ class Context(object):
                                               ptr(log_u)))
         return delta, log_u
 
+    def proposal_draw_univariate(self, kind, scale, n_chains, seed, step, first_chain=0, delta=None, log_u=None,
+                                 want_log_u=True):
+        """delta (n_chains, nparams): independent Normal (0) / Cauchy (1) / Laplace (2) draws per
+        component times scale[j] (beat/sampler/base.py:129-160); -> (delta, log_u)"""
+        self._adopt_stream(scale)
+        sc = f64(scale)
+        npar = int(sc.shape[0])
+        if delta is None:
+            delta = _empty_like(sc, (int(n_chains), npar))
+        if log_u is None and want_log_u:
+            log_u = _empty_like(sc, (int(n_chains),))
+        check(self._lib.beatamd_proposal_draw_univariate(self._h, int(n_chains), npar, int(kind), ptr(sc),
+                                                         int(seed) & (2 ** 64 - 1), int(step) & 0xffffffff,
+                                                         int(first_chain), ptr(delta), ptr(log_u)))
+        return delta, log_u
+
     def gather_rows(self, src, indexes, out=None):
         self._adopt_stream(src, indexes)
         S = f64(src)

@@ -11,7 +11,7 @@ returns to the host inside a stage.
 """
 import numpy as np
 
-from .base import covariance_factor, proposal_df
+from .base import covariance_factor, proposal_df, univariate_proposals
 from .ops import ops_for
 
 
@@ -39,17 +39,38 @@ class BatchedMetropolis(object):
         self._acc = torch.zeros(self.n_chains, dtype=torch.int32, device=self.device)
         self.seed = int(seed)
         self.factor, self.df = None, 0
+        self.kind, self.uscale = None, None   # per-parameter proposal family and its scales
 
     # -- proposal
+    def _set_univariate(self, proposal_name, scale=None):
+        """NormalProposal / CauchyProposal / LaplaceProposal (base.py:129-147): independent
+        components; the reference's Metropolis sets scale = ones (metropolis.py:209-212)"""
+        npar = int(self.lower.shape[0])
+        sc = np.ones(npar) if scale is None else np.broadcast_to(np.asarray(scale, dtype=np.float64), (npar,))
+        self.kind = univariate_proposals[proposal_name]
+        self.uscale = self.torch.from_numpy(np.ascontiguousarray(sc)).to(self.device)
+        self.factor, self.df = None, 0
+
     def set_proposal(self, cov, proposal_name="MultivariateNormal"):
-        """proposal N(0, cov) / multivariate Cauchy with scale matrix cov"""
+        """proposal N(0, cov) / multivariate Cauchy with scale matrix cov; for the per-parameter
+        families `cov` is the vector of scales (None: ones)"""
+        if proposal_name in univariate_proposals:
+            return self._set_univariate(proposal_name, cov)
         self.df = proposal_df(proposal_name)
+        self.kind = None
         self.factor = self.torch.from_numpy(covariance_factor(cov)).to(self.device)
 
     def set_proposal_from_population(self, population, weights, proposal_name="MultivariateNormal"):
         """proposal with the weighted sample covariance of the population (SMC.calc_covariance,
-        smc.py:167-186) through its factor; population / weights are tensors on self.device"""
+        smc.py:167-186) through its factor; population / weights are tensors on self.device.  The
+        per-parameter families keep their scales: the reference only refreshes a multivariate
+        proposal between stages (smc.py:514-520)"""
+        if proposal_name in univariate_proposals:
+            if self.kind is None:
+                self._set_univariate(proposal_name)
+            return
         self.df = proposal_df(proposal_name)
+        self.kind = None
         self.factor = self.ops.population_factor(population, weights)
 
     # -- evaluation / stepping
@@ -66,13 +87,17 @@ class BatchedMetropolis(object):
 
     def step(self, Q, L, beta):
         """one astep for every chain; beta scalar or per-chain tensor.  In place on Q, L."""
-        if self.factor is None:
+        if self.factor is None and self.kind is None:
             raise RuntimeError("no proposal set: call set_proposal / set_proposal_from_population")
         if self.tune and self.steps_until_tune == 0:
             self.ops.tune(self.scaling, self.accepted_since_tune, self.tune_interval)
             self.steps_until_tune = self.tune_interval
-        delta, log_u = self.ops.draw(self.factor, self.n_chains, self.seed, self.n_steps_total,
-                                     first_chain=self.first_chain, df=self.df)
+        if self.kind is not None:
+            delta, log_u = self.ops.draw_univariate(self.kind, self.uscale, self.n_chains, self.seed,
+                                                    self.n_steps_total, first_chain=self.first_chain)
+        else:
+            delta, log_u = self.ops.draw(self.factor, self.n_chains, self.seed, self.n_steps_total,
+                                         first_chain=self.first_chain, df=self.df)
         self.target.astep_batch(Q, L, delta, self.scaling, self.lower, self.upper, log_u, beta,
                                 self._acc)
         self.accepted_since_tune += self._acc

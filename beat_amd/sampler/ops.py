@@ -17,6 +17,8 @@ resample), beat/sampler/base.py:35-71, 163-186 (proposal draws), beat/sampler/me
 """
 import numpy as np
 
+BAD_COVARIANCE = ("Sample covariances contains Inf or NaN! Please try reducing the upper and lower bounds "
+                  "of hyper parameters!")
 TUNE_TABLE = ((0.001, 0.1), (0.05, 0.5), (0.2, 0.9))  # acc <  x -> factor (first match)
 TUNE_TABLE_UP = ((0.95, 10.0), (0.75, 2.0), (0.5, 1.1))  # acc > x -> factor (first match)
 
@@ -73,7 +75,11 @@ class HostOps(object):
         X, w = self._np(population), self._np(weights)
         v1, v2 = w.sum(), (w * w).sum()
         mean = (w[:, None] * X).sum(0) / v1
-        return self.torch.from_numpy(np.sqrt(w / (v1 - v2 / v1))[:, None] * (X - mean))
+        with np.errstate(all="ignore"):
+            F = np.sqrt(w / (v1 - v2 / v1))[:, None] * (X - mean)
+        if not (v1 - v2 / v1 > 0.0) or not np.isfinite(F).all():
+            raise ValueError(BAD_COVARIANCE)   # smc.py:181-185
+        return self.torch.from_numpy(F)
 
     def draw(self, factor, n_chains, seed, step, first_chain=0, df=0):
         F = self._np(factor)
@@ -84,6 +90,20 @@ class HostOps(object):
             rows = rows / np.sqrt((g * g).sum(1) / float(df))[:, None]
         log_u = np.log(rs.uniform(size=n_chains))
         return self.torch.from_numpy(rows), self.torch.from_numpy(log_u)
+
+    def draw_univariate(self, kind, scale, n_chains, seed, step, first_chain=0):
+        """NormalProposal / CauchyProposal / LaplaceProposal rows (base.py:129-160), numpy generator"""
+        sc = self._np(scale)
+        rs = np.random.RandomState((int(seed) * 1000003 + int(step) * 7919 + int(first_chain)) % (2 ** 32))
+        shape = (n_chains, sc.size)
+        if kind == 0:
+            rows = rs.standard_normal(shape)
+        elif kind == 1:
+            rows = rs.standard_cauchy(shape)
+        else:
+            rows = rs.standard_exponential(shape) - rs.standard_exponential(shape)
+        log_u = np.log(rs.uniform(size=n_chains))
+        return self.torch.from_numpy(rows * sc), self.torch.from_numpy(log_u)
 
     def gather(self, src, idx):
         return src[idx.long()].contiguous()
@@ -121,6 +141,9 @@ class DeviceOps(object):
         instead of `chains` normals per proposal row.  A population whose covariance is not
         numerically positive definite keeps the tall factor."""
         F = self.ctx.smc_population_factor(population, weights)
+        # degenerate weights / non-finite population: the kernel raised the status word; the
+        # reference's calc_covariance aborts here (ValueError, smc.py:181-185) -- once per stage
+        self.ctx.synchronize()
         if F.shape[0] >= 2 * F.shape[1]:
             R = self.ctx.factor_compact(F)
             if R is not None:
@@ -129,6 +152,9 @@ class DeviceOps(object):
 
     def draw(self, factor, n_chains, seed, step, first_chain=0, df=0):
         return self.ctx.proposal_draw(factor, n_chains, seed, step, first_chain=first_chain, df=df)
+
+    def draw_univariate(self, kind, scale, n_chains, seed, step, first_chain=0):
+        return self.ctx.proposal_draw_univariate(kind, scale, n_chains, seed, step, first_chain=first_chain)
 
     def gather(self, src, idx):
         return self.ctx.gather_rows(src, idx)

@@ -191,9 +191,16 @@ def load_stage(step, homepath, stage):
     z = np.load(os.path.join(stage_path(homepath, stage), "sampler_state.npz"))
     step.beta, step.old_beta, step.stage = float(z["beta"]), float(z["old_beta"]), int(z["stage"])
     t = step.torch
+    if z["population"].shape[0] != step.n_chains:
+        raise ValueError("stage %s holds %d chains, the sampler was set up for %d: resume with the same n_chains"
+                         % (stage, z["population"].shape[0], step.n_chains))
     step.Q_all = t.from_numpy(np.ascontiguousarray(z["population"])).to(step.device)
     step.L_all = t.from_numpy(np.ascontiguousarray(z["lpoints"])).to(step.device)
-    if "scaling" in z.files and z["scaling"].size == step.n_chains:
+    if "scaling" in z.files:
+        if z["scaling"].size != step.n_chains:
+            raise ValueError("stage %s holds the step sizes of %d chains, expected %d"
+                             % (stage, z["scaling"].size, step.n_chains))
+        # (the step counter and the seed key the proposal streams: a resumed run must not reuse them)
         step.stepper.load_state_dict(dict(scaling=z["scaling"], accepted_since_tune=z["accepted_since_tune"],
                                           n_steps_total=z["n_steps_total"],
                                           steps_until_tune=z["steps_until_tune"],

@@ -36,6 +36,13 @@ extern "C" {
 #define BEATAMD_ENOMEM (-4)
 #define BEATAMD_ENAN (-5)     /* non-finite likelihood at stage 0 (metropolis.py:279-284)  */
 #define BEATAMD_ENOTPSD (-6)  /* covariance not positive definite (numpy.linalg.LinAlgError) */
+#define BEATAMD_EBADCOV (-7)  /* weighted sample covariance of the population contains Inf/NaN
+                               * (reference: ValueError of SMC.calc_covariance, sampler/smc.py:167-186) */
+
+/* ABI revision: bumped whenever an entry point changes its signature or an error code is added
+ * (1.1: beatamd_weights_update gained kind/count in round 2; BEATAMD_EBADCOV).  beat_amd/_lib.py
+ * refuses a library whose revision differs from the header it was written against. */
+#define BEATAMD_VERSION 110
 
 #define BEATAMD_NEAREST_NEIGHBOR 0 /* interpolation="nearest_neighbor" */
 #define BEATAMD_MULTILINEAR 1      /* interpolation="multilinear"      */
@@ -290,6 +297,17 @@ int beatamd_smc_population_factor(beatamd_ctx *ctx, int64_t C, int64_t nparams,
 int beatamd_proposal_draw(beatamd_ctx *ctx, int64_t C, int64_t K, int64_t nparams,
                           const double *factor, uint64_t seed, uint32_t step, int64_t first_chain,
                           int32_t df, double *delta, double *log_u);
+/* replaces: NormalProposal / CauchyProposal / LaplaceProposal (per-parameter families)
+ *                                                              beat/sampler/base.py:129-160
+ *   delta [C,nparams]: every component an independent draw times scale[j] (the reference's
+ *   Metropolis passes scale = ones, metropolis.py:209-212); same Philox counters as above
+ *   (streams 3, 4); log_u [C] (nullable) = log of U(0,1).  PoissonProposal is not provided. */
+#define BEATAMD_PROPOSAL_NORMAL 0
+#define BEATAMD_PROPOSAL_CAUCHY 1
+#define BEATAMD_PROPOSAL_LAPLACE 2
+int beatamd_proposal_draw_univariate(beatamd_ctx *ctx, int64_t C, int64_t nparams, int32_t kind,
+                                     const double *scale, uint64_t seed, uint32_t step, int64_t first_chain,
+                                     double *delta, double *log_u);
 /* out[i,:] = src[indexes[i],:]: chains restart at their resampled parents (sampler/base.py:541-571),
  * replica exchange permutation (pt.py:573-633).  An index outside [0,nrows_src) is BEATAMD_EINDEX
  * at the next synchronisation. */

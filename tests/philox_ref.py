@@ -63,3 +63,26 @@ def t_row_scale(C, seed, step, df, first_chain=0):
         if m + 1 < df:
             x += g1 * g1
     return 1.0 / np.sqrt(x / df)
+
+
+def univariate(C, npar, kind, scale, seed, step, first_chain=0):
+    """delta [C, npar] as beatamd_proposal_draw_univariate generates it (streams 3, 4):
+    kind 0 normal, 1 Cauchy, 2 Laplace; each times scale[j]"""
+    npair = (npar + 1) // 2
+    cc, jj = np.meshgrid(np.arange(C, dtype=np.uint32) + np.uint32(first_chain),
+                         np.arange(npair, dtype=np.uint32), indexing="ij")
+    j, c = jj.ravel(), cc.ravel()
+    r = philox4x32_10(j, c, np.full_like(j, step), np.full_like(j, 3), seed & 0xffffffff, seed >> 32)
+    u1, u2 = u53(r[0], r[1]), u53(r[2], r[3])
+    if kind == 0:
+        rad, th = np.sqrt(-2.0 * np.log(u1)), 6.283185307179586476925286766559 * u2
+        a, b = rad * np.cos(th), rad * np.sin(th)
+    elif kind == 1:
+        a, b = np.tan(np.pi * (u1 - 0.5)), np.tan(np.pi * (u2 - 0.5))
+    else:
+        q = philox4x32_10(j, c, np.full_like(j, step), np.full_like(j, 4), seed & 0xffffffff, seed >> 32)
+        a, b = np.log(u53(q[0], q[1])) - np.log(u1), np.log(u53(q[2], q[3])) - np.log(u2)
+    z = np.empty((C, 2 * npair))
+    z[:, 0::2] = a.reshape(C, npair)
+    z[:, 1::2] = b.reshape(C, npair)
+    return z[:, :npar] * np.asarray(scale)[None, :]

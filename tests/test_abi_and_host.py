@@ -27,7 +27,8 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "libbeat_amd.so does not export %s" % name
     # and the python prototype table covers the header
     assert set(declared) == set(_lib.EXPORTS)
-    assert lib.beatamd_version() >= 100
+    from beat_amd._lib import ABI_VERSION
+    assert lib.beatamd_version() == ABI_VERSION == 110
 
 
 def test_header_cites_reference_interfaces():

@@ -123,8 +123,8 @@ def test_register_budget():
     assert gen.V_LAST < 128 and gen.NCONS + gen.NLOAD == 16 and gen.NQMIN >= 3
     for prog in (gen.consumer(), gen.loader(0), gen.loader(1)):
         for ln in prog:
-            for m in re.finditer(r"\bs\[(\d+):(\d+)\]", ln):
-                assert int(m.group(1)) % 2 == 0, ln
+            for m in re.finditer(r"\b[sv]\[(\d+):(\d+)\]", ln):
+                assert int(m.group(1)) % 2 == 0, ln   # (gfx950: SGPR address pairs and VGPR tuples are 64-bit aligned)
             for m in re.finditer(r"\bs\[(\d+):(\d+)\]|\bs(\d+)\b", ln):
                 hi = int(m.group(2) or m.group(3))
                 assert hi <= 95, ln

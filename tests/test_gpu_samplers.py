@@ -440,3 +440,67 @@ def test_bench_two_ranks_over_rccl():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_chains"] == 128
     assert d["stage_transition_ms"] > 0 and d["value"] > 0
+
+
+def test_degenerate_weights_raise_on_device(ctx):
+    """ADVICE r2 (medium): one dominant importance weight makes the weighted sample covariance 0/0;
+    k_pop_factor raises the status word and the stage transition raises the reference's ValueError
+    (smc.py:181-185) instead of sampling a stage with a NaN proposal factor"""
+    import torch
+    from beat_amd.sampler.ops import DeviceOps
+    ops = DeviceOps(ctx)
+    dev = torch.device("cuda", 0)
+    X = torch.randn((300, 7), dtype=torch.float64, device=dev)
+    w = torch.zeros(300, dtype=torch.float64, device=dev)
+    w[11] = 1.0
+    with pytest.raises(ValueError, match="Sample covariances contains Inf or NaN"):
+        ops.population_factor(X, w)
+    w = torch.full((300,), 1.0 / 300, dtype=torch.float64, device=dev)
+    F = ops.population_factor(X, w)          # the status word was cleared: a healthy population works
+    assert torch.isfinite(F).all()
+    X[5, 2] = float("nan")
+    with pytest.raises(ValueError, match="Sample covariances contains Inf or NaN"):
+        ops.population_factor(X, w)
+
+
+def test_univariate_proposals_match_philox_reference_and_their_laws(ctx):
+    """beatamd_proposal_draw_univariate (NormalProposal / CauchyProposal / LaplaceProposal,
+    beat/sampler/base.py:129-147): every draw equals the Python Philox twin, draws depend on (seed,
+    step, global chain) only, and 2e5 draws follow the laws (quartiles; variance where it exists)"""
+    import philox_ref as pr
+    seed = 0xfeedface12345
+    for kind in (0, 1, 2):
+        for npar in (7, 16, 1):
+            C = 29
+            scale = np.linspace(0.5, 2.0, npar)
+            d, lu = ctx.proposal_draw_univariate(kind, scale, C, seed=seed, step=3)
+            ref = pr.univariate(C, npar, kind, scale, seed, 3)
+            np.testing.assert_allclose(d, ref, rtol=1e-10, atol=1e-13)    # (tan near +-pi/2: device vs libm)
+            np.testing.assert_allclose(lu, pr.log_uniforms(C, seed, 3), rtol=1e-13)
+            d2, lu2 = ctx.proposal_draw_univariate(kind, scale, C - 9, seed=seed, step=3, first_chain=9)
+            assert np.array_equal(d2, d[9:]) and np.array_equal(lu2, lu[9:])
+        x, _ = ctx.proposal_draw_univariate(kind, np.ones(100), 2000, seed=11 + kind, step=0)
+        x = np.asarray(x).ravel()
+        q1, q2, q3 = np.quantile(x, [0.25, 0.5, 0.75])
+        want_q3 = {0: 0.6744897501960817, 1: 1.0, 2: np.log(2.0)}[kind]
+        assert abs(q2) < 0.01 and abs(q3 - want_q3) < 0.02 and abs(q1 + want_q3) < 0.02, (kind, q1, q2, q3)
+        if kind != 1:
+            assert abs(x.var() - {0: 1.0, 2: 2.0}[kind]) < 0.03, (kind, x.var())
+    with pytest.raises(ValueError):
+        ctx.proposal_draw_univariate(3, np.ones(4), 5, seed=1, step=0)
+
+
+def test_metropolis_with_per_parameter_proposal_on_device(ctx):
+    """BEAT configures Metropolis-style runs with proposal_dist Normal / Cauchy / Laplace: the batched
+    stepper draws them on the device (used to raise NotImplementedError)"""
+    import torch
+    from beat_amd.sampler import SMC, smc_sample
+    spec, prob, host, f, lay, _ = _small_model(ctx)
+    lo, up = lay.bounds(host["lower"], host["upper"])
+    for name in ("Normal", "Laplace", "Cauchy"):
+        step = SMC(f, lo, up, n_chains=64, device=torch.device("cuda", 0), random_seed=2, proposal_name=name,
+                   scale=1e-3, tune_interval=4)
+        pop, lp, betas = smc_sample(6, step, max_stages=2)
+        assert np.isfinite(lp[:, -1]).all() and pop.shape == (64, lo.size)
+        assert ((pop >= lo) & (pop <= up)).all()
+        assert 0.0 < np.mean(step.stage_acceptance) <= 1.0

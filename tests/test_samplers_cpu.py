@@ -171,10 +171,29 @@ def test_host_proposal_draws_normal_and_cauchy_statistics():
     B = rng.standard_normal((6, 2))
     Fs = covariance_factor(B @ B.T)
     np.testing.assert_allclose(Fs.T @ Fs, B @ B.T, atol=1e-10)
+    # the per-parameter families (base.py:129-147) are drawn component by component, no factor;
+    # PoissonProposal (integer steps) is the one family that is not provided
+    assert proposal_df("Normal") is None and proposal_df("Laplace") is None
     with pytest.raises(NotImplementedError):
-        proposal_df("Normal")
+        proposal_df("Poisson")
     with pytest.raises(ValueError):
         covariance_factor(np.array([[np.nan]]))
+    # host twin of the per-parameter draws: Laplace has variance 2 scale^2, Cauchy quartiles at +-scale
+    from beat_amd.sampler.ops import HostOps
+    ops = HostOps()
+    sc = torch.tensor([0.5, 2.0], dtype=torch.float64)
+    lap, lu = ops.draw_univariate(2, sc, 100000, seed=4, step=1)
+    assert np.allclose(lap.numpy().var(axis=0), 2.0 * sc.numpy() ** 2, rtol=0.05) and lu.shape == (100000,)
+    cau, _ = ops.draw_univariate(1, sc, 100000, seed=4, step=2)
+    assert np.allclose(np.quantile(cau.numpy(), 0.75, axis=0), sc.numpy(), rtol=0.05)
+    # a Metropolis stepper with a per-parameter proposal samples the toy target
+    from beat_amd.sampler import SMC, smc_sample
+    from beat_amd.sampler.hosttarget import HostTarget
+    f, n = _two_gaussians()
+    step = SMC(HostTarget(f, n), -2 * np.ones(n), 2 * np.ones(n), n_chains=200, tune_interval=10, random_seed=8,
+               proposal_name="Normal", scale=0.1)
+    pop, lp, betas = smc_sample(40, step)
+    assert np.allclose(np.abs(pop).mean(axis=0), 0.5, atol=0.08), np.abs(pop).mean(axis=0)
 
 
 def test_population_factor_equals_weighted_covariance():
@@ -193,3 +212,35 @@ def test_population_factor_equals_weighted_covariance():
         np.testing.assert_allclose(F.numpy().T @ F.numpy(), cov, rtol=1e-12, atol=1e-12)
         rows, _ = ops.draw(F, 300000, seed=2, step=0)
         np.testing.assert_allclose(np.cov(rows.numpy().T), cov, rtol=0.04, atol=0.04 * np.abs(cov).max())
+
+
+def test_degenerate_weights_raise_like_calc_covariance():
+    """one chain carries all the importance weight: v1 - v2/v1 = 0, the weighted sample covariance
+    is 0/0 -- the reference's calc_covariance raises (smc.py:181-185); a non-finite population
+    likewise (the device path used to continue with a NaN factor and a frozen population)"""
+    import torch
+    from beat_amd.sampler.ops import HostOps
+    ops = HostOps()
+    X = torch.from_numpy(np.random.default_rng(0).standard_normal((50, 4)))
+    w = torch.zeros(50, dtype=torch.float64)
+    w[7] = 1.0
+    with pytest.raises(ValueError, match="Sample covariances contains Inf or NaN"):
+        ops.population_factor(X, w)
+    w = torch.full((50,), 0.02, dtype=torch.float64)
+    X[3, 1] = float("inf")
+    with pytest.raises(ValueError, match="Sample covariances contains Inf or NaN"):
+        ops.population_factor(X, w)
+
+
+def test_resume_with_other_chain_count_is_refused(tmp_path):
+    """load_stage: a stage written for 40 chains cannot seed a 30-chain sampler (this used
+    to reset the step sizes and the Philox step counter silently)"""
+    from beat_amd.sampler import SMC, smc_sample
+    from beat_amd.sampler.hosttarget import HostTarget
+    from beat_amd.sampler.smc import load_stage
+    f, n = _two_gaussians()
+    step = SMC(HostTarget(f, n), -2 * np.ones(n), 2 * np.ones(n), n_chains=40, tune_interval=5, random_seed=1)
+    smc_sample(6, step, homepath=str(tmp_path), max_stages=1)
+    other = SMC(HostTarget(f, n), -2 * np.ones(n), 2 * np.ones(n), n_chains=30, tune_interval=5, random_seed=1)
+    with pytest.raises(ValueError, match="resume with the same n_chains"):
+        load_stage(other, str(tmp_path), 0)
