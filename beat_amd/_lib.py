@@ -80,6 +80,7 @@ _PROTOS = {
     "beatamd_ffi_model_nllk": [_vp, _i32, _pi64],
     "beatamd_ffi_model_destroy": [_vp, _i32],
     "beatamd_ffi_logp_batch": [_vp, _i32, _i64, _vp, _vp],
+    "beatamd_ffi_synthetics_batch": [_vp, _i32, _i32, _i64, _vp, _i32, _vp],
     "beatamd_ffi_astep_batch": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp],
     "beatamd_autocovariance_batch": [_vp, _i64, _i64, _vp, _vp, _vp],
     "beatamd_scaled_toeplitz_batch": [_vp, _i64, _i64, _vp, _vp, _vp],
@@ -96,6 +97,7 @@ _PROTOS = {
     "beatamd_metropolis_tune": [_vp, _i64, _vp, _vp, _i32],
     "beatamd_whiten_rows": [_vp, _vp, _i64, _i64, _vp],
     "beatamd_chol_inverse_batch": [_vp, _i64, _i64, _vp, _vp, _vp],
+    "beatamd_chol_inverse_batch_flags": [_vp, _i64, _i64, _vp, _vp, _vp, _vp],
     "beatamd_whitening_ratio_batch": [_vp, _i64, _i64, _vp, _vp, _vp],
     "beatamd_factor_compact": [_vp, _i64, _i64, _vp, _vp],
     "beatamd_ffi_model_update_data": [_vp, _i32, _i32, _vp],

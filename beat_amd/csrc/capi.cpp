@@ -767,6 +767,54 @@ static int model_check_layout(const FfiModel &m)
     return BEATAMD_OK;
 }
 
+int beatamd_ffi_synthetics_batch(beatamd_ctx *ctx, int32_t model_id, int32_t wavemap_index, int64_t C,
+                                 const double *Q, int32_t residuals, double *out)
+{
+    ENTER(ctx);
+    FfiModel *m = get_obj(ctx->models, model_id);
+    BA_CHECK(m, BEATAMD_EINVAL, "unknown model %d", model_id);
+    BA_CHECK(Q && out && C >= 0, BEATAMD_EINVAL, "ffi_synthetics: bad argument");
+    BA_CHECK(wavemap_index >= 0 && (size_t)wavemap_index < m->wavemaps.size(), BEATAMD_EINVAL,
+             "ffi_synthetics: model has no wavemap %d", wavemap_index);
+    BA_TRY(model_check_layout(*m));
+    if (C == 0) return BEATAMD_OK;
+    Wavemap &wm = m->wavemaps[wavemap_index];
+    const int64_t np = m->layout.nparams;
+    const void *d_q;
+    void *d_o, *p;
+    Arg rec;
+    BA_TRY(stage_in(ctx, SL_IN0, Q, (size_t)C * np * 8, &d_q));
+    BA_TRY(stage_out(ctx, SL_OUT0, out, (size_t)C * wm.T * wm.N * 8, &d_o, &rec));
+    const double *Qd = (const double *)d_q;
+    BA_TRY(ctx->get_scratch(SL_CHAINBAD, (size_t)C * sizeof(int32_t), &p));
+    int32_t *chain_bad = (int32_t *)p;
+    BA_HIP(hipMemsetAsync(chain_bad, 0, (size_t)C * sizeof(int32_t), ctx->stream));
+    BA_TRY(ctx->get_scratch(SL_ST0, (size_t)C * m->P * sizeof(double), &p));
+    double *st0 = (double *)p;
+    BA_TRY(launch_sweep_model(ctx, *m, Qd, C, st0, chain_bad));
+    GfStackCall k;
+    k.nvar = m->layout.nvar;
+    for (int v = 0; v < k.nvar; v++) {
+        k.libs[v] = get_obj(ctx->seislibs, wm.libs[v]);
+        BA_CHECK(k.libs[v] && k.libs[v]->g, BEATAMD_EINVAL, "wavemap refers to a destroyed / empty GF library");
+        k.slips[v] = ChainVec{Qd, np, m->layout.slip_off[v]};
+    }
+    k.durations = ChainVec{Qd, np, m->layout.durations_off};
+    k.st.starttimes0 = st0;
+    k.st.Q = Qd;
+    k.st.nparams = np;
+    k.st.shift_off = wm.shift_off;
+    k.st.chain_bad = chain_bad;
+    k.interp = wm.interp;
+    k.C = C;
+    k.data = wm.data;
+    k.mode = residuals ? GF_RESID_STORE : GF_STORE_SYN;
+    k.out = (double *)d_o;
+    BA_TRY(launch_gfstack(ctx, k));
+    BA_TRY(ctx->check_status());   // an index outside the library is the reference's IndexError
+    return finish_out(ctx, &rec, 1);
+}
+
 int beatamd_ffi_logp_batch(beatamd_ctx *ctx, int32_t model_id, int64_t C, const double *Q,
                            double *LL)
 {
@@ -1100,6 +1148,24 @@ int beatamd_chol_inverse_batch(beatamd_ctx *ctx, int64_t nd, int64_t n, const do
     BA_TRY(launch_chol_inverse(ctx, nd, n, (const double *)d_c, (double *)d_w, (double *)d_l));
     BA_TRY(ctx->check_status());
     return finish_out(ctx, recs, 2);
+}
+
+int beatamd_chol_inverse_batch_flags(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *covs, double *W,
+                                     double *log_pdet, int32_t *not_psd)
+{
+    ENTER(ctx);
+    BA_CHECK(covs && W && log_pdet && not_psd && nd >= 0 && n > 0, BEATAMD_EINVAL,
+             "chol_inverse_batch_flags: bad argument");
+    if (nd == 0) return BEATAMD_OK;
+    const void *d_c;
+    void *d_w, *d_l, *d_f;
+    Arg recs[3];
+    BA_TRY(stage_in(ctx, SL_IN0, covs, (size_t)nd * n * n * 8, &d_c));
+    BA_TRY(stage_out(ctx, SL_OUT0, W, (size_t)nd * n * n * 8, &d_w, &recs[0]));
+    BA_TRY(stage_out(ctx, SL_OUT1, log_pdet, (size_t)nd * 8, &d_l, &recs[1]));
+    BA_TRY(stage_out(ctx, SL_OUT2, not_psd, (size_t)nd * 4, &d_f, &recs[2]));
+    BA_TRY(launch_chol_inverse(ctx, nd, n, (const double *)d_c, (double *)d_w, (double *)d_l, (int32_t *)d_f));
+    return finish_out(ctx, recs, 3);
 }
 
 int beatamd_factor_compact(beatamd_ctx *ctx, int64_t K, int64_t n, const double *factor, double *R)

@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256) k_chol_unflip(const double *X, int64_t n,
 // Dinv[b][kb] (full 64 x 64, zeros above the diagonal) and into X's diagonal block, and
 // sum_j log L_jj to logd[b][kb].  A pivot <= 0 or NaN raises ST_NOT_PSD.
 __global__ void __launch_bounds__(256) k_chol_diag(double *A, int64_t np, int kb, double *Dinv, double *X,
-                                                   double *logd, int nblk, int *status)
+                                                   double *logd, int nblk, int *status, int32_t *notpsd)
 {
     constexpr int NB = CH_NB, PITCH = NB + 1;
     __shared__ double L[NB * PITCH];
@@ -111,7 +111,11 @@ __global__ void __launch_bounds__(256) k_chol_diag(double *A, int64_t np, int kb
         double s = 0.0;
         for (int j = 0; j < NB; j++) s += log(L[j * PITCH + j]);
         logd[b * nblk + kb] = s;
-        if (bad) atomicOr(status, ST_NOT_PSD);
+        // (per-matrix flags when the caller repairs the failing matrices itself, else the status word)
+        if (bad) {
+            if (notpsd) notpsd[b] = 1;
+            else atomicOr(status, ST_NOT_PSD);
+        }
     }
 }
 
@@ -128,13 +132,14 @@ __global__ void k_chol_logdet(const double *logd, int nblk, int64_t nbatch, doub
 // blocked right-looking Cholesky of the lower triangles of A [nbatch][np][np] in place (np a multiple
 // of 64): diagonal blocks by k_chol_diag (their inverses to Dinv and to X's diagonal blocks, their
 // log-determinants to logd), panels and trailing updates as batched GEMMs
-static int potrf_lower(beatamd_ctx *ctx, int64_t nbatch, int64_t np, double *A, double *Dinv, double *X, double *logd)
+static int potrf_lower(beatamd_ctx *ctx, int64_t nbatch, int64_t np, double *A, double *Dinv, double *X, double *logd,
+                       int32_t *notpsd = nullptr)
 {
     const int nblk = (int)(np / CH_NB);
     const int64_t sM = np * np;
     for (int kb = 0; kb < nblk; kb++) {
         hipLaunchKernelGGL(k_chol_diag, dim3((unsigned)nbatch), dim3(256), 0, ctx->stream, A, np, kb, Dinv, X,
-                           logd, nblk, ctx->d_status);
+                           logd, nblk, ctx->d_status, notpsd);
         const int64_t r0 = (int64_t)(kb + 1) * CH_NB, below = np - r0;
         if (below == 0) break;
         GemmCall g;
@@ -157,7 +162,8 @@ static int potrf_lower(beatamd_ctx *ctx, int64_t nbatch, int64_t np, double *A, 
     return BEATAMD_OK;
 }
 
-int launch_chol_inverse(beatamd_ctx *ctx, int64_t nbatch, int64_t n, const double *C, double *W, double *log_pdet)
+int launch_chol_inverse(beatamd_ctx *ctx, int64_t nbatch, int64_t n, const double *C, double *W, double *log_pdet,
+                        int32_t *notpsd)
 {
     if (nbatch == 0 || n == 0) return BEATAMD_OK;
     BA_CHECK(C && W && log_pdet && nbatch > 0 && n > 0 && nbatch <= 65535, BEATAMD_EINVAL,
@@ -182,7 +188,8 @@ int launch_chol_inverse(beatamd_ctx *ctx, int64_t nbatch, int64_t n, const doubl
         hipLaunchKernelGGL(k_chol_flip_pad, grid, dim3(256), 0, ctx->stream, C, n, np, A);
     }
     const int64_t sM = np * np;
-    BA_TRY(potrf_lower(ctx, nbatch, np, A, Dinv, X, logd));
+    if (notpsd) BA_HIP(hipMemsetAsync(notpsd, 0, (size_t)nbatch * sizeof(int32_t), ctx->stream));
+    BA_TRY(potrf_lower(ctx, nbatch, np, A, Dinv, X, logd, notpsd));
     // X = inv(M) by row blocks (X's diagonal blocks are in place already)
     for (int kb = 1; kb < nblk; kb++) {
         const int64_t kc = (int64_t)kb * CH_NB;

@@ -153,7 +153,10 @@ struct GemmCall {
 };
 int launch_gemm_f64(beatamd_ctx *ctx, const GemmCall &call);
 // chol.hip: W = cholesky(inv(C)).T and log det C of a stack of matrices (device pointers)
-int launch_chol_inverse(beatamd_ctx *ctx, int64_t nbatch, int64_t n, const double *C, double *W, double *log_pdet);
+// notpsd (nullable, device [nbatch]): per-matrix flag instead of the status word for a matrix that is not
+// positive definite (its W / log_pdet are then meaningless)
+int launch_chol_inverse(beatamd_ctx *ctx, int64_t nbatch, int64_t n, const double *C, double *W, double *log_pdet,
+                        int32_t *notpsd = nullptr);
 // R [n,n] upper triangular with R^T R = F^T F for a tall F [K,n] (device pointers)
 int launch_gram_cholesky(beatamd_ctx *ctx, int64_t K, int64_t n, const double *F, double *R);
 // M = Wn . inv(Wo) for stacks of upper-triangular matrices (device pointers)

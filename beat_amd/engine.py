@@ -335,6 +335,17 @@ class Context(object):
         check(self._lib.beatamd_ffi_logp_batch(self._h, model_id, Cn, ptr(Q), ptr(out)))
         return out
 
+    def ffi_synthetics_batch(self, model_id, wavemap_index, Q, T, N, residuals=False, out=None):
+        """synthetics (or data - synthetics) [C, T, N] of one wavemap at the points Q [C, nparams]"""
+        self._adopt_stream(Q)
+        Qc = f64(Q)
+        Cn = int(Qc.shape[0])
+        if out is None:
+            out = _empty_like(Qc, (Cn, int(T), int(N)))
+        check(self._lib.beatamd_ffi_synthetics_batch(self._h, model_id, int(wavemap_index), Cn, ptr(Qc),
+                                                     int(bool(residuals)), ptr(out)))
+        return out
+
     def ffi_astep_batch(self, model_id, Q0, L0, delta, scaling, lower, upper, log_u, beta,
                         accepted=None):
         """In-place update of Q0 / L0 (must be contiguous float64); returns accepted (int32)."""
@@ -485,6 +496,23 @@ class Context(object):
         lp = _empty_like(C, (nd,))
         check(self._lib.beatamd_chol_inverse_batch(self._h, nd, n, ptr(C), ptr(W), ptr(lp)))
         return W, lp
+
+    def chol_inverse_batch_flags(self, covs):
+        """like chol_inverse_batch, but a matrix that is not positive definite is reported in the
+        returned int32 flags (nd,) instead of raising: -> (W, log_pdet, not_psd)"""
+        if _is_dev(covs):
+            self._adopt_stream(covs)
+        C = f64(covs)
+        nd, n = int(C.shape[0]), int(C.shape[1])
+        W = _empty_like(C, (nd, n, n))
+        lp = _empty_like(C, (nd,))
+        if _is_dev(C):
+            import torch
+            bad = torch.empty((nd,), dtype=torch.int32, device=C.device)
+        else:
+            bad = np.empty((nd,), dtype=np.int32)
+        check(self._lib.beatamd_chol_inverse_batch_flags(self._h, nd, n, ptr(C), ptr(W), ptr(lp), ptr(bad)))
+        return W, lp, bad
 
     def factor_compact(self, factor):
         """tall proposal factor (K, n) -> upper-triangular R (n, n) with R^T R = factor^T factor, or

@@ -310,6 +310,7 @@ class LogpForwFunc(object):
         nblocks = (len(problem.wavemaps) + (problem.geodetic is not None)
                    + (problem.laplacian is not None) + 1)
         self._llk_index = nblocks - 1 + (len(problem.layout.varsizes) if self.return_rvs else 0)
+        self._dirty = None   # set while a weight update rewrites the HBM library in place
 
     @property
     def out_names(self):
@@ -322,12 +323,6 @@ class LogpForwFunc(object):
         if self.problem.laplacian is not None:
             names.append("laplacian_like")
         return names + ["like"]
-
-    def batch(self, Q, out=None):
-        """Q (C, nparams) numpy or torch-cuda -> LL (C, nllk)"""
-        if Q.shape[-1] != self.nparams:
-            raise ValueError("expected %d parameters, got %d" % (self.nparams, Q.shape[-1]))
-        return self.ctx.ffi_logp_batch(self.model_id, Q, self.nllk, out)
 
     def __call__(self, q):
         q = np.ascontiguousarray(q, dtype=np.float64).reshape(1, -1)
@@ -373,25 +368,57 @@ class LogpForwFunc(object):
             sh.append(_SharedView("geodetic_odws", lambda: g.odws))
         return sh
 
+    def synthetics(self, Q, wavemap_index=0, residuals=False):
+        """synthetics [C, T, N] (or data - synthetics) of one wavemap at the points Q [C, nparams]:
+        SeismicComposite.get_synthetics of the distributed-slip composite (seismic.py:1351-1507);
+        numpy or torch-cuda in, same kind out"""
+        wm = self.problem.wavemaps[wavemap_index]
+        T, N = wm.data.shape
+        return self.ctx.ffi_synthetics_batch(self.model_id, wavemap_index, Q, T, N, residuals=residuals)
+
+    def batch(self, Q, out=None):
+        """Q (C, nparams) numpy or torch-cuda -> LL (C, nllk)"""
+        if Q.shape[-1] != self.nparams:
+            raise ValueError("expected %d parameters, got %d" % (self.nparams, Q.shape[-1]))
+        if self._dirty:
+            raise RuntimeError("a weight update of this model did not complete: %s" % self._dirty)
+        return self.ctx.ffi_logp_batch(self.model_id, Q, self.nllk, out)
+
     def update_weights(self, wavemap_index, weights, slog_pdet):
         """seismic.py:1509-1534 update_weights: new chol_inverse + slog_pdet per dataset.  Kind
-        and size must match the uploaded set (checked by the library)."""
+        and size must match the uploaded set (checked by the library).  numpy arrays or torch-cuda
+        tensors (the per-stage covariance update keeps them on the device)."""
+        import torch
         wm = self.problem.wavemaps[wavemap_index]
-        w = np.ascontiguousarray(weights, dtype=np.float64)
-        sl = np.ascontiguousarray(slog_pdet, dtype=np.float64).ravel()
         T, N = wm.data.shape
+        on_dev = torch.is_tensor(weights) and weights.is_cuda
+        if on_dev:
+            w = weights.contiguous()
+            sl = (slog_pdet if torch.is_tensor(slog_pdet) else torch.from_numpy(np.asarray(slog_pdet))).to(w.device)
+            sl = sl.double().reshape(-1).contiguous()
+        else:
+            w = np.ascontiguousarray(weights, dtype=np.float64)
+            sl = np.ascontiguousarray(slog_pdet, dtype=np.float64).ravel()
         if getattr(wm, "is_prewhitened", False):
             # The old operator is folded into the library rows and the data: rows . W_new^T =
             # (rows . W_old^T) . M^T with M = W_new . inv(W_old) (upper triangular, solved on the
             # device), applied in place -- no copy of the unwhitened library is needed.
-            import torch
-            if w.shape != (T, N, N) or sl.shape != (T,):
+            if tuple(w.shape) != (T, N, N) or tuple(sl.shape) != (T,):
                 raise ValueError("a pre-whitened wavemap takes dense weights (%d,%d,%d) and slog_pdet (%d,)"
                                  % (T, N, N, T))
             dev = torch.device("cuda", self.ctx.device)
-            M = self.ctx.whitening_ratio_batch(torch.from_numpy(w).to(dev),
-                                               torch.from_numpy(np.ascontiguousarray(wm._whitened_with)).to(dev))
+            wd = w if on_dev else torch.from_numpy(w).to(dev)
+            old = wm._whitened_with
+            old = old if torch.is_tensor(old) else torch.from_numpy(np.ascontiguousarray(old)).to(dev)
+            # M is computed and checked (a singular old operator raises here) BEFORE any row is touched
+            M = self.ctx.whitening_ratio_batch(wd, old)
+            self.ctx.synchronize()
+            self._dirty = "re-whitening of wavemap %d was interrupted" % wavemap_index
+            seen = set()   # (two slip components may share one adopted tensor: whiten it once)
             for gf in wm.gfs.values():
+                if gf._device_tensor.data_ptr() in seen:
+                    continue
+                seen.add(gf._device_tensor.data_ptr())
                 rows = gf._device_tensor.view(T, -1, N)
                 for t in range(T):
                     self.ctx.whiten_rows(rows[t], M[t])
@@ -401,12 +428,17 @@ class LogpForwFunc(object):
             self.ctx.ffi_model_update_data(self.model_id, wavemap_index, d)
             self.ctx.weights_update(wm._wset, np.ones(T), sl)
             self.ctx.synchronize()
-            wm.data, wm.slog_pdet, wm._whitened_with = d.cpu().numpy(), sl, w
+            wm.data, wm.slog_pdet, wm._whitened_with = d.cpu().numpy(), _host(sl), wd
+            self._dirty = None
             return
-        if w.shape not in ((T,), (T, N, N)) or sl.shape != (T,):
+        if tuple(w.shape) not in ((T,), (T, N, N)) or tuple(sl.shape) != (T,):
             raise ValueError("weights must be (%d,) or (%d,%d,%d) and slog_pdet (%d,)" % (T, T, N, N, T))
         self.ctx.weights_update(wm._wset, w, sl)
-        wm.weights, wm.slog_pdet = w, sl
+        wm.weights, wm.slog_pdet = w, _host(sl)
+
+
+def _host(a):
+    return a.detach().cpu().numpy() if hasattr(a, "detach") else a
 
 
 def prior_logp_func(lower, upper):

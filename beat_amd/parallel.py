@@ -76,6 +76,18 @@ def _active():
     return dist.is_available() and dist.is_initialized()
 
 
+def _staged(X):
+    """The transport buffer of a collective.  RCCL ("nccl") moves device tensors directly.  A gloo group
+    fed with device tensors -- two ranks sharing ONE GPU in tests/test_gpu_dist.py, where RCCL refuses
+    duplicate devices -- goes through host memory: -> (tensor to hand to torch.distributed,
+    function that brings a result back to X's device)."""
+    import torch.distributed as dist
+    if X.is_cuda and dist.get_backend() == "gloo":
+        dev = X.device
+        return X.cpu(), (lambda t: t.to(dev))
+    return X, (lambda t: t)
+
+
 def allgather_rows(X):
     """rows of all ranks in rank order; X (n_local, width) -> (n_total, width).  Blocks may differ
     in length."""
@@ -84,18 +96,24 @@ def allgather_rows(X):
     if not _active():
         return X
     world = dist.get_world_size()   # (a single rank runs through the same collectives)
-    n_local = torch.tensor([X.shape[0]], device=X.device, dtype=torch.int64)
+    Xt, back = _staged(X)
+    n_local = torch.tensor([Xt.shape[0]], device=Xt.device, dtype=torch.int64)
     counts = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(counts, n_local)
     counts = [int(c.item()) for c in counts]
     nmax = max(counts)
-    buf = torch.zeros((nmax,) + tuple(X.shape[1:]), device=X.device, dtype=X.dtype)
-    buf[:X.shape[0]] = X
-    out = torch.empty((world * nmax,) + tuple(X.shape[1:]), device=X.device, dtype=X.dtype)
-    dist.all_gather_into_tensor(out, buf)
-    if all(c == nmax for c in counts):
-        return out
-    return torch.cat([out[r * nmax:r * nmax + counts[r]] for r in range(world)], 0)
+    buf = torch.zeros((nmax,) + tuple(Xt.shape[1:]), device=Xt.device, dtype=Xt.dtype)
+    buf[:Xt.shape[0]] = Xt
+    if dist.get_backend() == "gloo":
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf)
+        out = torch.cat(parts, 0)
+    else:
+        out = torch.empty((world * nmax,) + tuple(Xt.shape[1:]), device=Xt.device, dtype=Xt.dtype)
+        dist.all_gather_into_tensor(out, buf)
+    if not all(c == nmax for c in counts):
+        out = torch.cat([out[r * nmax:r * nmax + counts[r]] for r in range(world)], 0)
+    return back(out)
 
 
 def allgather_population(Q, L):
@@ -142,19 +160,20 @@ def exchange_rows(X, perm, n_total, gather=None):
         # rows rank r needs from this rank, in the order of r's destination rows
         send_src = perm[a:b][owner[perm[a:b]] == rank] - start
         if send_src.size:
-            sbuf = X[torch.from_numpy(send_src).to(X.device)].contiguous()
+            sbuf = _staged(X[torch.from_numpy(send_src).to(X.device)].contiguous())[0]
             ops.append(dist.P2POp(dist.isend, sbuf, r))
         # rows this rank needs from rank r
         need = np.nonzero(owner[src] == r)[0]
         if need.size:
-            rbuf = torch.empty((need.size,) + tuple(X.shape[1:]), device=X.device, dtype=X.dtype)
+            tdev = _staged(X[:0])[0].device
+            rbuf = torch.empty((need.size,) + tuple(X.shape[1:]), device=tdev, dtype=X.dtype)
             ops.append(dist.P2POp(dist.irecv, rbuf, r))
             recv.append((need, rbuf))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     for need, rbuf in recv:
-        out[torch.from_numpy(need).to(X.device)] = rbuf
+        out[torch.from_numpy(need).to(X.device)] = rbuf.to(X.device)
     return out
 
 
@@ -165,7 +184,7 @@ def broadcast_array(a, src=0):
     import torch.distributed as dist
     if not _active() or dist.get_world_size() == 1:
         return a
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"   # (a few bytes: always through the transport's memory)
     t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     dist.broadcast(t, src)
     return t.cpu().numpy()

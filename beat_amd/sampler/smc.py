@@ -212,12 +212,25 @@ def load_stage(step, homepath, stage):
     return step
 
 
+def update_last_samples(step, Q_local):
+    """sampler/base.py:664-704: the end points of the stage are evaluated again with the updated
+    weights (one draw at stage 0 = evaluation without a move, metropolis.py:277-286) and gathered"""
+    L = step.stepper.evaluate(Q_local)
+    return step.select_end_points(Q_local, L)
+
+
 def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, homepath=None,
-               layout=None, out_names=None, backend="bin", resume_stage=None):
+               layout=None, out_names=None, backend="bin", resume_stage=None, update=None):
     """smc.py:333-546 stage loop.  Returns the final population (n_chains, nparams), the
     likelihood vectors (host arrays) and the list of betas.  With ``homepath`` every stage leaves
     a ``stage_<k>`` / ``stage_final`` directory of NumpyChain/TextChain traces
-    (beat_amd.backend) and the state to resume from."""
+    (beat_amd.backend) and the state to resume from.
+
+    ``update`` (smc.py:492-503, ``update_covariances`` of the reference's config): an object with
+    ``update_weights(map_point)`` -- e.g. ``beat_amd.covariance.NoiseCovarianceUpdate`` -- called with
+    the maximum-likelihood end point after every stage; the population is then evaluated again with
+    the new weights before the next tempering step is chosen.  Every rank holds the same gathered
+    population, so every rank updates its own model copy identically."""
     step.n_steps = int(n_steps)
     if n_steps < 1:
         raise TypeError("Argument `n_steps` should be above 0.")
@@ -237,6 +250,10 @@ def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, 
         logger.info("Beta: %f Stage: %i", step.beta, step.stage)
         Q, L = step.sample_stage(n_steps)
         step.select_end_points(Q, L)
+        if update is not None:
+            logger.info("Updating Covariances ...")
+            update.update_weights(step.get_map_end_points())
+            update_last_samples(step, Q)
         betas.append(step.beta)
         _dump_stage(step, homepath, layout, out_names, backend)
         if on_stage is not None:

@@ -180,10 +180,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`"
-                             % (args.gpus, args.gpus))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one per GPU)
+        # through torch.distributed.run and hand its output through; under torchrun this is skipped
+        import socket
+        import subprocess
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     torch.cuda.set_device(local_rank)
     # BEATAMD_BENCH_FORCE_DIST=1: exercise the RCCL path with a single rank (1-GPU boxes)
     use_dist = world > 1 or bool(os.environ.get("BEATAMD_BENCH_FORCE_DIST"))

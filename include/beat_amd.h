@@ -224,6 +224,15 @@ int beatamd_ffi_model_set_laplacian(beatamd_ctx *ctx, int32_t model_id, int32_t 
 int beatamd_ffi_model_nllk(beatamd_ctx *ctx, int32_t model_id, int64_t *nllk);
 int beatamd_ffi_model_destroy(beatamd_ctx *ctx, int32_t model_id);
 
+/* replaces: SeismicComposite.get_synthetics(point) for the distributed-slip composite
+ *           (sweep -> start times -> stack_all), beat/models/seismic.py:1351-1507, as
+ *           update_weights / analyse_noise call it at the MAP point of a stage (:1509-1534,
+ *           beat/covariance.py:333-395)
+ *   Q [C,nparams] -> out [C,T,N] of wavemap `wavemap_index`: synthetics, or (residuals != 0)
+ *   data - synthetics (seismic.py:1332).  An index outside the library is BEATAMD_EINDEX. */
+int beatamd_ffi_synthetics_batch(beatamd_ctx *ctx, int32_t model_id, int32_t wavemap_index, int64_t C,
+                                 const double *Q, int32_t residuals, double *out);
+
 /* logp_forw_func batched: Q [C,nparams] -> LL [C,nllk] */
 int beatamd_ffi_logp_batch(beatamd_ctx *ctx, int32_t model_id, int64_t C, const double *Q,
                            double *LL);
@@ -335,6 +344,12 @@ int beatamd_whiten_rows(beatamd_ctx *ctx, double *rows, int64_t nrows, int64_t N
  *   is BEATAMD_ENOTPSD (numpy raises LinAlgError). */
 int beatamd_chol_inverse_batch(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *covs, double *W,
                                double *log_pdet);
+/* same, for callers that repair the failing matrices themselves (utility.ensure_cov_psd /
+ * repair_covariance, beat/utility.py:1034-1138; get_data_covariances, beat/covariance.py:413-427):
+ * not_psd [nd] = 1 where the factorisation met a non-positive pivot (W / log_pdet of that matrix
+ * are meaningless), no error is raised. */
+int beatamd_chol_inverse_batch_flags(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *covs, double *W,
+                                     double *log_pdet, int32_t *not_psd);
 
 /* replaces: the Cholesky factor inside pymc's MultivariateNormalProposal (base.py:163-186,
  *           numpy.linalg.cholesky of the proposal covariance) for the stage proposals of SMC:
