@@ -51,6 +51,7 @@ _PROTOS = {
     "beatamd_ctx_set_stream": [_vp, _vp],
     "beatamd_ctx_use_own_stream": [_vp],
     "beatamd_ctx_synchronize": [_vp],
+    "beatamd_ctx_set_step_counter": [_vp, _vp],
     "beatamd_ctx_enable_timing": [_vp, C.c_int],
     "beatamd_ctx_kernel_time": [_vp, C.c_char_p, C.POINTER(_f64), _pi64],
     "beatamd_ctx_reset_timing": [_vp],

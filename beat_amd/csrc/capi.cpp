@@ -1069,6 +1069,7 @@ int beatamd_proposal_draw(beatamd_ctx *ctx, int64_t C, int64_t K, int64_t nparam
     g.row_scale = rs;
     g.timer = "proposal";
     BA_TRY(launch_gemm_f64(ctx, g));
+    BA_TRY(launch_step_advance(ctx));
     return finish_out(ctx, recs, nrec);
 }
 
@@ -1095,6 +1096,7 @@ int beatamd_proposal_draw_univariate(beatamd_ctx *ctx, int64_t C, int64_t nparam
     BA_TRY(launch_philox_univariate(ctx, (double *)d_d, C, nparams, kind, (const double *)d_s, seed, step,
                                     (uint64_t)first_chain));
     if (d_u) BA_TRY(launch_philox_chain(ctx, C, seed, step, (uint64_t)first_chain, 0, (double *)d_u, nullptr));
+    BA_TRY(launch_step_advance(ctx));
     return finish_out(ctx, recs, nrec);
 }
 

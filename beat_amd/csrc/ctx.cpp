@@ -290,6 +290,15 @@ int beatamd_ctx_use_own_stream(beatamd_ctx *c)
     return BEATAMD_OK;
 }
 
+int beatamd_ctx_set_step_counter(beatamd_ctx *c, uint32_t *device_counter)
+{
+    BA_CHECK(c != nullptr, BEATAMD_EINVAL, "ctx is NULL");
+    BA_CHECK(device_counter == nullptr || is_device_ptr(device_counter), BEATAMD_EINVAL,
+             "ctx_set_step_counter: the counter must live in device memory");
+    c->step_dev = device_counter;
+    return BEATAMD_OK;
+}
+
 int beatamd_ctx_synchronize(beatamd_ctx *c)
 {
     BA_CHECK(c, BEATAMD_EINVAL, "ctx is NULL");

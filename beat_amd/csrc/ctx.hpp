@@ -161,6 +161,9 @@ struct beatamd_ctx {
     // measured chains-per-workgroup choice per problem shape: key -> (group size, row bound)
     std::map<std::vector<int64_t>, std::pair<int, int>> gs_tuned;
     int gs_cg = 0;
+    // device-resident Philox step counter (beatamd_ctx_set_step_counter): the proposal draws read it
+    // instead of their `step` argument and advance it, so that a captured step replays correctly
+    uint32_t *step_dev = nullptr;
 
     // grow-only scratch slot
     int get_scratch(int slot, size_t bytes, void **out);

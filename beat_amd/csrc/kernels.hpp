@@ -177,6 +177,7 @@ int launch_philox_normal(beatamd_ctx *ctx, double *z, int64_t C, int64_t K, uint
                          uint32_t step, uint64_t first_chain);
 int launch_philox_univariate(beatamd_ctx *ctx, double *delta, int64_t C, int64_t np, int kind,
                              const double *scale, uint64_t seed, uint32_t step, uint64_t first_chain);
+int launch_step_advance(beatamd_ctx *ctx);
 int launch_philox_chain(beatamd_ctx *ctx, int64_t C, uint64_t seed, uint32_t step, uint64_t first_chain,
                         int df, double *log_u, double *row_scale);
 

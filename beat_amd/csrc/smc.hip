@@ -310,8 +310,9 @@ __device__ __forceinline__ double u53(uint32_t hi, uint32_t lo)
 //   stream 1: chi-square normals of the multivariate-t divisor (base.py:35-71)
 //   stream 2: Metropolis uniforms
 __global__ void __launch_bounds__(256) k_philox_normal(double *z, int64_t C, int64_t K, uint64_t seed,
-                                                      uint32_t step, uint64_t first_chain)
+                                                      uint32_t step, uint64_t first_chain, const uint32_t *step_dev)
 {
+    if (step_dev) step = *step_dev;   // device-resident step counter (graph replay): replaces the argument
     const int64_t npair = (K + 1) / 2;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= C * npair) return;
@@ -330,8 +331,9 @@ __global__ void __launch_bounds__(256) k_philox_normal(double *z, int64_t C, int
 // df degrees of freedom, the row scale 1 / sqrt(chi2(df) / df)  (base.py:63-71)
 __global__ void __launch_bounds__(256) k_philox_chain(int64_t C, uint64_t seed, uint32_t step,
                                                      uint64_t first_chain, int df, double *log_u,
-                                                     double *row_scale)
+                                                     double *row_scale, const uint32_t *step_dev)
 {
+    if (step_dev) step = *step_dev;
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const uint64_t gc = first_chain + (uint64_t)c;
@@ -364,8 +366,9 @@ __global__ void __launch_bounds__(256) k_philox_chain(int64_t C, uint64_t seed, 
 //   kind 2  LaplaceProposal  (standard_exponential() - standard_exponential()) * scale
 __global__ void __launch_bounds__(256) k_philox_univariate(double *delta, int64_t C, int64_t np, int kind,
                                                           const double *scale, uint64_t seed, uint32_t step,
-                                                          uint64_t first_chain)
+                                                          uint64_t first_chain, const uint32_t *step_dev)
 {
+    if (step_dev) step = *step_dev;
     const int64_t npair = (np + 1) / 2;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= C * npair) return;
@@ -400,7 +403,7 @@ int launch_philox_univariate(beatamd_ctx *ctx, double *delta, int64_t C, int64_t
     if (n == 0) return BEATAMD_OK;
     ScopedTimer tm(ctx, "proposal");
     hipLaunchKernelGGL(k_philox_univariate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       delta, C, np, kind, scale, seed, step, first_chain);
+                       delta, C, np, kind, scale, seed, step, first_chain, ctx->step_dev);
     BA_HIP(hipGetLastError());
     return BEATAMD_OK;
 }
@@ -411,7 +414,7 @@ int launch_philox_normal(beatamd_ctx *ctx, double *z, int64_t C, int64_t K, uint
     const int64_t n = C * ((K + 1) / 2);
     if (n == 0) return BEATAMD_OK;
     hipLaunchKernelGGL(k_philox_normal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, z,
-                       C, K, seed, step, first_chain);
+                       C, K, seed, step, first_chain, ctx->step_dev);
     BA_HIP(hipGetLastError());
     return BEATAMD_OK;
 }
@@ -421,7 +424,18 @@ int launch_philox_chain(beatamd_ctx *ctx, int64_t C, uint64_t seed, uint32_t ste
 {
     if (C == 0) return BEATAMD_OK;
     hipLaunchKernelGGL(k_philox_chain, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, ctx->stream, C,
-                       seed, step, first_chain, df, log_u, row_scale);
+                       seed, step, first_chain, df, log_u, row_scale, ctx->step_dev);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
+__global__ void k_step_advance(uint32_t *step_dev) { *step_dev += 1u; }
+
+// after the draws of a step: the device-resident counter moves on (captured with the step in a graph)
+int launch_step_advance(beatamd_ctx *ctx)
+{
+    if (!ctx->step_dev) return BEATAMD_OK;
+    hipLaunchKernelGGL(k_step_advance, dim3(1), dim3(1), 0, ctx->stream, ctx->step_dev);
     BA_HIP(hipGetLastError());
     return BEATAMD_OK;
 }

@@ -98,6 +98,10 @@ class Context(object):
     def synchronize(self):
         check(self._lib.beatamd_ctx_synchronize(self._h))
 
+    def set_step_counter(self, counter):
+        """counter: torch int32 tensor (1,) on the device, or None -- see beatamd_ctx_set_step_counter"""
+        check(self._lib.beatamd_ctx_set_step_counter(self._h, ptr(counter) if counter is not None else None))
+
     def enable_timing(self, on=True):
         check(self._lib.beatamd_ctx_enable_timing(self._h, int(bool(on))))
 

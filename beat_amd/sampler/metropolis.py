@@ -85,13 +85,59 @@ class BatchedMetropolis(object):
                              "Or starting point outside prior bounds!")
         return L
 
-    def step(self, Q, L, beta):
-        """one astep for every chain; beta scalar or per-chain tensor.  In place on Q, L."""
-        if self.factor is None and self.kind is None:
-            raise RuntimeError("no proposal set: call set_proposal / set_proposal_from_population")
+    def _tune_if_due(self):
         if self.tune and self.steps_until_tune == 0:
             self.ops.tune(self.scaling, self.accepted_since_tune, self.tune_interval)
             self.steps_until_tune = self.tune_interval
+
+    def run(self, Q, L, beta, n_steps, n_acc, use_graph=False):
+        """n_steps steps of every chain, in place on Q, L; accepted moves are added to the 0-d tensor
+        n_acc.  use_graph (CUDA only): the step -- proposal draws, fused astep, acceptance
+        bookkeeping; nothing in it synchronises with the host -- is captured ONCE per call in a HIP
+        graph and replayed, with the Philox step counter resident on the device
+        (beatamd_ctx_set_step_counter), so the draws are exactly those of the eager loop.  For
+        launch-bound problems (geometry mode with ~1000 chains: a dozen launches of a few
+        microseconds each per step) that removes the launch overhead; the step-size tuning runs
+        between replays."""
+        torch = self.torch
+        n_steps = int(n_steps)
+        if not (use_graph and Q.is_cuda and n_steps >= 3 and hasattr(self.ops, "ctx")):
+            for _ in range(n_steps):
+                n_acc += self.step(Q, L, beta).sum()
+            return
+        n_acc += self.step(Q, L, beta).sum()      # eager: allocations, measured kernel choices
+        ctx = self.ops.ctx
+        counter = torch.tensor([self.n_steps_total], dtype=torch.int32, device=Q.device)
+        torch.cuda.synchronize(Q.device)
+        graph = torch.cuda.CUDAGraph()
+        ctx.set_step_counter(counter)
+        try:
+            with torch.cuda.graph(graph):
+                self._draw_and_astep(Q, L, beta)
+                self.accepted_since_tune += self._acc
+                n_acc += self._acc.sum()
+            for _ in range(n_steps - 1):
+                self._tune_if_due()
+                graph.replay()
+                self.steps_until_tune -= 1
+                self.n_steps_total += 1
+        finally:
+            ctx.set_step_counter(None)
+        if int(counter.item()) != self.n_steps_total & 0x7fffffff:
+            raise RuntimeError("device step counter %d != host %d" % (int(counter.item()), self.n_steps_total))
+
+    def step(self, Q, L, beta):
+        """one astep for every chain; beta scalar or per-chain tensor.  In place on Q, L."""
+        self._tune_if_due()
+        self._draw_and_astep(Q, L, beta)
+        self.accepted_since_tune += self._acc
+        self.steps_until_tune -= 1
+        self.n_steps_total += 1
+        return self._acc
+
+    def _draw_and_astep(self, Q, L, beta):
+        if self.factor is None and self.kind is None:
+            raise RuntimeError("no proposal set: call set_proposal / set_proposal_from_population")
         if self.kind is not None:
             delta, log_u = self.ops.draw_univariate(self.kind, self.uscale, self.n_chains, self.seed,
                                                     self.n_steps_total, first_chain=self.first_chain)
@@ -100,10 +146,6 @@ class BatchedMetropolis(object):
                                          first_chain=self.first_chain, df=self.df)
         self.target.astep_batch(Q, L, delta, self.scaling, self.lower, self.upper, log_u, beta,
                                 self._acc)
-        self.accepted_since_tune += self._acc
-        self.steps_until_tune -= 1
-        self.n_steps_total += 1
-        return self._acc
 
     # -- resume support
     def state_dict(self):

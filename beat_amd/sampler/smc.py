@@ -37,7 +37,7 @@ class SMC(object):
 
     def __init__(self, target, lower, upper, n_chains=100, tune=True, tune_interval=100,
                  coef_variation=1.0, check_bound=True, proposal_name="MultivariateNormal",
-                 device=None, random_seed=42, scale=1.0):
+                 device=None, random_seed=42, scale=1.0, use_graph=False):
         import torch
         self.torch = torch
         proposal_df(proposal_name)  # validates the name
@@ -61,6 +61,8 @@ class SMC(object):
         self.device = self.stepper.device
         self.ops = ops_for(self.device, target)
         self.n_steps = 1
+        # replay the Metropolis step of a stage from a HIP graph (launch-bound problems: geometry mode)
+        self.use_graph = bool(use_graph)
         self.stage_betas, self.stage_acceptance = [], []
         # gathered population of all ranks (tensors on self.device), weights, restart indices
         self.Q_all = self.L_all = self.w = self.idx = None
@@ -148,10 +150,12 @@ class SMC(object):
         self.beta"""
         Q, L = self.restart_points()
         n_acc = self.torch.zeros((), dtype=self.torch.int64, device=Q.device)
-        for i in range(int(n_steps)):
-            acc = self.stepper.step(Q, L, self.beta)
-            n_acc += acc.sum()
-            if on_step is not None:
+        if on_step is None:
+            self.stepper.run(Q, L, self.beta, n_steps, n_acc, use_graph=self.use_graph)
+        else:
+            for i in range(int(n_steps)):
+                acc = self.stepper.step(Q, L, self.beta)
+                n_acc += acc.sum()
                 on_step(i, Q, L, acc)
         self.stage_acceptance.append(float(n_acc.item()) / max(1.0, float(n_steps) * Q.shape[0]))
         return Q, L

@@ -276,3 +276,45 @@ def build_problem(spec, device_library=False, ctx=None):
     prob = FFIProblem(layout, spec.n_patch_dip, spec.n_patch_strike, spec.patch_size,
                       spec.slip_varnames, wavemaps, geodetic, lap, lower, upper)
     return prob, host
+
+
+def build_geometry_problem(sizes=(214, 205), seed=11):
+    """BASELINE configs[1] shape on synthetic inputs: one rectangular source in a homogeneous half
+    space (nine sampled source parameters with the bounds of the reference's
+    data/examples/Fernandina/config_geometry.yaml:26-99 in spirit, one hyper-parameter), two SAR
+    scenes of `sizes` points with full covariances (exponential in the point distance + a nugget),
+    random observation geometry and line-of-sight angles in the range of an ascending / descending
+    pair.  -> (GeodeticGeometryProblem, layout, lower, upper).  Input construction only; the
+    geometry-mode forward model itself has no BEAT-anchored parity check (pyrocko is not in the
+    reference tree -- DESIGN.md section 4)."""
+    from .heart import whitening
+    from .models import GeodeticGeometryProblem, ParameterLayout, los_vectors
+    rng = np.random.default_rng(seed)
+    nobs = int(sum(sizes))
+    east, north = rng.uniform(-15, 15, nobs), rng.uniform(-15, 15, nobs)
+    inc = np.concatenate([rng.uniform(33, 43, n) if i % 2 == 0 else rng.uniform(20, 28, n)
+                          for i, n in enumerate(sizes)])
+    head = np.concatenate([np.full(n, -12.0 if i % 2 == 0 else -168.0) + rng.normal(0, 0.3, n)
+                           for i, n in enumerate(sizes)])
+    names = OrderedDict([("depth", 1), ("dip", 1), ("east_shift", 1), ("length", 1), ("north_shift", 1),
+                         ("slip", 1), ("strike", 1), ("width", 1), ("h_SAR", 1)])
+    lay = ParameterLayout(names)
+    lower = dict(depth=0.5, dip=5.0, east_shift=-5.0, length=0.5, north_shift=-5.0, slip=0.01, strike=0.0,
+                 width=0.5, h_SAR=-2.0)
+    upper = dict(depth=9.0, dip=85.0, east_shift=5.0, length=10.0, north_shift=5.0, slip=1.0, strike=360.0,
+                 width=8.0, h_SAR=2.0)
+    data = 0.01 * rng.standard_normal(nobs)
+    odw = 0.5 + rng.random(nobs)
+    Ws, sls, o = [], [], 0
+    for n in sizes:
+        x, y = east[o:o + n], north[o:o + n]
+        dist = np.hypot(x[:, None] - x[None, :], y[:, None] - y[None, :])
+        C = 1e-4 * (np.exp(-dist / 5.0) + 0.1 * np.eye(n))
+        W, sl = whitening(C)
+        Ws.append(W)
+        sls.append(sl)
+        o += n
+    prob = GeodeticGeometryProblem(lay, ["rectangular"], east, north, los_vectors(inc, head), data, odw, sizes,
+                                   Ws, sls, [("h_SAR", 0)] * len(sizes), fixed=dict(rake=30.0, opening_fraction=0.25),
+                                   lower=lower, upper=upper)
+    return prob, lay, lower, upper

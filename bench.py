@@ -104,7 +104,18 @@ def cpu_baseline(spec, seconds=12.0):
             dt = time.perf_counter() - t0
         nsteps = int(sum(counts))
         rate_all = nsteps * (T_sub / spec.T) / dt
-    return dict(value=rate_all, unit="chain-steps/s", cores=ncores, kind="port",
+    phys = None
+    try:   # physical cores: distinct (package, core) pairs of the CPUs this process may use
+        cpus = sorted(os.sched_getaffinity(0))
+        ids = set()
+        for c in cpus:
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+            ids.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+        phys = len(ids)
+    except OSError:
+        pass
+    return dict(value=rate_all, unit="chain-steps/s", cores=ncores, cores_physical=phys, kind="port",
+                extrapolated_from="%d of %d targets per evaluation, scaled to a full chain-step" % (T_sub, spec.T),
                 value_1core=rate1,
                 sample="%d of %d targets (full %dx%d gather per target), %d sample evaluations, "
                        "oracle/beat_oracle.c (C restatement of the reference numpy/C path), "
@@ -164,6 +175,10 @@ def main():
     ap.add_argument("--no-batch-leg", action="store_true", help="skip the labelled 2048-chain batch leg")
     ap.add_argument("--no-narrow-leg", action="store_true",
                     help="skip the labelled round-1 narrow-prior leg")
+    ap.add_argument("--no-variant-legs", action="store_true",
+                    help="skip the labelled legs of the other configurations: multilinear (the reference's "
+                         "default interpolation), dense Toeplitz covariance, pre-whitened library, parallel "
+                         "tempering, geometry mode")
     ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "r2_bench_c512_nn_gfstack_summary.json"),
                     help="rocprofv3 PMC summary (tools/run_profile.sh + tools/summarize_rocpd.py) of THIS "
                          "command; supplies roofline.traffic when its configuration matches")
@@ -297,30 +312,36 @@ def main():
         stage_ms = (time.perf_counter() - t1) * 1e3
     assert Qn.shape == main_leg["Q"].shape and smc.Q_all.shape[0] == world * B
 
-    out = None
-    if rank == 0:
-        gf_ms, gf_n = main_leg["times"]["gfstack"]
-        alg = algorithmic_bytes_per_chain_step(spec) * B  # per launch
-        rows_per_patch = 4 if spec.interpolation == "multilinear" else 1
+    def stack_roofline(spec_leg, leg, n_chains):
+        """roofline of the stacking kernel of one leg: every candidate bound with its fraction, the
+        largest named `bound` (none is ever above 1); SURVEY 8(d)'s independent-chain byte count is
+        kept as a figure (`algorithmic_equiv_GBs`), not a fraction, for the chain-shared kernels"""
+        gf_ms, gf_n = leg["times"]["gfstack"]
+        alg = algorithmic_bytes_per_chain_step(spec_leg) * n_chains  # per launch
+        rows_per_patch = 4 if spec_leg.interpolation == "multilinear" else 1
         avg_ms = gf_ms / max(gf_n, 1)
-        alg_equiv = alg / (avg_ms * 1e-3) / 1e9 if gf_n else 0.0
-        st = main_leg["stats"]
+        st = leg["stats"]
         shared = st["row_bytes"] > 0
+        cell = leg["kernel"].startswith("k_gfstack_cell")
         # bytes the kernel has to move from HBM: every distinct row of every (group, target,
         # patch) once (chain-shared kernels) or every chain's rows (streaming kernel), + tables
-        tables = B * spec.T * spec.P * 4 * rows_per_patch * 2 + spec.T * spec.N * 8
-        need_bytes = (st["row_bytes"] if shared else float(B) * spec.T * spec.P * spec.N * 8 * rows_per_patch) + tables
-        lds_bytes = float(B) * spec.T * spec.P * spec.N * 8 * rows_per_patch
+        tables = n_chains * spec_leg.T * spec_leg.P * 4 * rows_per_patch * 2 + spec_leg.T * spec_leg.N * 8
+        need_bytes = (st["row_bytes"] if shared else
+                      float(n_chains) * spec_leg.T * spec_leg.P * spec_leg.N * 8 * rows_per_patch) + tables
+        # LDS operands: one 8-byte operand per FMA and lane for the lane <-> chain kernels; the
+        # cell kernel keeps the rows of a cell in registers (its LDS reads are per cell, not per chain)
+        lds_bytes = 0.0 if cell else float(n_chains) * spec_leg.T * spec_leg.P * spec_leg.N * 8 * rows_per_patch
         lds_floor_ms = lds_bytes / (LDS_PEAK_GBS * 1e9) * 1e3
-        flops = 2.0 * B * spec.T * spec.P * spec.N * rows_per_patch
-        hbm_frac = need_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if gf_n else 0.0
+        flops = 2.0 * n_chains * spec_leg.T * spec_leg.P * spec_leg.N * rows_per_patch
+        t = avg_ms * 1e-3
+        hbm_frac = need_bytes / t / 1e9 / HBM_PEAK_GBS if gf_n else 0.0
         lds_frac = lds_floor_ms / avg_ms if (gf_n and shared) else 0.0
+        valu_frac = flops / t / 1e12 / FP64_VALU_PEAK_TFLOPS if gf_n else 0.0
         bound = "lds" if (shared and lds_frac > hbm_frac) else "hbm"
         roof = {
-            # the resource closest to its peak for this launch (both fractions are reported)
             "bound": bound,
-            "kernel": main_leg["kernel"],
-            "achieved": (lds_bytes if bound == "lds" else need_bytes) / (avg_ms * 1e-3) / 1e9 if gf_n else 0.0,
+            "kernel": leg["kernel"],
+            "achieved": (lds_bytes if bound == "lds" else need_bytes) / t / 1e9 if gf_n else 0.0,
             "peak": LDS_PEAK_GBS if bound == "lds" else HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": lds_frac if bound == "lds" else hbm_frac,
@@ -331,17 +352,25 @@ def main():
             "lds_frac": lds_frac,
             "lds_gather_bytes_per_launch": lds_bytes,
             "lds_floor_ms": lds_floor_ms,
-            "fp64_valu_frac": flops / (avg_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS if gf_n else 0.0,
-            # SURVEY 8(d) figure (chains treated independently, no reuse credit): NOT a roofline
-            # fraction for the chain-shared kernels, which fetch a row once for all chains using it
+            "fp64_valu_frac": valu_frac,
             "algorithmic_bytes_per_launch": alg,
-            "algorithmic_equiv_GBs": alg_equiv,
+            "algorithmic_equiv_GBs": alg / t / 1e9 if gf_n else 0.0,
             "avg_launch_ms": avg_ms,
             "launches": gf_n,
             "chains_per_group": st["chains_per_group"],
             "distinct_rows_per_patch": {"mean": st["mean_rows"], "max": st["max_rows"],
-                                        "of": spec.D * spec.S},
+                                        "of": spec_leg.D * spec_leg.S},
         }
+        if cell:
+            roof["note"] = ("rows of a cell in registers, accumulators through the VGPR index: neither HBM, LDS "
+                            "nor the FP64 pipe is the limit -- a consumer wavefront issues at most one instruction "
+                            "per four cycles and runs ~33 instructions per batch record (profiles/r3_cell_*)")
+        return roof
+
+    out = None
+    if rank == 0:
+        roof = stack_roofline(spec, main_leg, B)
+        avg_ms = roof["avg_launch_ms"]
         out = {
             "metric": "SMC chain-steps/s (FFI seismic gfstacking 400 patches x %d targets x %d samples)"
                       % (spec.T, spec.N),
@@ -402,6 +431,7 @@ def main():
                 tr = pmc["hbm_read_bytes_per_launch_corrected"] + pmc.get("hbm_write_bytes_per_launch", 0.0)
                 roof["traffic"] = tr
                 roof["traffic_source"] = os.path.relpath(args.pmc_summary, ROOT)
+                roof["traffic_measured_in"] = "builder rocprofv3 --pmc pass of the same command (not this run)"
                 roof["hbm_counter_frac"] = tr / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
 
     # ---- reuse-free streaming leg: k_gfstack in (chain, target, tile) order, every chain's rows
@@ -449,6 +479,141 @@ def main():
             "chain_steps_per_s": B * max(K // 2, 3) / leg["dt"], "gfstack_avg_launch_ms": ms / max(n, 1),
             "distinct_rows_per_patch_mean": leg["stats"]["mean_rows"], "kernel": leg["kernel"],
             "hbm_required_bytes_per_launch": leg["stats"]["row_bytes"]}
+    # ---- labelled legs of the other configurations (never `value`): same library in HBM, same population
+    if world == 1 and not args.no_variant_legs and spec.interpolation == "nearest_neighbor" \
+            and spec.covariance == "scalar" and not args.prewhiten:
+        from beat_amd.models.problem import FFIProblem, SeismicWavemap
+        from beat_amd.synthetic import exponential_data_covariance
+        wm0 = prob.wavemaps[0]
+        Kl = max(K // 2, 3)
+
+        def variant(interp="nearest_neighbor", weights=None, slog=None, prewhiten=False):
+            """another compiled model over the SAME device library (no second copy unless pre-whitened)"""
+            wm = SeismicWavemap(wm0.gfs, wm0.data, wm0.weights if weights is None else weights,
+                                wm0.slog_pdet if slog is None else slog, wm0.hypers, wm0.time_shifts, interp)
+            pv = FFIProblem(prob.layout, prob.n_patch_dip, prob.n_patch_strike, prob.patch_sizes,
+                            prob.slip_varnames, [wm], None, None, prob.lower, prob.upper)
+            return pv.compile(ctx, prewhiten=prewhiten)
+
+        # multilinear: the reference's default interpolation (beat/config.py:571-575)
+        import copy
+        a_ml = copy.copy(args)
+        a_ml.interp = "multilinear"
+        spec_ml = make_spec(a_ml)
+        host_of[spec_ml] = host
+        f_ml = variant("multilinear")
+        leg = run_leg(spec_ml, f_ml, B, Kl, 2, seed_offset=1000)
+        out["multilinear_leg"] = {
+            "interpolation": "multilinear (4 rows per patch and chain; beat/ffi/base.py:663-704)",
+            "chains": B, "steps": Kl, "chain_steps_per_s": B * Kl / leg["dt"], "ms_per_step": leg["dt"] / Kl * 1e3,
+            "roofline": stack_roofline(spec_ml, leg, B),
+            "kernel_ms_per_step": {k: (v[0] / Kl) for k, v in leg["times"].items() if v[1]}}
+        del f_ml
+        # dense Toeplitz covariance (SURVEY 8(d) covariance (ii)): chain-batched W.R on the FP64 matrix cores
+        N, T = spec.N, spec.T
+        rng_w = np.random.default_rng(spec.seed + 1)
+        base = exponential_data_covariance(N, 0.5, 2.0)
+        Wb = np.linalg.cholesky(np.linalg.inv(base)).T
+        ldb = 2.0 * np.log(np.diag(np.linalg.cholesky(base))).sum()
+        scal = (spec.sigma * (1.0 + 0.1 * rng_w.random(T))) ** 2
+        Wd = np.empty((T, N, N))
+        for t in range(T):
+            np.divide(Wb, np.sqrt(scal[t]), out=Wd[t])
+        slog_d = np.array([ldb + N * np.log(x) for x in scal])
+        a_tp = copy.copy(args)
+        a_tp.covariance = "toeplitz"
+        spec_tp = make_spec(a_tp)
+        host_of[spec_tp] = host
+        f_tp = variant(weights=Wd, slog=slog_d)
+        leg = run_leg(spec_tp, f_tp, B, Kl, 2, seed_offset=1000)
+        q_ms, q_n = leg["times"]["quadform"]
+        qflops = 2.0 * T * N * N / 2.0 * B
+        qa = qflops / (q_ms / max(q_n, 1) * 1e-3) / 1e12
+        out["toeplitz_leg"] = {
+            "covariance": "Toeplitz sigma^2 exp(-|i-j| dt/T0), dt 0.5, T0 2: dense upper-triangular W (8.6 GB)",
+            "chains": B, "steps": Kl, "chain_steps_per_s": B * Kl / leg["dt"], "ms_per_step": leg["dt"] / Kl * 1e3,
+            "kernel_ms_per_step": {k: (v[0] / Kl) for k, v in leg["times"].items() if v[1]},
+            "roofline_quadform": {
+                "bound": "fp64_mfma", "kernel": "k_quadform<128>", "achieved": qa, "peak": FP64_VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": qa / FP64_VALU_PEAK_TFLOPS, "avg_launch_ms": q_ms / max(q_n, 1),
+                "launches": q_n, "flops_per_launch": qflops, "mfma_loop_ceiling_TFLOPs": 49.4,
+                "frac_of_mfma_loop_ceiling": qa / 49.4,
+                "note": "v_mfma_f64_16x16x4_f64; a register-resident MFMA loop reaches 49.4 TF on this part "
+                        "(tools/micro/mfma64.hip), nominal 78.6"}}
+        # parallel tempering: 4 temperatures x 256 replicas = the per-GPU share of BASELINE configs[4]
+        from beat_amd.sampler import pt_sample
+        n_rep, n_temp = 256, 4
+        kw = dict(n_chains_posterior=1, n_chains_tempered=n_temp - 1, n_replicas=n_rep, swap_interval=(3, 5),
+                  beta_tune_interval=4, proposal_cov=np.diag(((up - lo) * args.step_scale) ** 2), device=dev,
+                  random_seed=5)
+        for cov_name, f_pt in (("scalar", f), ("toeplitz", f_tp)):
+            pt_sample(f_pt, lo, up, n_samples=n_rep, **kw)   # warm-up: allocations, the measured group size
+            ctx.enable_timing(True)
+            ctx.reset_timing()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            s_pt, ls_pt, man = pt_sample(f_pt, lo, up, n_samples=3 * n_rep, **kw)
+            torch.cuda.synchronize()
+            dt_pt = time.perf_counter() - t0
+            g_ms, n_launch = ctx.kernel_time("gfstack")
+            ctx.enable_timing(False)
+            out.setdefault("pt_leg", {})[cov_name] = {
+                "replicas": "%d temperatures x %d replicas = %d chains on one GPU (the per-GPU share of "
+                            "BASELINE configs[4]), exchange round every 3-5 steps" % (n_temp, n_rep, n_temp * n_rep),
+                "chain_steps_per_s": n_launch * n_temp * n_rep / dt_pt, "forward_launches": n_launch,
+                "ms_per_launch_incl_exchange": dt_pt / max(n_launch, 1) * 1e3,
+                "gfstack_avg_launch_ms": g_ms / max(n_launch, 1), "exchange_rounds": len(man.history),
+                "finite": bool(np.isfinite(ls_pt).all())}
+        del f_tp, Wd
+        torch.cuda.empty_cache()
+        # pre-whitened library: W.G and W.d computed once, no dense W.r per step (needs a second library copy)
+        try:
+            Wd = np.empty((T, N, N))
+            for t in range(T):
+                np.divide(Wb, np.sqrt(scal[t]), out=Wd[t])
+            t0 = time.perf_counter()
+            f_pw = variant(weights=Wd, slog=slog_d, prewhiten=True)
+            torch.cuda.synchronize()
+            t_pw = time.perf_counter() - t0
+            leg = run_leg(spec_tp, f_pw, B, Kl, 2, seed_offset=1000)
+            out["prewhitened_leg"] = {
+                "covariance": "the Toeplitz covariance folded into a whitened COPY of the library (W.G, W.d once)",
+                "chains": B, "steps": Kl, "chain_steps_per_s": B * Kl / leg["dt"],
+                "ms_per_step": leg["dt"] / Kl * 1e3, "whitening_s": t_pw, "kernel": leg["kernel"]}
+            del f_pw, Wd
+            torch.cuda.empty_cache()
+        except (RuntimeError, MemoryError) as exc:   # not enough HBM for the copy beside other allocations
+            out["prewhitened_leg"] = {"skipped": str(exc)[:200]}
+        # geometry mode, BASELINE configs[1]: rectangular source, 2 SAR scenes (214 + 205 points, full
+        # covariances), 1024 SMC chains; synthetic observations; parity with BEAT unpinned (pyrocko absent)
+        from beat_amd.synthetic import build_geometry_problem
+        gprob, glay, glower, gupper = build_geometry_problem()
+        glo, gup = glay.bounds(glower, gupper)
+        gf_ = gprob.compile(ctx)
+        gleg = {}
+        for use_graph in (False, True):
+            gstep = SMC(gf_, glo, gup, n_chains=1024, tune_interval=10, device=dev, random_seed=2,
+                        use_graph=use_graph)
+            gQ = gstep.initialize_population()
+            gL = gstep.stepper.evaluate(gQ)
+            gstep.select_end_points(gQ, gL)
+            for stage in range(2):
+                gstep.transition()
+                gstep.stage += 1
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                gQ, gL = gstep.sample_stage(200)
+                torch.cuda.synchronize()
+                dt_g = time.perf_counter() - t0
+                gstep.select_end_points(gQ, gL)
+            gleg["graph" if use_graph else "eager"] = dt_g / 200 * 1e6
+        out["geometry_leg"] = {
+            "workload": "BASELINE configs[1] shape: rectangular source (Okada 1985), 2 SAR scenes 214 + 205 points "
+                        "with full covariances, 1024 SMC chains, synthetic observations",
+            "parity": "vs BEAT unpinned (pyrocko's layered GF engine is not in the reference tree); pinned to "
+                      "Okada's published check values",
+            "us_per_step_eager": gleg["eager"], "us_per_step_hip_graph": gleg["graph"],
+            "chain_steps_per_s": 1024 / (min(gleg.values()) * 1e-6)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec)

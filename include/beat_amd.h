@@ -65,6 +65,12 @@ int beatamd_ctx_destroy(beatamd_ctx *ctx);
 int beatamd_ctx_set_stream(beatamd_ctx *ctx, void *hip_stream);
 int beatamd_ctx_use_own_stream(beatamd_ctx *ctx);
 int beatamd_ctx_synchronize(beatamd_ctx *ctx);
+/* Device-resident step counter of the proposal generator.  With a counter set (uint32 in device
+ * memory, NULL to unset) beatamd_proposal_draw / _univariate take the Philox step from it instead
+ * of their `step` argument and add one to it afterwards: a Metropolis step captured in a HIP graph
+ * (nothing in it synchronises with the host) then replays with fresh, reproducible draws --
+ * the launch-bound geometry-mode problems run from a graph (beat_amd/sampler/metropolis.py). */
+int beatamd_ctx_set_step_counter(beatamd_ctx *ctx, uint32_t *device_counter);
 /* per-kernel HIP-event timing on the launch stream (bench.py roofline leg).
  * kernel names: "sweep", "tables", "gfstack", "quadform", "geostack", "finish", "astep" */
 int beatamd_ctx_enable_timing(beatamd_ctx *ctx, int on);

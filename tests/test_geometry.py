@@ -284,3 +284,42 @@ def test_seis_synthetics_seam_stacks_sources_like_the_reference():
     with pytest.raises(TypeError):
         seis_synthetics(Eng(), srcs, tgts, outmode="spectrum")
     assert SeisSynthesizer.__props__[0] == "engine" and len(SeisSynthesizer.__props__) == 13
+
+
+@pytest.mark.gpu
+def test_geometry_stage_from_a_graph_equals_the_eager_loop():
+    """BASELINE configs[1] (rectangular source, two SAR scenes with full
+    covariances, 1024 chains) is launch-bound -- the Metropolis step of a stage is captured in a HIP
+    graph and replayed with the Philox step counter on the device; populations, likelihoods and
+    acceptance equal the eager loop bit for bit"""
+    import time
+    import torch
+    import beat_amd
+    from beat_amd.sampler import SMC
+    from beat_amd.synthetic import build_geometry_problem
+    ctx = beat_amd.get_context(0)
+    prob, lay, lower, upper = build_geometry_problem()
+    lo, up = lay.bounds(lower, upper)
+    f = prob.compile(ctx)
+    dev = torch.device("cuda", 0)
+    out = {}
+    for use_graph in (False, True):
+        step = SMC(f, lo, up, n_chains=1024, tune_interval=7, device=dev, random_seed=2, use_graph=use_graph)
+        Q = step.initialize_population()
+        L = step.stepper.evaluate(Q)
+        step.select_end_points(Q, L)
+        for stage in range(2):
+            step.transition()
+            step.stage += 1
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            Q, L = step.sample_stage(60)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            step.select_end_points(Q, L)
+        out[use_graph] = (Q.cpu().numpy(), L.cpu().numpy(), list(step.stage_acceptance),
+                          step.stepper.scaling.cpu().numpy(), dt / 60 * 1e6)
+    (Qa, La, acca, sca, us_eager), (Qb, Lb, accb, scb, us_graph) = out[False], out[True]
+    assert np.array_equal(Qa, Qb) and np.array_equal(La, Lb) and acca == accb and np.array_equal(sca, scb)
+    assert np.isfinite(La[:, -1]).all() and 0.0 < acca[-1] < 1.0
+    print("geometry stage, 1024 chains: %.1f us per step eager, %.1f us from the graph" % (us_eager, us_graph))
