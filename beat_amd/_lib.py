@@ -18,7 +18,7 @@ W_SCALAR, W_DENSE = 0, 1
 INTERPOLATIONS = {"nearest_neighbor": NEAREST_NEIGHBOR, "multilinear": MULTILINEAR}
 
 OK, EINVAL, EHIP, EINDEX, ENOMEM, ENAN, ENOTPSD, EBADCOV = 0, -1, -2, -3, -4, -5, -6, -7
-ABI_VERSION = 110   # include/beat_amd.h BEATAMD_VERSION this module was written against
+ABI_VERSION = 111   # include/beat_amd.h BEATAMD_VERSION this module was written against
 
 
 class BeatAmdError(RuntimeError):
@@ -86,6 +86,8 @@ _PROTOS = {
     "beatamd_autocovariance_batch": [_vp, _i64, _i64, _vp, _vp, _vp],
     "beatamd_scaled_toeplitz_batch": [_vp, _i64, _i64, _vp, _vp, _vp],
     "beatamd_ffi_astep_batch_betas": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "beatamd_ffi_mstep_batch": [_vp, _i32, _i64, _vp, _vp, _vp, _i64, _i32, _i32, C.c_uint64, C.c_uint32, _i64,
+                                _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp],
     "beatamd_ctx_last_kernel": [_vp, C.c_char_p, _i64],
     "beatamd_ctx_gf_group_stats": [_vp, _pi64, C.POINTER(_f64), _pi64, _pi64],
     "beatamd_smc_calc_beta": [_vp, _i64, _vp, _i64, _f64, _f64, C.POINTER(_f64), _vp],

@@ -71,8 +71,16 @@ int wset_quad(beatamd_ctx *ctx, const WeightSet &w, int64_t C, const double *X, 
     return launch_quadform(ctx, q);
 }
 
+// what remains after the composites wrote their columns: the `like` sum.  A caller that passes a
+// LikeTail does that sum itself (the Metropolis step folds it into its accept kernel)
+struct LikeTail {
+    LikeGroups grp;
+    const int32_t *chain_bad = nullptr;
+};
+
 // logp_forw_func on device pointers
-int ffi_logp_device(beatamd_ctx *ctx, FfiModel &m, int64_t C, const double *Q, double *LL)
+int ffi_logp_device(beatamd_ctx *ctx, FfiModel &m, int64_t C, const double *Q, double *LL,
+                    LikeTail *tail = nullptr)
 {
     const int64_t nllk = m.nllk();
     const int64_t np = m.layout.nparams;
@@ -85,9 +93,13 @@ int ffi_logp_device(beatamd_ctx *ctx, FfiModel &m, int64_t C, const double *Q, d
 
     // chains whose indices leave the library grid / the patch grid: like = NaN (rejected by the
     // Metropolis step) in addition to the status word that the next synchronisation raises
-    BA_TRY(ctx->get_scratch(SL_CHAINBAD, (size_t)C * sizeof(int32_t), &p));
-    int32_t *chain_bad = (int32_t *)p;
-    BA_HIP(hipMemsetAsync(chain_bad, 0, (size_t)C * sizeof(int32_t), ctx->stream));
+    // (only the seismic index maps and the sweep flag chains: without wavemaps there is nothing to clear)
+    int32_t *chain_bad = nullptr;
+    if (!m.wavemaps.empty()) {
+        BA_TRY(ctx->get_scratch(SL_CHAINBAD, (size_t)C * sizeof(int32_t), &p));
+        chain_bad = (int32_t *)p;
+        BA_HIP(hipMemsetAsync(chain_bad, 0, (size_t)C * sizeof(int32_t), ctx->stream));
+    }
 
     if (!m.wavemaps.empty()) {
         BA_TRY(ctx->get_scratch(SL_ST0, (size_t)C * m.P * sizeof(double), &p));
@@ -138,26 +150,49 @@ int ffi_logp_device(beatamd_ctx *ctx, FfiModel &m, int64_t C, const double *Q, d
         BA_TRY(ctx->get_scratch(SL_MU, (size_t)C * g.Nobs * 2 * sizeof(double), &p));
         double *mu = (double *)p, *res = mu + C * g.Nobs;
         if (m.geo_is_geometry) {
-            BA_TRY(launch_geom_los(ctx, m.geom, Q, np, C, mu));
+            // synthetics, line of sight and weighted residual in one kernel
+            BA_TRY(launch_geom_los(ctx, m.geom, Q, np, C, nullptr, g.data, g.odws, res));
         } else {
             for (int v = 0; v < m.layout.nvar; v++) {
                 GeoLib *gl = get_obj(ctx->geolibs, g.libs[v]);
                 BA_CHECK(gl, BEATAMD_EINVAL, "geodetic composite refers to a destroyed GF library");
                 BA_TRY(launch_geo_stack(ctx, *gl, C, slips[v], v > 0, mu));
             }
+            BA_TRY(launch_geo_residual(ctx, C, g.Nobs, g.data, g.odws, mu, res));
         }
-        BA_TRY(launch_geo_residual(ctx, C, g.Nobs, g.data, g.odws, mu, res));
-        BA_TRY(ctx->get_scratch(SL_QUAD, (size_t)C * sizeof(double), &p));
-        double *quad = (double *)p;
+        // small dense datasets (SAR scenes / GNSS of a few hundred points): every dataset's
+        // quadratic form and MVN epilogue in one launch; otherwise per dataset on the 64-row tiles
+        QuadformSmallCall qs;
+        bool small = g.sizes.size() <= 8;
         int64_t o = 0;
         for (size_t d = 0; d < g.sizes.size(); d++) {
             WeightSet *ws = get_obj(ctx->wsets, g.wsets[d]);
             BA_CHECK(ws && ws->nd == 1 && ws->M == g.sizes[d], BEATAMD_EINVAL,
                      "geodetic dataset %zu: weight set missing or of the wrong size", d);
-            BA_TRY(wset_quad(ctx, *ws, C, res + o, g.Nobs, 0, quad));
-            BA_TRY(launch_mvn_finish(ctx, C, 1, ws->M, quad, ws->slog,
-                                     HpSrc{Q, np, g.hp_off + d}, LL + col + (int64_t)d, nllk));
+            small = small && ws->kind != BEATAMD_W_SCALAR;
+            if (small) {
+                qs.A[d] = ws->w; qs.M[d] = ws->M; qs.xoff[d] = o; qs.upper_tri[d] = ws->upper_tri;
+                qs.slog[d] = ws->slog; qs.hp_off[d] = g.hp_off + d;
+            }
             o += g.sizes[d];
+        }
+        small = small && quadform_small_applicable((int)g.sizes.size(), qs.M);
+        if (small) {
+            qs.nd = (int)g.sizes.size();
+            qs.C = C; qs.X = res; qs.xs_c = g.Nobs; qs.Q = Q; qs.nparams = np;
+            qs.LL = LL + col; qs.ld = nllk;
+            BA_TRY(launch_quadform_small(ctx, qs));
+        } else {
+            BA_TRY(ctx->get_scratch(SL_QUAD, (size_t)C * sizeof(double), &p));
+            double *quad = (double *)p;
+            o = 0;
+            for (size_t d = 0; d < g.sizes.size(); d++) {
+                WeightSet *ws = get_obj(ctx->wsets, g.wsets[d]);
+                BA_TRY(wset_quad(ctx, *ws, C, res + o, g.Nobs, 0, quad));
+                BA_TRY(launch_mvn_finish(ctx, C, 1, ws->M, quad, ws->slog,
+                                         HpSrc{Q, np, g.hp_off + d}, LL + col + (int64_t)d, nllk));
+                o += g.sizes[d];
+            }
         }
         col += (int64_t)g.sizes.size();
         grp.end[grp.n++] = (int32_t)col;
@@ -183,6 +218,11 @@ int ffi_logp_device(beatamd_ctx *ctx, FfiModel &m, int64_t C, const double *Q, d
         grp.end[grp.n++] = (int32_t)col;
     }
     BA_CHECK(col == nllk - 1, BEATAMD_EINVAL, "internal: llk layout mismatch");
+    if (tail) {
+        tail->grp = grp;
+        tail->chain_bad = chain_bad;
+        return BEATAMD_OK;
+    }
     return launch_like_sum(ctx, C, nllk, grp, LL, chain_bad);
 }
 
@@ -833,30 +873,38 @@ int beatamd_ffi_logp_batch(beatamd_ctx *ctx, int32_t model_id, int64_t C, const 
     return finish_out(ctx, &rec, 1);
 }
 
+// proposal source of a step: rows handed in (delta, log_u) or drawn here (factor / scales + Philox key)
+struct StepDraw {
+    const double *factor = nullptr;   // [K, np] or the per-parameter scales [np]
+    int64_t K = 0;
+    int32_t kind = -1, df = 0;
+    uint64_t seed = 0, first_chain = 0;
+    uint32_t step = 0;
+};
+
 static int astep_impl(beatamd_ctx *ctx, int32_t model_id, int64_t C, double *Q0, double *L0,
                       const double *delta, const double *scaling, const double *lower,
                       const double *upper, const double *log_u, double beta, const double *betas,
-                      int32_t *accepted)
+                      int32_t *accepted, const StepDraw *draw = nullptr, int32_t *acc_sum = nullptr,
+                      int64_t *n_acc = nullptr)
 {
     ENTER(ctx);
     FfiModel *m = get_obj(ctx->models, model_id);
     BA_CHECK(m, BEATAMD_EINVAL, "unknown model %d", model_id);
-    BA_CHECK(Q0 && L0 && delta && scaling && lower && upper && log_u && accepted && C >= 0,
+    BA_CHECK(Q0 && L0 && scaling && lower && upper && accepted && C >= 0 && (draw || (delta && log_u)),
              BEATAMD_EINVAL, "ffi_astep: NULL argument");
     BA_TRY(model_check_layout(*m));
     if (C == 0) return BEATAMD_OK;
     const int64_t np = m->layout.nparams, nllk = m->nllk();
-    const void *d_de, *d_sc, *d_lo, *d_up, *d_lu, *d_be = nullptr;
+    const void *d_de = nullptr, *d_sc, *d_lo, *d_up, *d_lu = nullptr, *d_be = nullptr, *d_f = nullptr;
     void *d_q0, *d_l0, *d_acc, *p;
     Arg recs[3];
     BA_TRY(stage_out(ctx, SL_OUT0, Q0, (size_t)C * np * 8, &d_q0, &recs[0], true));
     BA_TRY(stage_out(ctx, SL_OUT1, L0, (size_t)C * nllk * 8, &d_l0, &recs[1], true));
     BA_TRY(stage_out(ctx, SL_OUT2, accepted, (size_t)C * 4, &d_acc, &recs[2]));
-    BA_TRY(stage_in(ctx, SL_IN1, delta, (size_t)C * np * 8, &d_de));
     BA_TRY(stage_in(ctx, SL_IN2, scaling, (size_t)C * 8, &d_sc));
     BA_TRY(stage_in(ctx, SL_IN3, lower, (size_t)np * 8, &d_lo));
     BA_TRY(stage_in(ctx, SL_IN4, upper, (size_t)np * 8, &d_up));
-    BA_TRY(stage_in(ctx, SL_IN5, log_u, (size_t)C * 8, &d_lu));
     if (betas) BA_TRY(stage_in(ctx, SL_IN6, betas, (size_t)C * 8, &d_be));
     BA_TRY(ctx->get_scratch(SL_QPROP, (size_t)C * np * 8, &p));
     double *qprop = (double *)p;
@@ -864,12 +912,62 @@ static int astep_impl(beatamd_ctx *ctx, int32_t model_id, int64_t C, double *Q0,
     double *lprop = (double *)p;
     BA_TRY(ctx->get_scratch(SL_MISC, (size_t)C * 4 + 64, &p));
     int32_t *inb = (int32_t *)p;
-    BA_TRY(launch_propose(ctx, C, np, (const double *)d_q0, (const double *)d_de,
-                          (const double *)d_sc, (const double *)d_lo, (const double *)d_up, qprop,
-                          inb));
-    BA_TRY(ffi_logp_device(ctx, *m, C, qprop, lprop));
+    bool advance = false;
+    if (draw) {
+        BA_CHECK(is_device_ptr(Q0) && (!acc_sum || is_device_ptr(acc_sum)) && (!n_acc || is_device_ptr(n_acc)),
+                 BEATAMD_EINVAL, "ffi_mstep: chain states and counters live on the device");
+        const int64_t K = draw->kind < 0 ? draw->K : np;
+        BA_TRY(stage_in(ctx, SL_IN0, draw->factor, (size_t)(draw->kind < 0 ? K * np : np) * 8, &d_f));
+        BA_TRY(ctx->get_scratch(SL_LOGU, (size_t)C * 8, &p));
+        double *lu = (double *)p;
+        d_lu = lu;
+        if (draw_propose_applicable(K, np)) {
+            BA_TRY(launch_draw_propose(ctx, C, K, np, draw->kind, (const double *)d_f, draw->df, draw->seed,
+                                       draw->step, draw->first_chain, (const double *)d_q0, (const double *)d_sc,
+                                       (const double *)d_lo, (const double *)d_up, qprop, lu, inb));
+        } else {
+            BA_TRY(ctx->get_scratch(SL_DELTA, (size_t)C * np * 8, &p));
+            double *de = (double *)p;
+            if (draw->kind < 0) {
+                BA_TRY(ctx->get_scratch(SL_Z, (size_t)C * K * 8, &p));
+                double *z = (double *)p, *rs = nullptr;
+                if (draw->df > 0) {
+                    BA_TRY(ctx->get_scratch(SL_ROWSCALE, (size_t)C * 8, &p));
+                    rs = (double *)p;
+                }
+                BA_TRY(launch_philox_normal(ctx, z, C, K, draw->seed, draw->step, draw->first_chain));
+                BA_TRY(launch_philox_chain(ctx, C, draw->seed, draw->step, draw->first_chain, draw->df, lu, rs));
+                GemmCall g;
+                g.A = z; g.lda = K;
+                g.B = (const double *)d_f; g.ldb = np; g.b_kn = 1;
+                g.O = de; g.ldo = np;
+                g.M = C; g.N = np; g.K = K;
+                g.row_scale = rs;
+                g.timer = "proposal";
+                BA_TRY(launch_gemm_f64(ctx, g));
+            } else {
+                BA_TRY(launch_philox_univariate(ctx, de, C, np, draw->kind, (const double *)d_f, draw->seed,
+                                                draw->step, draw->first_chain));
+                BA_TRY(launch_philox_chain(ctx, C, draw->seed, draw->step, draw->first_chain, 0, lu, nullptr));
+            }
+            BA_TRY(launch_propose(ctx, C, np, (const double *)d_q0, de, (const double *)d_sc,
+                                  (const double *)d_lo, (const double *)d_up, qprop, inb));
+        }
+        advance = true;
+    } else {
+        BA_TRY(stage_in(ctx, SL_IN1, delta, (size_t)C * np * 8, &d_de));
+        BA_TRY(stage_in(ctx, SL_IN5, log_u, (size_t)C * 8, &d_lu));
+        BA_TRY(launch_propose(ctx, C, np, (const double *)d_q0, (const double *)d_de,
+                              (const double *)d_sc, (const double *)d_lo, (const double *)d_up, qprop,
+                              inb));
+    }
+    // the `like` sum rides in the accept kernel (one launch fewer) while the row fits its LDS stage
+    LikeTail tail;
+    const bool fold = nllk * 8 <= 48 * 1024;
+    BA_TRY(ffi_logp_device(ctx, *m, C, qprop, lprop, fold ? &tail : nullptr));
     BA_TRY(launch_accept(ctx, C, np, nllk, (double *)d_q0, (double *)d_l0, qprop, lprop, inb,
-                         (const double *)d_lu, beta, (const double *)d_be, (int32_t *)d_acc));
+                         (const double *)d_lu, beta, (const double *)d_be, (int32_t *)d_acc,
+                         fold ? &tail.grp : nullptr, tail.chain_bad, acc_sum, n_acc, advance));
     return finish_out(ctx, recs, 3);
 }
 
@@ -891,6 +989,23 @@ int beatamd_ffi_astep_batch_betas(beatamd_ctx *ctx, int32_t model_id, int64_t C,
     BA_CHECK(ctx != nullptr && betas != nullptr, BEATAMD_EINVAL, "ffi_astep_betas: NULL argument");
     return astep_impl(ctx, model_id, C, Q0, L0, delta, scaling, lower, upper, log_u, 1.0, betas,
                       accepted);
+}
+
+int beatamd_ffi_mstep_batch(beatamd_ctx *ctx, int32_t model_id, int64_t C, double *Q0, double *L0,
+                            const double *factor, int64_t K, int32_t kind, int32_t df, uint64_t seed,
+                            uint32_t step, int64_t first_chain, const double *scaling, const double *lower,
+                            const double *upper, double beta, const double *betas, int32_t *accepted,
+                            int32_t *accepted_sum, int64_t *n_accepted)
+{
+    BA_CHECK(ctx != nullptr, BEATAMD_EINVAL, "ctx is NULL");
+    BA_CHECK(factor && first_chain >= 0 && df >= 0 && df <= 64, BEATAMD_EINVAL, "ffi_mstep: bad argument");
+    BA_CHECK(kind >= -1 && kind <= BEATAMD_PROPOSAL_LAPLACE && (kind >= 0 || K > 0), BEATAMD_EINVAL,
+             "ffi_mstep: kind must be -1 (multivariate, K > 0 factor rows), Normal (0), Cauchy (1) or Laplace (2)");
+    StepDraw d;
+    d.factor = factor; d.K = K; d.kind = kind; d.df = kind < 0 ? df : 0;
+    d.seed = seed; d.step = step; d.first_chain = (uint64_t)first_chain;
+    return astep_impl(ctx, model_id, C, Q0, L0, nullptr, scaling, lower, upper, nullptr, betas ? 1.0 : beta,
+                      betas, accepted, &d, accepted_sum, n_accepted);
 }
 
 // ------------------------------------------------------------------ noise covariance

@@ -79,6 +79,25 @@ struct QuadformCall {
     int64_t q_stride = 0;
 };
 int launch_quadform(beatamd_ctx *ctx, const QuadformCall &call);
+// several small dense datasets (M <= 512 each) of one residual matrix in one launch, MVN epilogue
+// included: LL[c*ld + d] = -0.5 (slog_d + M_d (2 h + log 2pi) + exp(-2h) |W_d x_{c,d}|^2), h = Q[c, hp_off_d]
+struct QuadformSmallCall {
+    int nd = 0;
+    const double *A[8];
+    int64_t M[8], xoff[8];
+    int upper_tri[8];
+    const double *slog[8];
+    const int64_t *hp_off[8];
+    int64_t C = 0;
+    const double *X = nullptr;
+    int64_t xs_c = 0;
+    const double *Q = nullptr;
+    int64_t nparams = 0;
+    double *LL = nullptr;
+    int64_t ld = 0;
+};
+bool quadform_small_applicable(int nd, const int64_t *M);
+int launch_quadform_small(beatamd_ctx *ctx, const QuadformSmallCall &call);
 int launch_check_upper_tri(beatamd_ctx *ctx, const double *A, int64_t nd, int64_t M, int *flag_dev);
 
 // ---- logp.hip (small kernels) ------------------------------------------------------
@@ -117,13 +136,19 @@ int launch_gather_slips(beatamd_ctx *ctx, int64_t C, int nvar, int64_t P, const 
 int launch_propose(beatamd_ctx *ctx, int64_t C, int64_t nparams, const double *Q0,
                    const double *delta, const double *scaling, const double *lower,
                    const double *upper, double *Qprop, int32_t *inbounds);
+// grp (nullable): sum the `like` column of Lprop here instead of a launch_like_sum before; acc_sum /
+// n_acc (nullable): per-chain and population acceptance counters; advance_step: bump ctx->step_dev
 int launch_accept(beatamd_ctx *ctx, int64_t C, int64_t nparams, int64_t nllk, double *Q0,
-                  double *L0, const double *Qprop, const double *Lprop, const int32_t *inbounds,
-                  const double *log_u, double beta, const double *betas, int32_t *accepted);
+                  double *L0, const double *Qprop, double *Lprop, const int32_t *inbounds,
+                  const double *log_u, double beta, const double *betas, int32_t *accepted,
+                  const LikeGroups *grp = nullptr, const int32_t *chain_bad = nullptr,
+                  int32_t *acc_sum = nullptr, int64_t *n_acc = nullptr, bool advance_step = false);
 
 // geometry.hip: line-of-sight synthetics of rectangular / Mogi sources, mu [C, Nobs]
+// with res (and data, odw [Nobs]): res = (data - mu) * odw is stored instead of mu
 int launch_geom_los(beatamd_ctx *ctx, const GeomSources &g, const double *Q, int64_t nparams,
-                    int64_t C, double *mu);
+                    int64_t C, double *mu, const double *data = nullptr, const double *odw = nullptr,
+                    double *res = nullptr);
 // displacement components (n, e, up) per (parameter set, source, point): out [C, nsrc, Nobs, 3]
 int launch_geom_disp(beatamd_ctx *ctx, int nsrc, const int32_t *kind, const int64_t *poff,
                      const double *params, int64_t C, int64_t nobs, const double *east,
@@ -178,6 +203,13 @@ int launch_philox_normal(beatamd_ctx *ctx, double *z, int64_t C, int64_t K, uint
 int launch_philox_univariate(beatamd_ctx *ctx, double *delta, int64_t C, int64_t np, int kind,
                              const double *scale, uint64_t seed, uint32_t step, uint64_t first_chain);
 int launch_step_advance(beatamd_ctx *ctx);
+// small parameter vectors (K, np <= 64): draws + factor product + propose in one launch; kind -1
+// multivariate (factor [K, np]), 0/1/2 the per-parameter families (factor = scales [np], K == np)
+bool draw_propose_applicable(int64_t K, int64_t np);
+int launch_draw_propose(beatamd_ctx *ctx, int64_t C, int64_t K, int64_t np, int kind, const double *factor,
+                        int df, uint64_t seed, uint32_t step, uint64_t first_chain, const double *Q0,
+                        const double *scaling, const double *lower, const double *upper, double *Qprop,
+                        double *log_u, int32_t *inbounds);
 int launch_philox_chain(beatamd_ctx *ctx, int64_t C, uint64_t seed, uint32_t step, uint64_t first_chain,
                         int df, double *log_u, double *row_scale);
 

@@ -243,33 +243,79 @@ int launch_propose(beatamd_ctx *ctx, int64_t C, int64_t nparams, const double *Q
     return BEATAMD_OK;
 }
 
-// metropolis.py:344-385 + pymc metrop_select: accept iff in bounds, isfinite(mr), log u < mr
+// metropolis.py:344-385 + pymc metrop_select: accept iff in bounds, isfinite(mr), log u < mr.
+// One workgroup per chain.  Optional tail work of the step, so that a step needs no further launch:
+//   grp.n > 0   the `like` column of the proposal is summed here (k_like_sum's order: per composite,
+//               then over composites; chain_bad -> NaN) from an LDS copy of the row
+//   acc_sum     per-chain acceptance counter (+= flag), n_acc the population total (+= flags)
+//   step_dev    the device-resident Philox step counter moves on (read only by the draw kernels, which
+//               precede this launch in stream order)
 __global__ void __launch_bounds__(256) k_accept(int64_t C, int64_t nparams, int64_t nllk,
                                                double *Q0, double *L0, const double *Qprop,
-                                               const double *Lprop, const int32_t *inbounds,
+                                               double *Lprop, const int32_t *inbounds,
                                                const double *log_u, double beta,
-                                               const double *betas, int32_t *accepted)
+                                               const double *betas, int32_t *accepted, LikeGroups grp,
+                                               const int32_t *chain_bad, int32_t *acc_sum,
+                                               unsigned long long *n_acc, uint32_t *step_dev)
 {
+    extern __shared__ __attribute__((aligned(16))) double s_l[];
     const int64_t c = blockIdx.x;
+    double lp;
+    if (grp.n > 0) {
+        for (int64_t k = threadIdx.x; k < nllk - 1; k += 256) s_l[k] = Lprop[c * nllk + k];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double total = 0.0;
+            int k = 0;
+            for (int g = 0; g < grp.n; g++) {
+                double s = 0.0;
+                for (; k < grp.end[g]; k++) s += s_l[k];
+                total += s;
+            }
+            if (chain_bad && chain_bad[c]) total = __builtin_nan("");
+            s_l[nllk - 1] = total;
+            Lprop[c * nllk + nllk - 1] = total;
+        }
+        __syncthreads();
+        lp = s_l[nllk - 1];
+    } else {
+        lp = Lprop[c * nllk + nllk - 1];
+    }
     const double b = betas ? betas[c] : beta;  // per-replica beta for parallel tempering
-    const double mr = b * (Lprop[c * nllk + nllk - 1] - L0[c * nllk + nllk - 1]);
+    const double mr = b * (lp - L0[c * nllk + nllk - 1]);
     const bool acc = inbounds[c] && isfinite(mr) && (log_u[c] < mr);
     if (acc) {
         for (int64_t k = threadIdx.x; k < nparams; k += 256) Q0[c * nparams + k] = Qprop[c * nparams + k];
         __syncthreads();  // all lanes have read L0[like] before it is overwritten
-        for (int64_t k = threadIdx.x; k < nllk; k += 256) L0[c * nllk + k] = Lprop[c * nllk + k];
+        if (grp.n > 0) {
+            for (int64_t k = threadIdx.x; k < nllk; k += 256) L0[c * nllk + k] = s_l[k];
+        } else {
+            for (int64_t k = threadIdx.x; k < nllk; k += 256) L0[c * nllk + k] = Lprop[c * nllk + k];
+        }
     }
-    if (threadIdx.x == 0) accepted[c] = acc ? 1 : 0;
+    if (threadIdx.x == 0) {
+        accepted[c] = acc ? 1 : 0;
+        if (acc_sum && acc) acc_sum[c] += 1;
+        if (n_acc && acc) atomicAdd(n_acc, 1ull);
+        if (step_dev && c == 0) *step_dev += 1u;
+    }
 }
 
 int launch_accept(beatamd_ctx *ctx, int64_t C, int64_t nparams, int64_t nllk, double *Q0,
-                  double *L0, const double *Qprop, const double *Lprop, const int32_t *inbounds,
-                  const double *log_u, double beta, const double *betas, int32_t *accepted)
+                  double *L0, const double *Qprop, double *Lprop, const int32_t *inbounds,
+                  const double *log_u, double beta, const double *betas, int32_t *accepted,
+                  const LikeGroups *grp, const int32_t *chain_bad, int32_t *acc_sum, int64_t *n_acc,
+                  bool advance_step)
 {
     if (C == 0) return BEATAMD_OK;
+    LikeGroups g;
+    if (grp) g = *grp;
+    const size_t lds = grp ? (size_t)nllk * sizeof(double) : 0;
+    BA_CHECK(lds <= 48 * 1024, BEATAMD_EINVAL, "accept: likelihood vector of %lld entries", (long long)nllk);
     ScopedTimer tm(ctx, "astep");
-    hipLaunchKernelGGL(k_accept, dim3((unsigned)C), dim3(256), 0, ctx->stream, C, nparams, nllk,
-                       Q0, L0, Qprop, Lprop, inbounds, log_u, beta, betas, accepted);
+    hipLaunchKernelGGL(k_accept, dim3((unsigned)C), dim3(256), lds, ctx->stream, C, nparams, nllk,
+                       Q0, L0, Qprop, Lprop, inbounds, log_u, beta, betas, accepted, g, chain_bad, acc_sum,
+                       (unsigned long long *)n_acc, advance_step ? ctx->step_dev : nullptr);
     BA_HIP(hipGetLastError());
     return BEATAMD_OK;
 }

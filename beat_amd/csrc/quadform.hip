@@ -194,6 +194,142 @@ int launch_quadform(beatamd_ctx *ctx, const QuadformCall &k)
     return BEATAMD_OK;
 }
 
+// ---- small matrices (geodetic datasets of a few hundred points, geometry mode) ----------------
+// All datasets of a composite in ONE launch, the MVN epilogue (distributions.py:119-138) included:
+// workgroup = (16 chains, dataset); the residual rows of its chains sit in LDS (pitch = 17 mod 32
+// doubles: conflict-free B-operand reads), one wavefront per 16-row tile of W_d (round robin beyond
+// 16 tiles), A operands straight from global memory (W_d stays in L2: a few hundred KB), K ascending
+// from the tile's first row for upper-triangular W.  Sum of squares per chain: the tiles of a wave in
+// ascending order, then the waves in order -- fixed, so a chain's value does not depend on the batch.
+constexpr int QS_MAXD = 8, QS_CB = 16;
+
+struct QsArgs {
+    int nd;
+    const double *A[QS_MAXD];
+    int M[QS_MAXD], xoff[QS_MAXD], upper[QS_MAXD];
+    const double *slog[QS_MAXD];        // one value each
+    const int64_t *hp_off[QS_MAXD];     // one offset into q each
+    int64_t C;
+    const double *X;    // residuals [C, xs_c]
+    int64_t xs_c;
+    const double *Q;    // chain states (hyper-parameters)
+    int64_t nparams;
+    double *LL;         // logpts of dataset d -> LL[c * ld + d]
+    int64_t ld;
+    int pitch;
+};
+
+// QS_KB k-steps (4 columns each) of A operands are in flight while the previous batch multiplies: the
+// loads come from L2 with ~1 us latency and a workgroup has few waves, so the prefetch depth, not
+// the matrix cores, sets the time
+constexpr int QS_KB = 8, QS_MAXW = 16;
+
+__global__ void __launch_bounds__(64 * QS_MAXW) k_quadform_small(QsArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_x[];   // [QS_CB][pitch] + red[nwave][QS_CB]
+    const int d = blockIdx.y;
+    const int64_t c0 = (int64_t)blockIdx.x * QS_CB;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nthr = blockDim.x, nwave = nthr >> 6;
+    const int M = a.M[d], pitch = a.pitch;
+    const int Mp = (M + 4 * QS_KB - 1) / (4 * QS_KB) * (4 * QS_KB);   // zero padded to whole batches
+    double *red = s_x + QS_CB * pitch;
+    for (int i = tid; i < QS_CB * Mp; i += nthr) {
+        const int j = i / Mp, k = i - j * Mp;
+        const int64_t c = c0 + j;
+        s_x[j * pitch + k] = (c < a.C && k < M) ? a.X[c * a.xs_c + a.xoff[d] + k] : 0.0;
+    }
+    __syncthreads();
+    const double *A = a.A[d];
+    const int ntile = (M + 15) / 16;
+    const int li = lane & 15, lk = lane >> 4;
+    double wsum = 0.0;   // chain li
+    for (int t = wave; t < ntile; t += nwave) {
+        const int r0 = t * 16;
+        const int row = r0 + li;
+        const bool row_ok = row < M;
+        const double *Ap = A + (int64_t)row * M;
+        const double *xp = s_x + li * pitch;
+        v4f64 acc = v4f64{0.0, 0.0, 0.0, 0.0};
+        const int kstart = a.upper[d] ? (r0 / (4 * QS_KB)) * (4 * QS_KB) : 0;
+        double av[QS_KB], an[QS_KB];
+#pragma unroll
+        for (int e = 0; e < QS_KB; e++) {
+            const int k = kstart + 4 * e + lk;
+            av[e] = (row_ok && k < M) ? Ap[k] : 0.0;
+        }
+        for (int k0 = kstart; k0 < Mp; k0 += 4 * QS_KB) {
+            const int kn = k0 + 4 * QS_KB;
+            if (kn < Mp) {
+#pragma unroll
+                for (int e = 0; e < QS_KB; e++) {
+                    const int k = kn + 4 * e + lk;
+                    an[e] = (row_ok && k < M) ? Ap[k] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < QS_KB; e++)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[e], xp[k0 + 4 * e + lk], acc, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < QS_KB; e++) av[e] = an[e];
+        }
+        double sq = acc[0] * acc[0];
+        sq = fma(acc[1], acc[1], sq);
+        sq = fma(acc[2], acc[2], sq);
+        sq = fma(acc[3], acc[3], sq);
+        sq += __shfl_xor(sq, 16, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        wsum += sq;
+    }
+    if (lane < 16) red[wave * QS_CB + lane] = wsum;
+    __syncthreads();
+    if (tid < QS_CB) {
+        const int64_t c = c0 + tid;
+        if (c < a.C) {
+            double quad = 0.0;
+            for (int w = 0; w < nwave; w++) quad += red[w * QS_CB + tid];
+            const double h = a.Q[c * a.nparams + a.hp_off[d][0]];
+            const double norm = (double)(int16_t)M * (2 * h + 1.8378770664093453);
+            a.LL[c * a.ld + d] = (-0.5) * (a.slog[d][0] + norm + (1 / exp(h * 2)) * quad);
+        }
+    }
+}
+
+bool quadform_small_applicable(int nd, const int64_t *M)
+{
+    if (nd < 1 || nd > QS_MAXD) return false;
+    for (int d = 0; d < nd; d++)
+        if (M[d] < 1 || M[d] > 512) return false;
+    return true;
+}
+
+int launch_quadform_small(beatamd_ctx *ctx, const QuadformSmallCall &k)
+{
+    if (k.C == 0 || k.nd == 0) return BEATAMD_OK;
+    QsArgs a;
+    a.nd = k.nd;
+    int64_t mmax = 0;
+    for (int d = 0; d < k.nd; d++) {
+        a.A[d] = k.A[d]; a.M[d] = (int)k.M[d]; a.xoff[d] = (int)k.xoff[d]; a.upper[d] = k.upper_tri[d];
+        a.slog[d] = k.slog[d]; a.hp_off[d] = k.hp_off[d];
+        mmax = std::max(mmax, k.M[d]);
+    }
+    a.C = k.C; a.X = k.X; a.xs_c = k.xs_c; a.Q = k.Q; a.nparams = k.nparams; a.LL = k.LL; a.ld = k.ld;
+    static_assert((4 * QS_KB) % 32 == 0, "pitch = 17 mod 32 doubles");
+    a.pitch = (int)(((mmax + 4 * QS_KB - 1) / (4 * QS_KB)) * (4 * QS_KB) + 17);   // >= the zero-padded row
+    // one wave per 16-row tile of the largest dataset, at most 16 (then tiles round robin)
+    const int nwave = (int)std::min<int64_t>(QS_MAXW, (mmax + 15) / 16);
+    const size_t lds = ((size_t)QS_CB * a.pitch + (size_t)QS_MAXW * QS_CB) * sizeof(double);
+    if (lds > 64 * 1024)
+        BA_HIP(hipFuncSetAttribute((const void *)k_quadform_small, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+    ScopedTimer tm(ctx, "quadform");
+    hipLaunchKernelGGL(k_quadform_small, dim3((unsigned)((k.C + QS_CB - 1) / QS_CB), (unsigned)k.nd),
+                       dim3(64 * nwave), lds, ctx->stream, a);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
 // flag_dev[0] is cleared to 0 if any entry strictly below the diagonal is non-zero
 __global__ void __launch_bounds__(256) k_check_upper(const double *A, int64_t nd, int64_t M,
                                                     int *flag)

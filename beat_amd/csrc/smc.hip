@@ -429,6 +429,143 @@ int launch_philox_chain(beatamd_ctx *ctx, int64_t C, uint64_t seed, uint32_t ste
     return BEATAMD_OK;
 }
 
+// ---- small parameter vectors (geometry mode: ~10 parameters, ~1000 chains): the whole proposal of a
+// step in ONE launch -- the draws of k_philox_normal / k_philox_chain / k_philox_univariate (same counters,
+// so the same numbers), the factor product of the proposal GEMM (k ascending, one FMA chain per component)
+// and k_propose (q = q0 + delta * scaling, prior-box test, parked on q0 outside the box).  A workgroup
+// serves DP_CB chains; factor, normals and flags sit in LDS.
+constexpr int DP_CB = 16, DP_MAX = 64;
+
+struct DrawProposeArgs {
+    int64_t C, K, np;
+    int kind;                 // -1 multivariate (factor [K, np], df), else the univariate family
+    const double *factor;     // [K, np] or the per-parameter scales [np]
+    int df;
+    uint64_t seed, first_chain;
+    uint32_t step;
+    const uint32_t *step_dev;
+    const double *Q0, *scaling, *lower, *upper;
+    double *Qprop, *log_u;
+    int32_t *inbounds;
+};
+
+__device__ __forceinline__ void box_muller(const uint32_t (&r)[4], double &a, double &b)
+{
+    const double u1 = u53(r[0], r[1]), u2 = u53(r[2], r[3]);
+    const double rad = sqrt(-2.0 * log(u1));
+    const double th = 6.283185307179586476925286766559 * u2;
+    a = rad * cos(th);
+    b = rad * sin(th);
+}
+
+__global__ void __launch_bounds__(256) k_draw_propose(DrawProposeArgs a)
+{
+    __shared__ double Fs[DP_MAX * DP_MAX];
+    __shared__ double zs[DP_CB][DP_MAX];
+    __shared__ double rs[DP_CB];
+    __shared__ int ok[DP_CB];
+    const uint32_t step = a.step_dev ? *a.step_dev : a.step;
+    const int tid = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * DP_CB;
+    const int nc = (int)min((int64_t)DP_CB, a.C - c0);
+    const int K = (int)a.K, np = (int)a.np;
+    const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
+    if (a.kind < 0)
+        for (int i = tid; i < K * np; i += 256) Fs[i] = a.factor[i];
+    const int npair = (K + 1) / 2;
+    for (int i = tid; i < nc * npair; i += 256) {
+        const int c = i / npair, j = i - c * npair;
+        const uint32_t gc = (uint32_t)(a.first_chain + (uint64_t)(c0 + c));
+        uint32_t r[4];
+        double x, y;
+        if (a.kind < 0) {
+            philox4x32_10((uint32_t)j, gc, step, 0u, k0, k1, r);
+            box_muller(r, x, y);
+        } else {
+            philox4x32_10((uint32_t)j, gc, step, 3u, k0, k1, r);
+            if (a.kind == 0) {
+                box_muller(r, x, y);
+            } else if (a.kind == 1) {
+                x = tan(3.14159265358979323846 * (u53(r[0], r[1]) - 0.5));
+                y = tan(3.14159265358979323846 * (u53(r[2], r[3]) - 0.5));
+            } else {
+                uint32_t q[4];
+                philox4x32_10((uint32_t)j, gc, step, 4u, k0, k1, q);
+                x = log(u53(q[0], q[1])) - log(u53(r[0], r[1]));
+                y = log(u53(q[2], q[3])) - log(u53(r[2], r[3]));
+            }
+            x *= a.factor[2 * j];
+            if (2 * j + 1 < K) y *= a.factor[2 * j + 1];
+        }
+        zs[c][2 * j] = x;
+        if (2 * j + 1 < K) zs[c][2 * j + 1] = y;
+    }
+    if (tid < nc) {
+        const uint32_t gc = (uint32_t)(a.first_chain + (uint64_t)(c0 + tid));
+        uint32_t r[4];
+        philox4x32_10(0u, gc, step, 2u, k0, k1, r);
+        a.log_u[c0 + tid] = log(u53(r[0], r[1]));
+        double scale = 1.0;
+        if (a.kind < 0 && a.df > 0) {
+            double x = 0.0;
+            for (int m = 0; m < a.df; m += 2) {
+                philox4x32_10((uint32_t)(m / 2), gc, step, 1u, k0, k1, r);
+                double g0, g1;
+                box_muller(r, g0, g1);
+                x += g0 * g0;
+                if (m + 1 < a.df) x += g1 * g1;
+            }
+            scale = 1.0 / sqrt(x / (double)a.df);
+        }
+        rs[tid] = scale;
+        ok[tid] = 1;
+    }
+    __syncthreads();
+    for (int i = tid; i < nc * np; i += 256) {
+        const int c = i / np, n = i - c * np;
+        double o;
+        if (a.kind < 0) {
+            double acc = 0.0;
+            for (int k = 0; k < K; k++) acc = fma(zs[c][k], Fs[k * np + n], acc);
+            o = (a.df > 0) ? acc * rs[c] : acc;
+        } else {
+            o = zs[c][n];
+        }
+        const int64_t g = (c0 + c) * a.np + n;
+        const double q = a.Q0[g] + o * a.scaling[c0 + c];
+        a.Qprop[g] = q;
+        if (!(q >= a.lower[n] && q <= a.upper[n])) ok[c] = 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < nc * np; i += 256) {
+        const int c = i / np;
+        if (!ok[c]) {
+            const int64_t g = (c0 + c) * a.np + (i - c * np);
+            a.Qprop[g] = a.Q0[g];
+        }
+    }
+    if (tid < nc) a.inbounds[c0 + tid] = ok[tid];
+}
+
+bool draw_propose_applicable(int64_t K, int64_t np) { return K >= 1 && K <= DP_MAX && np >= 1 && np <= DP_MAX; }
+
+int launch_draw_propose(beatamd_ctx *ctx, int64_t C, int64_t K, int64_t np, int kind, const double *factor,
+                        int df, uint64_t seed, uint32_t step, uint64_t first_chain, const double *Q0,
+                        const double *scaling, const double *lower, const double *upper, double *Qprop,
+                        double *log_u, int32_t *inbounds)
+{
+    if (C == 0) return BEATAMD_OK;
+    DrawProposeArgs a;
+    a.C = C; a.K = K; a.np = np; a.kind = kind; a.factor = factor; a.df = df;
+    a.seed = seed; a.first_chain = first_chain; a.step = step; a.step_dev = ctx->step_dev;
+    a.Q0 = Q0; a.scaling = scaling; a.lower = lower; a.upper = upper;
+    a.Qprop = Qprop; a.log_u = log_u; a.inbounds = inbounds;
+    ScopedTimer tm(ctx, "proposal");
+    hipLaunchKernelGGL(k_draw_propose, dim3((unsigned)((C + DP_CB - 1) / DP_CB)), dim3(256), 0, ctx->stream, a);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
 __global__ void k_step_advance(uint32_t *step_dev) { *step_dev += 1u; }
 
 // after the draws of a step: the device-resident counter moves on (captured with the step in a graph)

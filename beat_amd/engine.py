@@ -373,6 +373,26 @@ class Context(object):
                                                           ptr(be), ptr(accepted)))
         return accepted
 
+    def ffi_mstep_batch(self, model_id, Q0, L0, factor, kind, df, seed, step, first_chain, scaling, lower,
+                        upper, beta, accepted, accepted_sum=None, n_accepted=None):
+        """One Metropolis step of every chain with the proposal drawn on the device
+        (beatamd_ffi_mstep_batch): device tensors only, nothing returns to the host.
+        kind None / -1: multivariate proposal with ``factor`` [K, nparams] (df > 0: multivariate t);
+        0/1/2: per-parameter Normal / Cauchy / Laplace with ``factor`` = scales [nparams]."""
+        self._adopt_stream(Q0, L0)
+        Cn = int(Q0.shape[0])
+        kind = -1 if kind is None else int(kind)
+        fa, sc, lo, up = f64(factor), f64(scaling), f64(lower), f64(upper)
+        K = int(fa.shape[0]) if kind < 0 else 0
+        scalar = np.ndim(beta) == 0 and not hasattr(beta, "data_ptr")
+        be = None if scalar else f64(beta)
+        check(self._lib.beatamd_ffi_mstep_batch(
+            self._h, model_id, Cn, ptr(Q0), ptr(L0), ptr(fa), K, kind, int(df), int(seed) & (2 ** 64 - 1),
+            int(step) & 0xffffffff, int(first_chain), ptr(sc), ptr(lo), ptr(up), float(beta) if scalar else 1.0,
+            None if scalar else ptr(be), ptr(accepted), None if accepted_sum is None else ptr(accepted_sum),
+            None if n_accepted is None else ptr(n_accepted)))
+        return accepted
+
     # -- introspection
     def last_kernel(self):
         """name<template arguments> of the stacking kernel the most recent call launched"""

@@ -348,6 +348,12 @@ class LogpForwFunc(object):
         return self.ctx.ffi_astep_batch(self.model_id, Q0, L0, delta, scaling, lower, upper, log_u,
                                         beta, accepted)
 
+    def mstep_batch(self, Q0, L0, factor, kind, df, seed, step, first_chain, scaling, lower, upper, beta,
+                    accepted, accepted_sum=None, n_accepted=None):
+        """the whole Metropolis step, proposal draw included, as one device call (metropolis.py:276-422)"""
+        return self.ctx.ffi_mstep_batch(self.model_id, Q0, L0, factor, kind, df, seed, step, first_chain,
+                                        scaling, lower, upper, beta, accepted, accepted_sum, n_accepted)
+
     def get_shared(self):
         """the model's shared storage under the reference's access pattern (name / get_value /
         set_value; sampler/base.py:274-282, 541-555 uses it to share memory between workers):

@@ -4,10 +4,10 @@ beat/sampler/metropolis.py:276-422 (``Metropolis.astep``).
 
 The reference advances one chain per process and call.  ``BatchedMetropolis`` keeps the state of
 all chains of a rank on the device (``Q [c, nparams]``, ``L [c, nllk]``, per-chain ``scaling`` and
-acceptance counters) and one ``step`` is: draw the proposal rows (``beatamd_proposal_draw``), the
-fused propose -> forward model -> tempered accept call (``beatamd_ffi_astep_batch``) and, every
-``tune_interval`` steps, the per-chain step-size update (``beatamd_metropolis_tune``).  Nothing
-returns to the host inside a stage.
+acceptance counters) and one ``step`` is ONE device call, ``beatamd_ffi_mstep_batch``: proposal
+draws -> propose -> forward model -> tempered accept -> acceptance counters (off the device the same
+in pieces: ``draw`` + ``astep_batch``) and, every ``tune_interval`` steps, the per-chain step-size
+update (``beatamd_metropolis_tune``).  Nothing returns to the host inside a stage.
 """
 import numpy as np
 
@@ -91,21 +91,19 @@ class BatchedMetropolis(object):
             self.steps_until_tune = self.tune_interval
 
     def run(self, Q, L, beta, n_steps, n_acc, use_graph=False):
-        """n_steps steps of every chain, in place on Q, L; accepted moves are added to the 0-d tensor
-        n_acc.  use_graph (CUDA only): the step -- proposal draws, fused astep, acceptance
-        bookkeeping; nothing in it synchronises with the host -- is captured ONCE per call in a HIP
-        graph and replayed, with the Philox step counter resident on the device
-        (beatamd_ctx_set_step_counter), so the draws are exactly those of the eager loop.  For
-        launch-bound problems (geometry mode with ~1000 chains: a dozen launches of a few
-        microseconds each per step) that removes the launch overhead; the step-size tuning runs
-        between replays."""
+        """n_steps steps of every chain, in place on Q, L; accepted moves are added to the 0-d int64
+        tensor n_acc.  On the device a step is ONE C call (beatamd_ffi_mstep_batch: draws, proposal,
+        forward model, accept, acceptance counters).  use_graph (CUDA only): the step is captured
+        ONCE per call in a HIP graph and replayed, with the Philox step counter resident on the
+        device (beatamd_ctx_set_step_counter), so the draws are exactly those of the eager loop;
+        the step-size tuning runs between replays."""
         torch = self.torch
         n_steps = int(n_steps)
         if not (use_graph and Q.is_cuda and n_steps >= 3 and hasattr(self.ops, "ctx")):
             for _ in range(n_steps):
-                n_acc += self.step(Q, L, beta).sum()
+                self.step(Q, L, beta, n_acc)
             return
-        n_acc += self.step(Q, L, beta).sum()      # eager: allocations, measured kernel choices
+        self.step(Q, L, beta, n_acc)      # eager: allocations, measured kernel choices
         ctx = self.ops.ctx
         counter = torch.tensor([self.n_steps_total], dtype=torch.int32, device=Q.device)
         torch.cuda.synchronize(Q.device)
@@ -113,9 +111,7 @@ class BatchedMetropolis(object):
         ctx.set_step_counter(counter)
         try:
             with torch.cuda.graph(graph):
-                self._draw_and_astep(Q, L, beta)
-                self.accepted_since_tune += self._acc
-                n_acc += self._acc.sum()
+                self._draw_and_astep(Q, L, beta, n_acc)
             for _ in range(n_steps - 1):
                 self._tune_if_due()
                 graph.replay()
@@ -126,18 +122,24 @@ class BatchedMetropolis(object):
         if int(counter.item()) != self.n_steps_total & 0x7fffffff:
             raise RuntimeError("device step counter %d != host %d" % (int(counter.item()), self.n_steps_total))
 
-    def step(self, Q, L, beta):
-        """one astep for every chain; beta scalar or per-chain tensor.  In place on Q, L."""
+    def step(self, Q, L, beta, n_acc=None):
+        """one astep for every chain; beta scalar or per-chain tensor.  In place on Q, L; the number
+        of moves is added to the 0-d int64 tensor n_acc when given."""
         self._tune_if_due()
-        self._draw_and_astep(Q, L, beta)
-        self.accepted_since_tune += self._acc
+        self._draw_and_astep(Q, L, beta, n_acc)
         self.steps_until_tune -= 1
         self.n_steps_total += 1
         return self._acc
 
-    def _draw_and_astep(self, Q, L, beta):
+    def _draw_and_astep(self, Q, L, beta, n_acc=None):
         if self.factor is None and self.kind is None:
             raise RuntimeError("no proposal set: call set_proposal / set_proposal_from_population")
+        if Q.is_cuda and hasattr(self.target, "mstep_batch"):
+            # draws, proposal, forward model, accept and the acceptance counters: one device call
+            self.target.mstep_batch(Q, L, self.factor if self.kind is None else self.uscale, self.kind, self.df,
+                                    self.seed, self.n_steps_total, self.first_chain, self.scaling, self.lower,
+                                    self.upper, beta, self._acc, self.accepted_since_tune, n_acc)
+            return
         if self.kind is not None:
             delta, log_u = self.ops.draw_univariate(self.kind, self.uscale, self.n_chains, self.seed,
                                                     self.n_steps_total, first_chain=self.first_chain)
@@ -146,6 +148,9 @@ class BatchedMetropolis(object):
                                          first_chain=self.first_chain, df=self.df)
         self.target.astep_batch(Q, L, delta, self.scaling, self.lower, self.upper, log_u, beta,
                                 self._acc)
+        self.accepted_since_tune += self._acc
+        if n_acc is not None:
+            n_acc += self._acc.sum()
 
     # -- resume support
     def state_dict(self):

@@ -154,8 +154,7 @@ class SMC(object):
             self.stepper.run(Q, L, self.beta, n_steps, n_acc, use_graph=self.use_graph)
         else:
             for i in range(int(n_steps)):
-                acc = self.stepper.step(Q, L, self.beta)
-                n_acc += acc.sum()
+                acc = self.stepper.step(Q, L, self.beta, n_acc)
                 on_step(i, Q, L, acc)
         self.stage_acceptance.append(float(n_acc.item()) / max(1.0, float(n_steps) * Q.shape[0]))
         return Q, L

@@ -548,22 +548,27 @@ def main():
                   random_seed=5)
         for cov_name, f_pt in (("scalar", f), ("toeplitz", f_tp)):
             pt_sample(f_pt, lo, up, n_samples=n_rep, **kw)   # warm-up: allocations, the measured group size
-            ctx.enable_timing(True)
-            ctx.reset_timing()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            s_pt, ls_pt, man = pt_sample(f_pt, lo, up, n_samples=3 * n_rep, **kw)
-            torch.cuda.synchronize()
-            dt_pt = time.perf_counter() - t0
-            g_ms, n_launch = ctx.kernel_time("gfstack")
-            ctx.enable_timing(False)
+            runs = []
+            for n_rounds in (2, 10):    # the difference of two run lengths = the rounds alone (no set-up)
+                ctx.enable_timing(True)
+                ctx.reset_timing()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                s_pt, ls_pt, man = pt_sample(f_pt, lo, up, n_samples=n_rounds * n_rep, **kw)
+                torch.cuda.synchronize()
+                dt_pt = time.perf_counter() - t0
+                g_ms, n_launch = ctx.kernel_time("gfstack")
+                ctx.enable_timing(False)
+                runs.append((dt_pt, n_launch, g_ms, man._round))
+            (t_a, n_a, g_a, r_a), (t_b, n_b, g_b, r_b) = runs
+            per_launch = (t_b - t_a) / max(n_b - n_a, 1)
             out.setdefault("pt_leg", {})[cov_name] = {
                 "replicas": "%d temperatures x %d replicas = %d chains on one GPU (the per-GPU share of "
                             "BASELINE configs[4]), exchange round every 3-5 steps" % (n_temp, n_rep, n_temp * n_rep),
-                "chain_steps_per_s": n_launch * n_temp * n_rep / dt_pt, "forward_launches": n_launch,
-                "ms_per_launch_incl_exchange": dt_pt / max(n_launch, 1) * 1e3,
-                "gfstack_avg_launch_ms": g_ms / max(n_launch, 1), "exchange_rounds": len(man.history),
-                "finite": bool(np.isfinite(ls_pt).all())}
+                "chain_steps_per_s": n_temp * n_rep / per_launch, "steps": n_b - n_a,
+                "exchange_rounds": r_b - r_a, "ms_per_step_incl_exchange": per_launch * 1e3,
+                "gfstack_avg_launch_ms": (g_b - g_a) / max(n_b - n_a, 1),
+                "setup_ms": (t_a - n_a * per_launch) * 1e3, "finite": bool(np.isfinite(ls_pt).all())}
         del f_tp, Wd
         torch.cuda.empty_cache()
         # pre-whitened library: W.G and W.d computed once, no dense W.r per step (needs a second library copy)

@@ -42,7 +42,7 @@ extern "C" {
 /* ABI revision: bumped whenever an entry point changes its signature or an error code is added
  * (1.1: beatamd_weights_update gained kind/count in round 2; BEATAMD_EBADCOV).  beat_amd/_lib.py
  * refuses a library whose revision differs from the header it was written against. */
-#define BEATAMD_VERSION 110
+#define BEATAMD_VERSION 111
 
 #define BEATAMD_NEAREST_NEIGHBOR 0 /* interpolation="nearest_neighbor" */
 #define BEATAMD_MULTILINEAR 1      /* interpolation="multilinear"      */
@@ -261,6 +261,26 @@ int beatamd_ffi_astep_batch_betas(beatamd_ctx *ctx, int32_t model_id, int64_t C,
                                   double *L0, const double *delta, const double *scaling,
                                   const double *lower, const double *upper, const double *log_u,
                                   const double *betas, int32_t *accepted);
+
+/* The whole Metropolis step with the proposal drawn on the device: what the two calls
+ * beatamd_proposal_draw[_univariate] + beatamd_ffi_astep_batch[_betas] do, as one call that touches
+ * the host for nothing (the sampling loop of a stage is then one C call per step, capturable in a
+ * HIP graph together with the device-resident step counter, beatamd_ctx_set_step_counter).
+ * replaces: Metropolis.astep incl. its proposal draw and bookkeeping
+ *           beat/sampler/metropolis.py:276-422 (proposal_dist(n_steps) :289-292, accepted :386-410)
+ *   factor, K, kind, df   kind -1: multivariate proposal, factor [K,nparams], delta = z.factor
+ *                         (df > 0: multivariate-t row scale, base.py:35-71);
+ *                         kind 0/1/2: per-parameter Normal/Cauchy/Laplace, factor = scales [nparams]
+ *   seed, step, first_chain   the Philox key/counter of beatamd_proposal_draw (same numbers)
+ *   beta / betas          betas != NULL: one beta per chain (parallel tempering), else the scalar
+ *   accepted [C] int32 out; accepted_sum [C] int32 (+= accepted) and n_accepted [1] int64
+ *   (+= number of moves) may be NULL.  Q0, L0 and the counters are device pointers.
+ * For nparams, K <= 64 the draws, the factor product and the prior-box test are one launch.       */
+int beatamd_ffi_mstep_batch(beatamd_ctx *ctx, int32_t model_id, int64_t C, double *Q0, double *L0,
+                            const double *factor, int64_t K, int32_t kind, int32_t df, uint64_t seed,
+                            uint32_t step, int64_t first_chain, const double *scaling,
+                            const double *lower, const double *upper, double beta, const double *betas,
+                            int32_t *accepted, int32_t *accepted_sum, int64_t *n_accepted);
 
 /* ---------------------------------------------------------------- noise covariance -------
  * Per-stage re-estimation of the data covariances (update_weights with the "non-toeplitz"

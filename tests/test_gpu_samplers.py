@@ -573,3 +573,60 @@ def test_covariance_update_end_to_end(ctx):
                                 on_stage=lambda s: seen.append(s.likelihoods.copy()))
     assert upd2.n_updates == len(seen) >= 1
     assert all(np.isfinite(x).all() for x in seen) and np.isfinite(lp[:, -1]).all()
+
+
+@pytest.mark.parametrize("ndip,kind,df,per_chain_beta", [(4, -1, 0, False), (4, -1, 3, True), (4, 1, 0, False),
+                                                         (6, -1, 0, True), (6, -1, 4, False), (6, 2, 0, False)])
+def test_fused_step_equals_draw_plus_astep(ctx, ndip, kind, df, per_chain_beta):
+    """beatamd_ffi_mstep_batch (draws + proposal + forward model + accept + counters in one call) against
+    the two calls it replaces, beatamd_proposal_draw[_univariate] + beatamd_ffi_astep_batch[_betas]: the
+    same Philox counters, so the same chains.  More than 64 parameters: the same kernels run -> bitwise;
+    up to 64 the draws, the factor product and the box test are one kernel (FMA chain instead of the
+    matrix-core GEMM: last-bit differences in the proposal)."""
+    import torch
+    from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
+    spec = SyntheticSpec((ndip,), (ndip,), (1.0,), T=3, N=32, D=3, S=25)
+    prob, host = build_problem(spec)
+    f = prob.compile(ctx)
+    lay = host["layout"]
+    npar = lay.size
+    assert (npar <= 64) == (ndip == 4)
+    dev = torch.device("cuda", 0)
+    C = 70
+    Q = torch.from_numpy(draw_population(spec, lay, host["lower"], host["upper"], C)).to(dev)
+    L = f.batch(Q)
+    lo_h, up_h = lay.bounds(host["lower"], host["upper"])
+    lo, up = torch.from_numpy(lo_h).to(dev), torch.from_numpy(up_h).to(dev)
+    rng = np.random.default_rng(3)
+    span = np.where(up_h > lo_h, up_h - lo_h, 1.0)
+    if kind < 0:
+        factor = torch.from_numpy(rng.standard_normal((npar, npar)) * 2e-3 * span[None, :] / np.sqrt(npar)).to(dev)
+    else:
+        factor = torch.from_numpy(2e-3 * span).to(dev)
+    scaling = torch.from_numpy(0.5 + rng.random(C)).to(dev)
+    beta = torch.from_numpy(rng.random(C)).to(dev) if per_chain_beta else 0.3
+    QA, LA, QB, LB = Q.clone(), L.clone(), Q.clone(), L.clone()
+    accA = torch.zeros(C, dtype=torch.int32, device=dev)
+    accB = torch.zeros(C, dtype=torch.int32, device=dev)
+    acc_sum = torch.zeros(C, dtype=torch.int32, device=dev)
+    n_acc = torch.zeros((), dtype=torch.int64, device=dev)
+    total = np.zeros(C, dtype=np.int64)
+    for step in range(4):
+        if kind < 0:
+            delta, log_u = ctx.proposal_draw(factor, C, 77, step, first_chain=5, df=df)
+        else:
+            delta, log_u = ctx.proposal_draw_univariate(kind, factor, C, 77, step, first_chain=5)
+        f.astep_batch(QA, LA, delta, scaling, lo, up, log_u, beta, accA)
+        f.mstep_batch(QB, LB, factor, None if kind < 0 else kind, df, 77, step, 5, scaling, lo, up, beta, accB,
+                      acc_sum, n_acc)
+        assert torch.equal(accA, accB), "step %d" % step
+        total += accA.cpu().numpy()
+        if npar > 64:
+            assert torch.equal(QA, QB) and torch.equal(LA, LB)
+        else:
+            np.testing.assert_allclose(QB.cpu().numpy(), QA.cpu().numpy(), rtol=1e-13, atol=1e-15)
+            np.testing.assert_allclose(LB.cpu().numpy(), LA.cpu().numpy(), rtol=1e-9)
+            QB.copy_(QA)
+            LB.copy_(LA)
+    assert 0 < total.sum() < 4 * C
+    assert np.array_equal(acc_sum.cpu().numpy(), total) and int(n_acc.item()) == total.sum()

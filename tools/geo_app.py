@@ -18,13 +18,14 @@ from test_geometry import _problem  # noqa: E402  (the test's problem builder: L
 
 n_chains = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+use_graph = len(sys.argv) > 3 and sys.argv[3] == "graph"
 ctx = beat_amd.get_context(0)
 rng = np.random.default_rng(11)
 prob, lay, lower, upper = _problem(rng, (214, 205))
 lo, up = lay.bounds(lower, upper)
 f = prob.compile(ctx)
 dev = torch.device("cuda", 0)
-step = SMC(f, lo, up, n_chains=n_chains, tune_interval=10, device=dev, random_seed=2)
+step = SMC(f, lo, up, n_chains=n_chains, tune_interval=10, device=dev, random_seed=2, use_graph=use_graph)
 Q = step.initialize_population()
 L = step.stepper.evaluate(Q)
 step.select_end_points(Q, L)
