@@ -274,6 +274,57 @@ def test_fullsize_fused_logp_through_dma_kernel(full, monkeypatch, C):
     ctx.synchronize()
 
 
+def test_fullsize_pt_1024_chains_toeplitz(full):
+    """The per-GPU share of BASELINE configs[4] on the configs[2] problem: parallel tempering with
+    4 temperatures x 256 replicas = 1024 chains, dense Toeplitz data covariance (64 x 4096^2 = 8.6 GB
+    of upper-triangular W on the FP64 matrix cores), the 62.9 GB library of the fixture.  The recorded
+    likelihoods are the model's (device batch on the recorded samples) and the oracle's composition
+    (rows rebuilt on the host, oracle index maps, oracle MVN with the dense W) on sampled targets."""
+    import torch
+    from beat_amd.models.problem import FFIProblem, SeismicWavemap
+    from beat_amd.sampler import pt_sample
+    from beat_amd.synthetic import exponential_data_covariance
+    from oracle import oracle as orc
+    ctx, prob, host, spec = full["ctx"], full["prob"], full["host"], full["spec"]
+    wm0 = prob.wavemaps[0]
+    rng = np.random.default_rng(5)
+    base = exponential_data_covariance(N, 0.5, 2.0)
+    Wb = np.linalg.cholesky(np.linalg.inv(base)).T
+    ldb = 2.0 * np.log(np.diag(np.linalg.cholesky(base))).sum()
+    scal = (spec.sigma * (1.0 + 0.1 * rng.random(T))) ** 2
+    Wd = np.empty((T, N, N))
+    for t in range(T):
+        np.divide(Wb, np.sqrt(scal[t]), out=Wd[t])
+    slog = np.array([ldb + N * np.log(x) for x in scal])
+    wm = SeismicWavemap(wm0.gfs, wm0.data, Wd, slog, wm0.hypers, wm0.time_shifts, "nearest_neighbor")
+    pv = FFIProblem(prob.layout, prob.n_patch_dip, prob.n_patch_strike, prob.patch_sizes, prob.slip_varnames,
+                    [wm], None, None, prob.lower, prob.upper)
+    f = pv.compile(ctx)
+    lo, up = host["layout"].bounds(host["lower"], host["upper"])
+    s, ls, man = pt_sample(f, lo, up, n_chains_posterior=1, n_chains_tempered=3, n_replicas=256, n_samples=512,
+                           swap_interval=(3, 5), beta_tune_interval=2,
+                           proposal_cov=np.diag(((up - lo) * 5e-4) ** 2), device=torch.device("cuda", 0),
+                           random_seed=5)
+    assert man.chain_betas.size == 1024 and np.unique(man.chain_betas).size == 4
+    assert s.shape == (512, host["layout"].size) and np.isfinite(ls).all()
+    assert man._round >= 2 and "k_gfstack" in ctx.last_kernel()
+    assert ((s >= lo) & (s <= up)).all()
+    L = f.batch(np.ascontiguousarray(s[:64]))
+    np.testing.assert_allclose(L, ls[:64], rtol=1e-11, atol=1e-9)
+    for c in (0, 300, 511):
+        st0, pt = _starttimes_oracle(full, s[c])
+        di, _ = orc.time2idx(pt["durations"], spec.du_min, spec.du_dt)
+        si, _ = orc.time2idx(st0, spec.st_min, spec.st_dt)
+        hp = pt["h_any_P_0_Z"][0]
+        for t in (0, 40, 63):
+            rows = _row_values(((t * P + np.arange(P)) * D + di) * S + si)
+            syn = (rows * pt["uparr"][:, None]).sum(0)
+            ref = orc.mvn_chol_logp(Wd[t], host["data"][t] - syn, slog[t], hp)
+            np.testing.assert_allclose(ls[c, t], ref, rtol=1e-6)    # north_star tolerance
+            np.testing.assert_allclose(ls[c, t], ref, rtol=1e-9)
+    np.testing.assert_allclose(ls[:, -1], ls[:, :-1].sum(1), rtol=1e-12)
+
+
 def test_config4_joint_multifault_shape():
     """BASELINE configs[3] shape (test_ffi_gfstacking_multifault.py): 2 subfaults (10x20 patches
     of 2 km), 35 targets, station time shifts, N = 120, joint with the geodetic composite on the
