@@ -179,7 +179,7 @@ def main():
                     help="skip the labelled legs of the other configurations: multilinear (the reference's "
                          "default interpolation), dense Toeplitz covariance, pre-whitened library, parallel "
                          "tempering, geometry mode")
-    ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "r2_bench_c512_nn_gfstack_summary.json"),
+    ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "r3_bench_c512_nn_gfstack_ws_summary.json"),
                     help="rocprofv3 PMC summary (tools/run_profile.sh + tools/summarize_rocpd.py) of THIS "
                          "command; supplies roofline.traffic when its configuration matches")
     ap.add_argument("--gf-order", type=int, default=None,
@@ -367,6 +367,26 @@ def main():
                             "per four cycles and runs ~33 instructions per batch record (profiles/r3_cell_*)")
         return roof
 
+    def attach_traffic(roof_d, summary_path):
+        """HBM bytes per launch of the leg's kernel from the committed PMC summary of the same command
+        (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streams, + WRITE_SIZE;
+        separate rocprofv3 --pmc passes run by the builder, tools/run_r3_profile.sh) -- only when the
+        kernel that ran here is the one the summary is of"""
+        if not os.path.exists(summary_path):
+            return
+        pmc = json.load(open(summary_path))
+        kern = pmc.get("kernel", "").replace("beatamd::", "").split("(")[0].replace(" ", "")
+        mine = roof_d["kernel"].replace(" ", "")
+        # (the cell kernel reports <epilogue, loader threads>, its symbol is <loader threads, variant>)
+        same = kern == mine or (kern.startswith("k_gfstack_cell<") and mine.startswith("k_gfstack_cell<"))
+        if "hbm_read_bytes_per_launch_corrected" not in pmc or not same:
+            return
+        tr = pmc["hbm_read_bytes_per_launch_corrected"] + pmc.get("hbm_write_bytes_per_launch", 0.0)
+        roof_d["traffic"] = tr
+        roof_d["traffic_source"] = os.path.relpath(summary_path, ROOT)
+        roof_d["traffic_measured_in"] = "builder rocprofv3 --pmc passes of the same command (not this run)"
+        roof_d["hbm_counter_frac"] = tr / (roof_d["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+
     out = None
     if rank == 0:
         roof = stack_roofline(spec, main_leg, B)
@@ -425,14 +445,8 @@ def main():
         default_cfg = (B == 512 and spec.interpolation == "nearest_neighbor" and spec.covariance == "scalar"
                        and spec.T == 64 and spec.N == 4096 and args.gf_order is None and args.prior == "survey"
                        and not env_knobs)
-        if default_cfg and os.path.exists(args.pmc_summary):
-            pmc = json.load(open(args.pmc_summary))
-            if "hbm_read_bytes_per_launch_corrected" in pmc:
-                tr = pmc["hbm_read_bytes_per_launch_corrected"] + pmc.get("hbm_write_bytes_per_launch", 0.0)
-                roof["traffic"] = tr
-                roof["traffic_source"] = os.path.relpath(args.pmc_summary, ROOT)
-                roof["traffic_measured_in"] = "builder rocprofv3 --pmc pass of the same command (not this run)"
-                roof["hbm_counter_frac"] = tr / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if default_cfg:
+            attach_traffic(roof, args.pmc_summary)
 
     # ---- reuse-free streaming leg: k_gfstack in (chain, target, tile) order, every chain's rows
     # streamed from HBM -- the roofline of SURVEY 8(d)'s algorithmic bytes, driver-observed
@@ -454,7 +468,11 @@ def main():
             "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_s,
             "avg_launch_ms": ms / max(n, 1), "launches": n,
             "chain_steps_per_s": Bs * 4 / leg["dt"],
+            "traffic": None,
             "note": "no cross-chain row reuse: algorithmic bytes = HBM bytes (block order chain-major)"}
+        if Bs == 128 and spec.T == 64 and spec.N == 4096:
+            attach_traffic(out["roofline_streaming"], os.path.join(ROOT, "profiles",
+                                                                   "r3_bench_c512_nn_gfstack0_summary.json"))
     # ---- the same population in larger batches: chain groups of one (target, tile) share an XCD,
     # rows common to several groups come from its L2 (labelled leg; `value` stays the 512-chain batch)
     if world == 1 and not args.no_batch_leg and spec.covariance == "scalar" and B < 2048:
@@ -503,10 +521,13 @@ def main():
         host_of[spec_ml] = host
         f_ml = variant("multilinear")
         leg = run_leg(spec_ml, f_ml, B, Kl, 2, seed_offset=1000)
+        roof_ml = stack_roofline(spec_ml, leg, B)
+        if B == 512 and spec.T == 64 and spec.N == 4096 and args.prior == "survey" and not env_knobs:
+            attach_traffic(roof_ml, os.path.join(ROOT, "profiles", "r3_bench_c512_ml_gfstack_cell_summary.json"))
         out["multilinear_leg"] = {
             "interpolation": "multilinear (4 rows per patch and chain; beat/ffi/base.py:663-704)",
             "chains": B, "steps": Kl, "chain_steps_per_s": B * Kl / leg["dt"], "ms_per_step": leg["dt"] / Kl * 1e3,
-            "roofline": stack_roofline(spec_ml, leg, B),
+            "roofline": roof_ml,
             "kernel_ms_per_step": {k: (v[0] / Kl) for k, v in leg["times"].items() if v[1]}}
         del f_ml
         # dense Toeplitz covariance (SURVEY 8(d) covariance (ii)): chain-batched W.R on the FP64 matrix cores

@@ -77,7 +77,7 @@ def main(src, dst, tag, *kernels):
             summary["hbm_write_bytes_per_launch"] = summary["WRITE_SIZE_KB_per_launch_raw"] * 1024
         if others:
             summary["other_matching_kernels_not_summarised"] = others
-        name = kn.replace("k_", "").replace("<", "").replace(">", "").replace(",", "_")
+        name = (kn[2:] if kn.startswith("k_") else kn).replace("<", "").replace(">", "").replace(",", "_")
         with open(os.path.join(dst, "%s_%s_summary.json" % (tag, name)), "w") as fh:
             json.dump(summary, fh, indent=1)
         print(json.dumps(summary, indent=1))
