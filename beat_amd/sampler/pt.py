@@ -152,10 +152,16 @@ def pt_sample(target, lower, upper, n_chains_posterior=1, n_chains_tempered=7, n
     p0, p1 = min(start, n_post), min(stop, n_post)
     samples, lsamples = [], []
     rounds = 0
+    # wall time and step count of the rounds alone (bench.py's pt_leg): man.loop_seconds / man.loop_steps
+    if Q.is_cuda:
+        torch.cuda.synchronize(dev)
+    import time
+    t_loop, man.loop_steps = time.perf_counter(), 0
     while sum(len(s) for s in samples) < n_samples:
         betas = torch.from_numpy(man.chain_betas[start:stop].copy()).to(dev)
         for _ in range(man.draw_swap_interval()):
             stepper.step(Q, L, betas)
+            man.loop_steps += 1
         ops.check()
         QL = torch.cat([Q, L], 1)
         if rounds % record_every == 0:
@@ -169,4 +175,7 @@ def pt_sample(target, lower, upper, n_chains_posterior=1, n_chains_tempered=7, n
         rounds += 1
         if rounds % beta_tune_interval == 0 and man.n_workers_tempered > 0:
             man.tune_betas()
+    if Q.is_cuda:
+        torch.cuda.synchronize(dev)
+    man.loop_seconds = time.perf_counter() - t_loop
     return np.concatenate(samples)[:n_samples], np.concatenate(lsamples)[:n_samples], man

@@ -179,6 +179,8 @@ def main():
                     help="skip the labelled legs of the other configurations: multilinear (the reference's "
                          "default interpolation), dense Toeplitz covariance, pre-whitened library, parallel "
                          "tempering, geometry mode")
+    ap.add_argument("--variant-legs", default="multilinear,toeplitz,pt,prewhitened,geometry",
+                    help="which of the labelled configuration legs to run (comma separated)")
     ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "r3_bench_c512_nn_gfstack_ws_summary.json"),
                     help="rocprofv3 PMC summary (tools/run_profile.sh + tools/summarize_rocpd.py) of THIS "
                          "command; supplies roofline.traffic when its configuration matches")
@@ -498,12 +500,16 @@ def main():
             "distinct_rows_per_patch_mean": leg["stats"]["mean_rows"], "kernel": leg["kernel"],
             "hbm_required_bytes_per_launch": leg["stats"]["row_bytes"]}
     # ---- labelled legs of the other configurations (never `value`): same library in HBM, same population
-    if world == 1 and not args.no_variant_legs and spec.interpolation == "nearest_neighbor" \
+    legs = set(x for x in args.variant_legs.split(",") if x)
+    if world == 1 and not args.no_variant_legs and legs and spec.interpolation == "nearest_neighbor" \
             and spec.covariance == "scalar" and not args.prewhiten:
+        import copy
+
         from beat_amd.models.problem import FFIProblem, SeismicWavemap
         from beat_amd.synthetic import exponential_data_covariance
         wm0 = prob.wavemaps[0]
         Kl = max(K // 2, 3)
+        N, T = spec.N, spec.T
 
         def variant(interp="nearest_neighbor", weights=None, slog=None, prewhiten=False):
             """another compiled model over the SAME device library (no second copy unless pre-whitened)"""
@@ -513,133 +519,140 @@ def main():
                             prob.slip_varnames, [wm], None, None, prob.lower, prob.upper)
             return pv.compile(ctx, prewhiten=prewhiten)
 
-        # multilinear: the reference's default interpolation (beat/config.py:571-575)
-        import copy
-        a_ml = copy.copy(args)
-        a_ml.interp = "multilinear"
-        spec_ml = make_spec(a_ml)
-        host_of[spec_ml] = host
-        f_ml = variant("multilinear")
-        leg = run_leg(spec_ml, f_ml, B, Kl, 2, seed_offset=1000)
-        roof_ml = stack_roofline(spec_ml, leg, B)
-        if B == 512 and spec.T == 64 and spec.N == 4096 and args.prior == "survey" and not env_knobs:
-            attach_traffic(roof_ml, os.path.join(ROOT, "profiles", "r3_bench_c512_ml_gfstack_cell_summary.json"))
-        out["multilinear_leg"] = {
-            "interpolation": "multilinear (4 rows per patch and chain; beat/ffi/base.py:663-704)",
-            "chains": B, "steps": Kl, "chain_steps_per_s": B * Kl / leg["dt"], "ms_per_step": leg["dt"] / Kl * 1e3,
-            "roofline": roof_ml,
-            "kernel_ms_per_step": {k: (v[0] / Kl) for k, v in leg["times"].items() if v[1]}}
-        del f_ml
-        # dense Toeplitz covariance (SURVEY 8(d) covariance (ii)): chain-batched W.R on the FP64 matrix cores
-        N, T = spec.N, spec.T
-        rng_w = np.random.default_rng(spec.seed + 1)
-        base = exponential_data_covariance(N, 0.5, 2.0)
-        Wb = np.linalg.cholesky(np.linalg.inv(base)).T
-        ldb = 2.0 * np.log(np.diag(np.linalg.cholesky(base))).sum()
-        scal = (spec.sigma * (1.0 + 0.1 * rng_w.random(T))) ** 2
-        Wd = np.empty((T, N, N))
-        for t in range(T):
-            np.divide(Wb, np.sqrt(scal[t]), out=Wd[t])
-        slog_d = np.array([ldb + N * np.log(x) for x in scal])
-        a_tp = copy.copy(args)
-        a_tp.covariance = "toeplitz"
-        spec_tp = make_spec(a_tp)
-        host_of[spec_tp] = host
-        f_tp = variant(weights=Wd, slog=slog_d)
-        leg = run_leg(spec_tp, f_tp, B, Kl, 2, seed_offset=1000)
-        q_ms, q_n = leg["times"]["quadform"]
-        qflops = 2.0 * T * N * N / 2.0 * B
-        qa = qflops / (q_ms / max(q_n, 1) * 1e-3) / 1e12
-        out["toeplitz_leg"] = {
-            "covariance": "Toeplitz sigma^2 exp(-|i-j| dt/T0), dt 0.5, T0 2: dense upper-triangular W (8.6 GB)",
-            "chains": B, "steps": Kl, "chain_steps_per_s": B * Kl / leg["dt"], "ms_per_step": leg["dt"] / Kl * 1e3,
-            "kernel_ms_per_step": {k: (v[0] / Kl) for k, v in leg["times"].items() if v[1]},
-            "roofline_quadform": {
-                "bound": "fp64_mfma", "kernel": "k_quadform<128>", "achieved": qa, "peak": FP64_VALU_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": qa / FP64_VALU_PEAK_TFLOPS, "avg_launch_ms": q_ms / max(q_n, 1),
-                "launches": q_n, "flops_per_launch": qflops, "mfma_loop_ceiling_TFLOPs": 49.4,
-                "frac_of_mfma_loop_ceiling": qa / 49.4,
-                "note": "v_mfma_f64_16x16x4_f64; a register-resident MFMA loop reaches 49.4 TF on this part "
-                        "(tools/micro/mfma64.hip), nominal 78.6"}}
-        # parallel tempering: 4 temperatures x 256 replicas = the per-GPU share of BASELINE configs[4]
-        from beat_amd.sampler import pt_sample
-        n_rep, n_temp = 256, 4
-        kw = dict(n_chains_posterior=1, n_chains_tempered=n_temp - 1, n_replicas=n_rep, swap_interval=(3, 5),
-                  beta_tune_interval=4, proposal_cov=np.diag(((up - lo) * args.step_scale) ** 2), device=dev,
-                  random_seed=5)
-        for cov_name, f_pt in (("scalar", f), ("toeplitz", f_tp)):
-            pt_sample(f_pt, lo, up, n_samples=n_rep, **kw)   # warm-up: allocations, the measured group size
-            runs = []
-            for n_rounds in (2, 10):    # the difference of two run lengths = the rounds alone (no set-up)
-                ctx.enable_timing(True)
-                ctx.reset_timing()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                s_pt, ls_pt, man = pt_sample(f_pt, lo, up, n_samples=n_rounds * n_rep, **kw)
-                torch.cuda.synchronize()
-                dt_pt = time.perf_counter() - t0
-                g_ms, n_launch = ctx.kernel_time("gfstack")
-                ctx.enable_timing(False)
-                runs.append((dt_pt, n_launch, g_ms, man._round))
-            (t_a, n_a, g_a, r_a), (t_b, n_b, g_b, r_b) = runs
-            per_launch = (t_b - t_a) / max(n_b - n_a, 1)
-            out.setdefault("pt_leg", {})[cov_name] = {
-                "replicas": "%d temperatures x %d replicas = %d chains on one GPU (the per-GPU share of "
-                            "BASELINE configs[4]), exchange round every 3-5 steps" % (n_temp, n_rep, n_temp * n_rep),
-                "chain_steps_per_s": n_temp * n_rep / per_launch, "steps": n_b - n_a,
-                "exchange_rounds": r_b - r_a, "ms_per_step_incl_exchange": per_launch * 1e3,
-                "gfstack_avg_launch_ms": (g_b - g_a) / max(n_b - n_a, 1),
-                "setup_ms": (t_a - n_a * per_launch) * 1e3, "finite": bool(np.isfinite(ls_pt).all())}
-        del f_tp, Wd
-        torch.cuda.empty_cache()
-        # pre-whitened library: W.G and W.d computed once, no dense W.r per step (needs a second library copy)
-        try:
+        def dense_weights():
+            """SURVEY 8(d) covariance (ii): sigma_t^2 exp(-|i-j| dt/T0), dt 0.5, T0 2 -> (W [T,N,N], slog [T])"""
+            rng_w = np.random.default_rng(spec.seed + 1)
+            base = exponential_data_covariance(N, 0.5, 2.0)
+            Wb = np.linalg.cholesky(np.linalg.inv(base)).T
+            ldb = 2.0 * np.log(np.diag(np.linalg.cholesky(base))).sum()
+            scal = (spec.sigma * (1.0 + 0.1 * rng_w.random(T))) ** 2
             Wd = np.empty((T, N, N))
             for t in range(T):
                 np.divide(Wb, np.sqrt(scal[t]), out=Wd[t])
-            t0 = time.perf_counter()
-            f_pw = variant(weights=Wd, slog=slog_d, prewhiten=True)
-            torch.cuda.synchronize()
-            t_pw = time.perf_counter() - t0
-            leg = run_leg(spec_tp, f_pw, B, Kl, 2, seed_offset=1000)
-            out["prewhitened_leg"] = {
-                "covariance": "the Toeplitz covariance folded into a whitened COPY of the library (W.G, W.d once)",
+            return Wd, np.array([ldb + N * np.log(x) for x in scal])
+
+        def spec_with(**kw):
+            a2 = copy.copy(args)
+            for k_, v_ in kw.items():
+                setattr(a2, k_, v_)
+            sp = make_spec(a2)
+            host_of[sp] = host
+            return sp
+
+        if "multilinear" in legs:
+            # the reference's default interpolation (beat/config.py:571-575)
+            spec_ml = spec_with(interp="multilinear")
+            f_ml = variant("multilinear")
+            leg = run_leg(spec_ml, f_ml, B, Kl, 2, seed_offset=1000)
+            roof_ml = stack_roofline(spec_ml, leg, B)
+            if B == 512 and T == 64 and N == 4096 and args.prior == "survey" and not env_knobs:
+                attach_traffic(roof_ml, os.path.join(ROOT, "profiles", "r3_bench_c512_ml_gfstack_cell_summary.json"))
+            out["multilinear_leg"] = {
+                "interpolation": "multilinear (4 rows per patch and chain; beat/ffi/base.py:663-704)",
                 "chains": B, "steps": Kl, "chain_steps_per_s": B * Kl / leg["dt"],
-                "ms_per_step": leg["dt"] / Kl * 1e3, "whitening_s": t_pw, "kernel": leg["kernel"]}
-            del f_pw, Wd
-            torch.cuda.empty_cache()
-        except (RuntimeError, MemoryError) as exc:   # not enough HBM for the copy beside other allocations
-            out["prewhitened_leg"] = {"skipped": str(exc)[:200]}
-        # geometry mode, BASELINE configs[1]: rectangular source, 2 SAR scenes (214 + 205 points, full
-        # covariances), 1024 SMC chains; synthetic observations; parity with BEAT unpinned (pyrocko absent)
-        from beat_amd.synthetic import build_geometry_problem
-        gprob, glay, glower, gupper = build_geometry_problem()
-        glo, gup = glay.bounds(glower, gupper)
-        gf_ = gprob.compile(ctx)
-        gleg = {}
-        for use_graph in (False, True):
-            gstep = SMC(gf_, glo, gup, n_chains=1024, tune_interval=10, device=dev, random_seed=2,
-                        use_graph=use_graph)
-            gQ = gstep.initialize_population()
-            gL = gstep.stepper.evaluate(gQ)
-            gstep.select_end_points(gQ, gL)
-            for stage in range(2):
-                gstep.transition()
-                gstep.stage += 1
-                torch.cuda.synchronize()
+                "ms_per_step": leg["dt"] / Kl * 1e3, "roofline": roof_ml,
+                "kernel_ms_per_step": {k: (v[0] / Kl) for k, v in leg["times"].items() if v[1]}}
+            del f_ml
+        f_tp = None
+        if legs & {"toeplitz", "pt", "prewhitened"}:
+            Wd, slog_d = dense_weights()
+            spec_tp = spec_with(covariance="toeplitz")
+        if "toeplitz" in legs:
+            # chain-batched W.R on the FP64 matrix cores
+            f_tp = variant(weights=Wd, slog=slog_d)
+            leg = run_leg(spec_tp, f_tp, B, Kl, 2, seed_offset=1000)
+            q_ms, q_n = leg["times"]["quadform"]
+            qflops = 2.0 * T * N * N / 2.0 * B
+            qa = qflops / (q_ms / max(q_n, 1) * 1e-3) / 1e12
+            out["toeplitz_leg"] = {
+                "covariance": "Toeplitz sigma^2 exp(-|i-j| dt/T0), dt 0.5, T0 2: dense upper-triangular W (8.6 GB)",
+                "chains": B, "steps": Kl, "chain_steps_per_s": B * Kl / leg["dt"],
+                "ms_per_step": leg["dt"] / Kl * 1e3,
+                "kernel_ms_per_step": {k: (v[0] / Kl) for k, v in leg["times"].items() if v[1]},
+                "roofline_quadform": {
+                    "bound": "fp64_mfma", "kernel": "k_quadform<128>", "achieved": qa,
+                    "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": qa / FP64_VALU_PEAK_TFLOPS,
+                    "avg_launch_ms": q_ms / max(q_n, 1), "launches": q_n, "flops_per_launch": qflops,
+                    "mfma_loop_ceiling_TFLOPs": 49.4, "frac_of_mfma_loop_ceiling": qa / 49.4,
+                    "note": "v_mfma_f64_16x16x4_f64; a register-resident MFMA loop reaches 49.4 TF on this part "
+                            "(tools/micro/mfma64.hip), nominal 78.6"}}
+        if "pt" in legs:
+            # parallel tempering: 4 temperatures x 256 replicas = the per-GPU share of BASELINE configs[4];
+            # the sampler times its own rounds (set-up of the replicas excluded)
+            from beat_amd.sampler import pt_sample
+            n_rep, n_temp = 256, 4
+            kw = dict(n_chains_posterior=1, n_chains_tempered=n_temp - 1, n_replicas=n_rep, swap_interval=(3, 5),
+                      beta_tune_interval=4, proposal_cov=np.diag(((up - lo) * args.step_scale) ** 2), device=dev,
+                      random_seed=5)
+            for cov_name, f_pt in (("scalar", f), ("toeplitz", f_tp)):
+                if f_pt is None:
+                    continue
+                pt_sample(f_pt, lo, up, n_samples=n_rep, **kw)   # warm-up: allocations, the measured group size
+                ctx.enable_timing(True)
+                ctx.reset_timing()
+                s_pt, ls_pt, man = pt_sample(f_pt, lo, up, n_samples=8 * n_rep, **kw)
+                g_ms, n_launch = ctx.kernel_time("gfstack")
+                ctx.enable_timing(False)
+                out.setdefault("pt_leg", {})[cov_name] = {
+                    "replicas": "%d temperatures x %d replicas = %d chains on one GPU (the per-GPU share of BASELINE "
+                                "configs[4]), exchange round every 3-5 steps" % (n_temp, n_rep, n_temp * n_rep),
+                    "steps": man.loop_steps, "exchange_rounds": man._round,
+                    "chain_steps_per_s": n_temp * n_rep * man.loop_steps / man.loop_seconds,
+                    "ms_per_step_incl_exchange": man.loop_seconds / man.loop_steps * 1e3,
+                    "gfstack_avg_launch_ms": g_ms / max(n_launch, 1), "finite": bool(np.isfinite(ls_pt).all())}
+        del f_tp
+        torch.cuda.empty_cache()
+        if "prewhitened" in legs:
+            # W.G and W.d computed once, no dense W.r per step (needs a second copy of the library)
+            try:
                 t0 = time.perf_counter()
-                gQ, gL = gstep.sample_stage(200)
+                f_pw = variant(weights=Wd, slog=slog_d, prewhiten=True)
                 torch.cuda.synchronize()
-                dt_g = time.perf_counter() - t0
+                t_pw = time.perf_counter() - t0
+                leg = run_leg(spec_tp, f_pw, B, Kl, 2, seed_offset=1000)
+                out["prewhitened_leg"] = {
+                    "covariance": "the Toeplitz covariance folded into a whitened COPY of the library (W.G, W.d once)",
+                    "chains": B, "steps": Kl, "chain_steps_per_s": B * Kl / leg["dt"],
+                    "ms_per_step": leg["dt"] / Kl * 1e3, "whitening_s": t_pw, "kernel": leg["kernel"]}
+                del f_pw
+            except (RuntimeError, MemoryError) as exc:   # not enough HBM for the copy beside other allocations
+                out["prewhitened_leg"] = {"skipped": str(exc)[:200]}
+            torch.cuda.empty_cache()
+        if "geometry" in legs:
+            # geometry mode, BASELINE configs[1]: rectangular source, 2 SAR scenes (214 + 205 points, full
+            # covariances), 1024 SMC chains; synthetic observations; parity with BEAT unpinned (pyrocko absent)
+            from beat_amd.synthetic import build_geometry_problem
+            gprob, glay, glower, gupper = build_geometry_problem()
+            glo, gup = glay.bounds(glower, gupper)
+            gf_ = gprob.compile(ctx)
+            gleg = {}
+            for use_graph in (False, True):
+                gstep = SMC(gf_, glo, gup, n_chains=1024, tune_interval=10, device=dev, random_seed=2,
+                            use_graph=use_graph)
+                gQ = gstep.initialize_population()
+                gL = gstep.stepper.evaluate(gQ)
                 gstep.select_end_points(gQ, gL)
-            gleg["graph" if use_graph else "eager"] = dt_g / 200 * 1e6
-        out["geometry_leg"] = {
-            "workload": "BASELINE configs[1] shape: rectangular source (Okada 1985), 2 SAR scenes 214 + 205 points "
-                        "with full covariances, 1024 SMC chains, synthetic observations",
-            "parity": "vs BEAT unpinned (pyrocko's layered GF engine is not in the reference tree); pinned to "
-                      "Okada's published check values",
-            "us_per_step_eager": gleg["eager"], "us_per_step_hip_graph": gleg["graph"],
-            "chain_steps_per_s": 1024 / (min(gleg.values()) * 1e-6)}
+                best = None
+                for stage in range(3):
+                    gstep.transition()
+                    gstep.stage += 1
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    gQ, gL = gstep.sample_stage(200)
+                    torch.cuda.synchronize()
+                    dt_g = time.perf_counter() - t0
+                    gstep.select_end_points(gQ, gL)
+                    if stage > 0:
+                        best = dt_g if best is None else min(best, dt_g)
+                gleg["graph" if use_graph else "eager"] = best / 200 * 1e6
+            out["geometry_leg"] = {
+                "workload": "BASELINE configs[1] shape: rectangular source (Okada 1985), 2 SAR scenes 214 + 205 points "
+                            "with full covariances, 1024 SMC chains, synthetic observations",
+                "parity": "vs BEAT unpinned (pyrocko's layered GF engine is not in the reference tree); pinned to "
+                          "Okada's published check values",
+                "launches_per_step": 4,
+                "us_per_step_eager": gleg["eager"], "us_per_step_hip_graph": gleg["graph"],
+                "chain_steps_per_s": 1024 / (min(gleg.values()) * 1e-6)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec)
