@@ -1,5 +1,5 @@
 #!/bin/bash
-# full GPU suite + smoke + default bench (+ optional rocprofv3 evidence with PROFILE=1)
+# full GPU suite + smoke + default bench (+ PROFILE=1: the round's rocprofv3 evidence, tools/run_r3_profile.sh)
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd $R
@@ -11,7 +11,6 @@ python -c "
 import json; d=json.loads(open('gpurun_out/bench_default.json').read().strip().splitlines()[-1])
 print('value %.0f ms/step %.3f' % (d['value'], d['ms_per_step']), d['roofline'], d['cpu_baseline']['value'])"
 if [ "$PROFILE" = "1" ]; then
-  rm -rf gpurun_out/prof
-  bash tools/run_profile.sh > gpurun_out/profile.log 2>&1
+  bash tools/run_r3_profile.sh > gpurun_out/profile.log 2>&1
   tail -3 gpurun_out/profile.log
 fi
