@@ -228,18 +228,19 @@ __device__ __forceinline__ void source_disp(const SrcConst &k, double nu, double
 // synthetics: res = (data - mu) * odw (geodetic.py:1072-1074 / 642-650).
 constexpr int GL_MAXC = 48;
 
-template <int WAVES>
+// SHARED = false: more (chain, source) pairs per workgroup than the LDS table holds (very few observation
+// points): every thread computes its own source constants
+template <int WAVES, bool SHARED>
 __global__ void __launch_bounds__(256, WAVES) k_geom_los(GeomSrcArgs a)
 {
-    __shared__ SrcConst sc[GL_MAXC];
+    __shared__ SrcConst sc[SHARED ? GL_MAXC : 1];
     const int64_t total = a.C * a.Nobs;
     const int64_t i0 = (int64_t)blockIdx.x * 256;
     const int64_t i = i0 + threadIdx.x;
     const int64_t c_first = i0 / a.Nobs;
     const int64_t c_last = (min(i0 + 255, total - 1)) / a.Nobs;
     const int ncs = (int)(c_last - c_first + 1) * a.nsrc;
-    const bool shared = ncs <= GL_MAXC;
-    if (shared) {
+    if (SHARED) {
         if ((int)threadIdx.x < ncs) {
             const int cc = threadIdx.x / a.nsrc, s = threadIdx.x - cc * a.nsrc;
             source_const(a, a.Q + (c_first + cc) * a.nparams, s, sc[threadIdx.x]);
@@ -252,7 +253,7 @@ __global__ void __launch_bounds__(256, WAVES) k_geom_los(GeomSrcArgs a)
     double ue = 0.0, un = 0.0, uz = 0.0;
     for (int s = 0; s < a.nsrc; s++) {
         double se, sn, sz;
-        if (shared) {
+        if (SHARED) {
             source_disp(sc[(int)(c - c_first) * a.nsrc + s], a.nu, e, n, se, sn, sz);
         } else {
             SrcConst own;
@@ -322,12 +323,17 @@ int launch_geom_los(beatamd_ctx *ctx, const GeomSources &g, const double *Q, int
     // waves per SIMD the register budget is cut for (the corner terms are long dependent fp64 chains)
     static const int waves = getenv("BEATAMD_GEOM_WAVES") ? atoi(getenv("BEATAMD_GEOM_WAVES")) : 2;
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (waves >= 4)
-        hipLaunchKernelGGL(k_geom_los<4>, grid, dim3(256), 0, ctx->stream, a);
+    // chains a workgroup of 256 (chain, point) pairs can touch, times the sources
+    const int64_t ncs_max = ((255 + g.Nobs - 1) / g.Nobs + 1) * g.nsrc;
+    static const bool force_own = getenv("BEATAMD_GEOM_OWN") != nullptr;
+    if (ncs_max > GL_MAXC || force_own)
+        hipLaunchKernelGGL((k_geom_los<2, false>), grid, dim3(256), 0, ctx->stream, a);
+    else if (waves >= 4)
+        hipLaunchKernelGGL((k_geom_los<4, true>), grid, dim3(256), 0, ctx->stream, a);
     else if (waves == 3)
-        hipLaunchKernelGGL(k_geom_los<3>, grid, dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL((k_geom_los<3, true>), grid, dim3(256), 0, ctx->stream, a);
     else
-        hipLaunchKernelGGL(k_geom_los<2>, grid, dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL((k_geom_los<2, true>), grid, dim3(256), 0, ctx->stream, a);
     BA_HIP(hipGetLastError());
     return BEATAMD_OK;
 }

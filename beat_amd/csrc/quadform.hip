@@ -222,8 +222,9 @@ struct QsArgs {
 // QS_KB k-steps (4 columns each) of A operands are in flight while the previous batch multiplies: the
 // loads come from L2 with ~1 us latency and a workgroup has few waves, so the prefetch depth, not
 // the matrix cores, sets the time
-constexpr int QS_KB = 8, QS_MAXW = 16;
+constexpr int QS_MAXW = 16, QS_KBMAX = 16;
 
+template <int QS_KB>
 __global__ void __launch_bounds__(64 * QS_MAXW) k_quadform_small(QsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double s_x[];   // [QS_CB][pitch] + red[nwave][QS_CB]
@@ -315,17 +316,17 @@ int launch_quadform_small(beatamd_ctx *ctx, const QuadformSmallCall &k)
         mmax = std::max(mmax, k.M[d]);
     }
     a.C = k.C; a.X = k.X; a.xs_c = k.xs_c; a.Q = k.Q; a.nparams = k.nparams; a.LL = k.LL; a.ld = k.ld;
-    static_assert((4 * QS_KB) % 32 == 0, "pitch = 17 mod 32 doubles");
-    a.pitch = (int)(((mmax + 4 * QS_KB - 1) / (4 * QS_KB)) * (4 * QS_KB) + 17);   // >= the zero-padded row
+    static const int kb = getenv("BEATAMD_QS_KB") ? atoi(getenv("BEATAMD_QS_KB")) : 8;
+    a.pitch = (int)(((mmax + 4 * QS_KBMAX - 1) / (4 * QS_KBMAX)) * (4 * QS_KBMAX) + 17);   // >= the zero-padded row, = 17 mod 32
     // one wave per 16-row tile of the largest dataset, at most 16 (then tiles round robin)
     const int nwave = (int)std::min<int64_t>(QS_MAXW, (mmax + 15) / 16);
     const size_t lds = ((size_t)QS_CB * a.pitch + (size_t)QS_MAXW * QS_CB) * sizeof(double);
+    void (*kern)(QsArgs) = kb == 16 ? k_quadform_small<16> : k_quadform_small<8>;
     if (lds > 64 * 1024)
-        BA_HIP(hipFuncSetAttribute((const void *)k_quadform_small, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
+        BA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ScopedTimer tm(ctx, "quadform");
-    hipLaunchKernelGGL(k_quadform_small, dim3((unsigned)((k.C + QS_CB - 1) / QS_CB), (unsigned)k.nd),
-                       dim3(64 * nwave), lds, ctx->stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((k.C + QS_CB - 1) / QS_CB), (unsigned)k.nd), dim3(64 * nwave), lds,
+                       ctx->stream, a);
     BA_HIP(hipGetLastError());
     return BEATAMD_OK;
 }

@@ -340,13 +340,16 @@ def main():
         lds_frac = lds_floor_ms / avg_ms if (gf_n and shared) else 0.0
         valu_frac = flops / t / 1e12 / FP64_VALU_PEAK_TFLOPS if gf_n else 0.0
         bound = "lds" if (shared and lds_frac > hbm_frac) else "hbm"
+        if cell and valu_frac > max(hbm_frac, lds_frac):
+            bound = "fp64_valu"   # the largest of its fractions; see `note` for what actually limits it
         roof = {
             "bound": bound,
             "kernel": leg["kernel"],
-            "achieved": (lds_bytes if bound == "lds" else need_bytes) / t / 1e9 if gf_n else 0.0,
-            "peak": LDS_PEAK_GBS if bound == "lds" else HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": lds_frac if bound == "lds" else hbm_frac,
+            "achieved": (flops / t / 1e12 if bound == "fp64_valu" else
+                         (lds_bytes if bound == "lds" else need_bytes) / t / 1e9) if gf_n else 0.0,
+            "peak": FP64_VALU_PEAK_TFLOPS if bound == "fp64_valu" else (LDS_PEAK_GBS if bound == "lds" else HBM_PEAK_GBS),
+            "unit": "TFLOP/s" if bound == "fp64_valu" else "GB/s",
+            "frac": valu_frac if bound == "fp64_valu" else (lds_frac if bound == "lds" else hbm_frac),
             # HBM bytes per launch from the PMC counters of the same command (profiles/), else null
             "traffic": None,
             "hbm_frac_required_bytes": hbm_frac,
@@ -364,9 +367,11 @@ def main():
                                         "of": spec_leg.D * spec_leg.S},
         }
         if cell:
-            roof["note"] = ("rows of a cell in registers, accumulators through the VGPR index: neither HBM, LDS "
-                            "nor the FP64 pipe is the limit -- a consumer wavefront issues at most one instruction "
-                            "per four cycles and runs ~33 instructions per batch record (profiles/r3_cell_*)")
+            roof["note"] = ("rows of a cell in registers, accumulators through the VGPR index register: the FP64 pipe is "
+                            "0.30 busy with FMAs (all VALU instructions: 0.55, LDS 0.49 by the SQ counters of "
+                            "profiles/r3_cell_v4_sq_counters.json), HBM 0.28 -- none of them is the limit: two thirds "
+                            "of the time is the per-record / per-chain control skeleton (an M0 write in index mode "
+                            "stalls the wave ~27 cycles; profiles/r3_variants.md)")
         return roof
 
     def attach_traffic(roof_d, summary_path):
