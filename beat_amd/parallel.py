@@ -177,6 +177,25 @@ def exchange_rows(X, perm, n_total, gather=None):
     return out
 
 
+def assert_same_on_all_ranks(what, *tensors):
+    """Debug aid (BEATAMD_CHECK_RANKS=1): the stage decisions are computed redundantly on every
+    rank from the gathered population and MUST be bit-identical -- a silent divergence would let the
+    ranks resample different parents.  All-gathers the raw bytes of the given tensors and raises if any
+    rank's differ from rank 0's."""
+    import torch
+    if not _active():
+        return
+    for i, t in enumerate(tensors):
+        t = torch.as_tensor(t)
+        flat = t.detach().contiguous().reshape(-1)
+        if flat.dtype != torch.float64:
+            flat = flat.to(torch.float64) if flat.dtype in (torch.int32, torch.int64, torch.float32) else flat.double()
+        allr = allgather_rows(flat[None])
+        if not bool((allr.view(torch.int64) == allr.view(torch.int64)[0:1]).all()):
+            bad = [r for r in range(allr.shape[0]) if not torch.equal(allr[r].view(torch.int64), allr[0].view(torch.int64))]
+            raise RuntimeError("%s: tensor %d differs between rank 0 and rank(s) %s" % (what, i, bad))
+
+
 def broadcast_array(a, src=0):
     """Broadcast a small numpy array from ``src`` (stage decisions are computed identically on
     every rank; this is only used for values that come from host RNG state)."""

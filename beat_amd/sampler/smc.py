@@ -137,6 +137,12 @@ class SMC(object):
             self.beta, self.old_beta, self.w = beta_new, old, w
         self.stepper.set_proposal_from_population(self.Q_all, self.w, self.proposal_name)
         self.idx = self.resample()
+        if os.environ.get("BEATAMD_CHECK_RANKS"):
+            fac = self.stepper.factor if self.stepper.factor is not None else self.stepper.uscale
+            parallel.assert_same_on_all_ranks("SMC stage %d transition (beta, weights, indices, proposal factor)"
+                                              % self.stage, self.torch.tensor([self.beta], dtype=self.torch.float64,
+                                                                              device=self.w.device),
+                                              self.w, self.idx, fac)
         return True
 
     def restart_points(self):

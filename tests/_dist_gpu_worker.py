@@ -27,6 +27,7 @@ def main():
     from beat_amd.sampler.ops import DeviceOps
     from beat_amd.synthetic import SyntheticSpec, build_problem
 
+    os.environ["BEATAMD_CHECK_RANKS"] = "1"   # transition(): beta, weights, indices, factor bitwise equal on all ranks
     world = int(os.environ.get("WORLD_SIZE", "1"))
     backend = os.environ.get("BEATAMD_TEST_BACKEND", "gloo")
     local = int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0

@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main():
+    os.environ["BEATAMD_CHECK_RANKS"] = "1"   # SMC.transition asserts bitwise equal decisions on all ranks
     import torch
     import torch.distributed as dist
 
