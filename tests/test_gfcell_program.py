@@ -131,3 +131,25 @@ def test_register_budget():
             for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", ln):
                 hi = int(m.group(2) or m.group(3))
                 assert hi <= gen.V_LAST, ln
+
+
+def test_committed_include_is_the_generators_output(tmp_path, monkeypatch):
+    """beat_amd/csrc/gfcell_asm.inc is generated (tools/gen_gfcell_asm.py) and committed: the file the library is
+    built from must be what the generator -- i.e. the program the emulator tests above run -- writes today"""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    gen = importlib.import_module("gen_gfcell_asm")
+    committed = open(os.path.join(root, "beat_amd", "csrc", "gfcell_asm.inc")).read()
+    monkeypatch.delenv("GC_ABLATIONS", raising=False)
+    real_join = os.path.join
+
+    def join(*a):
+        p = real_join(*a)
+        return str(tmp_path / "gfcell_asm.inc") if p.endswith("gfcell_asm.inc") else p
+    monkeypatch.setattr(gen.os.path, "join", join)
+    gen.main()
+    monkeypatch.undo()
+    assert open(str(tmp_path / "gfcell_asm.inc")).read() == committed
