@@ -123,6 +123,7 @@ int ffi_logp_device(beatamd_ctx *ctx, FfiModel &m, int64_t C, const double *Q, d
             k.st.shift_off = wm.shift_off;
             k.st.chain_bad = chain_bad;
             k.interp = wm.interp;
+            k.f32 = wm.f32;
             k.C = C;
             k.data = wm.data;
             BA_TRY(ctx->get_scratch(SL_QUAD, (size_t)C * wm.T * sizeof(double), &p));
@@ -286,6 +287,42 @@ static int seis_ensure_storage(beatamd_ctx *ctx, SeisLib *l)
     return BEATAMD_OK;
 }
 
+int beatamd_seis_gflib_store_f32(beatamd_ctx *ctx, int32_t lib_id)
+{
+    ENTER(ctx);
+    SeisLib *l = get_obj(ctx->seislibs, lib_id);
+    BA_CHECK(l && l->g, BEATAMD_EINVAL, "gflib_store_f32: unknown or empty GF library %d", lib_id);
+    if (!l->g32) {
+        hipError_t e = hipMalloc((void **)&l->g32, (size_t)l->elems() * sizeof(float));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            l->g32 = nullptr;
+            set_error("float copy of the GF library (%.2f GB) does not fit in HBM: %s", l->elems() * 4 / 1e9,
+                      hipGetErrorString(e));
+            return BEATAMD_ENOMEM;
+        }
+    }
+    BA_TRY(launch_round_to_f32(ctx, l->g, l->g32, l->elems()));
+    return BEATAMD_OK;
+}
+
+int beatamd_ffi_model_set_f32(beatamd_ctx *ctx, int32_t model_id, int32_t wavemap_index, int32_t on)
+{
+    ENTER(ctx);
+    FfiModel *m = get_obj(ctx->models, model_id);
+    BA_CHECK(m && wavemap_index >= 0 && wavemap_index < (int32_t)m->wavemaps.size(), BEATAMD_EINVAL,
+             "model_set_f32: unknown model / wavemap");
+    Wavemap &w = m->wavemaps[wavemap_index];
+    if (on)
+        for (int32_t id : w.libs) {
+            SeisLib *l = get_obj(ctx->seislibs, id);
+            BA_CHECK(l && l->g32, BEATAMD_EINVAL,
+                     "model_set_f32: library %d has no float copy (beatamd_seis_gflib_store_f32)", id);
+        }
+    w.f32 = on != 0;
+    return BEATAMD_OK;
+}
+
 int beatamd_seis_gflib_upload(beatamd_ctx *ctx, int32_t lib_id, const double *src, int64_t offset,
                               int64_t count)
 {
@@ -311,6 +348,7 @@ int beatamd_seis_gflib_adopt(beatamd_ctx *ctx, int32_t lib_id, double *device_pt
     BA_CHECK(((uintptr_t)device_ptr & 15) == 0, BEATAMD_EINVAL,
              "gflib_adopt: pointer must be 16-byte aligned");
     if (l->owned && l->g) BA_HIP(hipFree(l->g));
+    if (l->g32) { BA_HIP(hipFree(l->g32)); l->g32 = nullptr; }   // (a float copy belongs to the old storage)
     l->g = device_ptr;
     l->owned = false;
     return BEATAMD_OK;
@@ -333,6 +371,7 @@ int beatamd_seis_gflib_destroy(beatamd_ctx *ctx, int32_t lib_id)
     BA_CHECK(l, BEATAMD_EINVAL, "unknown GF library %d", lib_id);
     BA_HIP(hipStreamSynchronize(ctx->stream));
     if (l->owned && l->g) BA_HIP(hipFree(l->g));
+    if (l->g32) BA_HIP(hipFree(l->g32));
     ctx->seislibs[lib_id].reset();
     return BEATAMD_OK;
 }

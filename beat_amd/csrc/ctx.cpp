@@ -230,6 +230,8 @@ int beatamd_ctx_destroy(beatamd_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (auto &l : c->seislibs)
         if (l && l->owned && l->g) (void)hipFree(l->g);
+    for (auto &l : c->seislibs)
+        if (l && l->g32) (void)hipFree(l->g32);
     for (auto &l : c->geolibs)
         if (l && l->g) (void)hipFree(l->g);
     for (auto &w : c->wsets)

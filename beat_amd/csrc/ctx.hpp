@@ -56,6 +56,7 @@ struct SeisLib {
     int64_t T = 0, P = 0, D = 0, S = 0, N = 0;
     double st_min = 0, st_dt = 1, du_min = 0, du_dt = 1;
     double *g = nullptr;  // HBM, (T,P,D,S,N) C-order, N fastest
+    float *g32 = nullptr; // optional float copy of g (beatamd_seis_gflib_store_f32; g then holds float-representable values)
     bool owned = false;
     int64_t elems() const { return T * P * D * S * N; }
 };
@@ -87,6 +88,7 @@ struct Wavemap {
     int64_t *shift_off = nullptr;  // device [T] or nullptr
     int interp = 0;
     int64_t T = 0, N = 0;
+    bool f32 = false;   // read the libraries' float copies where a kernel supports it
 };
 
 struct Geodetic {

@@ -220,6 +220,7 @@ __global__ void k_gf_group_tables(GroupTabArgs a)
 
 struct GsArgs {
     const double *G[4];
+    const float *G32[4];   // float copies (k_gfstack_ws32) or nullptr
     int nvar, nrow;
     int64_t C, T, P, N;
     int CG, ucap, ustride, ntile, nt;
@@ -479,6 +480,21 @@ __device__ __forceinline__ void lds_rd8_b64(double (&x)[8], uint32_t addr, int t
         "ds_read_b64 %5, %8 offset:%c10+40\n\t"
         "ds_read_b64 %6, %8 offset:%c10+48\n\t"
         "ds_read_b64 %7, %8 offset:%c10+56"
+        : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7])
+        : "v"(addr), "s"(tok), "n"(OFF));
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_rd8_b32(float (&x)[8], uint32_t addr, int tok)
+{
+    asm("ds_read_b32 %0, %8 offset:%c10\n\t"
+        "ds_read_b32 %1, %8 offset:%c10+4\n\t"
+        "ds_read_b32 %2, %8 offset:%c10+8\n\t"
+        "ds_read_b32 %3, %8 offset:%c10+12\n\t"
+        "ds_read_b32 %4, %8 offset:%c10+16\n\t"
+        "ds_read_b32 %5, %8 offset:%c10+20\n\t"
+        "ds_read_b32 %6, %8 offset:%c10+24\n\t"
+        "ds_read_b32 %7, %8 offset:%c10+28"
         : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7])
         : "v"(addr), "s"(tok), "n"(OFF));
 }
@@ -1200,6 +1216,371 @@ k_gfstack_ws(GsArgs a)
 }
 
 
+// k_gfstack_ws32: k_gfstack_ws on the float copy of the library (beatamd_seis_gflib_store_f32): a row
+// segment of a 64-sample tile is 256 bytes -- one full-wave global_load_lds_dword --, the LDS rows hold
+// floats (pitch 65 dwords: conflict-free ds_read_b32 gather), every operand is widened by v_cvt_f64_f32 in
+// front of its FMA; accumulation, weights and epilogues stay f64.  The f64 library holds the same
+// (float-representable) values, so the result is bit for bit what the f64 kernels give.
+template <int MODE, int NB, int NTH>
+__global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3)))
+k_gfstack_ws32(GsArgs a)
+{
+    constexpr int CW = 8, LW = 4;
+    constexpr int GS_NT = 64;
+    constexpr int GS_PITCH = GS_NT + 1;   // dwords: ds_read_b32 layout
+    constexpr int KPRE = 16;              // list entries per loader fetched ahead (64 rows per step)
+    extern __shared__ __attribute__((aligned(16))) double xbuf[];  // float [3][slots][GS_PITCH] (+ the epilogue's data tile)
+    constexpr int CG = CW * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile;
+    int64_t t, g;
+    if (a.xcd_order) {
+        const int64_t b = blockIdx.x;
+        const int64_t x = b & 7, q = b >> 3;
+        g = q % a.ngroups;
+        const int64_t tt = (q / a.ngroups) * 8 + x;
+        if (tt >= a.T * a.ntile) return;
+        tile = (int)(tt % a.ntile);
+        t = tt / a.ntile;
+    } else {
+        tile = blockIdx.x % a.ntile;
+        const int64_t gt0 = blockIdx.x / a.ntile;
+        t = gt0 % a.T;
+        g = gt0 / a.T;
+    }
+    const int64_t gt = g * a.Ttab + (a.Ttab == 1 ? 0 : t);                       // table cell
+    const int64_t tbase = (a.Ttab == 1) ? t * a.rows_per_target * a.N : 0;      // doubles
+    const int64_t N = a.N;
+    const int64_t n0 = (int64_t)tile * GS_NT;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)xbuf;
+    const int bufsz = a.ucap * GS_PITCH;                          // floats per buffer
+    const int P = (int)a.P, nvar = a.nvar;
+    const int nsteps = P * nvar;
+    auto advance = [&](int &p, int &iv) {
+        if (++iv == nvar) { iv = 0; ++p; }
+        if (p >= P) { p = P - 1; iv = nvar - 1; }
+    };
+
+    if (wave >= CW) {
+        // ==================================== loader ====================================
+        const int lw = wave - CW;
+        const bool dma_lane = (n0 + lane < N);
+        const uint32_t voff = (uint32_t)((n0 + lane) * 4);          // byte offset inside a row
+        const uint32_t rowbytes = (uint32_t)(N * 4);
+        uint32_t keep = 0;
+        auto dma_row = [&](const float *Gv, uint32_t r, uint32_t slotidx, int boff, uint32_t &tk) {
+            const uint64_t off = (uint64_t)r * (uint64_t)rowbytes;
+            const char *rowp = reinterpret_cast<const char *>(Gv) + off;
+            const uint32_t dst = lds0 + (uint32_t)(boff * 4) + slotidx * (uint32_t)(GS_PITCH * 4);
+            // NTH: non-temporal requests -- a row segment is read by this CU once and by no other
+            // workgroup when the batch is a single chain group (several groups share rows through L2)
+            if (NTH)
+                asm("s_mov_b32 m0, %3\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dword %1, %2 nt"
+                    : "+s"(tk) : "v"(voff), "s"(rowp), "s"(dst));
+            else
+                asm("s_mov_b32 m0, %3\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dword %1, %2"
+                    : "+s"(tk) : "v"(voff), "s"(rowp), "s"(dst));
+        };
+        const int kstr = a.ustride / LW;
+        const char *const cnt_base = reinterpret_cast<const char *>(a.ucount + gt * a.P);
+        const char *const ent_base = reinterpret_cast<const char *>(a.uent + ((gt * a.P) * LW + lw) * kstr * 2);
+        const uint32_t ent_step = (uint32_t)(a.ustride * 8);
+        int U_a;
+        uint32_t rid[KPRE], rsl[KPRE];
+        const float *G_a = nullptr;
+        auto fetch_ids = [&](int p, int iv) {
+            // constant address space: the tables are written by k_gf_group_tables before this
+            // launch, never here, and must come in through scalar loads -- a vector load would be
+            // counted in this wavefront's vmcnt together with its row requests
+            typedef const __attribute__((address_space(4))) uint32_t *cu32;
+            typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+            typedef const __attribute__((address_space(4))) u32x16 *cent;
+            U_a = (int)*(cu32)(uintptr_t)(cnt_base + (uint32_t)p * 4u);
+            const char *e = ent_base + (uint32_t)p * ent_step;
+            const u32x16 e0 = *(cent)(uintptr_t)e;
+            const u32x16 e1 = *(cent)(uintptr_t)(e + 64);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                rid[k] = e0[2 * k];      rsl[k] = e0[2 * k + 1];
+                rid[8 + k] = e1[2 * k];  rsl[8 + k] = e1[2 * k + 1];
+            }
+            G_a = a.G32[iv] + tbase;
+        };
+        auto dma_count = [&](int U) { return U > lw ? (U - lw + LW - 1) / LW : 0; };
+        // rows lw, lw + LW, ... of the list whose entries are in rid / rsl -> buffer at boff
+        auto issue_rows = [&](int p, int boff) {
+            if (dma_lane) {
+                uint32_t tk = 0;
+#pragma unroll
+                for (int k = 0; k < KPRE; k++)
+                    if (lw + k * LW < U_a) dma_row(G_a, rid[k], rsl[k], boff, tk);
+                if (U_a > KPRE * LW) {   // rare: more than 64 distinct rows
+                    typedef const __attribute__((address_space(4))) uint32_t *cu32;
+                    cu32 ue = (cu32)(uintptr_t)(ent_base + (uint32_t)p * ent_step);
+                    for (int k = KPRE; lw + k * LW < U_a; k++) dma_row(G_a, ue[2 * k], ue[2 * k + 1], boff, tk);
+                }
+                keep |= tk;
+            }
+        };
+        // steps 0 .. NB-2 go out before the loop, then step s+NB-1 behind the barrier of step s
+        int boff[NB];
+#pragma unroll
+        for (int j = 0; j < NB; j++) boff[j] = j * bufsz;   // boff[j]: buffer of step s+j
+        int cnt[NB];                                          // cnt[j]: this loader's requests of step s+j
+#pragma unroll
+        for (int j = 0; j < NB; j++) cnt[j] = 0;
+        int pn = 0, ivn = 0;                                  // next step to fetch ids for
+        fetch_ids(pn, ivn);
+#pragma unroll
+        for (int j = 0; j < NB - 1; j++) {
+            if (j < nsteps) {
+                issue_rows(pn, boff[j]);
+                cnt[j] = dma_count(U_a);
+            }
+            advance(pn, ivn);
+            fetch_ids(pn, ivn);                               // ids of step j+1
+        }
+        int p_i = pn;                                         // step whose ids are in rid / rsl (s+NB-1)
+        for (int s = 0; s < nsteps; s++) {
+            __builtin_amdgcn_sched_barrier(0);
+            // this loader's rows of step s have landed when at most its requests of the NB-2
+            // younger steps stay in flight (s_waitcnt takes an immediate; an over-wait is safe)
+            {
+                int young = 0;
+#pragma unroll
+                for (int j = 1; j < NB - 1; j++) young += cnt[j];
+                uint32_t tk = 0;
+#define BA_LWAIT(NOUT) asm("s_waitcnt vmcnt(" #NOUT ")" : "+s"(tk) : "s"(s))
+                switch (young) {
+                case 0: BA_LWAIT(0); break;   case 1: BA_LWAIT(1); break;   case 2: BA_LWAIT(2); break;
+                case 3: BA_LWAIT(3); break;   case 4: BA_LWAIT(4); break;   case 5: BA_LWAIT(5); break;
+                case 6: BA_LWAIT(6); break;   case 7: BA_LWAIT(7); break;   case 8: BA_LWAIT(8); break;
+                case 9: BA_LWAIT(9); break;   case 10: BA_LWAIT(10); break; case 11: BA_LWAIT(11); break;
+                case 12: BA_LWAIT(12); break; case 13: BA_LWAIT(13); break; case 14: BA_LWAIT(14); break;
+                case 15: BA_LWAIT(15); break; case 16: BA_LWAIT(16); break; case 17: BA_LWAIT(17); break;
+                case 18: BA_LWAIT(18); break; case 19: BA_LWAIT(19); break; case 20: BA_LWAIT(20); break;
+                case 21: BA_LWAIT(21); break; case 22: BA_LWAIT(22); break; case 23: BA_LWAIT(23); break;
+                case 24: BA_LWAIT(24); break; case 25: BA_LWAIT(25); break; case 26: BA_LWAIT(26); break;
+                case 27: BA_LWAIT(27); break; case 28: BA_LWAIT(28); break; case 29: BA_LWAIT(29); break;
+                case 30: BA_LWAIT(30); break; case 31: BA_LWAIT(31); break; default: BA_LWAIT(32); break;
+                }
+#undef BA_LWAIT
+                keep |= tk;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();   // rows of step s published; buffer of step s-1 is free
+            __builtin_amdgcn_sched_barrier(0);
+            int k_new = 0;
+            if (s + NB - 1 < nsteps) {
+                issue_rows(p_i, boff[NB - 1]);
+                k_new = dma_count(U_a);
+            }
+            advance(pn, ivn);
+            p_i = pn;
+            fetch_ids(pn, ivn);
+            const int b0 = boff[0];
+#pragma unroll
+            for (int j = 0; j < NB - 1; j++) { boff[j] = boff[j + 1]; cnt[j] = cnt[j + 1]; }
+            boff[NB - 1] = b0;
+            cnt[NB - 1] = 0;
+            cnt[NB - 2] = k_new;
+        }
+        __builtin_amdgcn_s_barrier();   // the consumers' barrier "of step nsteps" (their pipelined loop)
+        // the consumers' epilogue passes the data tile through LDS behind two barriers
+        if (MODE != GF_STORE_SYN) {
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
+        }
+        if (keep != 0) a.out[0] = 0.0;   // never true: keeps the request statements alive
+        return;
+    }
+
+    // ==================================== consumer ====================================
+    const int64_t c = g * CG + tid;
+    double acc[GS_NT];
+#pragma unroll
+    for (int i = 0; i < GS_NT; i++) acc[i] = 0.0;
+    // the lane's slot and weight, fetched one step ahead by asm loads hipcc does not count
+    uint32_t sl_n;
+    double wl_n;
+    const uint32_t voff_s = (uint32_t)tid * 2u;
+    const char *const slot_base = reinterpret_cast<const char *>(a.slot + (gt * a.P) * CG);
+    const char *const w_base = reinterpret_cast<const char *>(a.w + (g * a.P) * CG);
+    const uint32_t slot_step = (uint32_t)(CG * 2);
+    const uint32_t w_step = (uint32_t)(CG * 8);
+    const int64_t w_var_bytes = a.w_var_stride * 8;
+    auto tab_slot = [&](int p) { return slot_base + (uint32_t)p * slot_step; };
+    auto tab_w = [&](int p, int iv) {
+        return w_base + (uint32_t)p * w_step + (nvar == 1 ? (int64_t)0 : (int64_t)iv * w_var_bytes);
+    };
+    auto fetch_tabs = [&](const char *ps, const char *pw) {
+        asm("global_load_ushort %0, %1, %2" : "=v"(sl_n) : "v"(voff_s), "s"(ps));
+        uint32_t voff_w;
+        asm("v_lshlrev_b32 %1, 2, %2\n\t"
+            "global_load_dwordx2 %0, %1, %3" : "=v"(wl_n), "=&v"(voff_w) : "v"(voff_s), "s"(pw));
+    };
+    // xs = LDS byte address of the lane's row = base + slot * (GS_PITCH * 4), GS_PITCH = 65
+    auto row_address = [&](uint32_t base) {
+        uint32_t x;
+        asm("s_waitcnt vmcnt(0)\n\t"
+            "v_lshl_add_u32 %0, %1, 6, %1\n\t"
+            "v_lshl_add_u32 %0, %0, 2, %2" : "=&v"(x) : "v"(sl_n), "s"(base), "v"(wl_n));
+        return x;
+    };
+    auto landed_weight = [&](uint32_t after) {   // `after`: the row address, i.e. behind the wait
+        double x;
+        asm("v_mov_b64 %0, %1" : "=v"(x) : "v"(wl_n), "v"(after));
+        return x;
+    };
+    static_assert(GS_PITCH == 65, "row_address multiplies by 65");
+    static_assert(GS_NT == 64, "the read schedule below is written for 64-sample tiles");
+    float ya[8], yb[8];
+    int p1 = 0, iv1 = 0;          // position of the step whose slot/weight are fetched next
+    advance(p1, iv1);
+    int gbuf = 0;                 // row buffer of the step being gathered
+    const int ring = NB * bufsz;
+    // The gather of a step is 8 groups of 8 ds_read_b32 + 8 (widen + FMA), two groups in flight,
+    // pipelined across the step boundary exactly like k_gfstack_ws.
+    double w;
+    uint32_t xs;
+    fetch_tabs(tab_slot(0), tab_w(0, 0));
+    xs = row_address(lds0);
+    w = landed_weight(xs);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();     // rows of step 0 visible
+    __builtin_amdgcn_sched_barrier(0);
+    lds_rd8_b32<0>(ya, xs, -1);
+    lds_rd8_b32<32>(yb, xs, -1);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_tabs(tab_slot(p1), tab_w(p1, iv1));
+    advance(p1, iv1);
+#pragma clang loop unroll(disable)
+    for (int s = 0; s < nsteps; s++) {
+        int gnext = gbuf + bufsz;
+        if (gnext == ring) gnext = 0;
+        const char *const ps2 = tab_slot(p1), *const pw2 = tab_w(p1, iv1);   // tables of step s+2
+        advance(p1, iv1);
+        __builtin_amdgcn_sched_barrier(0);
+        // operands: %0-%7 accumulators, %8-%15 the group's floats, %16-%19 widened temporaries, %20 weight,
+        // %21 row address
+#define F_FMA4A \
+    "v_cvt_f64_f32 %16, %8\n\tv_fmac_f64 %0, %16, %20\n\tv_cvt_f64_f32 %17, %9\n\tv_fmac_f64 %1, %17, %20\n\t" \
+    "v_cvt_f64_f32 %18, %10\n\tv_fmac_f64 %2, %18, %20\n\tv_cvt_f64_f32 %19, %11\n\tv_fmac_f64 %3, %19, %20\n\t"
+#define F_FMA4B \
+    "v_cvt_f64_f32 %16, %12\n\tv_fmac_f64 %4, %16, %20\n\tv_cvt_f64_f32 %17, %13\n\tv_fmac_f64 %5, %17, %20\n\t" \
+    "v_cvt_f64_f32 %18, %14\n\tv_fmac_f64 %6, %18, %20\n\tv_cvt_f64_f32 %19, %15\n\tv_fmac_f64 %7, %19, %20\n\t"
+#define F_RD4A(OFF) \
+    "ds_read_b32 %8, %21 offset:" #OFF "\n\tds_read_b32 %9, %21 offset:" #OFF "+4\n\t" \
+    "ds_read_b32 %10, %21 offset:" #OFF "+8\n\tds_read_b32 %11, %21 offset:" #OFF "+12\n\t"
+#define F_RD4B(OFF) \
+    "ds_read_b32 %12, %21 offset:" #OFF "+16\n\tds_read_b32 %13, %21 offset:" #OFF "+20\n\t" \
+    "ds_read_b32 %14, %21 offset:" #OFF "+24\n\tds_read_b32 %15, %21 offset:" #OFF "+28"
+#define F_ACC8(G) \
+    "+v"(acc[G * 8]), "+v"(acc[G * 8 + 1]), "+v"(acc[G * 8 + 2]), "+v"(acc[G * 8 + 3]), "+v"(acc[G * 8 + 4]), \
+        "+v"(acc[G * 8 + 5]), "+v"(acc[G * 8 + 6]), "+v"(acc[G * 8 + 7])
+#define F_Y8(Y) "+v"(Y[0]), "+v"(Y[1]), "+v"(Y[2]), "+v"(Y[3]), "+v"(Y[4]), "+v"(Y[5]), "+v"(Y[6]), "+v"(Y[7])
+#define F_T4 "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+#define F_GROUP(G, Y, OFFNEXT) \
+    asm("s_waitcnt lgkmcnt(12)\n\t" F_FMA4A F_RD4A(OFFNEXT) "s_waitcnt lgkmcnt(12)\n\t" F_FMA4B F_RD4B(OFFNEXT) \
+        : F_ACC8(G), F_Y8(Y), F_T4 : "v"(w), "v"(xs))
+        double t0, t1, t2, t3;
+        F_GROUP(0, ya, 64);
+        F_GROUP(1, yb, 96);
+        F_GROUP(2, ya, 128);
+        F_GROUP(3, yb, 160);
+        F_GROUP(4, ya, 192);
+        F_GROUP(5, yb, 224);
+        __builtin_amdgcn_sched_barrier(0);
+        // group 6: every read of this step is back once both groups in flight have landed
+        // (yb is named so that group 7 stays behind this wait)
+        asm("s_waitcnt lgkmcnt(0)\n\t" F_FMA4A F_FMA4B
+            : F_ACC8(6), F_Y8(ya), F_T4 : "v"(w), "v"(xs), "v"(yb[0]), "v"(yb[1]), "v"(yb[2]), "v"(yb[3]),
+              "v"(yb[4]), "v"(yb[5]), "v"(yb[6]), "v"(yb[7]));
+        __builtin_amdgcn_sched_barrier(0);
+        gbuf = gnext;
+        const uint32_t xs_n = row_address(lds0 + (uint32_t)(gbuf * 4));   // slot / weight of step s+1 have landed
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();   // rows of step s+1 visible; this wavefront is done with buffer s
+        __builtin_amdgcn_sched_barrier(0);
+        lds_rd8_b32<0>(ya, xs_n, s);    // first group of step s+1 (after the last step: unused rows)
+        __builtin_amdgcn_sched_barrier(0);
+        // group 7 with the weight of step s, then the weight of step s+1 and that step's second group
+        // (%20 = weight, tied; %21 = next row address; %22 = landed weight of the next step)
+        asm(F_FMA4A F_FMA4B
+            "v_mov_b64 %20, %22\n\t"
+            "ds_read_b32 %8, %21 offset:32\n\tds_read_b32 %9, %21 offset:36\n\t"
+            "ds_read_b32 %10, %21 offset:40\n\tds_read_b32 %11, %21 offset:44\n\t"
+            "ds_read_b32 %12, %21 offset:48\n\tds_read_b32 %13, %21 offset:52\n\t"
+            "ds_read_b32 %14, %21 offset:56\n\tds_read_b32 %15, %21 offset:60"
+            : F_ACC8(7), F_Y8(yb), F_T4, "+v"(w) : "v"(xs_n), "v"(wl_n));
+        xs = xs_n;
+        __builtin_amdgcn_sched_barrier(0);
+#undef F_GROUP
+#undef F_T4
+#undef F_Y8
+#undef F_ACC8
+#undef F_RD4B
+#undef F_RD4A
+#undef F_FMA4B
+#undef F_FMA4A
+        fetch_tabs(ps2, pw2);           // slot / weight of step s+2
+    }
+    // drain the reads issued for the step after the last (their registers stay reserved until here)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : "+v"(ya[0]), "+v"(ya[1]), "+v"(ya[2]), "+v"(ya[3]), "+v"(ya[4]), "+v"(ya[5]), "+v"(ya[6]),
+                   "+v"(ya[7]), "+v"(yb[0]), "+v"(yb[1]), "+v"(yb[2]), "+v"(yb[3]), "+v"(yb[4]), "+v"(yb[5]),
+                   "+v"(yb[6]), "+v"(yb[7]), "+v"(sl_n), "+v"(wl_n));
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue: lane = chain c, acc[i] = synthetics[c, t, n0 + i]
+    const bool live = (c < a.C);
+    const int nvalid = (int)min((int64_t)GS_NT, N - n0);
+    if (MODE == GF_STORE_SYN) {
+        if (live) {
+            double *o = a.out + (c * a.T + t) * N + n0;
+#pragma unroll
+            for (int i = 0; i < GS_NT; i++)
+                if (i < nvalid) o[i] = acc[i];
+        }
+        return;
+    }
+    __builtin_amdgcn_s_barrier();
+    if (tid < GS_NT) xbuf[tid] = (tid < nvalid) ? a.data[t * N + n0 + tid] : 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (MODE == GF_RESID_STORE) {
+        double *o = a.out + (c * a.T + t) * N + n0;
+#pragma unroll
+        for (int i0 = 0; i0 < GS_NT; i0 += 8) {
+#pragma unroll
+            for (int i = i0; i < i0 + 8; i++)
+                if (live && i < nvalid) o[i] = xbuf[i] - acc[i];  // seismic.py:1332
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        const double w = a.wscalar[t];
+        double q = 0.0;
+#pragma unroll
+        for (int i0 = 0; i0 < GS_NT; i0 += 8) {
+#pragma unroll
+            for (int i = i0; i < i0 + 8; i++)
+                if (i < nvalid) {
+                    const double tt = w * (xbuf[i] - acc[i]);
+                    q = fma(tt, tt, q);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (live) a.partial[(c * a.T + t) * a.ntile + tile] = q;
+    }
+}
+
+
 template <int WAVES, int NROW, int MODE>
 static void launch_shared_one(dim3 grid, size_t lds, hipStream_t s, const GsArgs &a)
 {
@@ -1237,17 +1618,26 @@ static void launch_shared_nrow(int nrow, int mode, dim3 grid, size_t lds, hipStr
 
 // (single-row interpolation only: with four rows per chain the consumers run out of registers and
 // hipcc spills the not-yet-landed results of the hidden table loads)
-static void launch_ws(int mode, dim3 grid, size_t lds, hipStream_t s, const GsArgs &a)
+static int launch_ws(int mode, dim3 grid, size_t lds, hipStream_t s, const GsArgs &a, bool f32)
 {
     void (*kern)(GsArgs);
-    if (a.nthint)
+    if (f32) {
+        if (a.nthint)
+            kern = mode == GF_STORE_SYN ? k_gfstack_ws32<GF_STORE_SYN, 3, 1>
+                   : mode == GF_RESID_SCALAR ? k_gfstack_ws32<GF_RESID_SCALAR, 3, 1> : k_gfstack_ws32<GF_RESID_STORE, 3, 1>;
+        else
+            kern = mode == GF_STORE_SYN ? k_gfstack_ws32<GF_STORE_SYN, 3, 0>
+                   : mode == GF_RESID_SCALAR ? k_gfstack_ws32<GF_RESID_SCALAR, 3, 0> : k_gfstack_ws32<GF_RESID_STORE, 3, 0>;
+    } else if (a.nthint) {
         kern = mode == GF_STORE_SYN ? k_gfstack_ws<1, GF_STORE_SYN, 3, 1>
                : mode == GF_RESID_SCALAR ? k_gfstack_ws<1, GF_RESID_SCALAR, 3, 1> : k_gfstack_ws<1, GF_RESID_STORE, 3, 1>;
-    else
+    } else {
         kern = mode == GF_STORE_SYN ? k_gfstack_ws<1, GF_STORE_SYN, 3, 0>
                : mode == GF_RESID_SCALAR ? k_gfstack_ws<1, GF_RESID_SCALAR, 3, 0> : k_gfstack_ws<1, GF_RESID_STORE, 3, 0>;
-    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    BA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, grid, dim3(768), lds, s, a);
+    return BEATAMD_OK;
 }
 
 // chains per group for a batch of C chains: the group size that minimises
@@ -1395,7 +1785,12 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
 
     GsArgs a;
     memset(&a, 0, sizeof(a));
-    for (int v = 0; v < k.nvar; v++) a.G[v] = k.libs[v]->g;
+    bool f32 = k.f32 && use_ws;
+    for (int v = 0; v < k.nvar; v++) {
+        a.G[v] = k.libs[v]->g;
+        a.G32[v] = k.libs[v]->g32;
+        f32 = f32 && a.G32[v] != nullptr;
+    }
     a.nvar = k.nvar; a.nrow = nrow;
     a.C = k.C; a.T = L.T; a.P = L.P; a.N = L.N;
     a.Ttab = Ttab; a.rows_per_target = L.P * L.D * L.S;
@@ -1477,8 +1872,12 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
             const char *e = getenv("BEATAMD_GS_NTHINT");
             a.nthint = e ? (atoi(e) != 0) : (GS_NTHINT_DEFAULT && ngroups == 1);
         }
-        if (a.ws) lds = (size_t)ucap * (a.nt + 1) * sizeof(double) * a.ws;
-        else if (a.dma) lds *= 2;
+        if (a.ws) {
+            lds = (size_t)ucap * (a.nt + 1) * (f32 ? sizeof(float) : sizeof(double)) * a.ws;
+            lds = std::max<size_t>(lds, 64 * sizeof(double));   // the epilogue's data tile
+        } else if (a.dma) {
+            lds *= 2;
+        }
     }
     {
         // chain groups of one (target, tile) on one XCD (several groups only)
@@ -1487,7 +1886,9 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         if (e && atoi(e) == 1 && a.dma) a.xcd_order = 1;
         if (a.xcd_order) nblocks = ((L.T * a.ntile + 7) / 8) * 8 * ngroups;
     }
-    if (a.ws)
+    if (a.ws && f32)
+        snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack_ws32<%d,%d,%d>", k.mode, a.ws, a.nthint);
+    else if (a.ws)
         snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack_ws<%d,%d,%d,%d>", nrow, k.mode, a.ws, a.nthint);
     else
         snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "%s<%d,%d,%d,%d,%d>",
@@ -1498,7 +1899,7 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     ctx->gs_cg = CG;
     {
         dim3 grid((unsigned)nblocks);
-        if (a.ws) launch_ws(k.mode, grid, lds, ctx->stream, a);
+        if (a.ws) BA_TRY(launch_ws(k.mode, grid, lds, ctx->stream, a, f32));
         else if (CG == 1024) launch_shared_nrow<16>(nrow, k.mode, grid, lds, ctx->stream, a);
         else if (CG == 512) launch_shared_nrow<8>(nrow, k.mode, grid, lds, ctx->stream, a);
         else if (CG == 256) launch_shared_nrow<4>(nrow, k.mode, grid, lds, ctx->stream, a);

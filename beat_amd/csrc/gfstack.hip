@@ -279,6 +279,26 @@ __global__ void __launch_bounds__(256) k_gfstack(GfArgs a)
     }
 }
 
+// float-storage copy of a library: g32 = (float)g and g itself rounded to the same values, so that
+// every kernel -- whichever copy it reads -- sees one library
+__global__ void __launch_bounds__(256) k_round_to_f32(double *g, float *g32, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float f = (float)g[i];
+        g32[i] = f;
+        g[i] = (double)f;
+    }
+}
+
+int launch_round_to_f32(beatamd_ctx *ctx, double *g, float *g32, int64_t n)
+{
+    if (n == 0) return BEATAMD_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 1 << 20);
+    hipLaunchKernelGGL(k_round_to_f32, dim3(grid), dim3(256), 0, ctx->stream, g, g32, n);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
 __global__ void __launch_bounds__(256) k_sum_tiles(const double *partial, int64_t n, int ntile,
                                                   double *quad)
 {

@@ -52,9 +52,12 @@ struct GfStackCall {
     const double *wscalar = nullptr;  // [T]     (mode 1)
     double *out = nullptr;            // [C,T,N] (modes 0,2)
     double *quad = nullptr;           // [C,T]   (mode 1) sum over tiles, fixed order
+    bool f32 = false;                 // rows from the libraries' float copies where the kernel supports it
 };
 int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &call);
 int launch_sum_tiles(beatamd_ctx *ctx, const double *partial, int64_t n, int ntile, double *quad);
+// g[i] = (double)(float)g[i]; g32[i] = (float)g[i]  (float-storage copy of a GF library)
+int launch_round_to_f32(beatamd_ctx *ctx, double *g, float *g32, int64_t n);
 // gfshared.hip: chain-shared variant (distinct rows staged once per chain group)
 bool gfstack_shared_applicable(const GfStackCall &call, int *cg, int *ucap);
 int gfstack_shared_candidates(const GfStackCall &call, int *cgs, int *ucaps);

@@ -207,6 +207,14 @@ class SeismicGFLibrary(GFLibrary):
                 ctx.seis_gflib_upload(self.lib_id, flat[o:o + step], o)
         self.lib_id_dirty = False
 
+    def store_f32(self, ctx=None):
+        """Keep a float copy of the library in HBM for the kernels that can read it (half the row
+        traffic) and round the float64 storage to the same values (every kernel then sees one
+        library; values change by up to 6e-8 relative).  Off unless called; see
+        ``LogpForwFunc.set_f32``."""
+        self.init_optimization(ctx)
+        self._ctx.seis_gflib_store_f32(self.lib_id)
+
     def adopt_device_tensor(self, tensor):
         """Use an existing torch CUDA float64 tensor of shape ``dimensions`` as the library
         (no host copy; e.g. libraries generated or loaded directly into HBM)."""

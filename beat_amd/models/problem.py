@@ -354,6 +354,16 @@ class LogpForwFunc(object):
         return self.ctx.ffi_mstep_batch(self.model_id, Q0, L0, factor, kind, df, seed, step, first_chain,
                                         scaling, lower, upper, beta, accepted, accepted_sum, n_accepted)
 
+    def set_f32(self, on=True):
+        """read the float copies of the seismic libraries (``SeismicGFLibrary.store_f32``, made here if
+        missing) where a kernel exists for them: half the row traffic of the 512-chain nearest-neighbour
+        kernel, same float64 accumulation; the float64 storage holds the same rounded values"""
+        for i, wm in enumerate(self.problem.wavemaps):
+            if on:
+                for gf in wm.gfs.values():
+                    gf.store_f32(self.ctx)
+            self.ctx.ffi_model_set_f32(self.model_id, i, on)
+
     def get_shared(self):
         """the model's shared storage under the reference's access pattern (name / get_value /
         set_value; sampler/base.py:274-282, 541-555 uses it to share memory between workers):

@@ -179,7 +179,7 @@ def main():
                     help="skip the labelled legs of the other configurations: multilinear (the reference's "
                          "default interpolation), dense Toeplitz covariance, pre-whitened library, parallel "
                          "tempering, geometry mode")
-    ap.add_argument("--variant-legs", default="multilinear,toeplitz,pt,prewhitened,geometry",
+    ap.add_argument("--variant-legs", default="multilinear,toeplitz,pt,prewhitened,geometry,fp32",
                     help="which of the labelled configuration legs to run (comma separated)")
     ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "r3_bench_c512_nn_gfstack_ws_summary.json"),
                     help="rocprofv3 PMC summary (tools/run_profile.sh + tools/summarize_rocpd.py) of THIS "
@@ -623,6 +623,26 @@ def main():
             except (RuntimeError, MemoryError) as exc:   # not enough HBM for the copy beside other allocations
                 out["prewhitened_leg"] = {"skipped": str(exc)[:200]}
             torch.cuda.empty_cache()
+        if "fp32" in legs:
+            # float-storage library (SURVEY 8(f) row 2 "optional fp32 layout"): float copy of the library, the
+            # float64 storage rounded to the same values (LAST leg on the shared library for that reason); rows
+            # move as 256-byte segments, operands are widened before the f64 FMA, accumulation stays f64
+            f.set_f32(True)
+            torch.cuda.synchronize()
+            leg = run_leg(spec, f, B, Kl, 2, seed_offset=1000)
+            ms32, n32 = leg["times"]["gfstack"]
+            need32 = main_leg["stats"]["row_bytes"] / 2.0
+            out["fp32_storage_leg"] = {
+                "storage": "library rows as float32 (31.5 GB copy; values rounded by <= 6e-8 relative), f64 accumulation, "
+                           "weights and likelihood; NOT the precision of `value`",
+                "chains": B, "steps": Kl, "chain_steps_per_s": B * Kl / leg["dt"], "ms_per_step": leg["dt"] / Kl * 1e3,
+                "kernel": leg["kernel"], "gfstack_avg_launch_ms": ms32 / max(n32, 1),
+                "hbm_required_bytes_per_launch": need32,
+                "hbm_frac_required_bytes": need32 / (ms32 / max(n32, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "half the bytes in the same time as the f64 kernel: the loader/consumer kernel is bound by the "
+                        "number of row segments it moves per step (LDS-DMA requests and their gather), not by HBM "
+                        "bytes -- float storage halves the library's footprint, not the step time (DESIGN 3.1b)"}
+            f.set_f32(False)
         if "geometry" in legs:
             # geometry mode, BASELINE configs[1]: rectangular source, 2 SAR scenes (214 + 205 points, full
             # covariances), 1024 SMC chains; synthetic observations; parity with BEAT unpinned (pyrocko absent)

@@ -42,7 +42,7 @@ extern "C" {
 /* ABI revision: bumped whenever an entry point changes its signature or an error code is added
  * (1.1: beatamd_weights_update gained kind/count in round 2; BEATAMD_EBADCOV).  beat_amd/_lib.py
  * refuses a library whose revision differs from the header it was written against. */
-#define BEATAMD_VERSION 111
+#define BEATAMD_VERSION 112
 
 #define BEATAMD_NEAREST_NEIGHBOR 0 /* interpolation="nearest_neighbor" */
 #define BEATAMD_MULTILINEAR 1      /* interpolation="multilinear"      */
@@ -115,6 +115,16 @@ int beatamd_seis_gflib_upload(beatamd_ctx *ctx, int32_t lib_id, const double *sr
                               int64_t offset, int64_t count);
 /* use a caller-owned device allocation as the library storage (no copy) */
 int beatamd_seis_gflib_adopt(beatamd_ctx *ctx, int32_t lib_id, double *device_ptr);
+/* float storage (SURVEY 8(f) row 2 "optional fp32 layout"; the reference keeps its libraries in
+ * float64, beat/ffi/base.py:381-385 tconfig.floatX aside): makes a float copy of the library in HBM
+ * and rounds the float64 storage to the same float-representable values, so that every kernel --
+ * whichever copy it reads -- works on ONE library.  Accumulation, weights and likelihoods stay
+ * float64.  Changes the library's values by up to 6e-8 relative: a choice of the caller, off by
+ * default.  beatamd_ffi_model_set_f32 lets a wavemap of a model read the float copies where a
+ * kernel exists for them (the 512-chain-group nearest-neighbour kernel); elsewhere the (equal)
+ * float64 values are read. */
+int beatamd_seis_gflib_store_f32(beatamd_ctx *ctx, int32_t lib_id);
+int beatamd_ffi_model_set_f32(beatamd_ctx *ctx, int32_t model_id, int32_t wavemap_index, int32_t on);
 int beatamd_seis_gflib_device_ptr(beatamd_ctx *ctx, int32_t lib_id, double **device_ptr);
 int beatamd_seis_gflib_destroy(beatamd_ctx *ctx, int32_t lib_id);
 

@@ -803,3 +803,44 @@ def test_covariance_class_and_mvn_adaptor(ctx):
     outb = multivariate_normal_chol(dsets, weights, {"h_any_P_T": np.array([[0.0, 0.3]] * 4)},
                                     np.stack([res] * 4), hp_specific=True)
     assert outb.shape == (4, 2) and np.allclose(outb[:, 0], out[0])
+
+
+@pytest.mark.parametrize("covariance,N", [("scalar", 128), ("scalar", 100), ("toeplitz", 192)])
+@pytest.mark.parametrize("C", [512, 700, 1100])
+def test_float_storage_kernel_equals_the_f64_kernels_on_the_rounded_library(ctx, monkeypatch, covariance, N, C):
+    """SURVEY 8(f) row 2 "optional fp32 layout": ``LogpForwFunc.set_f32`` makes float copies of the
+    libraries (rounding the float64 storage to the same values) and the 512-chain-group kernel reads
+    those (k_gfstack_ws32: 256-byte row segments, operands widened before the f64 FMA).  Because both
+    copies hold the same numbers the result equals -- bit for bit -- the f64 loader/consumer kernel on the
+    rounded library, the streaming kernel to 1e-12 and the oracle run on float-rounded G at 1e-9."""
+    from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
+    from oracle import problem_oracle
+    spec = SyntheticSpec((4,), (5,), (1.0,), T=3, N=N, D=3, S=25, covariance=covariance)
+    prob, host = build_problem(spec)
+    f = prob.compile(ctx)
+    Q = draw_population(spec, host["layout"], host["lower"], host["upper"], C)
+    monkeypatch.setenv("BEATAMD_GS_CG", "512")    # (tiny problems may measure a smaller group as faster)
+    before = f.batch(Q)
+    f.set_f32(True)
+    L32 = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack_ws32<"), ctx.last_kernel()
+    assert not np.array_equal(L32, before)      # the library was rounded: 1e-8-level changes
+    np.testing.assert_allclose(L32[:, -1], before[:, -1], rtol=2e-6)
+    f.set_f32(False)
+    L64 = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack_ws<"), ctx.last_kernel()
+    assert np.array_equal(L32, L64)
+    monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
+    Ls = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack<"), ctx.last_kernel()
+    np.testing.assert_allclose(Ls, L32, rtol=1e-12)     # (other tile sums of the misfit: not bitwise)
+    monkeypatch.delenv("BEATAMD_GF_KERNEL")
+    f.set_f32(True)
+    monkeypatch.delenv("BEATAMD_GS_CG")
+    sub = f.batch(np.ascontiguousarray(Q[100:164]))      # a small batch: no float kernel, the equal f64 values
+    assert not ctx.last_kernel().startswith("k_gfstack_ws32") and np.array_equal(sub, L32[100:164])
+    host32 = dict(host)
+    host32["Gs"] = [g.astype(np.float32).astype(np.float64) for g in host["Gs"]]
+    for c in (0, C // 2, C - 1):
+        ref, _ = problem_oracle.forward(host32, Q[c])
+        np.testing.assert_allclose(L32[c], ref, rtol=1e-9)
