@@ -484,6 +484,26 @@ __device__ __forceinline__ void lds_rd8_b64(double (&x)[8], uint32_t addr, int t
         : "v"(addr), "s"(tok), "n"(OFF));
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// four ds_read_b64 of float pairs (8 samples of a float row)
+template <int OFF>
+__device__ __forceinline__ void lds_rd4_f2(v2f (&x)[4], uint32_t addr, int tok)
+{
+    asm("ds_read_b64 %0, %4 offset:%c6\n\t"
+        "ds_read_b64 %1, %4 offset:%c6+8\n\t"
+        "ds_read_b64 %2, %4 offset:%c6+16\n\t"
+        "ds_read_b64 %3, %4 offset:%c6+24"
+        : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3])
+        : "v"(addr), "s"(tok), "n"(OFF));
+}
+
+template <int NLEFT>
+__device__ __forceinline__ void lds_wait4_f2(v2f (&x)[4])
+{
+    asm("s_waitcnt lgkmcnt(%c4)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "n"(NLEFT));
+}
+
 template <int OFF>
 __device__ __forceinline__ void lds_rd8_b32(float (&x)[8], uint32_t addr, int tok)
 {
@@ -1218,8 +1238,8 @@ k_gfstack_ws(GsArgs a)
 
 // k_gfstack_ws32: k_gfstack_ws on the float copy of the library (beatamd_seis_gflib_store_f32): a row
 // segment of a 64-sample tile is 256 bytes -- one full-wave global_load_lds_dword --, the LDS rows hold
-// floats (pitch 65 dwords: conflict-free ds_read_b32 gather), every operand is widened by v_cvt_f64_f32 in
-// front of its FMA; accumulation, weights and epilogues stay f64.  The f64 library holds the same
+// floats (pitch 66 dwords = 33 qwords: conflict-free ds_read_b64 gather of float PAIRS, half the LDS
+// instructions of the f64 kernel), every operand is widened by v_cvt_f64_f32 in front of its FMA; accumulation, weights and epilogues stay f64.  The f64 library holds the same
 // (float-representable) values, so the result is bit for bit what the f64 kernels give.
 template <int MODE, int NB, int NTH>
 __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3)))
@@ -1227,7 +1247,7 @@ k_gfstack_ws32(GsArgs a)
 {
     constexpr int CW = 8, LW = 4;
     constexpr int GS_NT = 64;
-    constexpr int GS_PITCH = GS_NT + 1;   // dwords: ds_read_b32 layout
+    constexpr int GS_PITCH = GS_NT + 2;   // dwords: 33 qwords, the conflict-free ds_read_b64 layout of float pairs
     constexpr int KPRE = 16;              // list entries per loader fetched ahead (64 rows per step)
     extern __shared__ __attribute__((aligned(16))) double xbuf[];  // float [3][slots][GS_PITCH] (+ the epilogue's data tile)
     constexpr int CG = CW * 64;
@@ -1424,12 +1444,12 @@ k_gfstack_ws32(GsArgs a)
         asm("v_lshlrev_b32 %1, 2, %2\n\t"
             "global_load_dwordx2 %0, %1, %3" : "=v"(wl_n), "=&v"(voff_w) : "v"(voff_s), "s"(pw));
     };
-    // xs = LDS byte address of the lane's row = base + slot * (GS_PITCH * 4), GS_PITCH = 65
+    // xs = LDS byte address of the lane's row = base + slot * (GS_PITCH * 4), GS_PITCH = 66 dwords = 33 qwords
     auto row_address = [&](uint32_t base) {
         uint32_t x;
         asm("s_waitcnt vmcnt(0)\n\t"
-            "v_lshl_add_u32 %0, %1, 6, %1\n\t"
-            "v_lshl_add_u32 %0, %0, 2, %2" : "=&v"(x) : "v"(sl_n), "s"(base), "v"(wl_n));
+            "v_lshl_add_u32 %0, %1, 5, %1\n\t"
+            "v_lshl_add_u32 %0, %0, 3, %2" : "=&v"(x) : "v"(sl_n), "s"(base), "v"(wl_n));
         return x;
     };
     auto landed_weight = [&](uint32_t after) {   // `after`: the row address, i.e. behind the wait
@@ -1437,15 +1457,18 @@ k_gfstack_ws32(GsArgs a)
         asm("v_mov_b64 %0, %1" : "=v"(x) : "v"(wl_n), "v"(after));
         return x;
     };
-    static_assert(GS_PITCH == 65, "row_address multiplies by 65");
+    static_assert(GS_PITCH == 66, "row_address multiplies by 33 qwords");
     static_assert(GS_NT == 64, "the read schedule below is written for 64-sample tiles");
-    float ya[8], yb[8];
+    // The gather of a step is 8 groups of 4 ds_read_b64 (two floats each) + 8 (widen + FMA), two groups
+    // in flight: HALF the LDS instructions of the f64 kernel per step -- its consumers are bound by the
+    // LDS instruction rate (1081 of ~1300 cycles per step, profiles/r2_variants.md), not by LDS bytes.
+    // Pipelined across the step boundary like k_gfstack_ws; the FMAs are plain fma() between wait
+    // statements that name the landing registers.
+    v2f ya[4], yb[4];
     int p1 = 0, iv1 = 0;          // position of the step whose slot/weight are fetched next
     advance(p1, iv1);
     int gbuf = 0;                 // row buffer of the step being gathered
     const int ring = NB * bufsz;
-    // The gather of a step is 8 groups of 8 ds_read_b32 + 8 (widen + FMA), two groups in flight,
-    // pipelined across the step boundary exactly like k_gfstack_ws.
     double w;
     uint32_t xs;
     fetch_tabs(tab_slot(0), tab_w(0, 0));
@@ -1454,11 +1477,23 @@ k_gfstack_ws32(GsArgs a)
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();     // rows of step 0 visible
     __builtin_amdgcn_sched_barrier(0);
-    lds_rd8_b32<0>(ya, xs, -1);
-    lds_rd8_b32<32>(yb, xs, -1);
+    lds_rd4_f2<0>(ya, xs, -1);
+    lds_rd4_f2<32>(yb, xs, -1);
     __builtin_amdgcn_sched_barrier(0);
     fetch_tabs(tab_slot(p1), tab_w(p1, iv1));
     advance(p1, iv1);
+#define F2_FMA(G, Y)                                                          \
+    _Pragma("unroll") for (int q = 0; q < 4; q++) {                           \
+        acc[(G) * 8 + 2 * q] = fma((double)Y[q].x, w, acc[(G) * 8 + 2 * q]);   \
+        acc[(G) * 8 + 2 * q + 1] = fma((double)Y[q].y, w, acc[(G) * 8 + 2 * q + 1]); \
+    }
+#define F2_GROUP(G, Y, OFFNEXT)              \
+    lds_wait4_f2<4>(Y);                      \
+    __builtin_amdgcn_sched_barrier(0);       \
+    F2_FMA(G, Y)                             \
+    __builtin_amdgcn_sched_barrier(0);       \
+    lds_rd4_f2<OFFNEXT>(Y, xs, s);           \
+    __builtin_amdgcn_sched_barrier(0);
 #pragma clang loop unroll(disable)
     for (int s = 0; s < nsteps; s++) {
         int gnext = gbuf + bufsz;
@@ -1466,75 +1501,40 @@ k_gfstack_ws32(GsArgs a)
         const char *const ps2 = tab_slot(p1), *const pw2 = tab_w(p1, iv1);   // tables of step s+2
         advance(p1, iv1);
         __builtin_amdgcn_sched_barrier(0);
-        // operands: %0-%7 accumulators, %8-%15 the group's floats, %16-%19 widened temporaries, %20 weight,
-        // %21 row address
-#define F_FMA4A \
-    "v_cvt_f64_f32 %16, %8\n\tv_fmac_f64 %0, %16, %20\n\tv_cvt_f64_f32 %17, %9\n\tv_fmac_f64 %1, %17, %20\n\t" \
-    "v_cvt_f64_f32 %18, %10\n\tv_fmac_f64 %2, %18, %20\n\tv_cvt_f64_f32 %19, %11\n\tv_fmac_f64 %3, %19, %20\n\t"
-#define F_FMA4B \
-    "v_cvt_f64_f32 %16, %12\n\tv_fmac_f64 %4, %16, %20\n\tv_cvt_f64_f32 %17, %13\n\tv_fmac_f64 %5, %17, %20\n\t" \
-    "v_cvt_f64_f32 %18, %14\n\tv_fmac_f64 %6, %18, %20\n\tv_cvt_f64_f32 %19, %15\n\tv_fmac_f64 %7, %19, %20\n\t"
-#define F_RD4A(OFF) \
-    "ds_read_b32 %8, %21 offset:" #OFF "\n\tds_read_b32 %9, %21 offset:" #OFF "+4\n\t" \
-    "ds_read_b32 %10, %21 offset:" #OFF "+8\n\tds_read_b32 %11, %21 offset:" #OFF "+12\n\t"
-#define F_RD4B(OFF) \
-    "ds_read_b32 %12, %21 offset:" #OFF "+16\n\tds_read_b32 %13, %21 offset:" #OFF "+20\n\t" \
-    "ds_read_b32 %14, %21 offset:" #OFF "+24\n\tds_read_b32 %15, %21 offset:" #OFF "+28"
-#define F_ACC8(G) \
-    "+v"(acc[G * 8]), "+v"(acc[G * 8 + 1]), "+v"(acc[G * 8 + 2]), "+v"(acc[G * 8 + 3]), "+v"(acc[G * 8 + 4]), \
-        "+v"(acc[G * 8 + 5]), "+v"(acc[G * 8 + 6]), "+v"(acc[G * 8 + 7])
-#define F_Y8(Y) "+v"(Y[0]), "+v"(Y[1]), "+v"(Y[2]), "+v"(Y[3]), "+v"(Y[4]), "+v"(Y[5]), "+v"(Y[6]), "+v"(Y[7])
-#define F_T4 "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-#define F_GROUP(G, Y, OFFNEXT) \
-    asm("s_waitcnt lgkmcnt(12)\n\t" F_FMA4A F_RD4A(OFFNEXT) "s_waitcnt lgkmcnt(12)\n\t" F_FMA4B F_RD4B(OFFNEXT) \
-        : F_ACC8(G), F_Y8(Y), F_T4 : "v"(w), "v"(xs))
-        double t0, t1, t2, t3;
-        F_GROUP(0, ya, 64);
-        F_GROUP(1, yb, 96);
-        F_GROUP(2, ya, 128);
-        F_GROUP(3, yb, 160);
-        F_GROUP(4, ya, 192);
-        F_GROUP(5, yb, 224);
-        __builtin_amdgcn_sched_barrier(0);
+        F2_GROUP(0, ya, 64)
+        F2_GROUP(1, yb, 96)
+        F2_GROUP(2, ya, 128)
+        F2_GROUP(3, yb, 160)
+        F2_GROUP(4, ya, 192)
+        F2_GROUP(5, yb, 224)
         // group 6: every read of this step is back once both groups in flight have landed
-        // (yb is named so that group 7 stays behind this wait)
-        asm("s_waitcnt lgkmcnt(0)\n\t" F_FMA4A F_FMA4B
-            : F_ACC8(6), F_Y8(ya), F_T4 : "v"(w), "v"(xs), "v"(yb[0]), "v"(yb[1]), "v"(yb[2]), "v"(yb[3]),
-              "v"(yb[4]), "v"(yb[5]), "v"(yb[6]), "v"(yb[7]));
+        lds_wait4_f2<0>(ya);
+        lds_wait4_f2<0>(yb);
+        __builtin_amdgcn_sched_barrier(0);
+        F2_FMA(6, ya)
         __builtin_amdgcn_sched_barrier(0);
         gbuf = gnext;
         const uint32_t xs_n = row_address(lds0 + (uint32_t)(gbuf * 4));   // slot / weight of step s+1 have landed
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();   // rows of step s+1 visible; this wavefront is done with buffer s
         __builtin_amdgcn_sched_barrier(0);
-        lds_rd8_b32<0>(ya, xs_n, s);    // first group of step s+1 (after the last step: unused rows)
+        lds_rd4_f2<0>(ya, xs_n, s);     // first group of step s+1 (after the last step: unused rows)
         __builtin_amdgcn_sched_barrier(0);
         // group 7 with the weight of step s, then the weight of step s+1 and that step's second group
-        // (%20 = weight, tied; %21 = next row address; %22 = landed weight of the next step)
-        asm(F_FMA4A F_FMA4B
-            "v_mov_b64 %20, %22\n\t"
-            "ds_read_b32 %8, %21 offset:32\n\tds_read_b32 %9, %21 offset:36\n\t"
-            "ds_read_b32 %10, %21 offset:40\n\tds_read_b32 %11, %21 offset:44\n\t"
-            "ds_read_b32 %12, %21 offset:48\n\tds_read_b32 %13, %21 offset:52\n\t"
-            "ds_read_b32 %14, %21 offset:56\n\tds_read_b32 %15, %21 offset:60"
-            : F_ACC8(7), F_Y8(yb), F_T4, "+v"(w) : "v"(xs_n), "v"(wl_n));
+        F2_FMA(7, yb)
+        __builtin_amdgcn_sched_barrier(0);
+        w = landed_weight(xs_n);
+        lds_rd4_f2<32>(yb, xs_n, s);
         xs = xs_n;
         __builtin_amdgcn_sched_barrier(0);
-#undef F_GROUP
-#undef F_T4
-#undef F_Y8
-#undef F_ACC8
-#undef F_RD4B
-#undef F_RD4A
-#undef F_FMA4B
-#undef F_FMA4A
         fetch_tabs(ps2, pw2);           // slot / weight of step s+2
     }
+#undef F2_GROUP
+#undef F2_FMA
     // drain the reads issued for the step after the last (their registers stay reserved until here)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
-                 : "+v"(ya[0]), "+v"(ya[1]), "+v"(ya[2]), "+v"(ya[3]), "+v"(ya[4]), "+v"(ya[5]), "+v"(ya[6]),
-                   "+v"(ya[7]), "+v"(yb[0]), "+v"(yb[1]), "+v"(yb[2]), "+v"(yb[3]), "+v"(yb[4]), "+v"(yb[5]),
-                   "+v"(yb[6]), "+v"(yb[7]), "+v"(sl_n), "+v"(wl_n));
+                 : "+v"(ya[0]), "+v"(ya[1]), "+v"(ya[2]), "+v"(ya[3]), "+v"(yb[0]), "+v"(yb[1]), "+v"(yb[2]),
+                   "+v"(yb[3]), "+v"(sl_n), "+v"(wl_n));
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- epilogue: lane = chain c, acc[i] = synthetics[c, t, n0 + i]
@@ -1873,7 +1873,7 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
             a.nthint = e ? (atoi(e) != 0) : (GS_NTHINT_DEFAULT && ngroups == 1);
         }
         if (a.ws) {
-            lds = (size_t)ucap * (a.nt + 1) * (f32 ? sizeof(float) : sizeof(double)) * a.ws;
+            lds = f32 ? (size_t)ucap * (a.nt + 2) * sizeof(float) * a.ws : (size_t)ucap * (a.nt + 1) * sizeof(double) * a.ws;
             lds = std::max<size_t>(lds, 64 * sizeof(double));   // the epilogue's data tile
         } else if (a.dma) {
             lds *= 2;

@@ -639,9 +639,10 @@ def main():
                 "kernel": leg["kernel"], "gfstack_avg_launch_ms": ms32 / max(n32, 1),
                 "hbm_required_bytes_per_launch": need32,
                 "hbm_frac_required_bytes": need32 / (ms32 / max(n32, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "note": "half the bytes in the same time as the f64 kernel: the loader/consumer kernel is bound by the "
-                        "number of row segments it moves per step (LDS-DMA requests and their gather), not by HBM "
-                        "bytes -- float storage halves the library's footprint, not the step time (DESIGN 3.1b)"}
+                "note": "float pairs gathered by ds_read_b64: half the LDS instructions of the f64 kernel per step; half "
+                        "the BYTES alone (same gather, ds_read_b32) ran in the f64 kernel's time -- the loader/consumer "
+                        "kernel is bound by its LDS-gather and row-request instruction counts, not by HBM bytes "
+                        "(DESIGN 3.1b)"}
             f.set_f32(False)
         if "geometry" in legs:
             # geometry mode, BASELINE configs[1]: rectangular source, 2 SAR scenes (214 + 205 points, full
