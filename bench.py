@@ -454,6 +454,9 @@ def main():
                        and not env_knobs)
         if default_cfg:
             attach_traffic(roof, args.pmc_summary)
+        roof["note"] = ("`bound` names the largest of the fractions; the float-storage leg (half the bytes, same gather: "
+                        "same time; half the LDS gather instructions: -9 %) shows the kernel is limited by its LDS-gather "
+                        "and row-request instruction counts, not by HBM bandwidth itself (DESIGN 3.1b)")
 
     # ---- reuse-free streaming leg: k_gfstack in (chain, target, tile) order, every chain's rows
     # streamed from HBM -- the roofline of SURVEY 8(d)'s algorithmic bytes, driver-observed
