@@ -486,20 +486,29 @@ __device__ __forceinline__ void lds_rd8_b64(double (&x)[8], uint32_t addr, int t
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// four ds_read_b64 of float pairs (8 samples of a float row)
-template <int OFF>
-__device__ __forceinline__ void lds_rd4_f2(v2f (&x)[4], uint32_t addr, int tok)
+// four pair reads (8 samples of a row): float pairs by ds_read_b64 (SCALE 1), double pairs by ds_read_b128
+// (SCALE 2: the offsets double)
+template <int SCALE, int OFF, typename PAIR>
+__device__ __forceinline__ void lds_rd4_pair(PAIR (&x)[4], uint32_t addr, int tok)
 {
-    asm("ds_read_b64 %0, %4 offset:%c6\n\t"
-        "ds_read_b64 %1, %4 offset:%c6+8\n\t"
-        "ds_read_b64 %2, %4 offset:%c6+16\n\t"
-        "ds_read_b64 %3, %4 offset:%c6+24"
-        : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3])
-        : "v"(addr), "s"(tok), "n"(OFF));
+    if constexpr (SCALE == 1)
+        asm("ds_read_b64 %0, %4 offset:%c6\n\t"
+            "ds_read_b64 %1, %4 offset:%c6+8\n\t"
+            "ds_read_b64 %2, %4 offset:%c6+16\n\t"
+            "ds_read_b64 %3, %4 offset:%c6+24"
+            : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3])
+            : "v"(addr), "s"(tok), "n"(OFF));
+    else
+        asm("ds_read_b128 %0, %4 offset:%c6\n\t"
+            "ds_read_b128 %1, %4 offset:%c6+16\n\t"
+            "ds_read_b128 %2, %4 offset:%c6+32\n\t"
+            "ds_read_b128 %3, %4 offset:%c6+48"
+            : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3])
+            : "v"(addr), "s"(tok), "n"(2 * OFF));
 }
 
-template <int NLEFT>
-__device__ __forceinline__ void lds_wait4_f2(v2f (&x)[4])
+template <int NLEFT, typename PAIR>
+__device__ __forceinline__ void lds_wait4_pair(PAIR (&x)[4])
 {
     asm("s_waitcnt lgkmcnt(%c4)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "n"(NLEFT));
 }
@@ -1241,13 +1250,18 @@ k_gfstack_ws(GsArgs a)
 // floats (pitch 66 dwords = 33 qwords: conflict-free ds_read_b64 gather of float PAIRS, half the LDS
 // instructions of the f64 kernel), every operand is widened by v_cvt_f64_f32 in front of its FMA; accumulation, weights and epilogues stay f64.  The f64 library holds the same
 // (float-representable) values, so the result is bit for bit what the f64 kernels give.
-template <int MODE, int NB, int NTH>
+// F32 = 0: the same pair gather on the float64 library (A/B: BEATAMD_GS_PAIR=1): double PAIRS by
+// ds_read_b128 at a pitch of 66 doubles = 33 x 16 bytes.
+template <int F32, int MODE, int NB, int NTH>
 __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3)))
-k_gfstack_ws32(GsArgs a)
+k_gfstack_wsp(GsArgs a)
 {
     constexpr int CW = 8, LW = 4;
     constexpr int GS_NT = 64;
-    constexpr int GS_PITCH = GS_NT + 2;   // dwords: 33 qwords, the conflict-free ds_read_b64 layout of float pairs
+    constexpr int GS_PITCH = GS_NT + 2;   // elements: 33 pairs, the conflict-free layout of the pair gather
+    constexpr int ES = F32 ? 4 : 8;       // bytes per element
+    typedef typename std::conditional<F32 != 0, float, double>::type elem_t;
+    typedef typename std::conditional<F32 != 0, v2f, v2d>::type pair_t;
     constexpr int KPRE = 16;              // list entries per loader fetched ahead (64 rows per step)
     extern __shared__ __attribute__((aligned(16))) double xbuf[];  // float [3][slots][GS_PITCH] (+ the epilogue's data tile)
     constexpr int CG = CW * 64;
@@ -1285,25 +1299,35 @@ k_gfstack_ws32(GsArgs a)
     if (wave >= CW) {
         // ==================================== loader ====================================
         const int lw = wave - CW;
-        const bool dma_lane = (n0 + lane < N);
-        const uint32_t voff = (uint32_t)((n0 + lane) * 4);          // byte offset inside a row
-        const uint32_t rowbytes = (uint32_t)(N * 4);
+        const bool dma_lane = F32 ? (n0 + lane < N) : ((lane < 32) && (n0 + lane * 2 < N));
+        const uint32_t voff = F32 ? (uint32_t)((n0 + lane) * 4) : (uint32_t)((n0 + lane * 2) * 8);   // byte offset inside a row
+        const uint32_t rowbytes = (uint32_t)(N * ES);
         uint32_t keep = 0;
-        auto dma_row = [&](const float *Gv, uint32_t r, uint32_t slotidx, int boff, uint32_t &tk) {
+        auto dma_row = [&](const elem_t *Gv, uint32_t r, uint32_t slotidx, int boff, uint32_t &tk) {
             const uint64_t off = (uint64_t)r * (uint64_t)rowbytes;
             const char *rowp = reinterpret_cast<const char *>(Gv) + off;
-            const uint32_t dst = lds0 + (uint32_t)(boff * 4) + slotidx * (uint32_t)(GS_PITCH * 4);
+            const uint32_t dst = lds0 + (uint32_t)(boff * ES) + slotidx * (uint32_t)(GS_PITCH * ES);
             // NTH: non-temporal requests -- a row segment is read by this CU once and by no other
             // workgroup when the batch is a single chain group (several groups share rows through L2)
-            if (NTH)
+            if (F32 && NTH)
                 asm("s_mov_b32 m0, %3\n\t"
                     "s_nop 0\n\t"
                     "global_load_lds_dword %1, %2 nt"
                     : "+s"(tk) : "v"(voff), "s"(rowp), "s"(dst));
-            else
+            else if (F32)
                 asm("s_mov_b32 m0, %3\n\t"
                     "s_nop 0\n\t"
                     "global_load_lds_dword %1, %2"
+                    : "+s"(tk) : "v"(voff), "s"(rowp), "s"(dst));
+            else if (NTH)
+                asm("s_mov_b32 m0, %3\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %1, %2 nt"
+                    : "+s"(tk) : "v"(voff), "s"(rowp), "s"(dst));
+            else
+                asm("s_mov_b32 m0, %3\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %1, %2"
                     : "+s"(tk) : "v"(voff), "s"(rowp), "s"(dst));
         };
         const int kstr = a.ustride / LW;
@@ -1312,7 +1336,7 @@ k_gfstack_ws32(GsArgs a)
         const uint32_t ent_step = (uint32_t)(a.ustride * 8);
         int U_a;
         uint32_t rid[KPRE], rsl[KPRE];
-        const float *G_a = nullptr;
+        const elem_t *G_a = nullptr;
         auto fetch_ids = [&](int p, int iv) {
             // constant address space: the tables are written by k_gf_group_tables before this
             // launch, never here, and must come in through scalar loads -- a vector load would be
@@ -1329,7 +1353,7 @@ k_gfstack_ws32(GsArgs a)
                 rid[k] = e0[2 * k];      rsl[k] = e0[2 * k + 1];
                 rid[8 + k] = e1[2 * k];  rsl[8 + k] = e1[2 * k + 1];
             }
-            G_a = a.G32[iv] + tbase;
+            if constexpr (F32 != 0) G_a = a.G32[iv] + tbase; else G_a = a.G[iv] + tbase;
         };
         auto dma_count = [&](int U) { return U > lw ? (U - lw + LW - 1) / LW : 0; };
         // rows lw, lw + LW, ... of the list whose entries are in rid / rsl -> buffer at boff
@@ -1444,12 +1468,12 @@ k_gfstack_ws32(GsArgs a)
         asm("v_lshlrev_b32 %1, 2, %2\n\t"
             "global_load_dwordx2 %0, %1, %3" : "=v"(wl_n), "=&v"(voff_w) : "v"(voff_s), "s"(pw));
     };
-    // xs = LDS byte address of the lane's row = base + slot * (GS_PITCH * 4), GS_PITCH = 66 dwords = 33 qwords
+    // xs = LDS byte address of the lane's row = base + slot * 33 pairs (8 or 16 bytes each)
     auto row_address = [&](uint32_t base) {
         uint32_t x;
         asm("s_waitcnt vmcnt(0)\n\t"
             "v_lshl_add_u32 %0, %1, 5, %1\n\t"
-            "v_lshl_add_u32 %0, %0, 3, %2" : "=&v"(x) : "v"(sl_n), "s"(base), "v"(wl_n));
+            "v_lshl_add_u32 %0, %0, %c4, %2" : "=&v"(x) : "v"(sl_n), "s"(base), "v"(wl_n), "n"(F32 ? 3 : 4));
         return x;
     };
     auto landed_weight = [&](uint32_t after) {   // `after`: the row address, i.e. behind the wait
@@ -1464,7 +1488,7 @@ k_gfstack_ws32(GsArgs a)
     // LDS instruction rate (1081 of ~1300 cycles per step, profiles/r2_variants.md), not by LDS bytes.
     // Pipelined across the step boundary like k_gfstack_ws; the FMAs are plain fma() between wait
     // statements that name the landing registers.
-    v2f ya[4], yb[4];
+    pair_t ya[4], yb[4];
     int p1 = 0, iv1 = 0;          // position of the step whose slot/weight are fetched next
     advance(p1, iv1);
     int gbuf = 0;                 // row buffer of the step being gathered
@@ -1477,8 +1501,8 @@ k_gfstack_ws32(GsArgs a)
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();     // rows of step 0 visible
     __builtin_amdgcn_sched_barrier(0);
-    lds_rd4_f2<0>(ya, xs, -1);
-    lds_rd4_f2<32>(yb, xs, -1);
+    lds_rd4_pair<F32 ? 1 : 2, 0>(ya, xs, -1);
+    lds_rd4_pair<F32 ? 1 : 2, 32>(yb, xs, -1);
     __builtin_amdgcn_sched_barrier(0);
     fetch_tabs(tab_slot(p1), tab_w(p1, iv1));
     advance(p1, iv1);
@@ -1488,11 +1512,11 @@ k_gfstack_ws32(GsArgs a)
         acc[(G) * 8 + 2 * q + 1] = fma((double)Y[q].y, w, acc[(G) * 8 + 2 * q + 1]); \
     }
 #define F2_GROUP(G, Y, OFFNEXT)              \
-    lds_wait4_f2<4>(Y);                      \
+    lds_wait4_pair<4>(Y);                      \
     __builtin_amdgcn_sched_barrier(0);       \
     F2_FMA(G, Y)                             \
     __builtin_amdgcn_sched_barrier(0);       \
-    lds_rd4_f2<OFFNEXT>(Y, xs, s);           \
+    lds_rd4_pair<F32 ? 1 : 2, OFFNEXT>(Y, xs, s);           \
     __builtin_amdgcn_sched_barrier(0);
 #pragma clang loop unroll(disable)
     for (int s = 0; s < nsteps; s++) {
@@ -1508,23 +1532,23 @@ k_gfstack_ws32(GsArgs a)
         F2_GROUP(4, ya, 192)
         F2_GROUP(5, yb, 224)
         // group 6: every read of this step is back once both groups in flight have landed
-        lds_wait4_f2<0>(ya);
-        lds_wait4_f2<0>(yb);
+        lds_wait4_pair<0>(ya);
+        lds_wait4_pair<0>(yb);
         __builtin_amdgcn_sched_barrier(0);
         F2_FMA(6, ya)
         __builtin_amdgcn_sched_barrier(0);
         gbuf = gnext;
-        const uint32_t xs_n = row_address(lds0 + (uint32_t)(gbuf * 4));   // slot / weight of step s+1 have landed
+        const uint32_t xs_n = row_address(lds0 + (uint32_t)(gbuf * ES));   // slot / weight of step s+1 have landed
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();   // rows of step s+1 visible; this wavefront is done with buffer s
         __builtin_amdgcn_sched_barrier(0);
-        lds_rd4_f2<0>(ya, xs_n, s);     // first group of step s+1 (after the last step: unused rows)
+        lds_rd4_pair<F32 ? 1 : 2, 0>(ya, xs_n, s);     // first group of step s+1 (after the last step: unused rows)
         __builtin_amdgcn_sched_barrier(0);
         // group 7 with the weight of step s, then the weight of step s+1 and that step's second group
         F2_FMA(7, yb)
         __builtin_amdgcn_sched_barrier(0);
         w = landed_weight(xs_n);
-        lds_rd4_f2<32>(yb, xs_n, s);
+        lds_rd4_pair<F32 ? 1 : 2, 32>(yb, xs_n, s);
         xs = xs_n;
         __builtin_amdgcn_sched_barrier(0);
         fetch_tabs(ps2, pw2);           // slot / weight of step s+2
@@ -1618,23 +1642,21 @@ static void launch_shared_nrow(int nrow, int mode, dim3 grid, size_t lds, hipStr
 
 // (single-row interpolation only: with four rows per chain the consumers run out of registers and
 // hipcc spills the not-yet-landed results of the hidden table loads)
-static int launch_ws(int mode, dim3 grid, size_t lds, hipStream_t s, const GsArgs &a, bool f32)
+// pair: 0 k_gfstack_ws, 1 the float-storage pair gather, 2 the float64 pair gather (A/B)
+static int launch_ws(int mode, dim3 grid, size_t lds, hipStream_t s, const GsArgs &a, int pair)
 {
     void (*kern)(GsArgs);
-    if (f32) {
-        if (a.nthint)
-            kern = mode == GF_STORE_SYN ? k_gfstack_ws32<GF_STORE_SYN, 3, 1>
-                   : mode == GF_RESID_SCALAR ? k_gfstack_ws32<GF_RESID_SCALAR, 3, 1> : k_gfstack_ws32<GF_RESID_STORE, 3, 1>;
-        else
-            kern = mode == GF_STORE_SYN ? k_gfstack_ws32<GF_STORE_SYN, 3, 0>
-                   : mode == GF_RESID_SCALAR ? k_gfstack_ws32<GF_RESID_SCALAR, 3, 0> : k_gfstack_ws32<GF_RESID_STORE, 3, 0>;
-    } else if (a.nthint) {
-        kern = mode == GF_STORE_SYN ? k_gfstack_ws<1, GF_STORE_SYN, 3, 1>
-               : mode == GF_RESID_SCALAR ? k_gfstack_ws<1, GF_RESID_SCALAR, 3, 1> : k_gfstack_ws<1, GF_RESID_STORE, 3, 1>;
-    } else {
-        kern = mode == GF_STORE_SYN ? k_gfstack_ws<1, GF_STORE_SYN, 3, 0>
-               : mode == GF_RESID_SCALAR ? k_gfstack_ws<1, GF_RESID_SCALAR, 3, 0> : k_gfstack_ws<1, GF_RESID_STORE, 3, 0>;
-    }
+#define BA_WS_PICK(NAME, ...)                                                                          \
+    (mode == GF_STORE_SYN ? NAME<__VA_ARGS__ GF_STORE_SYN, 3, 1>                                      \
+     : mode == GF_RESID_SCALAR ? NAME<__VA_ARGS__ GF_RESID_SCALAR, 3, 1> : NAME<__VA_ARGS__ GF_RESID_STORE, 3, 1>)
+#define BA_WS_PICK0(NAME, ...)                                                                         \
+    (mode == GF_STORE_SYN ? NAME<__VA_ARGS__ GF_STORE_SYN, 3, 0>                                      \
+     : mode == GF_RESID_SCALAR ? NAME<__VA_ARGS__ GF_RESID_SCALAR, 3, 0> : NAME<__VA_ARGS__ GF_RESID_STORE, 3, 0>)
+    if (pair == 1) kern = a.nthint ? BA_WS_PICK(k_gfstack_wsp, 1,) : BA_WS_PICK0(k_gfstack_wsp, 1,);
+    else if (pair == 2) kern = a.nthint ? BA_WS_PICK(k_gfstack_wsp, 0,) : BA_WS_PICK0(k_gfstack_wsp, 0,);
+    else kern = a.nthint ? BA_WS_PICK(k_gfstack_ws, 1,) : BA_WS_PICK0(k_gfstack_ws, 1,);
+#undef BA_WS_PICK0
+#undef BA_WS_PICK
     BA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, grid, dim3(768), lds, s, a);
     return BEATAMD_OK;
@@ -1786,6 +1808,8 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     GsArgs a;
     memset(&a, 0, sizeof(a));
     bool f32 = k.f32 && use_ws;
+    // A/B: the float64 kernel with the pair gather (ds_read_b128)
+    const bool pair64 = use_ws && getenv("BEATAMD_GS_PAIR") && atoi(getenv("BEATAMD_GS_PAIR")) == 1;
     for (int v = 0; v < k.nvar; v++) {
         a.G[v] = k.libs[v]->g;
         a.G32[v] = k.libs[v]->g32;
@@ -1873,7 +1897,8 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
             a.nthint = e ? (atoi(e) != 0) : (GS_NTHINT_DEFAULT && ngroups == 1);
         }
         if (a.ws) {
-            lds = f32 ? (size_t)ucap * (a.nt + 2) * sizeof(float) * a.ws : (size_t)ucap * (a.nt + 1) * sizeof(double) * a.ws;
+            lds = f32 ? (size_t)ucap * (a.nt + 2) * sizeof(float) * a.ws
+                      : (size_t)ucap * (a.nt + (pair64 ? 2 : 1)) * sizeof(double) * a.ws;
             lds = std::max<size_t>(lds, 64 * sizeof(double));   // the epilogue's data tile
         } else if (a.dma) {
             lds *= 2;
@@ -1886,8 +1911,9 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         if (e && atoi(e) == 1 && a.dma) a.xcd_order = 1;
         if (a.xcd_order) nblocks = ((L.T * a.ntile + 7) / 8) * 8 * ngroups;
     }
-    if (a.ws && f32)
-        snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack_ws32<%d,%d,%d>", k.mode, a.ws, a.nthint);
+    if (a.ws && (f32 || pair64))
+        snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack_ws%s<%d,%d,%d>", f32 ? "32" : "p64", k.mode,
+                 a.ws, a.nthint);
     else if (a.ws)
         snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack_ws<%d,%d,%d,%d>", nrow, k.mode, a.ws, a.nthint);
     else
@@ -1899,7 +1925,7 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     ctx->gs_cg = CG;
     {
         dim3 grid((unsigned)nblocks);
-        if (a.ws) BA_TRY(launch_ws(k.mode, grid, lds, ctx->stream, a, f32));
+        if (a.ws) BA_TRY(launch_ws(k.mode, grid, lds, ctx->stream, a, f32 ? 1 : (pair64 ? 2 : 0)));
         else if (CG == 1024) launch_shared_nrow<16>(nrow, k.mode, grid, lds, ctx->stream, a);
         else if (CG == 512) launch_shared_nrow<8>(nrow, k.mode, grid, lds, ctx->stream, a);
         else if (CG == 256) launch_shared_nrow<4>(nrow, k.mode, grid, lds, ctx->stream, a);

@@ -830,6 +830,11 @@ def test_float_storage_kernel_equals_the_f64_kernels_on_the_rounded_library(ctx,
     L64 = f.batch(Q)
     assert ctx.last_kernel().startswith("k_gfstack_ws<"), ctx.last_kernel()
     assert np.array_equal(L32, L64)
+    monkeypatch.setenv("BEATAMD_GS_PAIR", "1")            # the same pair gather on the float64 rows (ds_read_b128)
+    Lp = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack_wsp64<"), ctx.last_kernel()
+    assert np.array_equal(Lp, L64)
+    monkeypatch.delenv("BEATAMD_GS_PAIR")
     monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
     Ls = f.batch(Q)
     assert ctx.last_kernel().startswith("k_gfstack<"), ctx.last_kernel()
