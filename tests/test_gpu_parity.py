@@ -849,3 +849,27 @@ def test_float_storage_kernel_equals_the_f64_kernels_on_the_rounded_library(ctx,
     for c in (0, C // 2, C - 1):
         ref, _ = problem_oracle.forward(host32, Q[c])
         np.testing.assert_allclose(L32[c], ref, rtol=1e-9)
+
+
+@pytest.mark.parametrize("sizes", [(1,), (16,), (17, 33), (64, 5, 100), (257,), (512,), (300, 3, 31, 130), (513, 20)])
+@pytest.mark.parametrize("C", [1, 15, 16, 40])
+def test_small_dense_geodetic_datasets_in_one_launch(ctx, sizes, C):
+    """k_quadform_small: all dense geodetic datasets of a composite (M <= 512 each) in one launch with
+    the MVN epilogue -- sizes around the 16-row tiles, the 32-column prefetch batches, the 64 KB LDS
+    boundary (M = 512), several datasets, chain counts around the 16-chain blocks; a dataset above 512
+    points sends the composite through the tiled k_quadform path.  Against the oracle composition."""
+    from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
+    from oracle import problem_oracle
+    spec = SyntheticSpec((3,), (4,), (1.0,), T=0, N=0, D=3, S=25, geodetic_nobs=sizes, seed=sum(sizes) + C)
+    prob, host = build_problem(spec)
+    f = prob.compile(ctx)
+    Q = draw_population(spec, host["layout"], host["lower"], host["upper"], C)
+    LL = f.batch(Q)
+    assert LL.shape == (C, len(sizes) + 1)
+    for c in sorted({0, C // 2, C - 1}):
+        ref, _ = problem_oracle.forward(host, Q[c])
+        np.testing.assert_allclose(LL[c], ref, rtol=1e-6)      # north_star tolerance
+        np.testing.assert_allclose(LL[c], ref, rtol=1e-10, atol=1e-9)
+    # a chain's value does not depend on the batch it is evaluated in
+    if C > 1:
+        assert np.array_equal(f.batch(np.ascontiguousarray(Q[C - 1:])), LL[C - 1:])
