@@ -220,7 +220,8 @@ __global__ void k_gf_group_tables(GroupTabArgs a)
 
 struct GsArgs {
     const double *G[4];
-    const float *G32[4];   // float copies (k_gfstack_ws32) or nullptr
+    const float *G32[4];   // float copies (k_gfstack_wsp<1>, k_gfstack_dmaf) or nullptr
+    int f32pair;           // k_gfstack_dmaf instead of k_gfstack_dma
     int nvar, nrow;
     int64_t C, T, P, N;
     int CG, ucap, ustride, ntile, nt;
@@ -484,6 +485,21 @@ __device__ __forceinline__ void lds_rd8_b64(double (&x)[8], uint32_t addr, int t
         : "v"(addr), "s"(tok), "n"(OFF));
 }
 
+template <int OFF>
+__device__ __forceinline__ void lds_rd8_b32(float (&x)[8], uint32_t addr, int tok)
+{
+    asm("ds_read_b32 %0, %8 offset:%c10\n\t"
+        "ds_read_b32 %1, %8 offset:%c10+4\n\t"
+        "ds_read_b32 %2, %8 offset:%c10+8\n\t"
+        "ds_read_b32 %3, %8 offset:%c10+12\n\t"
+        "ds_read_b32 %4, %8 offset:%c10+16\n\t"
+        "ds_read_b32 %5, %8 offset:%c10+20\n\t"
+        "ds_read_b32 %6, %8 offset:%c10+24\n\t"
+        "ds_read_b32 %7, %8 offset:%c10+28"
+        : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7])
+        : "v"(addr), "s"(tok), "n"(OFF));
+}
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // four pair reads (8 samples of a row): float pairs by ds_read_b64 (SCALE 1), double pairs by ds_read_b128
@@ -511,21 +527,6 @@ template <int NLEFT, typename PAIR>
 __device__ __forceinline__ void lds_wait4_pair(PAIR (&x)[4])
 {
     asm("s_waitcnt lgkmcnt(%c4)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "n"(NLEFT));
-}
-
-template <int OFF>
-__device__ __forceinline__ void lds_rd8_b32(float (&x)[8], uint32_t addr, int tok)
-{
-    asm("ds_read_b32 %0, %8 offset:%c10\n\t"
-        "ds_read_b32 %1, %8 offset:%c10+4\n\t"
-        "ds_read_b32 %2, %8 offset:%c10+8\n\t"
-        "ds_read_b32 %3, %8 offset:%c10+12\n\t"
-        "ds_read_b32 %4, %8 offset:%c10+16\n\t"
-        "ds_read_b32 %5, %8 offset:%c10+20\n\t"
-        "ds_read_b32 %6, %8 offset:%c10+24\n\t"
-        "ds_read_b32 %7, %8 offset:%c10+28"
-        : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7])
-        : "v"(addr), "s"(tok), "n"(OFF));
 }
 
 template <int NLEFT>
@@ -853,6 +854,284 @@ k_gfstack_dma(GsArgs a)
         if (live) a.partial[(c * a.T + t) * a.ntile + tile] = q;
     }
 }
+
+
+// k_gfstack_dmaf: k_gfstack_dma on the float copies of the libraries (beatamd_seis_gflib_store_f32), 64-sample
+// tiles: 256-byte row segments by full-wave global_load_lds_dword, float rows at a pitch of 33 pairs, float
+// PAIRS gathered by ds_read_b64 (half the LDS instructions of the f64 kernel -- the multilinear instance of
+// which is bound by exactly those), operands widened in front of the f64 FMA.  Same values, same order:
+// bit-identical to the f64 kernels on the (float-representable) library.
+template <int WAVES, int NROW, int MODE>
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_gfstack_dmaf(GsArgs a)
+{
+    constexpr int GS_NT = 64;
+    constexpr int GS_PITCH = GS_NT + 2;   // floats: 33 pairs
+    // row ids per wavefront fetched ahead (scalar registers): 32 rows per workgroup and step are
+    // covered by the unrolled DMA slots, more (rare) go through a loop
+    constexpr int KPRE = WAVES >= 4 ? 64 / WAVES : 8;
+    extern __shared__ __attribute__((aligned(16))) double xbuf[];  // float [2][ucap][GS_PITCH] (+ the epilogue's data tile)
+    constexpr int CG = WAVES * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (a.guard_mode && ((a.guard_mode == 1) == (*a.guard_umax > (uint32_t)a.guard_fit))) return;
+    int tile;
+    int64_t t, g;
+    if (a.xcd_order) {
+        // Workgroups b, b+8, b+16, ... run on the same XCD (round-robin dispatch).  The chain
+        // groups of one (target, sample tile) are numbered b = 8*(ngroups*q + g) + x, so they
+        // run on one XCD at about the same time and walk the patches in step: the library rows the
+        // groups have in common are fetched from HBM once and served from that XCD's L2 to the
+        // others.  Scheduling only; results do not depend on it.
+        const int64_t b = blockIdx.x;
+        const int64_t x = b & 7, q = b >> 3;
+        g = q % a.ngroups;
+        const int64_t tt = (q / a.ngroups) * 8 + x;   // t * ntile + tile
+        if (tt >= a.T * a.ntile) return;              // grid padded to a multiple of 8 per group
+        tile = (int)(tt % a.ntile);
+        t = tt / a.ntile;
+    } else {
+        tile = blockIdx.x % a.ntile;
+        const int64_t gt0 = blockIdx.x / a.ntile;  // g*T + t
+        t = gt0 % a.T;
+        g = gt0 / a.T;
+    }
+    const int64_t gt = g * a.Ttab + (a.Ttab == 1 ? 0 : t);                       // table cell
+    const int64_t tbase = (a.Ttab == 1) ? t * a.rows_per_target * a.N : 0;      // doubles
+    const int64_t c = g * CG + tid;
+    const int64_t N = a.N;
+    const int64_t n0 = (int64_t)tile * GS_NT;
+    const bool dma_lane = (n0 + lane < N);
+    const uint32_t voff = (uint32_t)((n0 + lane) * 4);          // byte offset inside a row
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)xbuf;
+    const int bufsz = a.ucap * GS_PITCH;                          // floats per buffer
+
+    double acc[GS_NT];
+#pragma unroll
+    for (int i = 0; i < GS_NT; i++) acc[i] = 0.0;
+    uint32_t keep = 0;  // results of the DMA statements (always 0): keeps them alive
+
+    const int P = (int)a.P, nvar = a.nvar;
+    const int nsteps = P * nvar;
+    // steps run patch-major over (patch, variable); (p, iv) of the steps ahead are advanced
+    // incrementally (no integer divisions in the loop) and clamp at the last step
+    auto advance = [&](int &p, int &iv) {
+        if (++iv == nvar) { iv = 0; ++p; }
+        if (p >= P) { p = P - 1; iv = nvar - 1; }
+    };
+    // row j of the step lands at buf*bufsz + j*PITCH; lanes 0..LPR-1 move its NT samples.
+    // (scalar address arithmetic kept short: 32 x 32 -> 64 bit products, one exec region per step)
+    const uint32_t rowbytes = (uint32_t)(N * 4);
+    // `dep` is an ordering token only (not named in the text): a request that lists the destination
+    // register of the step's slot load as input cannot be placed in front of that load
+    // `tk` chains the requests of a step: every statement passes it through untouched (in/out
+    // operand, no instruction), its final value is folded into `keep` once per step -- the
+    // statements are not volatile (see above) and must not be dropped.
+    auto dma_row = [&](const float *Gv, uint32_t r, uint32_t slotidx, int boff, uint32_t dep, uint32_t &tk) {
+        const uint64_t off = (uint64_t)r * (uint64_t)rowbytes;
+        const char *rowp = reinterpret_cast<const char *>(Gv) + off;
+        const uint32_t dst = lds0 + (uint32_t)(boff * 4) + slotidx * (uint32_t)(GS_PITCH * 4);
+        if (a.nthint)   // non-temporal: single-group batches read every row segment exactly once
+            asm("s_mov_b32 m0, %3\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dword %1, %2 nt"
+                : "+s"(tk) : "v"(voff), "s"(rowp), "s"(dst), "v"(dep));
+        else
+            asm("s_mov_b32 m0, %3\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dword %1, %2"
+                : "+s"(tk) : "v"(voff), "s"(rowp), "s"(dst), "v"(dep));
+    };
+    // (row id, LDS slot) of this wavefront's first KPRE list entries: contiguous in memory, one
+    // scalar load instruction (the gather's lgkmcnt waits count scalar loads too)
+    struct alignas(KPRE * 8) EntBlock { uint32_t v[2 * KPRE]; };
+    const int kstr = a.ustride / WAVES;
+    // Table addresses: the (group, target) part is loop invariant and hoisted as 64-bit bases; the
+    // per-step part is a 32 x 32 bit product added as an unsigned byte offset (scalar loads take it
+    // as their offset operand).  Written out by hand: hipcc kept whole 64 x 64 bit index products
+    // inside the loop (about 60 scalar instructions per step).
+    const char *const cnt_base = reinterpret_cast<const char *>(a.ucount + gt * a.P);
+    const char *const ent_base = reinterpret_cast<const char *>(a.uent + ((gt * a.P) * WAVES + wave) * kstr * 2);
+    const uint32_t ent_step = (uint32_t)(a.ustride * 8);   // bytes per patch: WAVES * kstr entries of 8 B
+    const float *G_a = nullptr;   // library of the step whose list entries are in rid_a / rsl_a
+    auto fetch_ids = [&](int p, int iv, int &U, uint32_t (&rid)[KPRE], uint32_t (&rsl)[KPRE]) {
+        U = __builtin_amdgcn_readfirstlane(
+            (int)*reinterpret_cast<const uint32_t *>(cnt_base + (uint32_t)p * 4u));
+        const EntBlock eb = *reinterpret_cast<const EntBlock *>(ent_base + (uint32_t)p * ent_step);
+#pragma unroll
+        for (int k = 0; k < KPRE; k++) {   // padded: always in bounds
+            rid[k] = eb.v[2 * k];
+            rsl[k] = eb.v[2 * k + 1];
+        }
+        // library base pointer of that step: a scalar load from the kernel arguments, issued with
+        // the list entries one step before it is needed (selecting among four register pairs by a
+        // run-time index costs a branch maze of ~25 scalar instructions per step)
+        G_a = a.G32[iv] + tbase;
+    };
+    auto issue_rows_dep = [&](int p, int iv, int boff, int U, const uint32_t (&rid)[KPRE],
+                              const uint32_t (&rsl)[KPRE], uint32_t dep) {
+        const float *Gv = G_a;
+        if (dma_lane) {
+            uint32_t tk = 0;
+#pragma unroll
+            for (int k = 0; k < KPRE; k++)
+                if (wave + k * WAVES < U) dma_row(Gv, rid[k], rsl[k], boff, dep, tk);
+            if (U > KPRE * WAVES) {   // rare: more distinct rows than the prefetched ids cover
+                const uint32_t *ue = reinterpret_cast<const uint32_t *>(ent_base + (uint32_t)p * ent_step);
+                for (int k = KPRE; wave + k * WAVES < U; k++) dma_row(Gv, ue[2 * k], ue[2 * k + 1], boff, dep, tk);
+            }
+            keep |= tk;
+        }
+    };
+    auto issue_rows = [&](int p, int iv, int buf, int U, const uint32_t (&rid)[KPRE],
+                          const uint32_t (&rsl)[KPRE]) {
+        issue_rows_dep(p, iv, buf * bufsz, U, rid, rsl, voff);   // (any live VGPR: no ordering needed here)
+    };
+    // the lane's slot and weight of step s: asm loads (hipcc must not count them, see above);
+    // valid after the step-top wait statement, which names them
+    uint32_t sl_n[NROW];
+    double wl_n[NROW];
+    const char *const slot_base = reinterpret_cast<const char *>(a.slot + (gt * a.P * NROW) * CG + tid);
+    const char *const w_base = reinterpret_cast<const char *>(
+        (NROW == 1) ? a.w + (g * a.P) * CG + tid : a.w + (gt * a.P * 4) * CG + tid);
+    const uint32_t slot_step = (uint32_t)(NROW * CG * 2);                    // bytes per patch
+    const uint32_t w_step = (uint32_t)((NROW == 1 ? 1 : 4) * CG * 8);
+    const int64_t w_var_bytes = a.w_var_stride * 8;
+    auto fetch_tabs = [&](int p, int iv) {
+        const char *sp = slot_base + (uint32_t)p * slot_step;
+        const char *wp = w_base + (uint32_t)p * w_step + (nvar == 1 ? (int64_t)0 : (int64_t)iv * w_var_bytes);
+#pragma unroll
+        for (int k = 0; k < NROW; k++) {
+            const uint16_t *ps = reinterpret_cast<const uint16_t *>(sp) + k * CG;
+            const double *pw = reinterpret_cast<const double *>(wp) + k * CG;
+            asm("global_load_ushort %0, %1, off" : "=v"(sl_n[k]) : "v"(ps));
+            asm("global_load_dwordx2 %0, %1, off" : "=v"(wl_n[k]) : "v"(pw));
+        }
+    };
+
+    int p1 = 0, iv1 = 0;          // step s+1
+    advance(p1, iv1);
+    int p2 = p1, iv2 = iv1;       // step s+2
+    advance(p2, iv2);
+    int U_a;
+    uint32_t rid_a[KPRE], rsl_a[KPRE];
+    fetch_ids(0, 0, U_a, rid_a, rsl_a);
+    issue_rows(0, 0, 0, U_a, rid_a, rsl_a);
+    fetch_tabs(0, 0);
+    fetch_ids(p1, iv1, U_a, rid_a, rsl_a);
+    for (int s = 0; s < nsteps; s++) {
+        // the tables of this step and (older) the DMA of this step's rows have landed
+        __builtin_amdgcn_sched_barrier(0);
+        // (the copy into this step's registers is part of the statement: hipcc would otherwise
+        // place it in front of the wait and copy registers whose loads are still in flight)
+        uint32_t sl[NROW];
+        double wl[NROW];
+#define BA_WAIT_COPY(NOUT)                                                                      \
+        _Pragma("unroll") for (int k = 0; k < NROW; k++)                                        \
+            asm("s_waitcnt vmcnt(" #NOUT ")\n\t"                                                 \
+                "v_mov_b32 %0, %2\n\t"                                                          \
+                "v_mov_b64 %1, %3"                                                              \
+                : "=&v"(sl[k]), "=&v"(wl[k]) : "v"(sl_n[k]), "v"(wl_n[k]))
+        BA_WAIT_COPY(0);
+#undef BA_WAIT_COPY
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();  // rows of step s visible; everyone has left the FMA phase of step s-1
+        __builtin_amdgcn_sched_barrier(0);
+        // rows of step s+1 -> the other buffer, then that step's slot/weight and the ids of step s+2
+        if (s + 1 < nsteps) issue_rows(p1, iv1, (s + 1) & 1, U_a, rid_a, rsl_a);
+        fetch_tabs(p1, iv1);
+        fetch_ids(p2, iv2, U_a, rid_a, rsl_a);
+        p1 = p2; iv1 = iv2;
+        advance(p2, iv2);
+        __builtin_amdgcn_sched_barrier(0);
+        const int gbuf = (s & 1) * bufsz;   // doubles: the buffer of step s
+        // ---- every lane applies ITS rows with ITS weights.  The 2*NT/4 ds_read_b128 of a row
+        // are issued by hand in groups of 8, two groups in flight (hipcc keeps 3-4 reads in
+        // flight, which leaves the phase bound by LDS latency instead of LDS throughput); the
+        // wait statements name the destination registers, so no FMA can move above its wait.
+#pragma unroll
+        for (int k = 0; k < NROW; k++) {
+            const uint32_t xs = lds0 + (uint32_t)((gbuf + (int)sl[k] * GS_PITCH) * 4);
+            const double w = wl[k];
+            constexpr int NG = GS_NT / 8;   // groups of 4 pair reads = 8 samples
+            v2f ya[4], yb[4];
+            lds_rd4_pair<1, 0>(ya, xs, s);
+            lds_rd4_pair<1, 32>(yb, xs, s);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int gq = 0; gq < NG; gq++) {
+                v2f(&cur)[4] = (gq & 1) ? yb : ya;
+                if (gq + 1 < NG) lds_wait4_pair<4>(cur); else lds_wait4_pair<0>(cur);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    acc[gq * 8 + 2 * q] = fma((double)cur[q].x, w, acc[gq * 8 + 2 * q]);
+                    acc[gq * 8 + 2 * q + 1] = fma((double)cur[q].y, w, acc[gq * 8 + 2 * q + 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (gq + 2 < NG) switch (gq + 2) {
+                case 2: lds_rd4_pair<1, 64>(cur, xs, s); break;
+                case 3: lds_rd4_pair<1, 96>(cur, xs, s); break;
+                case 4: lds_rd4_pair<1, 128>(cur, xs, s); break;
+                case 5: lds_rd4_pair<1, 160>(cur, xs, s); break;
+                case 6: lds_rd4_pair<1, 192>(cur, xs, s); break;
+                case 7: lds_rd4_pair<1, 224>(cur, xs, s); break;
+                default: break;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // The slot/weight loads issued in the last step (for the step after the last) are still in
+    // flight: wait for them before their registers can be given to anything else.  Without this the
+    // epilogue's store addresses were built in those registers and overwritten by the late data
+    // (observed as a memory fault with RESID_STORE and >= 29 groups; tools/audit_hidden_loads.py
+    // now follows the loop's exit paths as well).
+#pragma unroll
+    for (int k = 0; k < NROW; k++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(sl_n[k]), "+v"(wl_n[k]));
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue: lane = chain c, acc[i] = synthetics[c, t, n0 + i]
+    const bool live = (c < a.C) && (keep == 0);
+    const int nvalid = (int)min((int64_t)GS_NT, N - n0);
+    if (MODE == GF_STORE_SYN) {
+        if (live) {
+            double *o = a.out + (c * a.T + t) * N + n0;
+#pragma unroll
+            for (int i = 0; i < GS_NT; i++)
+                if (i < nvalid) o[i] = acc[i];
+        }
+        return;
+    }
+    __syncthreads();
+    if (tid < GS_NT) xbuf[tid] = (tid < nvalid) ? a.data[t * N + n0 + tid] : 0.0;
+    __syncthreads();
+    if (MODE == GF_RESID_STORE) {
+        double *o = a.out + (c * a.T + t) * N + n0;
+#pragma unroll
+        for (int i0 = 0; i0 < GS_NT; i0 += 8) {
+#pragma unroll
+            for (int i = i0; i < i0 + 8; i++)
+                if (live && i < nvalid) o[i] = xbuf[i] - acc[i];  // seismic.py:1332
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        const double w = a.wscalar[t];
+        double q = 0.0;
+#pragma unroll
+        for (int i0 = 0; i0 < GS_NT; i0 += 8) {
+#pragma unroll
+            for (int i = i0; i < i0 + 8; i++)
+                if (i < nvalid) {
+                    const double tt = w * (xbuf[i] - acc[i]);
+                    q = fma(tt, tt, q);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (live) a.partial[(c * a.T + t) * a.ntile + tile] = q;
+    }
+}
+
 
 
 // ---------------------------------------------------------------------------------------------
@@ -1611,6 +1890,8 @@ static void launch_shared_one(dim3 grid, size_t lds, hipStream_t s, const GsArgs
     void (*kern)(GsArgs) = nullptr;
     if constexpr (WAVES == 16) {
         kern = k_gfstack_dma<WAVES, NROW, MODE, 32, 1>;   // 1024-chain groups exist as NT = 32 only
+    } else if (a.f32pair) {
+        kern = k_gfstack_dmaf<WAVES, NROW, MODE>;
     } else {
         kern = (a.dma == 2 && a.nt == 32) ? k_gfstack_dma<WAVES, NROW, MODE, 32, 1>
              : (a.dma == 2) ? k_gfstack_dma<WAVES, NROW, MODE, 64, 1>
@@ -1807,7 +2088,8 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
 
     GsArgs a;
     memset(&a, 0, sizeof(a));
-    bool f32 = k.f32 && use_ws;
+    bool f32 = k.f32;   // float copies: the loader/consumer pair gather (512-chain groups, one row per chain)
+                        // or k_gfstack_dmaf (LDS-DMA kernel, 64-sample tiles, groups up to 512 chains)
     // A/B: the float64 kernel with the pair gather (ds_read_b128)
     const bool pair64 = use_ws && getenv("BEATAMD_GS_PAIR") && atoi(getenv("BEATAMD_GS_PAIR")) == 1;
     for (int v = 0; v < k.nvar; v++) {
@@ -1896,10 +2178,14 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
             const char *e = getenv("BEATAMD_GS_NTHINT");
             a.nthint = e ? (atoi(e) != 0) : (GS_NTHINT_DEFAULT && ngroups == 1);
         }
+        a.f32pair = 0;
         if (a.ws) {
             lds = f32 ? (size_t)ucap * (a.nt + 2) * sizeof(float) * a.ws
                       : (size_t)ucap * (a.nt + (pair64 ? 2 : 1)) * sizeof(double) * a.ws;
             lds = std::max<size_t>(lds, 64 * sizeof(double));   // the epilogue's data tile
+        } else if (a.dma == 2 && a.nt == 64 && CG <= 512 && f32) {
+            a.f32pair = 1;
+            lds = std::max<size_t>((size_t)ucap * (a.nt + 2) * sizeof(float) * 2, 64 * sizeof(double));
         } else if (a.dma) {
             lds *= 2;
         }
@@ -1911,7 +2197,9 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         if (e && atoi(e) == 1 && a.dma) a.xcd_order = 1;
         if (a.xcd_order) nblocks = ((L.T * a.ntile + 7) / 8) * 8 * ngroups;
     }
-    if (a.ws && (f32 || pair64))
+    if (a.f32pair)
+        snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack_dmaf<%d,%d,%d>", CG / 64, nrow, k.mode);
+    else if (a.ws && (f32 || pair64))
         snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack_ws%s<%d,%d,%d>", f32 ? "32" : "p64", k.mode,
                  a.ws, a.nthint);
     else if (a.ws)

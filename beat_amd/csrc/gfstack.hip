@@ -381,7 +381,11 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &k)
     }
     BA_HIP(hipGetLastError());
 
-    if (gfstack_cell_applicable(k)) return launch_gfstack_cell(ctx, k, ta.rowoff, ta.fac, Ttab);
+    // float storage requested and every library has its float copy: the lane <-> chain kernels read it (the
+    // cell kernel works on the float64 rows)
+    bool f32_all = k.f32;
+    for (int v = 0; v < k.nvar; v++) f32_all = f32_all && k.libs[v]->g32 != nullptr;
+    if (!f32_all && gfstack_cell_applicable(k)) return launch_gfstack_cell(ctx, k, ta.rowoff, ta.fac, Ttab);
     {
         int cg = 0, ucap = 0;
         if (gfstack_shared_applicable(k, &cg, &ucap)) {
@@ -394,7 +398,7 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &k)
             const bool tune = !getenv("BEATAMD_GS_CG") &&
                               !(getenv("BEATAMD_GS_TUNE") && atoi(getenv("BEATAMD_GS_TUNE")) == 0);
             if (tune) {
-                const std::vector<int64_t> key = {k.C, nrow, k.nvar, k.mode, L.T, L.P, L.D, L.S, L.N, Ttab};
+                const std::vector<int64_t> key = {k.C, nrow, k.nvar, k.mode, L.T, L.P, L.D, L.S, L.N, Ttab, f32_all ? 1 : 0};
                 auto it = ctx->gs_tuned.find(key);
                 if (it == ctx->gs_tuned.end()) {
                     int cgs[4], ucaps[4];

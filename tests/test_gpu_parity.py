@@ -873,3 +873,32 @@ def test_small_dense_geodetic_datasets_in_one_launch(ctx, sizes, C):
     # a chain's value does not depend on the batch it is evaluated in
     if C > 1:
         assert np.array_equal(f.batch(np.ascontiguousarray(Q[C - 1:])), LL[C - 1:])
+
+
+@pytest.mark.parametrize("interp,covariance,C", [("multilinear", "scalar", 512), ("multilinear", "toeplitz", 300),
+                                                  ("multilinear", "scalar", 100), ("nearest_neighbor", "scalar", 300),
+                                                  ("nearest_neighbor", "toeplitz", 130)])
+def test_float_storage_lds_dma_kernel(ctx, monkeypatch, interp, covariance, C):
+    """k_gfstack_dmaf: the LDS-DMA kernel on the float copies (multilinear: the four-row blend of the
+    reference's default interpolation; nearest neighbour in groups below 512 chains) -- bit for bit the
+    float64 kernels (cell kernel / k_gfstack_dma) on the rounded library, oracle on float-rounded G at 1e-9."""
+    from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
+    from oracle import problem_oracle
+    spec = SyntheticSpec((4,), (5,), (1.0,), T=3, N=136, D=3, S=25, covariance=covariance, interpolation=interp)
+    prob, host = build_problem(spec)
+    f = prob.compile(ctx)
+    Q = draw_population(spec, host["layout"], host["lower"], host["upper"], C)
+    f.set_f32(True)
+    L32 = f.batch(Q)
+    # (300 nearest-neighbour chains run as one 512-chain group: the loader/consumer float kernel)
+    assert ctx.last_kernel().startswith(("k_gfstack_dmaf<", "k_gfstack_ws32<")), ctx.last_kernel()
+    assert interp != "multilinear" or ctx.last_kernel().startswith("k_gfstack_dmaf<")
+    f.set_f32(False)
+    L64 = f.batch(Q)
+    assert not ctx.last_kernel().startswith(("k_gfstack_dmaf", "k_gfstack_ws32")), ctx.last_kernel()
+    assert np.array_equal(L32, L64), ctx.last_kernel()
+    host32 = dict(host)
+    host32["Gs"] = [g.astype(np.float32).astype(np.float64) for g in host["Gs"]]
+    for c in (0, C // 2, C - 1):
+        ref, _ = problem_oracle.forward(host32, Q[c])
+        np.testing.assert_allclose(L32[c], ref, rtol=1e-9)
