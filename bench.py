@@ -651,8 +651,8 @@ def main():
                 "hbm_required_bytes_per_launch": need32,
                 "hbm_frac_required_bytes": need32 / (ms32 / max(n32, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "note": "float pairs gathered by ds_read_b64: half the bytes and half the LDS gather instructions of the "
-                        "f64 kernel for ~2 % -- most of the difference to `value` is the DATA: the f64 kernel itself "
-                        "runs ~7 % faster on float-representable values (zero low mantissa bits, less switching "
+                        "f64 kernel for 2-4 % -- the rest of the difference to `value` is the DATA: the f64 kernel itself "
+                        "runs 4-7 % faster on float-representable values (zero low mantissa bits, less switching "
                         "power, higher sustained clocks).  The kernel is limited by its instruction streams and the "
                         "power envelope, not by HBM bytes (DESIGN 3.1b)"}
         if "geometry" in legs:
