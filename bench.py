@@ -456,7 +456,9 @@ def main():
             attach_traffic(roof, args.pmc_summary)
         roof["note"] = ("`bound` names the largest of the fractions; the float-storage leg (half the bytes, same gather: "
                         "same time; half the LDS gather instructions: -9 %) shows the kernel is limited by its LDS-gather "
-                        "and row-request instruction counts, not by HBM bandwidth itself (DESIGN 3.1b)")
+                        "and row-request instruction counts under a power envelope -- GRBM_GUI_ACTIVE gives 1.72 GHz sustained on "
+                        "these values, 1.90 GHz on float-rounded ones for the same cycle count "
+                        "(profiles/r3_clock_ws_kernels.json) -- not by HBM bandwidth itself (DESIGN 3.1b)")
 
     # ---- reuse-free streaming leg: k_gfstack in (chain, target, tile) order, every chain's rows
     # streamed from HBM -- the roofline of SURVEY 8(d)'s algorithmic bytes, driver-observed
