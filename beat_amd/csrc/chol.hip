@@ -132,32 +132,61 @@ __global__ void k_chol_logdet(const double *logd, int nblk, int64_t nbatch, doub
 // blocked right-looking Cholesky of the lower triangles of A [nbatch][np][np] in place (np a multiple
 // of 64): diagonal blocks by k_chol_diag (their inverses to Dinv and to X's diagonal blocks, their
 // log-determinants to logd), panels and trailing updates as batched GEMMs
+// Two-level blocking: 64-wide inner steps (diagonal block in LDS, panel solve) update only the rest
+// of their CH_NBO-wide outer panel; the matrix behind the panel gets ONE trailing update per outer
+// panel with K = CH_NBO instead of four with K = 64 (a 64 x 128 tile then runs 16 k-steps per load /
+// store of its accumulators instead of 4: the K = 64 updates ran at 12 TF, bound by re-reading the
+// trailing matrix).
+static int ch_nbo()
+{
+    static const int v = getenv("BEATAMD_CHOL_NBO") ? std::max(64, atoi(getenv("BEATAMD_CHOL_NBO")) / 64 * 64) : 256;
+    return v;
+}
+
 static int potrf_lower(beatamd_ctx *ctx, int64_t nbatch, int64_t np, double *A, double *Dinv, double *X, double *logd,
                        int32_t *notpsd = nullptr)
 {
     const int nblk = (int)(np / CH_NB);
     const int64_t sM = np * np;
-    for (int kb = 0; kb < nblk; kb++) {
-        hipLaunchKernelGGL(k_chol_diag, dim3((unsigned)nbatch), dim3(256), 0, ctx->stream, A, np, kb, Dinv, X,
-                           logd, nblk, ctx->d_status, notpsd);
-        const int64_t r0 = (int64_t)(kb + 1) * CH_NB, below = np - r0;
-        if (below == 0) break;
-        GemmCall g;
-        // panel: A[r0:, kb] <- A[r0:, kb] . inv(L_kk)^T
-        g.A = A + r0 * np + (int64_t)kb * CH_NB; g.lda = np; g.sA = sM;
-        g.B = Dinv + (int64_t)kb * CH_NB * CH_NB; g.ldb = CH_NB; g.sB = (int64_t)nblk * CH_NB * CH_NB;
-        g.O = A + r0 * np + (int64_t)kb * CH_NB; g.ldo = np; g.sO = sM;
-        g.M = below; g.N = CH_NB; g.K = CH_NB; g.b_kn = 0; g.nbatch = (int)nbatch;
-        g.timer = nullptr;
-        BA_TRY(launch_gemm_f64(ctx, g));
-        // trailing update of the lower triangle: A[r0:, r0:] -= P . P^T with P = A[r0:, kb]
-        GemmCall u;
-        u.A = A + r0 * np + (int64_t)kb * CH_NB; u.lda = np; u.sA = sM;
-        u.B = u.A; u.ldb = np; u.sB = sM;
-        u.O = A + r0 * np + r0; u.ldo = np; u.sO = sM;
-        u.M = below; u.N = below; u.K = CH_NB; u.b_kn = 0; u.nbatch = (int)nbatch;
-        u.alpha = -1.0; u.accumulate = 1; u.lower_only = 1;
-        BA_TRY(launch_gemm_f64(ctx, u));
+    const int64_t CH_NBO = ch_nbo();
+    for (int64_t ko = 0; ko < np; ko += CH_NBO) {
+        const int64_t ko_end = std::min<int64_t>(ko + CH_NBO, np);
+        for (int kb = (int)(ko / CH_NB); kb < (int)(ko_end / CH_NB); kb++) {
+            hipLaunchKernelGGL(k_chol_diag, dim3((unsigned)nbatch), dim3(256), 0, ctx->stream, A, np, kb, Dinv, X,
+                               logd, nblk, ctx->d_status, notpsd);
+            const int64_t r0 = (int64_t)(kb + 1) * CH_NB, below = np - r0;
+            if (below == 0) break;
+            GemmCall g;
+            // panel: A[r0:, kb] <- A[r0:, kb] . inv(L_kk)^T
+            g.A = A + r0 * np + (int64_t)kb * CH_NB; g.lda = np; g.sA = sM;
+            g.B = Dinv + (int64_t)kb * CH_NB * CH_NB; g.ldb = CH_NB; g.sB = (int64_t)nblk * CH_NB * CH_NB;
+            g.O = A + r0 * np + (int64_t)kb * CH_NB; g.ldo = np; g.sO = sM;
+            g.M = below; g.N = CH_NB; g.K = CH_NB; g.b_kn = 0; g.nbatch = (int)nbatch;
+            g.timer = nullptr;
+            BA_TRY(launch_gemm_f64(ctx, g));
+            // inside the outer panel: A[r0:, r0:ko_end] -= P . P[:ko_end - r0]^T with P = A[r0:, kb] (lower tiles)
+            const int64_t ncol = ko_end - r0;
+            if (ncol > 0) {
+                GemmCall u;
+                u.A = A + r0 * np + (int64_t)kb * CH_NB; u.lda = np; u.sA = sM;
+                u.B = u.A; u.ldb = np; u.sB = sM;
+                u.O = A + r0 * np + r0; u.ldo = np; u.sO = sM;
+                u.M = below; u.N = ncol; u.K = CH_NB; u.b_kn = 0; u.nbatch = (int)nbatch;
+                u.alpha = -1.0; u.accumulate = 1; u.lower_only = 1;
+                BA_TRY(launch_gemm_f64(ctx, u));
+            }
+        }
+        // behind the panel: A[ko_end:, ko_end:] -= Q . Q^T with Q = A[ko_end:, ko:ko_end], K = panel width
+        const int64_t below = np - ko_end;
+        if (below > 0) {
+            GemmCall u;
+            u.A = A + ko_end * np + ko; u.lda = np; u.sA = sM;
+            u.B = u.A; u.ldb = np; u.sB = sM;
+            u.O = A + ko_end * np + ko_end; u.ldo = np; u.sO = sM;
+            u.M = below; u.N = below; u.K = ko_end - ko; u.b_kn = 0; u.nbatch = (int)nbatch;
+            u.alpha = -1.0; u.accumulate = 1; u.lower_only = 1;
+            BA_TRY(launch_gemm_f64(ctx, u));
+        }
     }
     return BEATAMD_OK;
 }
