@@ -206,7 +206,7 @@ int launch_chol_inverse(beatamd_ctx *ctx, int64_t nbatch, int64_t n, const doubl
     double *X = (double *)p;
     BA_TRY(ctx->get_scratch(SL_CHOL_D, (size_t)nbatch * nblk * CH_NB * CH_NB * 8, &p));
     double *Dinv = (double *)p;
-    BA_TRY(ctx->get_scratch(SL_CHOL_T, (size_t)nbatch * CH_NB * np * 8, &p));
+    BA_TRY(ctx->get_scratch(SL_CHOL_T, (size_t)nbatch * ch_nbo() * np * 8, &p));
     double *T = (double *)p;
     BA_TRY(ctx->get_scratch(SL_CHOL_L, (size_t)nbatch * nblk * 8, &p));
     double *logd = (double *)p;
@@ -219,20 +219,40 @@ int launch_chol_inverse(beatamd_ctx *ctx, int64_t nbatch, int64_t n, const doubl
     const int64_t sM = np * np;
     if (notpsd) BA_HIP(hipMemsetAsync(notpsd, 0, (size_t)nbatch * sizeof(int32_t), ctx->stream));
     BA_TRY(potrf_lower(ctx, nbatch, np, A, Dinv, X, logd, notpsd));
-    // X = inv(M) by row blocks (X's diagonal blocks are in place already)
-    for (int kb = 1; kb < nblk; kb++) {
-        const int64_t kc = (int64_t)kb * CH_NB;
-        GemmCall g;   // T = -M[kb, :kc] . X[:kc, :kc]
-        g.A = A + kc * np; g.lda = np; g.sA = sM;
+    // X = inv(M), M lower triangular, by row panels of CH_NBO rows (X's 64 x 64 diagonal blocks are in place
+    // already): first the panel's own diagonal block of the inverse by 64-row steps, then everything to its
+    // left with two panel-high products,   X[R, :po] = X[R, R] . (-M[R, :po] . X[:po, :po])
+    const int64_t nbo = ch_nbo();
+    for (int64_t po = 0; po < np; po += nbo) {
+        const int64_t pe = std::min<int64_t>(po + nbo, np);
+        for (int kb = (int)(po / CH_NB) + 1; kb < (int)(pe / CH_NB); kb++) {
+            const int64_t kc = (int64_t)kb * CH_NB, w = kc - po;
+            GemmCall g;   // T = -M[kb, po:kc] . X[po:kc, po:kc]
+            g.A = A + kc * np + po; g.lda = np; g.sA = sM;
+            g.B = X + po * np + po; g.ldb = np; g.sB = sM;
+            g.O = T; g.ldo = np; g.sO = nbo * np;
+            g.M = CH_NB; g.N = w; g.K = w; g.b_kn = 1; g.b_lower = 1; g.alpha = -1.0; g.nbatch = (int)nbatch;
+            BA_TRY(launch_gemm_f64(ctx, g));
+            GemmCall h;   // X[kb, po:kc] = inv(L_kk) . T
+            h.A = Dinv + (int64_t)kb * CH_NB * CH_NB; h.lda = CH_NB; h.sA = (int64_t)nblk * CH_NB * CH_NB;
+            h.B = T; h.ldb = np; h.sB = nbo * np;
+            h.O = X + kc * np + po; h.ldo = np; h.sO = sM;
+            h.M = CH_NB; h.N = w; h.K = CH_NB; h.b_kn = 1; h.nbatch = (int)nbatch;
+            BA_TRY(launch_gemm_f64(ctx, h));
+        }
+        if (po == 0) continue;
+        const int64_t rows = pe - po;
+        GemmCall g;   // T = -M[R, :po] . X[:po, :po]
+        g.A = A + po * np; g.lda = np; g.sA = sM;
         g.B = X; g.ldb = np; g.sB = sM;
-        g.O = T; g.ldo = np; g.sO = (int64_t)CH_NB * np;
-        g.M = CH_NB; g.N = kc; g.K = kc; g.b_kn = 1; g.b_lower = 1; g.alpha = -1.0; g.nbatch = (int)nbatch;
+        g.O = T; g.ldo = np; g.sO = nbo * np;
+        g.M = rows; g.N = po; g.K = po; g.b_kn = 1; g.b_lower = 1; g.alpha = -1.0; g.nbatch = (int)nbatch;
         BA_TRY(launch_gemm_f64(ctx, g));
-        GemmCall h;   // X[kb, :kc] = inv(L_kk) . T
-        h.A = Dinv + (int64_t)kb * CH_NB * CH_NB; h.lda = CH_NB; h.sA = (int64_t)nblk * CH_NB * CH_NB;
-        h.B = T; h.ldb = np; h.sB = (int64_t)CH_NB * np;
-        h.O = X + kc * np; h.ldo = np; h.sO = sM;
-        h.M = CH_NB; h.N = kc; h.K = CH_NB; h.b_kn = 1; h.nbatch = (int)nbatch;
+        GemmCall h;   // X[R, :po] = X[R, R] . T
+        h.A = X + po * np + po; h.lda = np; h.sA = sM;
+        h.B = T; h.ldb = np; h.sB = nbo * np;
+        h.O = X + po * np; h.ldo = np; h.sO = sM;
+        h.M = rows; h.N = po; h.K = rows; h.b_kn = 1; h.nbatch = (int)nbatch;
         BA_TRY(launch_gemm_f64(ctx, h));
     }
     {
