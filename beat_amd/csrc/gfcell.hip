@@ -31,6 +31,7 @@
 
 #include "kernels.hpp"
 #include "gfcell_asm.inc"
+#include "gfml_asm.inc"
 
 namespace beatamd {
 
@@ -463,6 +464,302 @@ int launch_gfstack_cell(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *
             const int var = ev ? atoi(ev) : 0;
             if (var == 1) kern = k_gfstack_cell<1, 1>;
             if (var == 2) kern = k_gfstack_cell<1, 2>;
+        }
+#endif
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(1024), lds, ctx->stream, a);
+    }
+    BA_HIP(hipGetLastError());
+    if (k.mode == GF_RESID_SCALAR) BA_TRY(launch_sum_tiles(ctx, a.partial, k.C * L.T, a.ntile, k.quad));
+    return BEATAMD_OK;
+}
+
+// =============================================================================== k_gfstack_ml (round 4)
+// Multilinear stacking with STATIC accumulators (tools/gen_gfml_asm.py).  Same workgroup shape, loaders,
+// row ring and epilogues as k_gfstack_cell, but a consumer wavefront walks its 37 chains in a fixed order:
+// no VGPR index register, no per-chain scalar work.  What makes that possible is the DENSE row layout of a
+// step's LDS buffer -- slot(d, s') = d*(S+1) + s', s' = s + 1; slot s' = 0 of a duration line holds a copy of
+// its LAST start-time node when a chain's floor node wrapped to it (base.py:513-517: ceil - 1 = -1 -> S-1) --
+// so the four rows of ANY chain are A, A+512 (floor-duration line) and B, B+512 (ceil-duration line).
+struct GmTabArgs {
+    int64_t C, T, P, D, S, DS, nslot;   // T: targets the tables are built for (1 or all)
+    int64_t nsteps;
+    const uint32_t *rowoff;       // [C,T,P,4] global row ids (k_gf_tables: cc, fc, cf, ff)
+    const double *fac;            // [C,T,P,4]
+    ChainVec slips;
+    const uint32_t *order;        // [ngroups*GC_CG]
+    char *wtab;                   // [(g*T+t)][consumer][step 0..nsteps][GM_NREC] records of 16 entries {weight, dword, pad}
+    uint32_t *ltab;               // [(g*T+t)][step 0..nsteps+2][loader][32 dwords]: count, row requests
+    uint32_t *ucount;             // [(g*T+t)*P+p] row segments the loaders move (statistics)
+};
+
+// one workgroup per (group, target, patch); thread <-> chain slot of the group order
+__global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
+{
+    __shared__ uint32_t flags[256];
+    __shared__ uint32_t reqs[256];
+    __shared__ uint32_t nreq_s;
+    const int tid = threadIdx.x;
+    const int64_t gtp = blockIdx.x;
+    const int64_t p = gtp % a.P;
+    const int64_t gt = gtp / a.P;
+    const int64_t t = gt % a.T;
+    const int64_t g = gt / a.T;
+    const bool slot = tid < GC_CG;
+    const uint32_t cid = slot ? a.order[g * GC_CG + tid] : GC_DEAD;
+    const bool live = cid != GC_DEAD;
+    const int64_t c = live ? (int64_t)cid : 0;
+    const int64_t row0 = (t * a.P + p) * a.DS;
+    const uint32_t S = (uint32_t)a.S, S1 = S + 1;
+
+    for (int i = tid; i < 256; i += GC_TB) flags[i] = 0;
+    __syncthreads();
+    uint32_t sa = 0, sb = 0;       // LDS slots of (floor d, floor s) and (ceil d, floor s)
+    double fr[4] = {0, 0, 0, 0};
+    if (live) {
+        const int64_t e = ((c * a.T + t) * a.P + p) * 4;
+        const uint32_t v0 = a.rowoff[e] - (uint32_t)row0;        // (ceil d, ceil s)
+        const uint32_t v2 = a.rowoff[e + 2] - (uint32_t)row0;    // (floor d, ceil s)
+        const uint32_t dc = v0 / S, sc = v0 % S, df = v2 / S;
+        sb = dc * S1 + sc;        // the floor node of ceil node sc is slot sc of the line (sc = 0: the wrap copy)
+        sa = df * S1 + sc;
+        flags[sa] = 1; flags[sa + 1] = 1; flags[sb] = 1; flags[sb + 1] = 1;   // benign race: every writer stores 1
+        for (int k = 0; k < 4; k++) fr[k] = a.fac[e + k];
+    }
+    __syncthreads();
+    // row requests in slot order: a pair moves two rows into adjacent slots (lanes 0-31 / 32-63 of one LDS-DMA
+    // instruction); rowA | (rowB - rowA) << 8 | slotA << 16 | single << 24, rows relative to the step's first row
+    if (tid == 0) {
+        uint32_t n = 0, moved = 0;
+        auto row_of = [&](uint32_t sl) { const uint32_t d = sl / S1, s1 = sl % S1; return d * S + (s1 ? s1 - 1 : S - 1); };
+        for (uint32_t sl = 0; sl < (uint32_t)a.nslot;) {
+            if (!flags[sl]) { sl++; continue; }
+            const uint32_t ra = row_of(sl);
+            if (sl + 1 < (uint32_t)a.nslot && flags[sl + 1]) {
+                const uint32_t rb = row_of(sl + 1);
+                if (rb > ra && rb - ra < 256) {
+                    reqs[n++] = ra | ((rb - ra) << 8) | (sl << 16);
+                    sl += 2; moved += 2;
+                    continue;
+                }
+            }
+            reqs[n++] = ra | (sl << 16) | (1u << 24);
+            sl++; moved++;
+        }
+        nreq_s = n;
+        a.ucount[gtp] = moved;
+    }
+    __syncthreads();
+    const int nreq = (int)nreq_s;   // <= 2 * GC_LPAIR (launcher: (nslot + 1) / 2 + D)
+    const int64_t s = p;            // one slip variable: step = patch
+    for (int i = tid; i < GC_NLOAD * 32; i += GC_TB) {
+        const int ll = i / 32, d = i % 32;
+        uint32_t val;
+        if (d == 0) val = (nreq > ll) ? (uint32_t)((nreq - ll + GC_NLOAD - 1) / GC_NLOAD) : 0u;
+        else {
+            const int r = ll + GC_NLOAD * (d - 1);
+            val = r < nreq ? reqs[r] : 0u;
+        }
+        a.ltab[((gt * (a.nsteps + 3) + s) * GC_NLOAD + ll) * 32 + d] = val;
+    }
+    if (!slot) return;
+    const int w = tid / GC_NCHAIN, j = tid % GC_NCHAIN;
+    const uint32_t ring = (uint32_t)((s % 3) * a.nslot);
+    char *rec = a.wtab + ((gt * GC_NCONS + w) * (a.nsteps + 1) + s) * (int64_t)GM_WSTRIDE + (j >> 2) * GM_REC;
+    const int q = j & 3;
+    const double sl = live ? a.slips.base[c * a.slips.stride + a.slips.off + p] : 0.0;
+    for (int k = 0; k < 4; k++)
+        *reinterpret_cast<double *>(rec + (4 * q + k) * 16) = fr[k] * sl;     // base.py:676-679 x slip, as k_gfstack
+    // a dead chain slot reads slot 0 of the buffer (its accumulator is never stored)
+    *reinterpret_cast<uint32_t *>(rec + (2 * q) * 16 + 8) = (ring + sa) * 512u;
+    *reinterpret_cast<uint32_t *>(rec + (2 * q + 1) * 16 + 8) = (ring + sb) * 512u;
+}
+
+template <int NTH, int VAR>
+__global__ void __launch_bounds__(1024) k_gfstack_ml(GcArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t gsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile;
+    int64_t t, g;
+    if (a.xcd_order) {
+        const int64_t b = blockIdx.x;
+        const int64_t x = b & 7, q = b >> 3;
+        g = q % a.ngroups;
+        const int64_t tt = (q / a.ngroups) * 8 + x;
+        if (tt >= a.T * a.ntile) return;
+        tile = (int)(tt % a.ntile);
+        t = tt / a.ntile;
+    } else {
+        tile = blockIdx.x % a.ntile;
+        const int64_t gt0 = blockIdx.x / a.ntile;
+        t = gt0 % a.T;
+        g = gt0 / a.T;
+    }
+    const int64_t gt = g * a.Ttab + (a.Ttab == 1 ? 0 : t);
+    const int64_t n0 = (int64_t)tile * 64;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)gsm;
+    const uint32_t rb0 = lds0 + GC_PARAM_BYTES;
+    if (lane == 0) {
+        uint32_t *pb = gsm + wave * 32;
+        auto put64 = [&](int k, uint64_t x) { pb[k] = (uint32_t)x; pb[k + 1] = (uint32_t)(x >> 32); };
+        if (wave < GC_NCONS) {
+            put64(GC_P_WP, (uint64_t)(uintptr_t)(a.wtab + ((gt * GC_NCONS + wave) * (a.nsteps + 1)) * (int64_t)GM_WSTRIDE));
+            pb[GC_P_RB0] = rb0;
+            pb[GC_P_NSTEP] = (uint32_t)a.nsteps;
+            put64(GC_P_OUT, (uint64_t)(uintptr_t)(a.out + t * a.N + n0));
+            pb[GC_P_CTN] = (uint32_t)(a.T * a.N * 8);
+            pb[GC_P_MODE] = (uint32_t)a.mode;
+            put64(GC_P_DATA, (uint64_t)(uintptr_t)(a.data + t * a.N + n0));
+            const double wt = a.wscalar ? a.wscalar[t] : 0.0;
+            put64(GC_P_W, (uint64_t)__double_as_longlong(wt));
+            put64(GC_P_CID, (uint64_t)(uintptr_t)(a.order + g * GC_CG + wave * GC_NCHAIN));
+            put64(GC_P_PART, (uint64_t)(uintptr_t)(a.partial + t * a.ntile + tile));
+            pb[GC_P_PCS] = (uint32_t)(a.T * a.ntile * 8);
+            pb[GC_P_NVALID] = (uint32_t)min((int64_t)64, a.N - n0);
+            pb[GC_P_TRB] = rb0 + (uint32_t)(wave * 16 * GC_TPITCH);
+        } else {
+            const int ll = wave - GC_NCONS;
+            put64(GC_PL_LT, (uint64_t)(uintptr_t)(a.ltab + ((gt * (a.nsteps + 3)) * GC_NLOAD + ll) * 32));
+            put64(GC_PL_GROW, (uint64_t)(uintptr_t)(a.G[0] + (t * a.rows_per_target) * a.N + n0));
+            pb[GC_PL_DSRB] = (uint32_t)(a.DS * a.N * 8);
+            pb[GC_PL_ROWB] = (uint32_t)(a.N * 8);
+            pb[GC_PL_RB0] = rb0;
+            pb[GC_PL_BUFB] = (uint32_t)(a.ucap * 512);      // ucap: slots of a step's row buffer
+            pb[GC_PL_NSTEP] = (uint32_t)a.nsteps;
+            pb[GC_PL_NLANES] = (uint32_t)min((int64_t)32, (a.N - n0 + 1) / 2);
+        }
+    }
+    __syncthreads();
+    const uint32_t paddr = lds0 + (uint32_t)(wave * 128);
+    if constexpr (VAR == 0) {
+        if (wave < GC_NCONS) { GM_CONSUMER_0(paddr); }
+        else if (NTH) { GC_LOADER_0_1(paddr); }
+        else { GC_LOADER_0_0(paddr); }
+    }
+#if GM_NVARIANT > 1
+#define GM_VARIANT(V, CONS, LOAD) \
+    if constexpr (VAR == V) { if (wave < GC_NCONS) { CONS(paddr); } else { LOAD(paddr); } }
+    GM_VARIANT(1, GM_CONSUMER_1, GC_LOADER_0_1)
+    GM_VARIANT(2, GM_CONSUMER_2, GC_LOADER_0_1)
+    GM_VARIANT(3, GM_CONSUMER_3, GC_LOADER_0_1)
+    GM_VARIANT(4, GM_CONSUMER_4, GC_LOADER_0_1)
+    GM_VARIANT(5, GM_CONSUMER_5, GM_LOADER_NODMA)
+    GM_VARIANT(6, GM_CONSUMER_6, GC_LOADER_0_1)
+    GM_VARIANT(7, GM_CONSUMER_7, GC_LOADER_0_1)
+    GM_VARIANT(8, GM_CONSUMER_8, GM_LOADER_NODMA)
+    GM_VARIANT(9, GM_CONSUMER_9, GM_LOADER_NODMA)
+#endif
+}
+
+static int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+bool gfstack_ml_applicable(const GfStackCall &k)
+{
+    // A/B and test knobs, read per call so that one process can compare kernels (a few getenv calls next to a
+    // launch of milliseconds; the launch-bound geometry step reads its knobs once)
+    const int knob = env_int("BEATAMD_GS_ML", -1);   // 0: off, 1: forced also for small batches
+    const int gfk = env_int("BEATAMD_GF_KERNEL", -1);
+    const bool cg_fixed = getenv("BEATAMD_GS_CG") != nullptr;
+    const SeisLib &L = *k.libs[0];
+    if (knob == 0 || gfk == 0) return false;
+    if (k.interp != BEATAMD_MULTILINEAR || k.nvar != 1) return false;
+    if (L.N % 2 != 0) return false;
+    const int64_t DS = L.D * L.S, nslot = L.D * (L.S + 1);
+    // three dense row buffers in LDS; request table of the two loaders; 8-bit row / slot fields of a request
+    if (DS < 1 || DS > 255 || nslot > 255 || (nslot + 1) / 2 + L.D > 2 * GC_LPAIR) return false;
+    if (GC_PARAM_BYTES + 3 * nslot * 512 > 160 * 1024) return false;
+    if (L.T * L.N * 8 >= (int64_t)1 << 32 || DS * L.N * 8 >= (int64_t)1 << 32) return false;
+    const bool forced = knob == 1;
+    if (!forced && k.C < 192) return false;          // small batches: k_gfstack_dma groups of 64..256
+    if (!forced && cg_fixed) return false;           // an explicit group size asks for the k_gfstack_dma family
+    return true;
+}
+
+int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *rowoff, const double *fac, int64_t Ttab)
+{
+    const SeisLib &L = *k.libs[0];
+    const int64_t DS = L.D * L.S, nslot = L.D * (L.S + 1);
+    const int64_t ngroups = (k.C + GC_CG - 1) / GC_CG;
+    const int64_t nsteps = L.P;
+    const int64_t GT = ngroups * Ttab;
+    void *p = nullptr;
+
+    GcOrderArgs oa;
+    oa.C = k.C; oa.T = Ttab; oa.P = L.P; oa.S = L.S; oa.rowoff = rowoff;
+    oa.sort = 0;   // the order of the chains does not matter to a static program
+    BA_TRY(ctx->get_scratch(SL_GC_ORDER, (size_t)(ngroups * GC_CG + 64) * sizeof(uint32_t), &p));
+    oa.order = (uint32_t *)p;
+
+    GmTabArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.C = k.C; ta.T = Ttab; ta.P = L.P; ta.D = L.D; ta.S = L.S; ta.DS = DS; ta.nslot = nslot;
+    ta.nsteps = nsteps;
+    ta.rowoff = rowoff; ta.fac = fac;
+    ta.slips = k.slips[0];
+    ta.order = oa.order;
+    BA_TRY(ctx->get_scratch(SL_GC_STREAM, (size_t)GT * GC_NCONS * (nsteps + 1) * GM_WSTRIDE + 8192, &p));
+    ta.wtab = (char *)p;
+    const size_t lt_pitch = (size_t)(nsteps + 3) * GC_NLOAD * GC_LTAB;
+    BA_TRY(ctx->get_scratch(SL_GC_HDR, (size_t)GT * lt_pitch, &p));
+    ta.ltab = (uint32_t *)p;
+    BA_TRY(ctx->get_scratch(SL_GS_UCOUNT, (size_t)GT * L.P * sizeof(uint32_t), &p));
+    ta.ucount = (uint32_t *)p;
+    {
+        ScopedTimer tm(ctx, "grouptables");
+        hipLaunchKernelGGL(k_gc_order, dim3((unsigned)ngroups), dim3(GC_TB), 0, ctx->stream, oa);
+        // the request tables behind the last step stay empty
+        BA_HIP(hipMemset2DAsync((char *)ta.ltab + (size_t)nsteps * GC_NLOAD * GC_LTAB, lt_pitch, 0,
+                                (size_t)3 * GC_NLOAD * GC_LTAB, (size_t)GT, ctx->stream));
+        hipLaunchKernelGGL(k_gm_tables, dim3((unsigned)(GT * L.P)), dim3(GC_TB), 0, ctx->stream, ta);
+    }
+    BA_HIP(hipGetLastError());
+
+    GcArgs a;
+    memset(&a, 0, sizeof(a));
+    a.G[0] = L.g;
+    a.nvar = 1; a.ucap = (int)nslot;
+    a.ntile = (int)((L.N + 63) / 64);
+    a.mode = k.mode;
+    a.C = k.C; a.T = L.T; a.P = L.P; a.N = L.N; a.DS = DS;
+    a.Ttab = Ttab; a.rows_per_target = L.P * DS;
+    a.ngroups = ngroups; a.nsteps = nsteps;
+    a.wtab = ta.wtab; a.ltab = ta.ltab; a.order = oa.order;
+    a.data = k.data; a.wscalar = k.wscalar; a.out = k.out;
+    if (k.mode == GF_RESID_SCALAR) {
+        BA_TRY(ctx->get_scratch(SL_PARTIAL, (size_t)k.C * L.T * a.ntile * sizeof(double), &p));
+        a.partial = (double *)p;
+    }
+    int64_t nblocks = ngroups * L.T * a.ntile;
+    const int order_knob = env_int("BEATAMD_GS_ORDER", 1);
+    a.xcd_order = (ngroups > 1 && order_knob != 0) ? 1 : 0;
+    if (a.xcd_order) nblocks = ((L.T * a.ntile + 7) / 8) * 8 * ngroups;
+    BA_CHECK(nblocks < (int64_t)0x7fffffff, BEATAMD_EINVAL, "gfstack: batch too large");
+    const int nth_knob = env_int("BEATAMD_GS_NTHINT", -1);
+    const int nth = nth_knob >= 0 ? (nth_knob != 0) : (ngroups == 1);
+    const size_t ring = std::max<size_t>((size_t)3 * nslot * 512, (size_t)GC_NCONS * 16 * GC_TPITCH);
+    const size_t lds = GC_PARAM_BYTES + ring;
+    BA_CHECK(lds <= 160 * 1024, BEATAMD_EINVAL, "internal: k_gfstack_ml row buffers exceed LDS");
+    snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack_ml<%d,%d>", k.mode, nth);
+    ctx->gs_ngtp = GT * L.P;
+    ctx->gs_trep = L.T / Ttab;
+    ctx->gs_N = L.N;
+    ctx->gs_cg = GC_CG;
+    {
+        ScopedTimer tm(ctx, "gfstack");
+        void (*kern)(GcArgs) = nth ? k_gfstack_ml<1, 0> : k_gfstack_ml<0, 0>;
+#if GM_NVARIANT > 1
+        {
+            const int var = env_int("BEATAMD_GM_VAR", 0);   // timing experiments (GM_ABLATIONS builds; wrong results)
+            void (*vk[])(GcArgs) = {kern, k_gfstack_ml<1, 1>, k_gfstack_ml<1, 2>, k_gfstack_ml<1, 3>, k_gfstack_ml<1, 4>,
+                                    k_gfstack_ml<1, 5>, k_gfstack_ml<1, 6>, k_gfstack_ml<1, 7>, k_gfstack_ml<1, 8>,
+                                    k_gfstack_ml<1, 9>};
+            if (var >= 1 && var < GM_NVARIANT) kern = vk[var];
         }
 #endif
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

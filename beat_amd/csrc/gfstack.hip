@@ -385,6 +385,7 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &k)
     // cell kernel works on the float64 rows)
     bool f32_all = k.f32;
     for (int v = 0; v < k.nvar; v++) f32_all = f32_all && k.libs[v]->g32 != nullptr;
+    if (!f32_all && gfstack_ml_applicable(k)) return launch_gfstack_ml(ctx, k, ta.rowoff, ta.fac, Ttab);
     if (!f32_all && gfstack_cell_applicable(k)) return launch_gfstack_cell(ctx, k, ta.rowoff, ta.fac, Ttab);
     {
         int cg = 0, ucap = 0;

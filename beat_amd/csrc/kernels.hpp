@@ -68,6 +68,10 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &call, const uint3
 bool gfstack_cell_applicable(const GfStackCall &call);
 int launch_gfstack_cell(beatamd_ctx *ctx, const GfStackCall &call, const uint32_t *rowoff,
                         const double *fac, int64_t Ttab);
+// gfcell.hip: multilinear stacking with static accumulators and a dense LDS row layout (round 4)
+bool gfstack_ml_applicable(const GfStackCall &call);
+int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &call, const uint32_t *rowoff,
+                      const double *fac, int64_t Ttab);
 
 // ---- quadform.hip ----------------------------------------------------------------
 // quad[c,d] = || A_d x_{c,d} ||^2 ; A [nd or 1, M, M] row-major ; x(c,d,k) = X[c*xs_c + d*xs_d + k]

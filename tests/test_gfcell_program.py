@@ -32,26 +32,36 @@ def _reference(G, ro, fa, sl, T, P, N):
     return out
 
 
-def _run(T, P, D, S, N, C, Ttab_is_one, mode, sort, nth, seed):
+def _run(T, P, D, S, N, C, Ttab_is_one, mode, sort, nth, seed, static_acc=False, below_grid=False):
     rng = np.random.default_rng(seed)
     G = rng.standard_normal((T, P, D, S, N))
     du = rng.uniform(0.5, 0.5 + 0.5 * (D - 1), (C, P))
-    st = rng.uniform(0.0, 0.5 * (S - 1) - 0.01, (C, 1 if Ttab_is_one else T, P))
+    st = rng.uniform(0.0, max(0.5 * (S - 1) - 0.01, 0.0), (C, 1 if Ttab_is_one else T, P))
     st[0, 0, 0] = 0.0        # exactly on node 0: the floor node wraps to the last one with factor 0
     du[min(1, C - 1), P - 1] = 0.5
+    if below_grid:
+        # times below the first grid node: the reference's floor node wraps to the LAST node with a non-zero weight
+        # (base.py:513-517, python negative index)
+        st[min(2, C - 1), 0, P - 1] = -0.2
+        du[min(3, C - 1), 0] = 0.3
     sl = rng.uniform(0, 5, (C, P))
     Ttab = 1 if Ttab_is_one else T
     ro, fa = emu.gf_tables_ml(st, du, 0.0, 0.5, 0.5, 0.5, D, S, Ttab, P)
     DS = D * S
     order = emu.gc_order(ro, C, Ttab, P, S, sort)
     assert sorted(order[order != emu.DEAD].tolist()) == list(range(C))
-    wtab, ltab, ucount = emu.gc_tables(ro, fa, [sl], order, C, Ttab, P, DS)
+    if static_acc:
+        wtab, ltab, ucount = emu.gm_tables(ro, fa, sl, order, C, Ttab, P, D, S)
+    else:
+        wtab, ltab, ucount = emu.gc_tables(ro, fa, [sl], order, C, Ttab, P, DS)
     data = rng.standard_normal((T, N))
     wsc = rng.uniform(0.5, 2.0, T)
     ntile = (N + 63) // 64
     mem = emu.Memory()
     a = dict(T=T, P=P, N=N, DS=DS, Ttab=Ttab, rows_per_target=P * DS, nsteps=P, mode=mode, ntile=ntile,
              wscalar=wsc)
+    if static_acc:
+        a["wstride"], a["ucap"] = emu.genml.WSTRIDE, D * (S + 1)
     a["G"] = mem.alloc(G.nbytes, G)
     a["wtab"] = mem.alloc(wtab.nbytes, wtab)
     a["ltab"] = mem.alloc(ltab.nbytes, ltab)
@@ -65,7 +75,8 @@ def _run(T, P, D, S, N, C, Ttab_is_one, mode, sort, nth, seed):
         for t in range(T):
             for tile in range(ntile):
                 params = [emu.wave_params(w, g, t, tile, a) for w in range(emu.WAVES)]
-                wg = emu.Workgroup(mem, nth, emu.lds_bytes(DS), params).run()
+                nlds = emu.lds_bytes_ml(D * (S + 1)) if static_acc else emu.lds_bytes(DS)
+                wg = emu.Workgroup(mem, nth, nlds, params, static_acc=static_acc).run()
                 assert all(w.done and not w.idx_en and w.exec == emu.MASK64 for w in wg.waves)
                 assert {w.nbarrier for w in wg.waves} == {P + 1}
                 stats.append(wg)
@@ -115,13 +126,33 @@ def test_program_two_groups():
     assert stats[0].dma_bytes == int(ucount[:2].sum()) * 512
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_static_program_one_group(mode):
+    """k_gfstack_ml (static accumulators, dense LDS rows with a wrap slot per duration line): same cases as above
+    plus start times / durations BELOW the first grid node, where the wrapped floor node carries weight"""
+    _run(T=2, P=4, D=3, S=6, N=70, C=45, Ttab_is_one=False, mode=mode, sort=False, nth=mode & 1, seed=5 + mode,
+         static_acc=True, below_grid=True)
+
+
+def test_static_program_tables_per_patch_and_two_groups():
+    stats, _ = _run(T=2, P=3, D=2, S=5, N=64, C=80, Ttab_is_one=True, mode=0, sort=False, nth=0, seed=11, static_acc=True)
+    # four FMAs per chain SLOT of a step (dead slots run with zero weights): nothing depends on the data
+    assert sum(w.fma_count for w in stats[0].waves) == emu.CG * 3 * 4
+    stats, ucount = _run(T=1, P=2, D=2, S=4, N=64, C=519, Ttab_is_one=True, mode=1, sort=False, nth=1, seed=3,
+                         static_acc=True)
+    assert stats[0].dma_bytes == int(ucount[:2].sum()) * 512
+    # D = S = 1: one node, every index wraps onto it
+    _run(T=1, P=2, D=1, S=1, N=64, C=3, Ttab_is_one=True, mode=0, sort=False, nth=0, seed=4, static_acc=True)
+
+
 def test_register_budget():
     """the programs stay inside the registers the kernel may use: 128 VGPRs (16 wavefronts per
     workgroup = 4 per SIMD) and user SGPRs below s96 (VCC, FLAT_SCRATCH, XNACK_MASK above); SGPR
     pairs used as addresses are even-aligned"""
     import re
     assert gen.V_LAST < 128 and gen.NCONS + gen.NLOAD == 16 and gen.NQMIN >= 3
-    for prog in (gen.consumer(), gen.loader(0), gen.loader(1)):
+    assert emu.genml.V_LAST < 128
+    for prog in (gen.consumer(), gen.loader(0), gen.loader(1), emu.genml.consumer()):
         for ln in prog:
             for m in re.finditer(r"\b[sv]\[(\d+):(\d+)\]", ln):
                 assert int(m.group(1)) % 2 == 0, ln   # (gfx950: SGPR address pairs and VGPR tuples are 64-bit aligned)
@@ -130,7 +161,7 @@ def test_register_budget():
                 assert hi <= 95, ln
             for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", ln):
                 hi = int(m.group(2) or m.group(3))
-                assert hi <= gen.V_LAST, ln
+                assert hi <= max(gen.V_LAST, emu.genml.V_LAST), ln
 
 
 def test_committed_include_is_the_generators_output(tmp_path, monkeypatch):
@@ -153,3 +184,14 @@ def test_committed_include_is_the_generators_output(tmp_path, monkeypatch):
     gen.main()
     monkeypatch.undo()
     assert open(str(tmp_path / "gfcell_asm.inc")).read() == committed
+    genml = importlib.import_module("gen_gfml_asm")
+    committed = open(os.path.join(root, "beat_amd", "csrc", "gfml_asm.inc")).read()
+    monkeypatch.delenv("GM_ABLATIONS", raising=False)
+
+    def join2(*a):
+        p = real_join(*a)
+        return str(tmp_path / "gfml_asm.inc") if p.endswith("gfml_asm.inc") else p
+    monkeypatch.setattr(genml.os.path, "join", join2)
+    genml.main()
+    monkeypatch.undo()
+    assert open(str(tmp_path / "gfml_asm.inc")).read() == committed

@@ -204,11 +204,16 @@ def test_fullsize_shipped_dma_kernel_at_bench_shape(full, monkeypatch, C):
         assert ctx.last_kernel().startswith("k_gfstack<"), ctx.last_kernel()
         monkeypatch.delenv("BEATAMD_GF_KERNEL")
         assert torch.equal(out, ref), "k_gfstack_dma differs from the streaming kernel (%s)" % interp
-        if nrow == 4:   # the shipped multilinear kernel (rows of a cell in registers, gfcell.hip)
+        if nrow == 4:   # the shipped multilinear kernel (static accumulators, dense LDS rows) and the round-3 cell kernel
             monkeypatch.delenv("BEATAMD_GS_CG")
+            out2 = gf.stack_all_batch(dur_d, st_d, sl_d, interpolation=interp)
+            assert ctx.last_kernel().startswith("k_gfstack_ml<0,"), ctx.last_kernel()
+            assert torch.equal(out2, ref), "k_gfstack_ml differs from the streaming kernel"
+            monkeypatch.setenv("BEATAMD_GS_ML", "0")
             out2 = gf.stack_all_batch(dur_d, st_d, sl_d, interpolation=interp)
             assert ctx.last_kernel().startswith("k_gfstack_cell<0,"), ctx.last_kernel()
             assert torch.equal(out2, ref), "k_gfstack_cell differs from the streaming kernel"
+            monkeypatch.delenv("BEATAMD_GS_ML")
             del out2
             monkeypatch.setenv("BEATAMD_GS_CG", "512")
         del ref
@@ -271,6 +276,74 @@ def test_fullsize_fused_logp_through_dma_kernel(full, monkeypatch, C):
             syn = (rows * pt["uparr"][:, None]).sum(0)
             ref = orc.mvn_chol_logp(host["weights"][t], host["data"][t] - syn, host["slog"][t], hp)
             np.testing.assert_allclose(LL[c, t], ref, rtol=1e-10)
+    ctx.synchronize()
+
+
+@pytest.mark.parametrize("cov", ["scalar", "dense"])
+def test_fullsize_fused_logp_multilinear(full, monkeypatch, cov):
+    """the kernel the multilinear legs of bench.py time, asserted BY NAME at the bench shape
+    in its fused epilogues -- k_gfstack_ml<1,..> (scalar-covariance misfit) and <2,..> (residual store feeding the
+    dense-W quadratic form) -- against the streaming kernel (1e-12) and the round-3 cell kernel, and on sampled
+    (chain, target) pairs against the oracle composition (oracle index maps + closed-form rows + oracle MVN) at
+    1e-10.  No BEATAMD_GS_CG: that knob selects the lane <-> chain family instead."""
+    import torch
+    from beat_amd.models.problem import FFIProblem, SeismicWavemap
+    from oracle import oracle as orc
+    ctx, prob, host, spec = full["ctx"], full["prob"], full["host"], full["spec"]
+    wm0 = prob.wavemaps[0]
+    C = 512
+    if cov == "dense":
+        free, _ = torch.cuda.mem_get_info(0)
+        if free < 30e9:
+            pytest.skip("needs 30 GB of free HBM for the dense weights")
+        from beat_amd.synthetic import exponential_data_covariance
+        rng = np.random.default_rng(7)
+        base = exponential_data_covariance(N, 0.5, 2.0)
+        Wb = np.linalg.cholesky(np.linalg.inv(base)).T
+        ldb = 2.0 * np.log(np.diag(np.linalg.cholesky(base))).sum()
+        scal = (spec.sigma * (1.0 + 0.1 * rng.random(T))) ** 2
+        weights = np.empty((T, N, N))
+        for t in range(T):
+            np.divide(Wb, np.sqrt(scal[t]), out=weights[t])
+        slog = np.array([ldb + N * np.log(x) for x in scal])
+    else:
+        weights, slog = host["weights"], host["slog"]
+    wm = SeismicWavemap(wm0.gfs, wm0.data, weights, slog, wm0.hypers, wm0.time_shifts, "multilinear")
+    pm = FFIProblem(prob.layout, prob.n_patch_dip, prob.n_patch_strike, prob.patch_sizes, prob.slip_varnames,
+                    [wm], None, None, prob.lower, prob.upper)
+    f = pm.compile(ctx)
+    Q = _population(full, C, seed_offset=31000)
+    Qd = torch.from_numpy(Q).to("cuda:0")
+    for name in ("BEATAMD_GF_KERNEL", "BEATAMD_GS_CG", "BEATAMD_GS_ML", "BEATAMD_GS_CELL"):
+        monkeypatch.delenv(name, raising=False)
+    mode = 1 if cov == "scalar" else 2
+    LM = f.batch(Qd).cpu().numpy()
+    assert ctx.last_kernel().startswith("k_gfstack_ml<%d," % mode), ctx.last_kernel()
+    monkeypatch.setenv("BEATAMD_GS_ML", "0")
+    LC = f.batch(Qd).cpu().numpy()
+    assert ctx.last_kernel().startswith("k_gfstack_cell<%d," % mode), ctx.last_kernel()
+    monkeypatch.delenv("BEATAMD_GS_ML")
+    monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
+    LS = f.batch(Qd).cpu().numpy()
+    assert ctx.last_kernel().startswith("k_gfstack<1,"), ctx.last_kernel()
+    monkeypatch.delenv("BEATAMD_GF_KERNEL")
+    assert np.isfinite(LM).all()
+    if cov == "dense":
+        # the residuals are bitwise those of the streaming kernel, the quadratic form is the same kernel
+        assert np.array_equal(LM, LS) and np.array_equal(LC, LS)
+    else:
+        # the tile sums of the scalar misfit are taken in another order (64-sample tiles)
+        np.testing.assert_allclose(LM, LS, rtol=1e-12)
+        assert np.array_equal(LM, LC)
+    for c in (0, C // 2 + 1, C - 1):
+        st0, pt = _starttimes_oracle(full, Q[c])
+        hp = pt["h_any_P_0_Z"][0]
+        for t in (0, 40, 63):
+            syn = _stack_reference(full, pt["durations"], st0, pt["uparr"], t, "multilinear")
+            ref = orc.mvn_chol_logp(weights[t], host["data"][t] - syn, slog[t], hp)
+            np.testing.assert_allclose(LM[c, t], ref, rtol=1e-6)     # north_star tolerance
+            np.testing.assert_allclose(LM[c, t], ref, rtol=1e-10)
+    del f
     ctx.synchronize()
 
 

@@ -210,17 +210,19 @@ def test_shared_row_kernel_equals_streaming_kernel(ctx, orc, monkeypatch, C, int
         ref = orc.stack_all(G, dur[c], st[c], sl[c], 0.5, 0.25, 0.0, 0.5, interp)
         assert np.abs(b[c] - ref).max() <= 1e-11 * np.abs(ref).max()
     if interp == "multilinear":
-        # rows of a cell in registers, accumulators through the VGPR index (gfcell.hip): the default
-        # from 192 chains on, forced below; chain order and non-temporal requests are scheduling only
+        # lane <-> sample kernels of gfcell.hip: static accumulators over dense LDS rows (k_gfstack_ml, the default
+        # from 192 chains on) and rows of a cell in registers with accumulators through the VGPR index
+        # (k_gfstack_cell, round 3); forced below; chain order and non-temporal requests are scheduling only
         if C >= 192:
-            assert ctx.last_kernel().startswith("k_gfstack_cell<0,"), ctx.last_kernel()
-        for srt, nth in (("1", "1"), ("0", "0")):
+            assert ctx.last_kernel().startswith("k_gfstack_ml<0,"), ctx.last_kernel()
+        for ml, srt, nth in (("1", "0", "1"), ("1", "0", "0"), ("0", "1", "1"), ("0", "0", "0")):
+            monkeypatch.setenv("BEATAMD_GS_ML", ml)
             monkeypatch.setenv("BEATAMD_GS_CELL", "1")
             monkeypatch.setenv("BEATAMD_GC_SORT", srt)
             monkeypatch.setenv("BEATAMD_GS_NTHINT", nth)
-            assert np.array_equal(gf.stack_all_batch(dur, st, sl, interpolation=interp), a), (C, srt, nth)
-            assert ctx.last_kernel() == "k_gfstack_cell<0,%s>" % nth, ctx.last_kernel()
-        for name in ("BEATAMD_GS_CELL", "BEATAMD_GC_SORT", "BEATAMD_GS_NTHINT"):
+            assert np.array_equal(gf.stack_all_batch(dur, st, sl, interpolation=interp), a), (C, ml, srt, nth)
+            assert ctx.last_kernel() == "k_gfstack_%s<0,%s>" % ("ml" if ml == "1" else "cell", nth), ctx.last_kernel()
+        for name in ("BEATAMD_GS_ML", "BEATAMD_GS_CELL", "BEATAMD_GC_SORT", "BEATAMD_GS_NTHINT"):
             monkeypatch.delenv(name)
     seen = set()
     for cg in ("64", "128", "256", "512", "1024"):
@@ -253,6 +255,39 @@ def test_shared_row_kernel_equals_streaming_kernel(ctx, orc, monkeypatch, C, int
             assert "k_gfstack_shared<%d,%d,0,64,0>" % (w[cg], nrow) in seen, seen
     if nrow == 1 and C > 0:
         assert "k_gfstack_ws<1,0,3,0>" in seen and "k_gfstack_ws<1,0,3,1>" in seen, seen
+
+
+@pytest.mark.parametrize("C", [200, 530])
+def test_ml_kernel_wrapped_floor_nodes(ctx, orc, monkeypatch, C):
+    """k_gfstack_ml keeps a chain's four rows at two LDS addresses (dense rows; slot 0 of a duration line = a copy of
+    its LAST start-time node).  Times exactly on node 0 (floor node wraps with weight 0), times BELOW the first node
+    (the reference's python index -1 wraps to the last node WITH weight, base.py:513-517) and one-node axes must come
+    out as in the streaming kernel (bitwise) and the oracle"""
+    rng = np.random.default_rng(40 + C)
+    for (T, P, D, S, N) in ((2, 7, 3, 6, 130), (1, 3, 1, 1, 64), (2, 4, 2, 25, 64)):
+        G = rng.standard_normal((T, P, D, S, N))
+        gf = _make_lib(ctx, G, 0.0, 0.5, 0.5, 0.5)
+        dur = rng.uniform(0.5, 0.5 + 0.5 * (D - 1), (C, P)) if D > 1 else np.full((C, P), 0.5)
+        st = rng.uniform(0.0, 0.5 * (S - 1) - 0.01, (C, T, P)) if S > 1 else np.zeros((C, T, P))
+        if S > 1:
+            st[0::7, :, 0] = 0.0                   # on node 0
+            st[1::7, :, P - 1] = -0.2               # below node 0: the last node enters with weight 0.4
+            st[2::9, 0, 1] = 0.5 * (S - 1)          # on the last node
+        if D > 1:
+            dur[3::5, 1] = 0.5                      # on duration node 0
+            dur[4::11, 0] = 0.3                     # below it
+        sl = rng.uniform(0, 5, (C, P))
+        monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
+        a = gf.stack_all_batch(dur, st, sl, interpolation="multilinear")
+        monkeypatch.delenv("BEATAMD_GF_KERNEL")
+        monkeypatch.setenv("BEATAMD_GS_ML", "1")
+        b = gf.stack_all_batch(dur, st, sl, interpolation="multilinear")
+        assert ctx.last_kernel().startswith("k_gfstack_ml<0,"), ctx.last_kernel()
+        monkeypatch.delenv("BEATAMD_GS_ML")
+        assert np.array_equal(a, b), (T, P, D, S, N)
+        for c in (0, 1, 2, 3, 4, C - 1):
+            ref = orc.stack_all(G, dur[c], st[c], sl[c], 0.5, 0.5, 0.0, 0.5, "multilinear")
+            assert np.abs(b[c] - ref).max() <= 1e-11 * max(np.abs(ref).max(), 1.0)
 
 
 @pytest.mark.parametrize("interp", ["nearest_neighbor", "multilinear"])

@@ -240,54 +240,16 @@ def out_of_line(v):
         br("s_branch", "BATCH_%d" % nxt)
 
 
-def consumer():
-    del L[:]
-    lane_setup()
-    e("v_lshlrev_b32 v%d, 3, v%d" % (V_RING, V_T0))
-    e("v_lshlrev_b32 v%d, 4, v%d" % (V_L16, V_T0))
-    e("v_and_b32 v%d, 15, v%d" % (V_AB, V_T0))
-    e("v_lshlrev_b32 v%d, 3, v%d" % (V_WB, V_AB))
-    e("v_lshlrev_b32 v%d, 2, v%d" % (V_AB, V_AB))
-    read_params()
-    for sreg, k in ((S_WP, P_WP), (S_WP + 1, P_WP + 1), (S_RB0, P_RB0), (S_NSTEP, P_NSTEP), (S_BNC, P_BNC)):
-        readlane(sreg, k)
-    e("s_nop 4")
-    e("v_add_u32 v%d, s%d, v%d" % (V_RING, S_RB0, V_RING))
-    e("v_add_u32 v%d, s%d, v%d" % (V_WB, S_BNC, V_WB))
-    e("v_add_u32 v%d, s%d, v%d" % (V_AB, S_BNC, V_AB))
-    e("v_add_u32 v%d, s%d, v%d" % (V_BW, S_BNC, V_L16))
-    for j in range(NCHAIN):
-        e("v_mov_b32 v%d, 0" % (ACC + 2 * j))
-        e("v_mov_b32 v%d, 0" % (ACC + 2 * j + 1))
-    e("s_add_u32 s%d, s%d, %d" % (S_WN, S_WP, WSTRIDE))
-    e("s_addc_u32 s%d, s%d, 0" % (S_WN + 1, S_WP + 1))
-    # quad 0 -> first half of the bounce buffer, quad 1 in flight, record 0 in registers
-    request_quad()
-    e("s_add_u32 s%d, s%d, %d" % (S_WP, S_WP, QUAD))
-    e("s_addc_u32 s%d, s%d, 0" % (S_WP + 1, S_WP + 1))
-    e("s_waitcnt vmcnt(0)")
-    e("ds_write_b128 v%d, v[%d:%d]" % (V_BW, V_S, V_S + 3))
-    request_quad()
-    e("s_add_u32 s%d, s%d, %d" % (S_WP, S_WP, QUAD))
-    e("s_addc_u32 s%d, s%d, 0" % (S_WP + 1, S_WP + 1))
-    read_record(0)
-    e("s_barrier")                                     # rows of steps 0..2 in LDS
-    # VGPR index mode stays on for the whole loop: M0 = 0x8000 | 2 * chain slot selects the accumulator
-    # of the v_fmac_f64_dpp; every other vector instruction runs with index 0
-    e("s_mov_b32 s%d, 0" % T0)
-    e("s_set_gpr_idx_on s%d, 0x8" % T0)
-    e("s_waitcnt lgkmcnt(0)")
-    x_prefetch(AUXA, A_XO, XA)
-    e("s_waitcnt lgkmcnt(0)")
-    _in_loop[0] = True
-    for v in range(8):
-        batch(v)
-    for v in range(8):
-        out_of_line(v)
-    _in_loop[0] = False
-    # ---------------------------------------------------------------- epilogue
+def epilogue(XA, XB, ACC, NCHAIN, idx_mode):
+    """the three epilogues of a consumer wavefront (synthetics | residual store | scalar-covariance misfit); shared
+    by the cell program above and the static-accumulator program of tools/gen_gfml_asm.py.  XA, XB: eight free
+    VGPRs each (the row registers), ACC: first accumulator (chain j = v[ACC+2j : ACC+2j+1])"""
+    V_D = XA
+    V_T1 = XA + 2
+    V_T2 = XA + 4
     lab("EPI")
-    e("s_set_gpr_idx_off")
+    if idx_mode:
+        e("s_set_gpr_idx_off")
     e("s_waitcnt vmcnt(0)")                            # records requested beyond the last step
     e("s_barrier")                                     # every wavefront is done with the row ring
     S_OUT, S_CTN, S_MODE, S_DATA, S_W, S_CID, S_PART, S_PCS, S_NVAL, S_TRB = 22, 24, 25, 26, 28, 30, 84, 86, 87, 88
@@ -385,6 +347,54 @@ def consumer():
         e("s_waitcnt vmcnt(0)")
     lab("END")
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+
+
+def consumer():
+    del L[:]
+    lane_setup()
+    e("v_lshlrev_b32 v%d, 3, v%d" % (V_RING, V_T0))
+    e("v_lshlrev_b32 v%d, 4, v%d" % (V_L16, V_T0))
+    e("v_and_b32 v%d, 15, v%d" % (V_AB, V_T0))
+    e("v_lshlrev_b32 v%d, 3, v%d" % (V_WB, V_AB))
+    e("v_lshlrev_b32 v%d, 2, v%d" % (V_AB, V_AB))
+    read_params()
+    for sreg, k in ((S_WP, P_WP), (S_WP + 1, P_WP + 1), (S_RB0, P_RB0), (S_NSTEP, P_NSTEP), (S_BNC, P_BNC)):
+        readlane(sreg, k)
+    e("s_nop 4")
+    e("v_add_u32 v%d, s%d, v%d" % (V_RING, S_RB0, V_RING))
+    e("v_add_u32 v%d, s%d, v%d" % (V_WB, S_BNC, V_WB))
+    e("v_add_u32 v%d, s%d, v%d" % (V_AB, S_BNC, V_AB))
+    e("v_add_u32 v%d, s%d, v%d" % (V_BW, S_BNC, V_L16))
+    for j in range(NCHAIN):
+        e("v_mov_b32 v%d, 0" % (ACC + 2 * j))
+        e("v_mov_b32 v%d, 0" % (ACC + 2 * j + 1))
+    e("s_add_u32 s%d, s%d, %d" % (S_WN, S_WP, WSTRIDE))
+    e("s_addc_u32 s%d, s%d, 0" % (S_WN + 1, S_WP + 1))
+    # quad 0 -> first half of the bounce buffer, quad 1 in flight, record 0 in registers
+    request_quad()
+    e("s_add_u32 s%d, s%d, %d" % (S_WP, S_WP, QUAD))
+    e("s_addc_u32 s%d, s%d, 0" % (S_WP + 1, S_WP + 1))
+    e("s_waitcnt vmcnt(0)")
+    e("ds_write_b128 v%d, v[%d:%d]" % (V_BW, V_S, V_S + 3))
+    request_quad()
+    e("s_add_u32 s%d, s%d, %d" % (S_WP, S_WP, QUAD))
+    e("s_addc_u32 s%d, s%d, 0" % (S_WP + 1, S_WP + 1))
+    read_record(0)
+    e("s_barrier")                                     # rows of steps 0..2 in LDS
+    # VGPR index mode stays on for the whole loop: M0 = 0x8000 | 2 * chain slot selects the accumulator
+    # of the v_fmac_f64_dpp; every other vector instruction runs with index 0
+    e("s_mov_b32 s%d, 0" % T0)
+    e("s_set_gpr_idx_on s%d, 0x8" % T0)
+    e("s_waitcnt lgkmcnt(0)")
+    x_prefetch(AUXA, A_XO, XA)
+    e("s_waitcnt lgkmcnt(0)")
+    _in_loop[0] = True
+    for v in range(8):
+        batch(v)
+    for v in range(8):
+        out_of_line(v)
+    _in_loop[0] = False
+    epilogue(XA, XB, ACC, NCHAIN, True)
     return list(L)
 
 
@@ -423,10 +433,12 @@ def issue_requests(tag, nth):
         e("s_mul_i32 s%d, s%d, s%d" % (T1, T1, LS_ROWB))
         e("s_add_u32 s%d, s%d, s%d" % (T2, LS_GROW, T0))
         e("s_addc_u32 s%d, s%d, 0" % (T3, LS_GROW + 1))
+        # (the lane offsets are written under the pair mask: a single-row request in the middle of a list -- the
+        # dense layout of k_gfstack_ml has them -- must not leave the upper half's offsets stale)
+        e("s_mov_b64 exec, %s" % sp(LS_MP))
         e("v_mad_u32_u24 v%d, v%d, s%d, v%d" % (LV_OFF, LV_HI, T1, LV_DMA))
         e("s_bfe_u32 s%d, s%d, 0x80010" % (T0, ent))           # LDS slot of rowA
         e("s_lshl_b32 s%d, s%d, 9" % (T0, T0))
-        e("s_mov_b64 exec, %s" % sp(LS_MP))
         e("s_bitcmp1_b32 s%d, 24" % ent)
         e("s_cselect_b64 exec, %s, exec" % sp(LS_MS))
         e("s_add_u32 m0, s%d, s%d" % (T0, LS_RBREQ))

@@ -21,6 +21,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import gen_gfcell_asm as gen  # noqa: E402
+import gen_gfml_asm as genml  # noqa: E402
 
 U32 = np.uint32
 MASK64 = (1 << 64) - 1
@@ -192,13 +193,80 @@ def gc_tables(rowoff, fac, slips, order, C, T, P, DS, nvar=1):
     return wtab, ltab, ucount
 
 
+def gm_tables(rowoff, fac, slips, order, C, T, P, D, S):
+    """numpy twin of k_gm_tables (gfcell.hip): record table, request table and moved-row counts of k_gfstack_ml"""
+    ngroups = order.size // CG
+    nsteps, GT, DS, S1 = P, ngroups * T, D * S, S + 1
+    nslot = D * S1
+    wtab = np.zeros(GT * NCONS * (nsteps + 1) * genml.WSTRIDE + 8192, dtype=np.uint8)
+    ltab = np.zeros(GT * (nsteps + 3) * NLOAD * 32, dtype=np.uint32)
+    ucount = np.zeros(GT * P, dtype=np.uint32)
+
+    def row_of(sl):
+        d, s1 = divmod(sl, S1)
+        return d * S + (s1 - 1 if s1 else S - 1)
+    for g in range(ngroups):
+        ids = order[g * CG:(g + 1) * CG]
+        live = ids != DEAD
+        for t in range(T):
+            gt = g * T + t
+            for p in range(P):
+                row0 = (t * P + p) * DS
+                rel = np.zeros((CG, 4), dtype=np.int64)
+                rel[live] = rowoff[ids[live], t, p].astype(np.int64) - row0
+                dc, sc, df = rel[:, 0] // S, rel[:, 0] % S, rel[:, 2] // S
+                sb, sa = dc * S1 + sc, df * S1 + sc
+                sa[~live] = 0
+                sb[~live] = 0
+                present = np.zeros(nslot + 1, dtype=bool)
+                for arr in (sa[live], sa[live] + 1, sb[live], sb[live] + 1):
+                    present[arr] = True
+                reqs, sl, moved = [], 0, 0
+                while sl < nslot:
+                    if not present[sl]:
+                        sl += 1
+                        continue
+                    ra = row_of(sl)
+                    if sl + 1 < nslot and present[sl + 1]:
+                        rb = row_of(sl + 1)
+                        if rb > ra and rb - ra < 256:
+                            reqs.append(ra | ((rb - ra) << 8) | (sl << 16))
+                            sl += 2
+                            moved += 2
+                            continue
+                    reqs.append(ra | (sl << 16) | (1 << 24))
+                    sl += 1
+                    moved += 1
+                ucount[gt * P + p] = moved
+                s = p
+                for ll in range(NLOAD):
+                    h = ltab[((gt * (nsteps + 3) + s) * NLOAD + ll) * 32:][:32]
+                    mine = reqs[ll::NLOAD]
+                    assert len(mine) <= 31
+                    h[0] = len(mine)
+                    h[1:1 + len(mine)] = mine
+                ring = (s % 3) * nslot
+                for w in range(NCONS):
+                    for j in range(NCH):
+                        k = w * NCH + j
+                        rec = ((gt * NCONS + w) * (nsteps + 1) + s) * genml.WSTRIDE + (j // 4) * genml.REC
+                        q = j % 4
+                        c = int(ids[k]) if live[k] else 0
+                        for kk in range(4):
+                            wv = (fac[c, t, p, kk] * slips[c, p]) if live[k] else 0.0
+                            wtab[rec + (4 * q + kk) * 16:rec + (4 * q + kk) * 16 + 8].view(np.float64)[0] = wv
+                        wtab[rec + (2 * q) * 16 + 8:rec + (2 * q) * 16 + 12].view(np.uint32)[0] = (ring + sa[k]) * 512
+                        wtab[rec + (2 * q + 1) * 16 + 8:rec + (2 * q + 1) * 16 + 12].view(np.uint32)[0] = (ring + sb[k]) * 512
+    return wtab, ltab, ucount
+
+
 # =============================================================================== interpreter
 class Barrier(Exception):
     pass
 
 
 def _parse_program(kind, nth):
-    lines = gen.consumer() if kind == "consumer" else gen.loader(nth)
+    lines = gen.consumer() if kind == "consumer" else genml.consumer() if kind == "consumer_ml" else gen.loader(nth)
     labels, prog = {}, []
     for ln in lines:
         m = re.match(r"^(\w+)_%=:$", ln)
@@ -475,11 +543,16 @@ class Wave(object):
                 self.wr32(self.vreg(ops[0]), a_.astype(np.uint64) + self.src32(ops[2]))
             elif op == "v_fmac_f64_dpp":
                 # D = dpp(S0) * S1 + D ; row_newbcast:k: lane k of the lane's own 16-lane row
-                assert self.idx_en and ((self.m0 >> 12) & 0xF) == 0x8, ln
                 k = int(re.search(r"row_newbcast:(\d+)", ln).group(1))
                 ops = [o.split()[0] for o in ops]
-                d = self.vreg(ops[0]) + (self.m0 & 0xFF)
-                assert gen.ACC <= d <= gen.V_LAST - 1 and (d - gen.ACC) % 2 == 0, (ln, d)
+                if self.wg.static_acc:
+                    assert not self.idx_en, ln
+                    d = self.vreg(ops[0])
+                    assert genml.ACC <= d <= genml.V_LAST - 1 and (d - genml.ACC) % 2 == 0, (ln, d)
+                else:
+                    assert self.idx_en and ((self.m0 >> 12) & 0xF) == 0x8, ln
+                    d = self.vreg(ops[0]) + (self.m0 & 0xFF)
+                    assert gen.ACC <= d <= gen.V_LAST - 1 and (d - gen.ACC) % 2 == 0, (ln, d)
                 a_ = self.src_f64(ops[1])[(np.arange(64) // 16) * 16 + k]
                 b_ = self.src_f64(ops[2])
                 c_ = (self.v[d].astype(np.uint64) | (self.v[d + 1].astype(np.uint64) << np.uint64(32))).view(np.float64)
@@ -582,12 +655,14 @@ class Wave(object):
 class Workgroup(object):
     """one (group g, target t, tile) workgroup of k_gfstack_cell: 14 consumers + 2 loaders"""
 
-    def __init__(self, mem, nth, lds_bytes, params, max_instr=5000000):
+    def __init__(self, mem, nth, lds_bytes, params, max_instr=5000000, static_acc=False):
         self.mem = mem
+        self.static_acc = static_acc   # k_gfstack_ml: the consumer program of tools/gen_gfml_asm.py
         self.lds = np.zeros(lds_bytes, dtype=np.uint8)
         self.max_instr = max_instr
         self.dma_bytes = 0
-        self.programs = {"consumer": _parse_program("consumer", nth), "loader": _parse_program("loader", nth)}
+        self.programs = {"consumer": _parse_program("consumer_ml" if static_acc else "consumer", nth),
+                         "loader": _parse_program("loader", nth)}
         self.waves = []
         for w in range(WAVES):
             self.lds[w * 128:(w + 1) * 128].view(np.uint32)[:] = params[w]
@@ -622,7 +697,7 @@ def wave_params(w, g, t, tile, a):
     n0 = tile * 64
     N, T = a["N"], a["T"]
     if w < NCONS:
-        put64(gen.P_WP, a["wtab"] + ((gt * NCONS + w) * (a["nsteps"] + 1)) * WSTRIDE)
+        put64(gen.P_WP, a["wtab"] + ((gt * NCONS + w) * (a["nsteps"] + 1)) * a.get("wstride", WSTRIDE))
         P[gen.P_RB0] = PARAM_BYTES
         P[gen.P_NSTEP] = a["nsteps"]
         P[gen.P_BNC] = PARAM_BYTES + 3 * a["DS"] * 512 + w * BOUNCE
@@ -643,7 +718,7 @@ def wave_params(w, g, t, tile, a):
         P[gen.PL_DSRB] = a["DS"] * N * 8
         P[gen.PL_ROWB] = N * 8
         P[gen.PL_RB0] = PARAM_BYTES
-        P[gen.PL_BUFB] = a["DS"] * 512
+        P[gen.PL_BUFB] = a.get("ucap", a["DS"]) * 512
         P[gen.PL_NSTEP] = a["nsteps"]
         P[gen.PL_NLANES] = min(32, (N - n0 + 1) // 2)
     return P
@@ -651,3 +726,7 @@ def wave_params(w, g, t, tile, a):
 
 def lds_bytes(DS):
     return PARAM_BYTES + max(3 * DS * 512 + NCONS * BOUNCE, NCONS * 16 * TPITCH)
+
+
+def lds_bytes_ml(nslot):
+    return PARAM_BYTES + max(3 * nslot * 512, NCONS * 16 * TPITCH)
