@@ -18,7 +18,7 @@ W_SCALAR, W_DENSE = 0, 1
 INTERPOLATIONS = {"nearest_neighbor": NEAREST_NEIGHBOR, "multilinear": MULTILINEAR}
 
 OK, EINVAL, EHIP, EINDEX, ENOMEM, ENAN, ENOTPSD, EBADCOV = 0, -1, -2, -3, -4, -5, -6, -7
-ABI_VERSION = 112   # include/beat_amd.h BEATAMD_VERSION this module was written against
+ABI_VERSION = 113   # include/beat_amd.h BEATAMD_VERSION this module was written against
 
 
 class BeatAmdError(RuntimeError):
@@ -59,7 +59,7 @@ _PROTOS = {
     "beatamd_seis_gflib_create": [_vp, _i64, _i64, _i64, _i64, _i64, _f64, _f64, _f64, _f64, _pi32],
     "beatamd_seis_gflib_upload": [_vp, _i32, _vp, _i64, _i64],
     "beatamd_seis_gflib_adopt": [_vp, _i32, _vp],
-    "beatamd_seis_gflib_store_f32": [_vp, _i32],
+    "beatamd_seis_gflib_round_to_f32": [_vp, _i32],
     "beatamd_ffi_model_set_f32": [_vp, _i32, _i32, _i32],
     "beatamd_seis_gflib_device_ptr": [_vp, _i32, C.POINTER(_vp)],
     "beatamd_seis_gflib_destroy": [_vp, _i32],

@@ -118,6 +118,12 @@ class NoiseCovarianceUpdate(object):
         dev = torch.device("cuda", f.ctx.device)
         q = torch.as_tensor(np.ascontiguousarray(q_map, dtype=np.float64).reshape(1, -1)).to(dev)
         res = f.synthetics(q, wavemap_index, residuals=True)[0]            # seismic.py:1332
+        wm = f.problem.wavemaps[wavemap_index]
+        if getattr(wm, "is_prewhitened", False):
+            # library rows and data of a pre-whitened model hold W_old G and W_old d: the model's residuals are
+            # W_old (d - s).  The reference estimates the noise on d - s (covariance.py:307-325,
+            # seismic.py:1509-1534): take W_old off again, r_t = inv(W_old,t) . res_t
+            res = self._unwhiten(res, wm._whitened_with, dev)
         n = int(res.shape[1])
         window = n // 5
         if window == 0:
@@ -126,6 +132,23 @@ class NoiseCovarianceUpdate(object):
         stds = running_window_rms_batch(res, window)
         coeffs = f.ctx.autocovariance_batch((res / stds).contiguous())
         return f.ctx.scaled_toeplitz_batch(coeffs, stds.contiguous()), res
+
+    def _unwhiten(self, res, w_old, dev, chunk=8):
+        """rows r_t = inv(W_t) res_t for upper-triangular W [T, n, n] (host or device); the inverses come from the
+        library's own triangular solve (``beatamd_whitening_ratio_batch`` with the identity as numerator), a few
+        datasets at a time, the products from ``beatamd_whiten_rows`` (res_t^T . inv(W_t)^T)"""
+        import torch
+        T, n = res.shape
+        out = res.clone()
+        eye = torch.eye(n, dtype=torch.float64, device=dev)
+        for t0 in range(0, T, chunk):
+            t1 = min(T, t0 + chunk)
+            wo = w_old[t0:t1]
+            wo = wo.to(dev) if torch.is_tensor(wo) else torch.from_numpy(np.ascontiguousarray(wo)).to(dev)
+            inv = self.f.ctx.whitening_ratio_batch(eye.expand(t1 - t0, n, n).contiguous(), wo.contiguous())
+            for t in range(t0, t1):
+                self.f.ctx.whiten_rows(out[t:t + 1], inv[t - t0])
+        return out
 
     def update_weights(self, q_map):
         import time

@@ -287,11 +287,33 @@ static int seis_ensure_storage(beatamd_ctx *ctx, SeisLib *l)
     return BEATAMD_OK;
 }
 
-int beatamd_seis_gflib_store_f32(beatamd_ctx *ctx, int32_t lib_id)
+// The float copy and the float64 storage hold the same values only as long as nobody rewrites the float64 rows:
+// an upload or an in-place (re-)whitening drops the copy and takes the models' wavemaps off it.
+static void drop_f32_overlapping(beatamd_ctx *ctx, const void *p, size_t bytes)
+{
+    const char *a = (const char *)p, *b = a + bytes;
+    for (size_t id = 0; id < ctx->seislibs.size(); id++) {
+        SeisLib *l = ctx->seislibs[id].get();
+        if (!l || !l->g32 || !l->g) continue;
+        const char *la = (const char *)l->g, *lb = la + (size_t)l->elems() * sizeof(double);
+        if (b <= la || lb <= a) continue;
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(l->g32);
+        l->g32 = nullptr;
+        for (auto &m : ctx->models) {
+            if (!m) continue;
+            for (Wavemap &w : m->wavemaps)
+                for (int32_t lid : w.libs)
+                    if ((size_t)lid == id) w.f32 = false;
+        }
+    }
+}
+
+int beatamd_seis_gflib_round_to_f32(beatamd_ctx *ctx, int32_t lib_id)
 {
     ENTER(ctx);
     SeisLib *l = get_obj(ctx->seislibs, lib_id);
-    BA_CHECK(l && l->g, BEATAMD_EINVAL, "gflib_store_f32: unknown or empty GF library %d", lib_id);
+    BA_CHECK(l && l->g, BEATAMD_EINVAL, "gflib_round_to_f32: unknown or empty GF library %d", lib_id);
     if (!l->g32) {
         hipError_t e = hipMalloc((void **)&l->g32, (size_t)l->elems() * sizeof(float));
         if (e != hipSuccess) {
@@ -317,7 +339,8 @@ int beatamd_ffi_model_set_f32(beatamd_ctx *ctx, int32_t model_id, int32_t wavema
         for (int32_t id : w.libs) {
             SeisLib *l = get_obj(ctx->seislibs, id);
             BA_CHECK(l && l->g32, BEATAMD_EINVAL,
-                     "model_set_f32: library %d has no float copy (beatamd_seis_gflib_store_f32)", id);
+                     "model_set_f32: library %d has no float copy (beatamd_seis_gflib_round_to_f32; an upload or a "
+                     "re-whitening of its rows drops the copy)", id);
         }
     w.f32 = on != 0;
     return BEATAMD_OK;
@@ -333,6 +356,7 @@ int beatamd_seis_gflib_upload(beatamd_ctx *ctx, int32_t lib_id, const double *sr
              "gflib_upload: range [%lld, %lld) outside the library (%lld elements)",
              (long long)offset, (long long)(offset + count), (long long)l->elems());
     BA_TRY(seis_ensure_storage(ctx, l));
+    drop_f32_overlapping(ctx, l->g + offset, (size_t)count * 8);
     BA_HIP(hipMemcpyAsync(l->g + offset, src, (size_t)count * 8, hipMemcpyDefault, ctx->stream));
     BA_HIP(hipStreamSynchronize(ctx->stream));
     return BEATAMD_OK;
@@ -1038,8 +1062,9 @@ int beatamd_ffi_mstep_batch(beatamd_ctx *ctx, int32_t model_id, int64_t C, doubl
 {
     BA_CHECK(ctx != nullptr, BEATAMD_EINVAL, "ctx is NULL");
     BA_CHECK(factor && first_chain >= 0 && df >= 0 && df <= 64, BEATAMD_EINVAL, "ffi_mstep: bad argument");
-    BA_CHECK(kind >= -1 && kind <= BEATAMD_PROPOSAL_LAPLACE && (kind >= 0 || K > 0), BEATAMD_EINVAL,
-             "ffi_mstep: kind must be -1 (multivariate, K > 0 factor rows), Normal (0), Cauchy (1) or Laplace (2)");
+    BA_CHECK(kind >= -1 && kind <= BEATAMD_PROPOSAL_POISSON && (kind >= 0 || K > 0), BEATAMD_EINVAL,
+             "ffi_mstep: kind must be -1 (multivariate, K > 0 factor rows), Normal (0), Cauchy (1), Laplace (2) or "
+             "Poisson (3)");
     StepDraw d;
     d.factor = factor; d.K = K; d.kind = kind; d.df = kind < 0 ? df : 0;
     d.seed = seed; d.step = step; d.first_chain = (uint64_t)first_chain;
@@ -1234,8 +1259,8 @@ int beatamd_proposal_draw_univariate(beatamd_ctx *ctx, int64_t C, int64_t nparam
     ENTER(ctx);
     BA_CHECK(scale && delta && C >= 0 && nparams > 0 && first_chain >= 0, BEATAMD_EINVAL,
              "proposal_draw_univariate: bad argument");
-    BA_CHECK(kind >= BEATAMD_PROPOSAL_NORMAL && kind <= BEATAMD_PROPOSAL_LAPLACE, BEATAMD_EINVAL,
-             "proposal_draw_univariate: kind must be Normal (0), Cauchy (1) or Laplace (2)");
+    BA_CHECK(kind >= BEATAMD_PROPOSAL_NORMAL && kind <= BEATAMD_PROPOSAL_POISSON, BEATAMD_EINVAL,
+             "proposal_draw_univariate: kind must be Normal (0), Cauchy (1), Laplace (2) or Poisson (3)");
     if (C == 0) return BEATAMD_OK;
     const void *d_s;
     void *d_d, *d_u = nullptr;
@@ -1375,6 +1400,7 @@ int beatamd_whiten_rows(beatamd_ctx *ctx, double *rows, int64_t nrows, int64_t N
     BA_CHECK(rows && W && nrows >= 0 && N > 0, BEATAMD_EINVAL, "whiten_rows: bad argument");
     BA_CHECK(is_device_ptr(rows), BEATAMD_EINVAL, "whiten_rows: rows must live in HBM");
     if (nrows == 0) return BEATAMD_OK;
+    drop_f32_overlapping(ctx, rows, (size_t)nrows * N * 8);
     const void *d_w;
     void *p;
     BA_TRY(stage_in(ctx, SL_IN0, W, (size_t)N * N * 8, &d_w));

@@ -364,6 +364,24 @@ __global__ void __launch_bounds__(256) k_philox_chain(int64_t C, uint64_t seed, 
 //   kind 0  NormalProposal   normal(scale)                                  (Box-Muller pair)
 //   kind 1  CauchyProposal   standard_cauchy() * scale = tan(pi (u - 1/2)) * scale
 //   kind 2  LaplaceProposal  (standard_exponential() - standard_exponential()) * scale
+//   kind 3  PoissonProposal  poisson(lam = scale) - scale        (base.py:150-155; integer steps around zero mean)
+// Poisson variate from ONE uniform by inversion (sequential search from k = 0, pmf recurrence p_k = p_{k-1} lam / k).
+// Exact in law while exp(-lam) is a normal double; the callers accept step widths lam <= 500 (a wider integer
+// proposal is refused by the host side, beat_amd/sampler/metropolis.py) -- beyond that the draw is NaN.
+__device__ __forceinline__ double poisson_from_uniform(double u, double lam)
+{
+    if (!(lam > 0.0)) return 0.0;
+    if (lam > 500.0) return __builtin_nan("");
+    double p = exp(-lam), F = p;
+    int k = 0;
+    while (u > F && k < 4096) {
+        k++;
+        p *= lam / (double)k;
+        F += p;
+    }
+    return (double)k;
+}
+
 __global__ void __launch_bounds__(256) k_philox_univariate(double *delta, int64_t C, int64_t np, int kind,
                                                           const double *scale, uint64_t seed, uint32_t step,
                                                           uint64_t first_chain, const uint32_t *step_dev)
@@ -386,11 +404,16 @@ __global__ void __launch_bounds__(256) k_philox_univariate(double *delta, int64_
     } else if (kind == 1) {
         a = tan(3.14159265358979323846 * (u1 - 0.5));
         b = tan(3.14159265358979323846 * (u2 - 0.5));
-    } else {
+    } else if (kind == 2) {
         uint32_t q[4];
         philox4x32_10((uint32_t)j, (uint32_t)gc, step, 4u, (uint32_t)seed, (uint32_t)(seed >> 32), q);
         a = log(u53(q[0], q[1])) - log(u1);     // E1 - E2 with E = -log u
         b = log(u53(q[2], q[3])) - log(u2);
+    } else {
+        const double la = scale[2 * j], lb = (2 * j + 1 < np) ? scale[2 * j + 1] : 0.0;
+        delta[c * np + 2 * j] = poisson_from_uniform(u1, la) - la;
+        if (2 * j + 1 < np) delta[c * np + 2 * j + 1] = poisson_from_uniform(u2, lb) - lb;
+        return;
     }
     delta[c * np + 2 * j] = a * scale[2 * j];
     if (2 * j + 1 < np) delta[c * np + 2 * j + 1] = b * scale[2 * j + 1];
@@ -488,14 +511,20 @@ __global__ void __launch_bounds__(256) k_draw_propose(DrawProposeArgs a)
             } else if (a.kind == 1) {
                 x = tan(3.14159265358979323846 * (u53(r[0], r[1]) - 0.5));
                 y = tan(3.14159265358979323846 * (u53(r[2], r[3]) - 0.5));
-            } else {
+            } else if (a.kind == 2) {
                 uint32_t q[4];
                 philox4x32_10((uint32_t)j, gc, step, 4u, k0, k1, q);
                 x = log(u53(q[0], q[1])) - log(u53(r[0], r[1]));
                 y = log(u53(q[2], q[3])) - log(u53(r[2], r[3]));
             }
-            x *= a.factor[2 * j];
-            if (2 * j + 1 < K) y *= a.factor[2 * j + 1];
+            if (a.kind == 3) {
+                const double la = a.factor[2 * j], lb = (2 * j + 1 < K) ? a.factor[2 * j + 1] : 0.0;
+                x = poisson_from_uniform(u53(r[0], r[1]), la) - la;
+                y = poisson_from_uniform(u53(r[2], r[3]), lb) - lb;
+            } else {
+                x *= a.factor[2 * j];
+                if (2 * j + 1 < K) y *= a.factor[2 * j + 1];
+            }
         }
         zs[c][2 * j] = x;
         if (2 * j + 1 < K) zs[c][2 * j + 1] = y;

@@ -149,9 +149,9 @@ class Context(object):
         self._adopt_stream(device_tensor)
         check(self._lib.beatamd_seis_gflib_adopt(self._h, lib_id, ptr(device_tensor)))
 
-    def seis_gflib_store_f32(self, lib_id):
+    def seis_gflib_round_to_f32(self, lib_id):
         """float copy of the library + the float64 storage rounded to the same values"""
-        check(self._lib.beatamd_seis_gflib_store_f32(self._h, lib_id))
+        check(self._lib.beatamd_seis_gflib_round_to_f32(self._h, lib_id))
 
     def ffi_model_set_f32(self, model_id, wavemap_index, on=True):
         check(self._lib.beatamd_ffi_model_set_f32(self._h, model_id, int(wavemap_index), 1 if on else 0))

@@ -207,13 +207,15 @@ class SeismicGFLibrary(GFLibrary):
                 ctx.seis_gflib_upload(self.lib_id, flat[o:o + step], o)
         self.lib_id_dirty = False
 
-    def store_f32(self, ctx=None):
-        """Keep a float copy of the library in HBM for the kernels that can read it (half the row
-        traffic) and round the float64 storage to the same values (every kernel then sees one
-        library; values change by up to 6e-8 relative).  Off unless called; see
-        ``LogpForwFunc.set_f32``."""
+    def round_to_f32(self, ctx=None):
+        """ROUND THE LIBRARY IN HBM TO FLOAT-REPRESENTABLE VALUES, irreversibly (values change by up to 6e-8
+        relative; an adopted caller-owned tensor is overwritten too), and keep a float copy of the same values
+        for the kernels that can read it (half the row traffic).  Every kernel then sees one library whichever
+        copy it reads.  Never called implicitly; reload the library to get the unrounded values back.  See
+        ``LogpForwFunc.round_libraries_to_f32``."""
         self.init_optimization(ctx)
-        self._ctx.seis_gflib_store_f32(self.lib_id)
+        self._ctx.seis_gflib_round_to_f32(self.lib_id)
+        self.rounded_to_f32 = True
 
     def adopt_device_tensor(self, tensor):
         """Use an existing torch CUDA float64 tensor of shape ``dimensions`` as the library

@@ -354,14 +354,32 @@ class LogpForwFunc(object):
         return self.ctx.ffi_mstep_batch(self.model_id, Q0, L0, factor, kind, df, seed, step, first_chain,
                                         scaling, lower, upper, beta, accepted, accepted_sum, n_accepted)
 
-    def set_f32(self, on=True):
-        """read the float copies of the seismic libraries (``SeismicGFLibrary.store_f32``, made here if
-        missing) where a kernel exists for them: half the row traffic of the 512-chain nearest-neighbour
-        kernel, same float64 accumulation; the float64 storage holds the same rounded values"""
+    def round_libraries_to_f32(self):
+        """Float-storage mode (SURVEY 8(f) row 2 "optional fp32 layout"), an explicit and IRREVERSIBLE choice of
+        the caller: every seismic library of the model is rounded in HBM to float-representable values
+        (``SeismicGFLibrary.round_to_f32``: up to 6e-8 relative; likelihoods move by about that much) and the
+        kernels that can read the float copies do so -- half the row traffic, float64 accumulation.  The float64
+        storage holds the same rounded values, so small batches and fall-back kernels agree bit for bit.
+        Pre-whitened wavemaps are refused: whitened rows are not float-representable and a re-whitening rewrites
+        them (the library drops the float copy when its rows are rewritten)."""
+        for wm in self.problem.wavemaps:
+            if getattr(wm, "is_prewhitened", False):
+                raise ValueError("float storage is not offered for a pre-whitened wavemap (%s)" % wm.name)
         for i, wm in enumerate(self.problem.wavemaps):
-            if on:
-                for gf in wm.gfs.values():
-                    gf.store_f32(self.ctx)
+            for gf in wm.gfs.values():
+                gf.round_to_f32(self.ctx)
+            self.ctx.ffi_model_set_f32(self.model_id, i, True)
+
+    def set_f32(self, on=True):
+        """which kernels read the rows of ALREADY ROUNDED libraries (``round_libraries_to_f32``): the float
+        copies (on) or the float64 storage holding the same values (off) -- identical results, a timing choice.
+        ``set_f32(False)`` restores nothing: the unrounded values are gone until the library is reloaded."""
+        for wm in self.problem.wavemaps:
+            for gf in wm.gfs.values():
+                if not getattr(gf, "rounded_to_f32", False):
+                    raise ValueError("library %s holds unrounded float64 values: float storage has to be chosen "
+                                     "explicitly with round_libraries_to_f32() (irreversible)" % gf.filename)
+        for i in range(len(self.problem.wavemaps)):
             self.ctx.ffi_model_set_f32(self.model_id, i, on)
 
     def get_shared(self):

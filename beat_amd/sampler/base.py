@@ -19,15 +19,15 @@ from ..utility import ensure_cov_psd
 from .ops import step_tune  # noqa: F401  (re-export: pymc's tune table)
 
 multivariate_proposals = ("MultivariateNormal", "MultivariateCauchy")
-# per-parameter families (base.py:129-147): kernel kinds of beatamd_proposal_draw_univariate
-univariate_proposals = {"Normal": 0, "Cauchy": 1, "Laplace": 2}
+# per-parameter families (base.py:129-155): kernel kinds of beatamd_proposal_draw_univariate
+univariate_proposals = {"Normal": 0, "Cauchy": 1, "Laplace": 2, "Poisson": 3}
 available_proposals = multivariate_proposals + tuple(univariate_proposals)
 
 
 def proposal_df(proposal_name):
     """degrees of freedom of the multivariate t the proposal is drawn from (0 = normal);
     MultivariateCauchy = t with one degree of freedom (base.py:177-186); None for the
-    per-parameter families.  PoissonProposal (integer steps, base.py:150-155) is not provided."""
+    per-parameter families (Normal, Cauchy, Laplace, Poisson: base.py:129-155)."""
     if proposal_name in univariate_proposals:
         return None
     if proposal_name not in multivariate_proposals:

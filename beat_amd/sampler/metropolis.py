@@ -47,6 +47,8 @@ class BatchedMetropolis(object):
         components; the reference's Metropolis sets scale = ones (metropolis.py:209-212)"""
         npar = int(self.lower.shape[0])
         sc = np.ones(npar) if scale is None else np.broadcast_to(np.asarray(scale, dtype=np.float64), (npar,))
+        if proposal_name == "Poisson" and not (np.all(sc >= 0.0) and np.all(sc <= 500.0)):
+            raise ValueError("PoissonProposal: the step widths (lam) must lie in [0, 500]")
         self.kind = univariate_proposals[proposal_name]
         self.uscale = self.torch.from_numpy(np.ascontiguousarray(sc)).to(self.device)
         self.factor, self.df = None, 0

@@ -92,7 +92,7 @@ class HostOps(object):
         return self.torch.from_numpy(rows), self.torch.from_numpy(log_u)
 
     def draw_univariate(self, kind, scale, n_chains, seed, step, first_chain=0):
-        """NormalProposal / CauchyProposal / LaplaceProposal rows (base.py:129-160), numpy generator"""
+        """NormalProposal / CauchyProposal / LaplaceProposal / PoissonProposal rows (base.py:129-160), numpy generator"""
         sc = self._np(scale)
         rs = np.random.RandomState((int(seed) * 1000003 + int(step) * 7919 + int(first_chain)) % (2 ** 32))
         shape = (n_chains, sc.size)
@@ -100,8 +100,12 @@ class HostOps(object):
             rows = rs.standard_normal(shape)
         elif kind == 1:
             rows = rs.standard_cauchy(shape)
-        else:
+        elif kind == 2:
             rows = rs.standard_exponential(shape) - rs.standard_exponential(shape)
+        else:   # base.py:150-155: poisson(lam=scale) - scale
+            rows = rs.poisson(lam=np.broadcast_to(sc, shape)).astype(np.float64) - sc
+            log_u = np.log(rs.uniform(size=n_chains))
+            return self.torch.from_numpy(rows), self.torch.from_numpy(log_u)
         log_u = np.log(rs.uniform(size=n_chains))
         return self.torch.from_numpy(rows * sc), self.torch.from_numpy(log_u)
 

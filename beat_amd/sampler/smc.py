@@ -186,10 +186,16 @@ def _dump_stage(step, homepath, layout, out_names, backend):
         path = stage_path(homepath, step.stage)
         os.makedirs(path, exist_ok=True)
     rs = step.rng.get_state()
+    extra = {}
+    if getattr(step, "update_map_point", None) is not None:
+        # the point the weights of this stage were estimated at (smc.py:492-503): a resumed run re-derives the
+        # weights from it -- the saved lpoints belong to THOSE weights (the reference pickles update.get_weights()
+        # in save_sampler_state; 8.6 GB of operators per wavemap here, a parameter vector does the same)
+        extra["update_map_point"] = np.asarray(step.update_map_point, dtype=np.float64)
     np.savez(os.path.join(path, "sampler_state.npz"), beta=step.beta, old_beta=step.old_beta,
              stage=step.stage, population=pop, lpoints=lp, scaling=sc, accepted_since_tune=ac,
              n_steps_total=st["n_steps_total"], steps_until_tune=st["steps_until_tune"], seed=st["seed"],
-             rng_keys=rs[1], rng_pos=rs[2], rng_has_gauss=rs[3], rng_cached=rs[4])
+             rng_keys=rs[1], rng_pos=rs[2], rng_has_gauss=rs[3], rng_cached=rs[4], **extra)
 
 
 def load_stage(step, homepath, stage):
@@ -218,7 +224,16 @@ def load_stage(step, homepath, stage):
     if "rng_keys" in z.files:
         step.rng.set_state(("MT19937", z["rng_keys"], int(z["rng_pos"]), int(z["rng_has_gauss"]),
                             float(z["rng_cached"])))
+    step.update_map_point = np.array(z["update_map_point"]) if "update_map_point" in z.files else None
     return step
+
+
+def _update_covariances(step, update, Q_local):
+    """smc.py:492-503: new weights from the maximum-likelihood end point, then the end points evaluated again"""
+    logger.info("Updating Covariances ...")
+    step.update_map_point = step.get_map_end_points()
+    update.update_weights(step.update_map_point)
+    return update_last_samples(step, Q_local)
 
 
 def update_last_samples(step, Q_local):
@@ -243,13 +258,22 @@ def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, 
     step.n_steps = int(n_steps)
     if n_steps < 1:
         raise TypeError("Argument `n_steps` should be above 0.")
+    step.update_map_point = None
     if resume_stage is not None:
         load_stage(step, homepath, resume_stage)
+        if update is not None and step.update_map_point is not None:
+            # the saved likelihoods were evaluated with the weights of the stage's covariance update: install
+            # them again before anything is proposed against those likelihoods
+            update.update_weights(step.update_map_point)
     else:
         # stage 0: evaluate the prior population (draws = 1, no move)
         Q = step.initialize_population()
         L = step.stepper.evaluate(Q)
         step.select_end_points(Q, L)
+        if update is not None:
+            # the reference's update block sits inside the stage loop and therefore also runs after the initial
+            # stage, BEFORE the first calc_beta (smc.py:459-503)
+            _update_covariances(step, update, Q)
         _dump_stage(step, homepath, layout, out_names, backend)
     betas = [step.beta]
     while step.beta < 1.0 and step.stage < max_stages:
@@ -260,9 +284,7 @@ def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, 
         Q, L = step.sample_stage(n_steps)
         step.select_end_points(Q, L)
         if update is not None:
-            logger.info("Updating Covariances ...")
-            update.update_weights(step.get_map_end_points())
-            update_last_samples(step, Q)
+            _update_covariances(step, update, Q)
         betas.append(step.beta)
         _dump_stage(step, homepath, layout, out_names, backend)
         if on_stage is not None:

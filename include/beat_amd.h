@@ -42,7 +42,7 @@ extern "C" {
 /* ABI revision: bumped whenever an entry point changes its signature or an error code is added
  * (1.1: beatamd_weights_update gained kind/count in round 2; BEATAMD_EBADCOV).  beat_amd/_lib.py
  * refuses a library whose revision differs from the header it was written against. */
-#define BEATAMD_VERSION 112
+#define BEATAMD_VERSION 113
 
 #define BEATAMD_NEAREST_NEIGHBOR 0 /* interpolation="nearest_neighbor" */
 #define BEATAMD_MULTILINEAR 1      /* interpolation="multilinear"      */
@@ -116,14 +116,16 @@ int beatamd_seis_gflib_upload(beatamd_ctx *ctx, int32_t lib_id, const double *sr
 /* use a caller-owned device allocation as the library storage (no copy) */
 int beatamd_seis_gflib_adopt(beatamd_ctx *ctx, int32_t lib_id, double *device_ptr);
 /* float storage (SURVEY 8(f) row 2 "optional fp32 layout"; the reference keeps its libraries in
- * float64, beat/ffi/base.py:381-385 tconfig.floatX aside): makes a float copy of the library in HBM
- * and rounds the float64 storage to the same float-representable values, so that every kernel --
- * whichever copy it reads -- works on ONE library.  Accumulation, weights and likelihoods stay
- * float64.  Changes the library's values by up to 6e-8 relative: a choice of the caller, off by
- * default.  beatamd_ffi_model_set_f32 lets a wavemap of a model read the float copies where a
- * kernel exists for them (the 512-chain-group nearest-neighbour kernel); elsewhere the (equal)
- * float64 values are read. */
-int beatamd_seis_gflib_store_f32(beatamd_ctx *ctx, int32_t lib_id);
+ * float64, beat/ffi/base.py:381-385 tconfig.floatX aside).  beatamd_seis_gflib_round_to_f32 ROUNDS THE
+ * LIBRARY IN PLACE -- the float64 storage (also a caller-owned adopted allocation) is overwritten with
+ * (double)(float)value, irreversibly, values change by up to 6e-8 relative -- and keeps a float copy of
+ * the same values in HBM, so that every kernel, whichever copy it reads, works on ONE library.
+ * Accumulation, weights and likelihoods stay float64.  Never called by the library itself.
+ * beatamd_ffi_model_set_f32 lets a wavemap of a model read the float copies where a kernel exists for
+ * them (on = 0: the float64 kernels on the same rounded values; it does NOT restore anything).  An upload
+ * into the library or an in-place whitening of its rows (beatamd_whiten_rows) drops the float copy and
+ * takes every wavemap off it: the copies would no longer agree. */
+int beatamd_seis_gflib_round_to_f32(beatamd_ctx *ctx, int32_t lib_id);
 int beatamd_ffi_model_set_f32(beatamd_ctx *ctx, int32_t model_id, int32_t wavemap_index, int32_t on);
 int beatamd_seis_gflib_device_ptr(beatamd_ctx *ctx, int32_t lib_id, double **device_ptr);
 int beatamd_seis_gflib_destroy(beatamd_ctx *ctx, int32_t lib_id);
@@ -342,14 +344,16 @@ int beatamd_smc_population_factor(beatamd_ctx *ctx, int64_t C, int64_t nparams,
 int beatamd_proposal_draw(beatamd_ctx *ctx, int64_t C, int64_t K, int64_t nparams,
                           const double *factor, uint64_t seed, uint32_t step, int64_t first_chain,
                           int32_t df, double *delta, double *log_u);
-/* replaces: NormalProposal / CauchyProposal / LaplaceProposal (per-parameter families)
+/* replaces: NormalProposal / CauchyProposal / LaplaceProposal / PoissonProposal (per-parameter families)
  *                                                              beat/sampler/base.py:129-160
  *   delta [C,nparams]: every component an independent draw times scale[j] (the reference's
  *   Metropolis passes scale = ones, metropolis.py:209-212); same Philox counters as above
- *   (streams 3, 4); log_u [C] (nullable) = log of U(0,1).  PoissonProposal is not provided. */
+ *   (streams 3, 4); log_u [C] (nullable) = log of U(0,1).  Poisson: poisson(lam = scale[j]) - scale[j]
+ *   (inversion of one uniform by sequential search; scale[j] <= 500, NaN rows beyond). */
 #define BEATAMD_PROPOSAL_NORMAL 0
 #define BEATAMD_PROPOSAL_CAUCHY 1
 #define BEATAMD_PROPOSAL_LAPLACE 2
+#define BEATAMD_PROPOSAL_POISSON 3   /* poisson(lam = scale) - scale (beat/sampler/base.py:150-155) */
 int beatamd_proposal_draw_univariate(beatamd_ctx *ctx, int64_t C, int64_t nparams, int32_t kind,
                                      const double *scale, uint64_t seed, uint32_t step, int64_t first_chain,
                                      double *delta, double *log_u);

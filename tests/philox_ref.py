@@ -67,7 +67,8 @@ def t_row_scale(C, seed, step, df, first_chain=0):
 
 def univariate(C, npar, kind, scale, seed, step, first_chain=0):
     """delta [C, npar] as beatamd_proposal_draw_univariate generates it (streams 3, 4):
-    kind 0 normal, 1 Cauchy, 2 Laplace; each times scale[j]"""
+    kind 0 normal, 1 Cauchy, 2 Laplace; each times scale[j]; kind 3 Poisson: poisson(lam=scale[j]) - scale[j] by
+    inversion of ONE uniform (sequential search)"""
     npair = (npar + 1) // 2
     cc, jj = np.meshgrid(np.arange(C, dtype=np.uint32) + np.uint32(first_chain),
                          np.arange(npair, dtype=np.uint32), indexing="ij")
@@ -79,9 +80,30 @@ def univariate(C, npar, kind, scale, seed, step, first_chain=0):
         a, b = rad * np.cos(th), rad * np.sin(th)
     elif kind == 1:
         a, b = np.tan(np.pi * (u1 - 0.5)), np.tan(np.pi * (u2 - 0.5))
-    else:
+    elif kind == 2:
         q = philox4x32_10(j, c, np.full_like(j, step), np.full_like(j, 4), seed & 0xffffffff, seed >> 32)
         a, b = np.log(u53(q[0], q[1])) - np.log(u1), np.log(u53(q[2], q[3])) - np.log(u2)
+    else:
+        sc = np.concatenate([np.asarray(scale, dtype=np.float64), [0.0]])
+
+        def inv(u, lam):
+            out = np.zeros(u.size)
+            for i in range(u.size):
+                if lam[i] <= 0:
+                    continue
+                p = F = np.exp(-lam[i])
+                k = 0
+                while u[i] > F and k < 4096:
+                    k += 1
+                    p *= lam[i] / k
+                    F += p
+                out[i] = k
+            return out - lam
+        la, lb = sc[np.minimum(2 * j, npar)], sc[np.minimum(2 * j + 1, npar)]
+        z = np.empty((C, 2 * npair))
+        z[:, 0::2] = inv(u1, la).reshape(C, npair)
+        z[:, 1::2] = inv(u2, lb).reshape(C, npair)
+        return z[:, :npar]
     z = np.empty((C, 2 * npair))
     z[:, 0::2] = a.reshape(C, npair)
     z[:, 1::2] = b.reshape(C, npair)

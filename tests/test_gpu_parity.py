@@ -843,8 +843,8 @@ def test_covariance_class_and_mvn_adaptor(ctx):
 @pytest.mark.parametrize("covariance,N", [("scalar", 128), ("scalar", 100), ("toeplitz", 192)])
 @pytest.mark.parametrize("C", [512, 700, 1100])
 def test_float_storage_kernel_equals_the_f64_kernels_on_the_rounded_library(ctx, monkeypatch, covariance, N, C):
-    """SURVEY 8(f) row 2 "optional fp32 layout": ``LogpForwFunc.set_f32`` makes float copies of the
-    libraries (rounding the float64 storage to the same values) and the 512-chain-group kernel reads
+    """SURVEY 8(f) row 2 "optional fp32 layout": ``LogpForwFunc.round_libraries_to_f32`` rounds the libraries in
+    place (explicit, irreversible) and keeps float copies of the same values; the 512-chain-group kernel reads
     those (k_gfstack_ws32: 256-byte row segments, operands widened before the f64 FMA).  Because both
     copies hold the same numbers the result equals -- bit for bit -- the f64 loader/consumer kernel on the
     rounded library, the streaming kernel to 1e-12 and the oracle run on float-rounded G at 1e-9."""
@@ -856,11 +856,15 @@ def test_float_storage_kernel_equals_the_f64_kernels_on_the_rounded_library(ctx,
     Q = draw_population(spec, host["layout"], host["lower"], host["upper"], C)
     monkeypatch.setenv("BEATAMD_GS_CG", "512")    # (tiny problems may measure a smaller group as faster)
     before = f.batch(Q)
-    f.set_f32(True)
+    with pytest.raises(ValueError):
+        f.set_f32(True)          # nothing rounds a library implicitly
+    f.round_libraries_to_f32()
     L32 = f.batch(Q)
     assert ctx.last_kernel().startswith("k_gfstack_ws32<"), ctx.last_kernel()
     assert not np.array_equal(L32, before)      # the library was rounded: 1e-8-level changes
-    np.testing.assert_allclose(L32[:, -1], before[:, -1], rtol=2e-6)
+    # float storage is NOT inside north_star's 1e-6 on every problem (a labelled option, never `value`): the
+    # misfit of a chain near the data is a small difference of large synthetics.  Here: 1e-5 on `like`
+    np.testing.assert_allclose(L32[:, -1], before[:, -1], rtol=1e-5)
     f.set_f32(False)
     L64 = f.batch(Q)
     assert ctx.last_kernel().startswith("k_gfstack_ws<"), ctx.last_kernel()
@@ -884,6 +888,60 @@ def test_float_storage_kernel_equals_the_f64_kernels_on_the_rounded_library(ctx,
     for c in (0, C // 2, C - 1):
         ref, _ = problem_oracle.forward(host32, Q[c])
         np.testing.assert_allclose(L32[c], ref, rtol=1e-9)
+
+
+def test_float_copy_is_dropped_when_the_rows_are_rewritten(ctx, monkeypatch):
+    """the float copy of a rounded library must never outlive its float64 rows.  An upload into the
+    library and an in-place whitening (``beatamd_whiten_rows``, what a covariance update of a pre-whitened model
+    does) drop the copy and take the model off it -- the likelihoods are those of the NEW float64 rows, through
+    the float64 kernel; float storage is refused for a pre-whitened wavemap and is never switched on implicitly."""
+    import torch
+    from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
+    spec = SyntheticSpec((4,), (5,), (1.0,), T=3, N=128, D=3, S=25)
+    prob, host = build_problem(spec)
+    f = prob.compile(ctx)
+    Q = draw_population(spec, host["layout"], host["lower"], host["upper"], 512)
+    monkeypatch.setenv("BEATAMD_GS_CG", "512")
+    f.round_libraries_to_f32()
+    L32 = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack_ws32<"), ctx.last_kernel()
+    gf = prob.wavemaps[0].gfs["uparr"]
+    # (1) new values uploaded into the library
+    G2 = host["Gs"][0] * 1.5
+    ctx.seis_gflib_upload(gf.lib_id, np.ascontiguousarray(G2).reshape(-1), 0)
+    L2 = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack_ws<"), ctx.last_kernel()     # off the (dropped) float copy
+    host2 = dict(host)
+    host2["Gs"] = [G2]
+    from oracle import problem_oracle
+    for c in (0, 300, 511):
+        ref, _ = problem_oracle.forward(host2, Q[c])
+        np.testing.assert_allclose(L2[c], ref, rtol=1e-9)
+    with pytest.raises(Exception):
+        f.set_f32(True)         # the copy is gone: asking for it fails loudly (round again to get one)
+    # (2) rows rewritten in place by a whitening (what a covariance update of a pre-whitened model does)
+    prob_d, host_d = build_problem(spec, device_library=True, ctx=ctx)
+    f_d = prob_d.compile(ctx)
+    f_d.round_libraries_to_f32()
+    assert f_d.batch(Q) is not None and ctx.last_kernel().startswith("k_gfstack_ws32<"), ctx.last_kernel()
+    gd = prob_d.wavemaps[0].gfs["uparr"]
+    N = spec.N
+    W = np.triu(np.random.default_rng(1).standard_normal((N, N)) * 0.01) + np.eye(N)
+    G_rounded = gd._device_tensor.cpu().numpy().copy()
+    ctx.whiten_rows(gd._device_tensor.view(-1, N), W)
+    L3 = f_d.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack_ws<"), ctx.last_kernel()
+    host3 = dict(host_d)
+    host3["Gs"] = [G_rounded @ W.T]
+    for c in (0, 300, 511):
+        ref, _ = problem_oracle.forward(host3, Q[c])
+        np.testing.assert_allclose(L3[c], ref, rtol=1e-9)
+    # (3) a pre-whitened wavemap refuses float storage
+    spec_t = SyntheticSpec((4,), (5,), (1.0,), T=3, N=64, D=3, S=25, covariance="toeplitz")
+    prob_t, _ = build_problem(spec_t)
+    f_t = prob_t.compile(ctx, prewhiten=True)
+    with pytest.raises(ValueError):
+        f_t.round_libraries_to_f32()
 
 
 @pytest.mark.parametrize("sizes", [(1,), (16,), (17, 33), (64, 5, 100), (257,), (512,), (300, 3, 31, 130), (513, 20)])
@@ -923,7 +981,7 @@ def test_float_storage_lds_dma_kernel(ctx, monkeypatch, interp, covariance, C):
     prob, host = build_problem(spec)
     f = prob.compile(ctx)
     Q = draw_population(spec, host["layout"], host["lower"], host["upper"], C)
-    f.set_f32(True)
+    f.round_libraries_to_f32()
     L32 = f.batch(Q)
     # (300 nearest-neighbour chains run as one 512-chain group: the loader/consumer float kernel)
     assert ctx.last_kernel().startswith(("k_gfstack_dmaf<", "k_gfstack_ws32<")), ctx.last_kernel()

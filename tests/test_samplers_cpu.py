@@ -171,11 +171,10 @@ def test_host_proposal_draws_normal_and_cauchy_statistics():
     B = rng.standard_normal((6, 2))
     Fs = covariance_factor(B @ B.T)
     np.testing.assert_allclose(Fs.T @ Fs, B @ B.T, atol=1e-10)
-    # the per-parameter families (base.py:129-147) are drawn component by component, no factor;
-    # PoissonProposal (integer steps) is the one family that is not provided
-    assert proposal_df("Normal") is None and proposal_df("Laplace") is None
+    # the per-parameter families (base.py:129-155) are drawn component by component, no factor
+    assert proposal_df("Normal") is None and proposal_df("Laplace") is None and proposal_df("Poisson") is None
     with pytest.raises(NotImplementedError):
-        proposal_df("Poisson")
+        proposal_df("Binomial")
     with pytest.raises(ValueError):
         covariance_factor(np.array([[np.nan]]))
     # host twin of the per-parameter draws: Laplace has variance 2 scale^2, Cauchy quartiles at +-scale
@@ -186,6 +185,8 @@ def test_host_proposal_draws_normal_and_cauchy_statistics():
     assert np.allclose(lap.numpy().var(axis=0), 2.0 * sc.numpy() ** 2, rtol=0.05) and lu.shape == (100000,)
     cau, _ = ops.draw_univariate(1, sc, 100000, seed=4, step=2)
     assert np.allclose(np.quantile(cau.numpy(), 0.75, axis=0), sc.numpy(), rtol=0.05)
+    poi, _ = ops.draw_univariate(3, sc, 100000, seed=4, step=3)       # poisson(lam = scale) - scale (base.py:150-155)
+    assert np.allclose(poi.numpy().var(axis=0), sc.numpy(), rtol=0.05) and np.all(np.abs(poi.numpy().mean(axis=0)) < 0.02)
     # a Metropolis stepper with a per-parameter proposal samples the toy target
     from beat_amd.sampler import SMC, smc_sample
     from beat_amd.sampler.hosttarget import HostTarget

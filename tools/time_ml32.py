@@ -14,8 +14,11 @@ for interp in ("multilinear", "nearest_neighbor"):
     prob, host = build_problem(spec, device_library=True, ctx=ctx)
     f = prob.compile(ctx)
     Q = torch.from_numpy(draw_population(spec, host["layout"], host["lower"], host["upper"], C)).cuda()
-    for f32 in (False, True, False, True):
-        f.set_f32(f32)
+    for f32 in (None, True, False, True):   # None: the unrounded library; then float / float64 kernels on the rounded one
+        if f32 is True and not getattr(prob.wavemaps[0].gfs["uparr"], "rounded_to_f32", False):
+            f.round_libraries_to_f32()
+        elif f32 is not None:
+            f.set_f32(f32)
         L = f.batch(Q)
         ctx.synchronize()
         ctx.enable_timing(True)
@@ -25,6 +28,6 @@ for interp in ("multilinear", "nearest_neighbor"):
         ctx.synchronize()
         ms, n = ctx.kernel_time("gfstack")
         ctx.enable_timing(False)
-        print("TIME %s f32=%d: %.3f ms per launch  %s  like[0] %.6f" % (interp, f32, ms / n, ctx.last_kernel(), float(L[0, -1])))
+        print("TIME %s f32=%s: %.3f ms per launch  %s  like[0] %.6f" % (interp, f32, ms / n, ctx.last_kernel(), float(L[0, -1])))
     del f, prob
     torch.cuda.empty_cache()
