@@ -101,6 +101,7 @@ _PROTOS = {
     "beatamd_gather_rows": [_vp, _i64, _i64, _vp, _i64, _vp, _vp],
     "beatamd_metropolis_tune": [_vp, _i64, _vp, _vp, _i32],
     "beatamd_whiten_rows": [_vp, _vp, _i64, _i64, _vp],
+    "beatamd_whiten_rows_batch": [_vp, _vp, _i64, _i64, _i64, _vp],
     "beatamd_chol_inverse_batch": [_vp, _i64, _i64, _vp, _vp, _vp],
     "beatamd_chol_inverse_batch_flags": [_vp, _i64, _i64, _vp, _vp, _vp, _vp],
     "beatamd_whitening_ratio_batch": [_vp, _i64, _i64, _vp, _vp, _vp],

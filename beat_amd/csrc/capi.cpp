@@ -1429,6 +1429,49 @@ int beatamd_whiten_rows(beatamd_ctx *ctx, double *rows, int64_t nrows, int64_t N
     return BEATAMD_OK;
 }
 
+// All datasets of a wavemap at once, IN PLACE and without a second buffer: with upper-triangular operators
+// (chol_inverse, heart.py:233) the product column n of a row needs the row's entries k >= n only, so the columns
+// are produced 128 at a time in ascending order, each launch covering that column block of every row of every
+// dataset (grid.y = dataset): what a block overwrites is never read by a later launch.  No chunk buffer, no
+// copy back, no triangular load imbalance inside a launch, one host synchronisation (the triangularity check).
+int beatamd_whiten_rows_batch(beatamd_ctx *ctx, double *rows, int64_t nbatch, int64_t nrows, int64_t N,
+                              const double *W)
+{
+    ENTER(ctx);
+    BA_CHECK(rows && W && nbatch >= 0 && nrows >= 0 && N > 0, BEATAMD_EINVAL, "whiten_rows_batch: bad argument");
+    BA_CHECK(is_device_ptr(rows), BEATAMD_EINVAL, "whiten_rows_batch: rows must live in HBM");
+    BA_CHECK(nbatch <= 65535, BEATAMD_EINVAL, "whiten_rows_batch: at most 65535 datasets per call");
+    if (nrows == 0 || nbatch == 0) return BEATAMD_OK;
+    drop_f32_overlapping(ctx, rows, (size_t)nbatch * nrows * N * 8);
+    const void *d_w;
+    void *p;
+    BA_TRY(stage_in(ctx, SL_IN1, W, (size_t)nbatch * N * N * 8, &d_w));
+    BA_TRY(ctx->get_scratch(SL_MISC, 64, &p));
+    BA_TRY(launch_check_upper_tri(ctx, (const double *)d_w, nbatch, N, (int *)p));
+    int upper = 0;
+    BA_HIP(hipMemcpyAsync(&upper, p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    BA_HIP(hipStreamSynchronize(ctx->stream));
+    if (!upper) {
+        // general operators (a QR-fallback chol_inverse, heart.py:234-237): dataset by dataset through a buffer
+        for (int64_t b = 0; b < nbatch; b++)
+            BA_TRY(beatamd_whiten_rows(ctx, rows + b * nrows * N, nrows, N, (const double *)d_w + b * N * N));
+        return BEATAMD_OK;
+    }
+    const int ncb = (int)((N + 127) / 128);
+    for (int cb = 0; cb < ncb; cb++) {
+        GemmCall g;
+        g.A = rows; g.lda = N; g.sA = nrows * N;
+        g.B = (const double *)d_w; g.ldb = N; g.sB = N * N; g.b_kn = 0; g.b_upper = 1;
+        g.O = rows; g.ldo = N; g.sO = nrows * N;
+        g.M = nrows; g.N = N; g.K = N;
+        g.nbatch = (int)nbatch;
+        g.col_block = cb;
+        g.timer = "whiten";
+        BA_TRY(launch_gemm_f64(ctx, g));
+    }
+    return BEATAMD_OK;
+}
+
 // ------------------------------------------------------------------ half-space synthetics
 int beatamd_halfspace_displacements_batch(beatamd_ctx *ctx, int64_t C, int32_t nsrc,
                                           const int32_t *kind, const double *params, int64_t nobs,

@@ -37,6 +37,7 @@ struct GemmArgs {
     int accumulate;
     int lower_only;       // M x N output with M == N: tiles strictly above the diagonal are skipped
     int b_lower;          // NN only: Bop[k, n] == 0 for k < n (lower-triangular B)
+    int cb0;              // first column block of this launch (ncb counts the blocks of the launch)
 };
 
 __device__ __forceinline__ void gm_load4(const double *p, int64_t k, int64_t K, bool ok, int vec_ok,
@@ -59,7 +60,7 @@ __global__ void __launch_bounds__(256) k_gemm_f64(GemmArgs a)
     __shared__ double As[2][GM_BM * GM_PITCH];
     __shared__ double Bs[2][GM_BN * GM_PITCH];
 
-    const int cb = (int)(blockIdx.x % a.ncb);
+    const int cb = a.cb0 + (int)(blockIdx.x % a.ncb);
     const int64_t rb = blockIdx.x / a.ncb;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t i0 = rb * GM_BM, n0 = (int64_t)cb * GM_BN;
@@ -173,6 +174,14 @@ int launch_gemm_f64(beatamd_ctx *ctx, const GemmCall &k)
     if (k.nbatch > 1)
         a.vec_ok = a.vec_ok && (k.sA % 2 == 0) && (k.sB % 2 == 0);
     a.ncb = (int)((k.N + GM_BN - 1) / GM_BN);
+    a.cb0 = 0;
+    if (k.col_block >= 0) {
+        // one column block per launch: with an upper-triangular NT operand the tile (rb, cb) reads A[:, k >= n0]
+        // only, so launches in ascending block order may write O over A (in-place whitening, capi.cpp)
+        BA_CHECK(k.col_block < a.ncb, BEATAMD_EINVAL, "gemm: column block %d of %d", k.col_block, a.ncb);
+        a.cb0 = k.col_block;
+        a.ncb = 1;
+    }
     const int64_t nrb = (k.M + GM_BM - 1) / GM_BM;
     const int64_t nblocks = nrb * a.ncb;
     BA_CHECK(nblocks < (int64_t)0x7fffffff, BEATAMD_EINVAL, "gemm: too many tiles");

@@ -182,6 +182,7 @@ struct GemmCall {
     int accumulate = 0;
     int lower_only = 0;   // M == N: tiles strictly above the diagonal are skipped
     int b_lower = 0;      // NN only: Bop[k,n] == 0 for k < n
+    int col_block = -1;   // >= 0: only this 128-column block of the product (in-place whitening)
 };
 int launch_gemm_f64(beatamd_ctx *ctx, const GemmCall &call);
 // chol.hip: W = cholesky(inv(C)).T and log det C of a stack of matrices (device pointers)

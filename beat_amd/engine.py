@@ -573,6 +573,19 @@ class Context(object):
         d = f64(data)
         check(self._lib.beatamd_ffi_model_update_data(self._h, int(model_id), int(wavemap_index), ptr(d)))
 
+    def whiten_rows_batch(self, rows, W):
+        """rows (B, R, N) device tensor, in place: rows[b] <- rows[b] . W[b]^T for all datasets in one call
+        (W (B, N, N) numpy or device; upper-triangular operators need no second buffer)"""
+        self._adopt_stream(rows)
+        if rows.dim() != 3 or not rows.is_contiguous():
+            raise ValueError("whiten_rows_batch: rows must be a contiguous (B, R, N) device tensor")
+        Wc = f64(W)
+        if tuple(Wc.shape) != (rows.shape[0], rows.shape[2], rows.shape[2]):
+            raise ValueError("whiten_rows_batch: W must be (%d, %d, %d)" % (rows.shape[0], rows.shape[2], rows.shape[2]))
+        check(self._lib.beatamd_whiten_rows_batch(self._h, ptr(rows), int(rows.shape[0]), int(rows.shape[1]),
+                                                  int(rows.shape[2]), ptr(Wc)))
+        return rows
+
     def whiten_rows(self, rows, W):
         """rows (R, N) device tensor, in place: rows <- rows . W^T"""
         self._adopt_stream(rows)

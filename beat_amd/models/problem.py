@@ -116,14 +116,13 @@ class SeismicWavemap(object):
         dev = torch.device("cuda", ctx.device)
         T, N = self.data.shape
         gfs = {}
+        w = torch.from_numpy(np.ascontiguousarray(w)).to(dev)    # (one upload; a host array would be staged per call)
         for name, gf in self.gfs.items():
             if gf._device_tensor is not None:
                 G = gf._device_tensor if inplace else gf._device_tensor.clone()
             else:
                 G = torch.from_numpy(np.ascontiguousarray(gf._gfmatrix)).to(dev)
-            rows = G.view(T, -1, N)
-            for t in range(T):
-                ctx.whiten_rows(rows[t], w[t])
+            ctx.whiten_rows_batch(G.view(T, -1, N), w)
             cfg = gf.config
             g2 = SeismicGFLibrary(SeismicGFLibraryConfig(
                 dimensions=cfg.dimensions, starttime_sampling=cfg.starttime_sampling,
@@ -133,8 +132,7 @@ class SeismicWavemap(object):
             g2.adopt_device_tensor(G)
             gfs[name] = g2
         d = torch.from_numpy(self.data).to(dev).contiguous()
-        for t in range(T):
-            ctx.whiten_rows(d[t:t + 1], w[t])     # (W d)^T = d^T W^T
+        ctx.whiten_rows_batch(d.view(T, 1, N), w)     # (W d)^T = d^T W^T
         ctx.synchronize()
         wm = SeismicWavemap(gfs, d.cpu().numpy(), np.ones(T), self.slog_pdet, self.hypers,
                             self.time_shifts, self.interpolation, self.name)
@@ -453,12 +451,9 @@ class LogpForwFunc(object):
                 if gf._device_tensor.data_ptr() in seen:
                     continue
                 seen.add(gf._device_tensor.data_ptr())
-                rows = gf._device_tensor.view(T, -1, N)
-                for t in range(T):
-                    self.ctx.whiten_rows(rows[t], M[t])
+                self.ctx.whiten_rows_batch(gf._device_tensor.view(T, -1, N), M)
             d = torch.from_numpy(np.ascontiguousarray(wm.data)).to(dev)
-            for t in range(T):
-                self.ctx.whiten_rows(d[t:t + 1], M[t])
+            self.ctx.whiten_rows_batch(d.view(T, 1, N), M)
             self.ctx.ffi_model_update_data(self.model_id, wavemap_index, d)
             self.ctx.weights_update(wm._wset, np.ones(T), sl)
             self.ctx.synchronize()

@@ -373,6 +373,13 @@ int beatamd_metropolis_tune(beatamd_ctx *ctx, int64_t C, double *scaling, int32_
  * of the dataset instead of once per chain step (SeismicWavemap.prewhitened).  FP64 MFMA GEMM;
  * an upper-triangular W (heart.py:233) skips its zero half. */
 int beatamd_whiten_rows(beatamd_ctx *ctx, double *rows, int64_t nrows, int64_t N, const double *W);
+/* the same for all datasets of a wavemap in one call: rows [nbatch, nrows, N] (device, in place),
+ * W [nbatch, N, N] (host or device).  Upper-triangular operators are applied column block by column block
+ * in ascending order with no second buffer (a product column n needs the row's entries k >= n only);
+ * anything else goes dataset by dataset through beatamd_whiten_rows.  This is what a covariance update of
+ * a pre-whitened model costs per stage (seismic.py:1509-1534 on 62.9 GB of rows at config 3). */
+int beatamd_whiten_rows_batch(beatamd_ctx *ctx, double *rows, int64_t nbatch, int64_t nrows, int64_t N,
+                              const double *W);
 
 /* ---------------------------------------------------------------- whitening operator ------
  * replaces: heart.Covariance.chol_inverse / .log_pdet                beat/heart.py:216-253

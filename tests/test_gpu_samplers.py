@@ -175,6 +175,31 @@ def test_whiten_rows_vs_numpy(ctx, R, N):
         np.testing.assert_allclose(d.cpu().numpy(), ref, rtol=1e-11, atol=1e-11 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("B,R,N", [(1, 1, 6), (3, 300, 130), (2, 1000, 512), (5, 70, 1000), (4, 129, 257)])
+def test_whiten_rows_batch_in_place_vs_numpy(ctx, B, R, N):
+    """beatamd_whiten_rows_batch: rows[b] <- rows[b] . W[b]^T for all datasets of a wavemap in one call.  Upper
+    triangular operators (chol_inverse) run IN PLACE column block by column block (ascending: a product column n needs
+    the row's entries k >= n only -- sizes around the 64-row / 128-column tiles and the 16-wide k steps); one full
+    operator in the batch sends the call through the buffered per-dataset route; host and device operators"""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(B + R + N)
+    rows = rng.standard_normal((B, R, N))
+    for upper in (True, False):
+        W = rng.standard_normal((B, N, N)) + 3.0 * np.eye(N)
+        if upper:
+            W = np.triu(W)
+        else:
+            W[:B - 1] = np.triu(W[:B - 1])       # only the last operator is full
+        ref = np.einsum("brk,bnk->brn", rows, W)
+        for on_device in (False, True):
+            d = torch.from_numpy(rows.copy()).to(dev)
+            ctx.whiten_rows_batch(d, torch.from_numpy(W).to(dev) if on_device else W)
+            np.testing.assert_allclose(d.cpu().numpy(), ref, rtol=1e-11, atol=1e-11 * np.abs(ref).max())
+    with pytest.raises(ValueError):
+        ctx.whiten_rows_batch(torch.zeros((2, 3, 8), dtype=torch.float64, device=dev), np.zeros((3, 8, 8)))
+
+
 # ----------------------------------------------------------------------------- failure behaviour
 def _small_model(ctx, **kw):
     from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population

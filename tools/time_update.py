@@ -5,7 +5,11 @@ NoiseCovarianceUpdate.update_weights (synthetics at the MAP point, residuals, ru
 autocovariance, scaled Toeplitz, factorisation = PSD test, weights installed) and of re-evaluating
 the 512 end points with the new weights.
 
-    python tools/time_update.py [chains=512]"""
+    python tools/time_update.py [chains=512] [prewhiten]
+
+With ``prewhiten`` the model is compiled on a library whitened in place: an update then re-whitens all 62.9 GB of rows
+(``beatamd_whiten_rows_batch`` with M = W_new . inv(W_old)) -- the stage-boundary cost of update_covariances on the
+pre-whitened path."""
 import os
 import sys
 import time
@@ -23,7 +27,8 @@ ctx.use_torch_stream()
 spec = SyntheticSpec((20,), (20,), (1.0,), T=64, N=4096, D=3, S=25, time_bounds=(0.0, 0.0), covariance="toeplitz")
 t0 = time.perf_counter()
 prob, host = build_problem(spec, device_library=True, ctx=ctx)
-f = prob.compile(ctx)
+PW = len(sys.argv) > 2 and sys.argv[2] == "prewhiten"
+f = prob.compile(ctx, prewhiten="inplace" if PW else False)
 torch.cuda.synchronize()
 print("problem with dense weights built in %.1f s" % (time.perf_counter() - t0))
 Q = torch.from_numpy(draw_population(spec, host["layout"], host["lower"], host["upper"], C)).cuda()
@@ -31,8 +36,15 @@ L = f.batch(Q)
 upd = NoiseCovarianceUpdate(f)
 q_map = Q[int(torch.argmax(L[:, -1]))].cpu().numpy()
 for rep in range(3):
+    ctx.enable_timing(True)
+    ctx.reset_timing()
     upd.update_weights(q_map)
     torch.cuda.synchronize()
+    wms, wn = ctx.kernel_time("whiten")
+    ctx.enable_timing(False)
+    if wn:
+        flops = 64 * 400 * 3 * 25 * 4096.0 * 4096.0     # rows x N x N (upper-triangular operators: half of 2 N^2)
+        print("  re-whitening: %d launches, %.1f ms, %.1f TFLOP/s" % (wn, wms, flops / (wms * 1e-3) / 1e12))
     t1 = time.perf_counter()
     L2 = f.batch(Q)
     torch.cuda.synchronize()
