@@ -244,7 +244,7 @@ def update_last_samples(step, Q_local):
 
 
 def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, homepath=None,
-               layout=None, out_names=None, backend="bin", resume_stage=None, update=None):
+               layout=None, out_names=None, backend="bin", resume_stage=None, update=None, final_stage=True):
     """smc.py:333-546 stage loop.  Returns the final population (n_chains, nparams), the
     likelihood vectors (host arrays) and the list of betas.  With ``homepath`` every stage leaves
     a ``stage_<k>`` / ``stage_final`` directory of NumpyChain/TextChain traces
@@ -254,11 +254,27 @@ def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, 
     ``update_weights(map_point)`` -- e.g. ``beat_amd.covariance.NoiseCovarianceUpdate`` -- called with
     the maximum-likelihood end point after every stage; the population is then evaluated again with
     the new weights before the next tempering step is chosen.  Every rank holds the same gathered
-    population, so every rank updates its own model copy identically."""
+    population, so every rank updates its own model copy identically.
+
+    ``final_stage=False`` stops after ``max_stages`` tempering stages WITHOUT the stage at beta = 1 (the state of the
+    last stage can be resumed from its directory); by default a run that exhausts ``max_stages`` still ends with the
+    final stage like a converged one."""
+    import time
     step.n_steps = int(n_steps)
     if n_steps < 1:
         raise TypeError("Argument `n_steps` should be above 0.")
     step.update_map_point = None
+    # wall-clock split of the call (every part ends on a host-visible result, so no extra synchronisation):
+    # Metropolis steps | stage transitions (weights, beta, proposal factor, resampling, restart gathers) |
+    # all-gather of the end points | covariance updates | trace / state files
+    tm = step.timings = dict(sample_s=0.0, transition_s=0.0, gather_s=0.0, update_s=0.0, io_s=0.0, steps=0)
+
+    def timed(key, fn, *a, **kw):
+        t0 = time.perf_counter()
+        out = fn(*a, **kw)
+        tm[key] += time.perf_counter() - t0
+        return out
+
     if resume_stage is not None:
         load_stage(step, homepath, resume_stage)
         if update is not None and step.update_map_point is not None:
@@ -268,34 +284,46 @@ def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, 
     else:
         # stage 0: evaluate the prior population (draws = 1, no move)
         Q = step.initialize_population()
-        L = step.stepper.evaluate(Q)
-        step.select_end_points(Q, L)
+        L = timed("sample_s", step.stepper.evaluate, Q)
+        timed("gather_s", step.select_end_points, Q, L)
         if update is not None:
             # the reference's update block sits inside the stage loop and therefore also runs after the initial
             # stage, BEFORE the first calc_beta (smc.py:459-503)
-            _update_covariances(step, update, Q)
-        _dump_stage(step, homepath, layout, out_names, backend)
+            timed("update_s", _update_covariances, step, update, Q)
+        timed("io_s", _dump_stage, step, homepath, layout, out_names, backend)
     betas = [step.beta]
+
+    def synced_transition(**kw):
+        ok = step.transition(**kw)
+        if ok and step.idx is not None and hasattr(step.idx, "is_cuda") and step.idx.is_cuda:
+            step.torch.cuda.synchronize(step.idx.device)    # (the split below is wall clock)
+        return ok
+
     while step.beta < 1.0 and step.stage < max_stages:
-        if not step.transition():
+        if not timed("transition_s", synced_transition):
             break
         step.stage += 1
         logger.info("Beta: %f Stage: %i", step.beta, step.stage)
-        Q, L = step.sample_stage(n_steps)
-        step.select_end_points(Q, L)
+        Q, L = timed("sample_s", step.sample_stage, n_steps)
+        tm["steps"] += int(n_steps)
+        timed("gather_s", step.select_end_points, Q, L)
         if update is not None:
-            _update_covariances(step, update, Q)
+            timed("update_s", _update_covariances, step, update, Q)
         betas.append(step.beta)
-        _dump_stage(step, homepath, layout, out_names, backend)
+        timed("io_s", _dump_stage, step, homepath, layout, out_names, backend)
         if on_stage is not None:
             on_stage(step)
+    if not final_stage and step.beta < 1.0:
+        step.stage_betas = betas
+        return step.array_population, step.array_lpoints, betas
     # final stage at beta = 1 (smc.py:526-543)
     step.stage = -1
-    step.transition(final=True)
-    Q, L = step.sample_stage(n_steps * sample_factor_final_stage)
-    step.select_end_points(Q, L)
+    timed("transition_s", synced_transition, final=True)
+    Q, L = timed("sample_s", step.sample_stage, n_steps * sample_factor_final_stage)
+    tm["steps"] += int(n_steps * sample_factor_final_stage)
+    timed("gather_s", step.select_end_points, Q, L)
     betas.append(1.0)
-    _dump_stage(step, homepath, layout, out_names, backend)
+    timed("io_s", _dump_stage, step, homepath, layout, out_names, backend)
     step.stage_betas = betas
     return step.array_population, step.array_lpoints, betas
 

@@ -179,7 +179,7 @@ def main():
                     help="skip the labelled legs of the other configurations: multilinear (the reference's "
                          "default interpolation), dense Toeplitz covariance, pre-whitened library, parallel "
                          "tempering, geometry mode")
-    ap.add_argument("--variant-legs", default="multilinear,toeplitz,pt,prewhitened,geometry,fp32",
+    ap.add_argument("--variant-legs", default="multilinear,toeplitz,default_config,stage_update,smc,pt,prewhitened,geometry,fp32",
                     help="which of the labelled configuration legs to run (comma separated)")
     ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "r3_bench_c512_nn_gfstack_ws_summary.json"),
                     help="rocprofv3 PMC summary (tools/run_profile.sh + tools/summarize_rocpd.py) of THIS "
@@ -325,6 +325,7 @@ def main():
         st = leg["stats"]
         shared = st["row_bytes"] > 0
         cell = leg["kernel"].startswith("k_gfstack_cell")
+        ml_static = leg["kernel"].startswith("k_gfstack_ml")
         # bytes the kernel has to move from HBM: every distinct row of every (group, target,
         # patch) once (chain-shared kernels) or every chain's rows (streaming kernel), + tables
         tables = n_chains * spec_leg.T * spec_leg.P * 4 * rows_per_patch * 2 + spec_leg.T * spec_leg.N * 8
@@ -366,6 +367,13 @@ def main():
             "distinct_rows_per_patch": {"mean": st["mean_rows"], "max": st["max_rows"],
                                         "of": spec_leg.D * spec_leg.S},
         }
+        if ml_static:
+            roof["note"] = ("static accumulators, lane <-> sample: every FMA takes its 8-byte row operand from LDS by contiguous "
+                            "512-byte ds_read_b64 (no bank conflicts); SQ_LDS_IDX_ACTIVE = 0.77 of the CU cycles from the row reads "
+                            "alone, ~0.87 with the LDS-DMA writes of the row ring, at the 2.0 GHz the part sustains under this "
+                            "kernel (GRBM_GUI_ACTIVE; `lds_frac` is quoted against 2.4 GHz) -- LDS-bound; only sharing rows "
+                            "between chains lowers the floor, and that needs dynamic accumulator addressing (k_gfstack_cell: "
+                            "control-bound at 18.2 ms; profiles/r4_variants.md)")
         if cell:
             roof["note"] = ("rows of a cell in registers, accumulators through the VGPR index register: the FP64 pipe is "
                             "0.30 busy with FMAs (all VALU instructions: 0.55, LDS 0.49 by the SQ counters of "
@@ -385,7 +393,7 @@ def main():
         kern = pmc.get("kernel", "").replace("beatamd::", "").split("(")[0].replace(" ", "")
         mine = roof_d["kernel"].replace(" ", "")
         # (the cell kernel reports <epilogue, loader threads>, its symbol is <loader threads, variant>)
-        same = kern == mine or (kern.startswith("k_gfstack_cell<") and mine.startswith("k_gfstack_cell<"))
+        same = kern == mine or any(kern.startswith(x) and mine.startswith(x) for x in ("k_gfstack_cell<", "k_gfstack_ml<"))
         if "hbm_read_bytes_per_launch_corrected" not in pmc or not same:
             return
         tr = pmc["hbm_read_bytes_per_launch_corrected"] + pmc.get("hbm_write_bytes_per_launch", 0.0)
@@ -549,6 +557,45 @@ def main():
             host_of[sp] = host
             return sp
 
+        if "smc" in legs:
+            # the sampler a user runs, end to end (beat/sampler/smc.py:333-546): smc_sample on this problem -- initial
+            # stage + 3 tempering stages of 50 Metropolis steps each through the one-call step
+            # (beatamd_ffi_mstep_batch: Philox proposals from the population factor, forward model, accept), stage
+            # transitions on the device, with and without the stage directories (NumpyChain one-draw traces + state)
+            import shutil
+            import tempfile
+
+            from beat_amd.sampler import smc_sample
+            n_smc = 50
+            smc_out = {}
+            for nch, with_files in ((B, False), (B, True), (2048, False)):
+                if nch == 2048 and B >= 2048:
+                    continue
+                st = SMC(f, lo, up, n_chains=nch, device=dev, random_seed=11, tune_interval=25)
+                home = tempfile.mkdtemp(prefix="beatamd_smc_") if with_files else None
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                pop_s, lp_s, betas_s = smc_sample(n_smc, st, max_stages=3, homepath=home, final_stage=False,
+                                                  layout=lay if with_files else None,
+                                                  out_names=prob.out_names if with_files else None)
+                torch.cuda.synchronize()
+                dt_s = time.perf_counter() - t0
+                if home:
+                    shutil.rmtree(home, ignore_errors=True)
+                tmg = dict(st.timings)
+                nsteps_s = tmg.pop("steps")
+                smc_out["%d_chains%s" % (nch, "_with_stage_files" if with_files else "")] = {
+                    "chains": nch, "stages": len(betas_s) - 1, "steps_per_stage": n_smc, "metropolis_steps": nsteps_s,
+                    "wall_s": dt_s, "chain_steps_per_s_whole_call": nch * nsteps_s / dt_s,
+                    "chain_steps_per_s_sampling_only": nch * nsteps_s / tmg["sample_s"],
+                    "split_s": tmg, "betas": [float(b_) for b_ in betas_s],
+                    "acceptance_per_stage": [float(a_) for a_ in st.stage_acceptance], "finite": bool(np.isfinite(lp_s).all())}
+                del st
+            smc_out["note"] = ("whole call incl. the initial evaluation of the prior population, transitions, all-gathers and "
+                               "(where stated) stage files; `value` above is the same step with torch-drawn proposal rows "
+                               "handed in (beatamd_ffi_astep_batch) on the prior population -- later stages concentrate the "
+                               "population (fewer distinct rows per patch), which is why sampling-only can exceed `value`")
+            out["smc_leg"] = smc_out
         if "multilinear" in legs:
             # the reference's default interpolation (beat/config.py:571-575)
             spec_ml = spec_with(interp="multilinear")
@@ -556,12 +603,18 @@ def main():
             leg = run_leg(spec_ml, f_ml, B, Kl, 2, seed_offset=1000)
             roof_ml = stack_roofline(spec_ml, leg, B)
             if B == 512 and T == 64 and N == 4096 and args.prior == "survey" and not env_knobs:
-                attach_traffic(roof_ml, os.path.join(ROOT, "profiles", "r3_bench_c512_ml_gfstack_cell_summary.json"))
+                attach_traffic(roof_ml, os.path.join(ROOT, "profiles", "r4_bench_c512_ml_gfstack_ml_summary.json"))
             out["multilinear_leg"] = {
                 "interpolation": "multilinear (4 rows per patch and chain; beat/ffi/base.py:663-704)",
                 "chains": B, "steps": Kl, "chain_steps_per_s": B * Kl / leg["dt"],
                 "ms_per_step": leg["dt"] / Kl * 1e3, "roofline": roof_ml,
                 "kernel_ms_per_step": {k: (v[0] / Kl) for k, v in leg["times"].items() if v[1]}}
+            if B < 2048:
+                leg2 = run_leg(spec_ml, f_ml, 2048, 3, 1, seed_offset=1000)
+                ms2, n2 = leg2["times"]["gfstack"]
+                out["multilinear_leg"]["batch_2048"] = {
+                    "chains": 2048, "chain_steps_per_s": 2048 * 3 / leg2["dt"], "kernel": leg2["kernel"],
+                    "gfstack_avg_launch_ms": ms2 / max(n2, 1), "gfstack_ms_per_512_chains": ms2 / max(n2, 1) / 4.0}
             del f_ml
         f_tp = None
         if legs & {"toeplitz", "pt", "prewhitened"}:
@@ -586,6 +639,19 @@ def main():
                     "mfma_loop_ceiling_TFLOPs": 49.4, "frac_of_mfma_loop_ceiling": qa / 49.4,
                     "note": "v_mfma_f64_16x16x4_f64; a register-resident MFMA loop reaches 49.4 TF on this part "
                             "(tools/micro/mfma64.hip), nominal 78.6"}}
+            if "default_config" in legs:
+                # the configuration a real FFI run uses: the reference's default interpolation (multilinear,
+                # beat/config.py:571-575) TOGETHER with a non-diagonal data covariance (beat/covariance.py:397-427,
+                # models/seismic.py:1509-1534): stacking with the residual-store epilogue + dense W on the matrix cores
+                f_mt = variant("multilinear", weights=Wd, slog=slog_d)
+                spec_mt = spec_with(interp="multilinear", covariance="toeplitz")
+                leg = run_leg(spec_mt, f_mt, B, Kl, 2, seed_offset=1000)
+                out["default_config_leg"] = {"multilinear_dense_W": {
+                    "configuration": "multilinear interpolation + Toeplitz data covariance (dense upper-triangular W, 8.6 GB)",
+                    "chains": B, "steps": Kl, "chain_steps_per_s": B * Kl / leg["dt"], "ms_per_step": leg["dt"] / Kl * 1e3,
+                    "kernel": leg["kernel"],
+                    "kernel_ms_per_step": {k: (v[0] / Kl) for k, v in leg["times"].items() if v[1]}}}
+                del f_mt
         if "pt" in legs:
             # parallel tempering: 4 temperatures x 256 replicas = the per-GPU share of BASELINE configs[4];
             # the sampler times its own rounds (set-up of the replicas excluded)
@@ -610,6 +676,27 @@ def main():
                     "chain_steps_per_s": n_temp * n_rep * man.loop_steps / man.loop_seconds,
                     "ms_per_step_incl_exchange": man.loop_seconds / man.loop_steps * 1e3,
                     "gfstack_avg_launch_ms": g_ms / max(n_launch, 1), "finite": bool(np.isfinite(ls_pt).all())}
+        if "stage_update" in legs and f_tp is not None:
+            # what update_covariances costs at a stage boundary (smc.py:492-503): covariance re-estimation at the
+            # MAP point + factorisation + new weights installed, then the end points evaluated again
+            from beat_amd.covariance import NoiseCovarianceUpdate
+            upd = NoiseCovarianceUpdate(f_tp)
+            q_map = leg_q = None
+            Lq = f_tp.batch(main_leg["Q"])
+            q_map = main_leg["Q"][int(torch.argmax(Lq[:, -1]))].cpu().numpy()
+            for rep in range(2):      # (first call allocates)
+                upd.update_weights(q_map)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                f_tp.batch(main_leg["Q"])
+                torch.cuda.synchronize()
+                t_re = time.perf_counter() - t0
+            out["stage_update_leg"] = {"dense_W": {
+                "what": "64 noise covariances of 4096^2 re-estimated at the MAP point (synthetics, running rms, "
+                        "autocovariance, scaled Toeplitz), factorised (= the PSD test), weights installed; then the %d end "
+                        "points evaluated again" % B,
+                "stage_update_s": upd.last_ms * 1e-3 + t_re, "update_weights_s": upd.last_ms * 1e-3,
+                "reevaluation_s": t_re, "repaired_on_host": upd.n_repaired}}
         del f_tp
         torch.cuda.empty_cache()
         if "prewhitened" in legs:
@@ -624,6 +711,44 @@ def main():
                     "covariance": "the Toeplitz covariance folded into a whitened COPY of the library (W.G, W.d once)",
                     "chains": B, "steps": Kl, "chain_steps_per_s": B * Kl / leg["dt"],
                     "ms_per_step": leg["dt"] / Kl * 1e3, "whitening_s": t_pw, "kernel": leg["kernel"]}
+                if "default_config" in legs:
+                    # multilinear on the SAME whitened copy (no dense W.r per step)
+                    wm_pw = f_pw.problem.wavemaps[0]
+                    wm_ml = SeismicWavemap(wm_pw.gfs, wm_pw.data, wm_pw.weights, wm_pw.slog_pdet, wm_pw.hypers,
+                                           wm_pw.time_shifts, "multilinear")
+                    f_pm = FFIProblem(prob.layout, prob.n_patch_dip, prob.n_patch_strike, prob.patch_sizes,
+                                      prob.slip_varnames, [wm_ml], None, None, prob.lower, prob.upper).compile(ctx)
+                    leg = run_leg(spec_with(interp="multilinear", covariance="toeplitz"), f_pm, B, Kl, 2, seed_offset=1000)
+                    out.setdefault("default_config_leg", {})["multilinear_prewhitened"] = {
+                        "configuration": "multilinear interpolation on the pre-whitened library (Toeplitz covariance folded in)",
+                        "chains": B, "steps": Kl, "chain_steps_per_s": B * Kl / leg["dt"],
+                        "ms_per_step": leg["dt"] / Kl * 1e3, "kernel": leg["kernel"]}
+                    del f_pm
+                if "stage_update" in legs:
+                    # on the pre-whitened path an update re-whitens all 62.9 GB of rows in place (M = W_new inv(W_old))
+                    from beat_amd.covariance import NoiseCovarianceUpdate
+                    upd = NoiseCovarianceUpdate(f_pw)
+                    Lq = f_pw.batch(main_leg["Q"])
+                    q_map = main_leg["Q"][int(torch.argmax(Lq[:, -1]))].cpu().numpy()
+                    for rep in range(2):
+                        ctx.enable_timing(True)
+                        ctx.reset_timing()
+                        upd.update_weights(q_map)
+                        torch.cuda.synchronize()
+                        w_ms, w_n = ctx.kernel_time("whiten")
+                        ctx.enable_timing(False)
+                        t0 = time.perf_counter()
+                        f_pw.batch(main_leg["Q"])
+                        torch.cuda.synchronize()
+                        t_re = time.perf_counter() - t0
+                    wflops = float(spec.T) * spec.P * spec.D * spec.S * N * N
+                    out.setdefault("stage_update_leg", {})["prewhitened"] = {
+                        "what": "the same update on the pre-whitened model: residuals un-whitened, covariances, factorisation, "
+                                "M = W_new inv(W_old), all %.1f GB of library rows re-whitened in place (beatamd_whiten_rows_batch), "
+                                "end points evaluated again" % (spec.lib_bytes / 1e9),
+                        "stage_update_s": upd.last_ms * 1e-3 + t_re, "update_weights_s": upd.last_ms * 1e-3,
+                        "rewhitening_s": w_ms * 1e-3, "rewhitening_TFLOPs": wflops / (w_ms * 1e-3) / 1e12 if w_ms else None,
+                        "reevaluation_s": t_re}
                 del f_pw
             except (RuntimeError, MemoryError) as exc:   # not enough HBM for the copy beside other allocations
                 out["prewhitened_leg"] = {"skipped": str(exc)[:200]}
@@ -632,8 +757,11 @@ def main():
             # float-storage library (SURVEY 8(f) row 2 "optional fp32 layout"): float copy of the library, the
             # float64 storage rounded to the same values (LAST leg on the shared library for that reason); rows
             # move as 256-byte segments, operands are widened before the f64 FMA, accumulation stays f64
-            f.set_f32(True)
+            L_unrounded = f.batch(main_leg["Q"]).clone()
+            f.round_libraries_to_f32()      # explicit, irreversible: from here on the shared library holds rounded values
             torch.cuda.synchronize()
+            L_rounded = f.batch(main_leg["Q"])
+            rel_err = ((L_rounded - L_unrounded).abs() / L_unrounded.abs()).max(0).values
             leg = run_leg(spec, f, B, Kl, 2, seed_offset=1000)
             ms32, n32 = leg["times"]["gfstack"]
             # the float64 kernel on the SAME (now float-representable) values: separates what the data does
@@ -652,6 +780,9 @@ def main():
                                                       "chain_steps_per_s": B * Kl / leg64["dt"]},
                 "hbm_required_bytes_per_launch": need32,
                 "hbm_frac_required_bytes": need32 / (ms32 / max(n32, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "max_rel_err_vs_unrounded_library": {"like": float(rel_err[-1]), "dataset_logpts": float(rel_err[:-1].max()),
+                                                     "chains": int(L_rounded.shape[0]),
+                                                     "north_star_tolerance": 1e-6},
                 "note": "float pairs gathered by ds_read_b64: half the bytes and half the LDS gather instructions of the "
                         "f64 kernel for 2-4 % -- the rest of the difference to `value` is the DATA: the f64 kernel itself "
                         "runs 4-7 % faster on float-representable values (zero low mantissa bits, less switching "
