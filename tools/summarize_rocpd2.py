@@ -44,12 +44,13 @@ def main(src, dst, tag, *kernels):
         if not disp:
             print("no dispatch of", kn)
             continue
-        # several kernels may match (the stacking path times every chain-group size once per
-        # problem shape before settling): the summary is of the instance launched most often
+        # several kernels may match (the stacking path times every chain-group size once per problem shape
+        # before settling; "k_quadform" also names k_quadform_small): the summary is of the instance that took
+        # the most TIME in total -- give the template arguments ("k_quadform<128>") to pin one
         by_name = {}
         for d in disp:
             by_name.setdefault(d[0], []).append(d)
-        exact = max(by_name, key=lambda k: len(by_name[k]))
+        exact = max(by_name, key=lambda k: sum(x[1] for x in by_name[k]))
         others = {k.replace("void ", ""): len(v) for k, v in by_name.items() if k != exact}
         disp = by_name[exact]
         durs = [d[1] for d in disp]
