@@ -88,19 +88,27 @@ def _staged(X):
     return X, (lambda t: t)
 
 
-def allgather_rows(X):
+def allgather_rows(X, n_total=None):
     """rows of all ranks in rank order; X (n_local, width) -> (n_total, width).  Blocks may differ
-    in length."""
+    in length.  ``n_total`` (the global row count, when the caller knows it and the blocks are those of
+    ``chain_block``): the block lengths follow from it and the exchange of the counts -- a second collective
+    and a host synchronisation per call -- is skipped (one likelihood all-gather per PT exchange round)."""
     import torch
     import torch.distributed as dist
     if not _active():
         return X
     world = dist.get_world_size()   # (a single rank runs through the same collectives)
     Xt, back = _staged(X)
-    n_local = torch.tensor([Xt.shape[0]], device=Xt.device, dtype=torch.int64)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local)
-    counts = [int(c.item()) for c in counts]
+    if n_total is not None:
+        counts = [b - a for a, b in (chain_block(n_total, r, world) for r in range(world))]
+        if counts[dist.get_rank()] != Xt.shape[0]:
+            raise ValueError("allgather_rows: this rank holds %d rows, chain_block(%d) gives it %d"
+                             % (Xt.shape[0], n_total, counts[dist.get_rank()]))
+    else:
+        n_local = torch.tensor([Xt.shape[0]], device=Xt.device, dtype=torch.int64)
+        counts = [torch.zeros_like(n_local) for _ in range(world)]
+        dist.all_gather(counts, n_local)
+        counts = [int(c.item()) for c in counts]
     nmax = max(counts)
     buf = torch.zeros((nmax,) + tuple(Xt.shape[1:]), device=Xt.device, dtype=Xt.dtype)
     buf[:Xt.shape[0]] = Xt
@@ -116,13 +124,13 @@ def allgather_rows(X):
     return back(out)
 
 
-def allgather_population(Q, L):
+def allgather_population(Q, L, n_total=None):
     """All ranks' end points and likelihood vectors, in global chain order.
     Q (c_local, nparams), L (c_local, nllk) torch tensors (cuda or cpu) -> (Qall, Lall)."""
     import torch
     if not _active():
         return Q, L
-    allp = allgather_rows(torch.cat([Q, L], 1))
+    allp = allgather_rows(torch.cat([Q, L], 1), n_total)
     return allp[:, :Q.shape[1]].contiguous(), allp[:, Q.shape[1]:].contiguous()
 
 

@@ -168,7 +168,7 @@ def pt_sample(target, lower, upper, n_chains_posterior=1, n_chains_tempered=7, n
             post = parallel.allgather_rows(QL[p0 - start:p1 - start]).cpu().numpy()
             samples.append(post[:, :npar].copy())
             lsamples.append(post[:, npar:].copy())
-        like = parallel.allgather_rows(L[:, -1:].contiguous())[:, 0].cpu().numpy()
+        like = parallel.allgather_rows(L[:, -1:].contiguous(), n_total)[:, 0].cpu().numpy()
         perm = man.swap_round(like)
         QL = parallel.exchange_rows(QL, perm, n_total, gather=ops.gather)
         Q, L = QL[:, :npar].contiguous(), QL[:, npar:].contiguous()

@@ -96,7 +96,7 @@ class SMC(object):
         """smc.py:188-240 -- instead of reading trace files: all-gather the ranks' blocks; the
         gathered arrays stay on the device."""
         self.ops.check()  # surfaces an out-of-library index of the finished stage (IndexError)
-        self.Q_all, self.L_all = parallel.allgather_population(Q_local, L_local)
+        self.Q_all, self.L_all = parallel.allgather_population(Q_local, L_local, self.n_chains)
         if self.Q_all.shape[0] != self.n_chains:
             raise RuntimeError("gathered %d chains, expected %d (process group not initialised?)"
                                % (self.Q_all.shape[0], self.n_chains))

@@ -209,14 +209,24 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
+    # BEATAMD_BENCH_BACKEND=gloo (tests/test_gpu_dist.py): every rank uses cuda:0 -- N ranks share ONE GPU and the
+    # collectives are staged through host memory (beat_amd.parallel._staged; RCCL refuses duplicate devices).
+    # The contract (n_gpus, global chains, value = all ranks' chain-steps / max time, a stage transition whose
+    # all-gather really had N ranks) is exercised without a multi-GPU node; the numbers are not a scaling curve.
+    backend = os.environ.get("BEATAMD_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     # BEATAMD_BENCH_FORCE_DIST=1: exercise the RCCL path with a single rank (1-GPU boxes)
     use_dist = world > 1 or bool(os.environ.get("BEATAMD_BENCH_FORCE_DIST"))
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     import beat_amd
     from beat_amd.sampler import SMC
@@ -238,6 +248,19 @@ def main():
     lay = host["layout"]
     lo, up = lay.bounds(host["lower"], host["upper"])
 
+    PBLK = 64   # proposal rows are seeded per block of 64 GLOBAL chains: the same rows whatever the sharding
+
+    def seeded_blocks(draw, n_chains, first_chain, tail):
+        """(n_steps + n_warm, n_chains) + tail draws, chains [64 j, 64 j + 64) of the global population from
+        generator seed 4242 + j"""
+        assert first_chain % PBLK == 0, "chains per GPU must be a multiple of %d" % PBLK
+        gen = torch.Generator(device=dev)
+        parts = []
+        for j in range((n_chains + PBLK - 1) // PBLK):
+            gen.manual_seed(4242 + first_chain // PBLK + j)
+            parts.append(draw((min(PBLK, n_chains - j * PBLK),) + tail, gen))
+        return torch.cat(parts, 0)
+
     def run_leg(spec_leg, f_leg, n_chains, n_steps, n_warm, seed_offset, beta=2e-6):
         """n_steps timed astep batches of n_chains chains; everything resident in HBM beforehand.
         -> dict(dt, kernel times, in-box fraction, acceptance)"""
@@ -248,13 +271,14 @@ def main():
         lo_h, up_h = lay_l.bounds(box["lower"], box["upper"])
         lo_s, up_s = torch.from_numpy(lo_h).to(dev), torch.from_numpy(up_h).to(dev)
         L0 = f_leg.batch(Q0)
-        gen = torch.Generator(device=dev)
-        gen.manual_seed(4242 + rank)
         # proposal rows: proposal_samples_array[stage_sample] of every chain (metropolis.py:289-313)
-        delta = torch.randn((n_steps + n_warm, n_chains, lay_l.size), generator=gen, device=dev,
-                            dtype=torch.float64) * (args.step_scale * (up_s - lo_s))
-        log_u = torch.log(torch.rand((n_steps + n_warm, n_chains), generator=gen, device=dev,
-                                     dtype=torch.float64))
+        first = seed_offset - 1000      # (the global index of this leg's first chain)
+        nsw = n_steps + n_warm
+        delta = seeded_blocks(lambda shp, g: torch.randn(shp, generator=g, device=dev, dtype=torch.float64),
+                              n_chains, first, (nsw, lay_l.size)).permute(1, 0, 2).contiguous()
+        delta = delta * (args.step_scale * (up_s - lo_s))
+        log_u = torch.log(seeded_blocks(lambda shp, g: torch.rand(shp, generator=g, device=dev, dtype=torch.float64),
+                                        n_chains, first, (nsw,)).permute(1, 0).contiguous())
         scaling = torch.ones(n_chains, device=dev, dtype=torch.float64)
         accepted = torch.zeros(n_chains, device=dev, dtype=torch.int32)
         # fraction of proposals inside the prior box (the reference evaluates the forward model
@@ -294,7 +318,7 @@ def main():
     host_of = {spec: host}
     main_leg = run_leg(spec, f, B, K, W, seed_offset=1000 + rank * B)
     dt = main_leg["dt"]
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    tmax = torch.tensor([dt], device="cpu" if backend == "gloo" else dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt_max = float(tmax.item())
@@ -313,6 +337,8 @@ def main():
         torch.cuda.synchronize()
         stage_ms = (time.perf_counter() - t1) * 1e3
     assert Qn.shape == main_leg["Q"].shape and smc.Q_all.shape[0] == world * B
+    # the gathered end points of all ranks (identical on every rank): sums as a sharding-independent fingerprint
+    pop_sum = (float(smc.Q_all.sum().item()), float(smc.L_all[:, -1].sum().item()), float(smc.beta))
 
     def stack_roofline(spec_leg, leg, n_chains):
         """roofline of the stacking kernel of one leg: every candidate bound with its fraction, the
@@ -441,6 +467,9 @@ def main():
             "in_box_fraction": main_leg["in_box"],
             "accept_rate_last_step": main_leg["accept_last"],
             "stage_transition_ms": stage_ms,
+            "stage_transition": {"ranks_in_all_gather": world if use_dist else 1, "gathered_chains": int(smc.Q_all.shape[0]),
+                                 "population_checksum": {"sum_Q": pop_sum[0], "sum_like": pop_sum[1], "next_beta": pop_sum[2]},
+                                 "backend": (backend if use_dist else None)},
             "setup_s": t_build,
         }
         q_ms, q_n = main_leg["times"]["quadform"]
