@@ -181,7 +181,7 @@ def main():
                          "tempering, geometry mode")
     ap.add_argument("--variant-legs", default="multilinear,toeplitz,default_config,stage_update,smc,pt,prewhitened,geometry,fp32",
                     help="which of the labelled configuration legs to run (comma separated)")
-    ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "r3_bench_c512_nn_gfstack_ws_summary.json"),
+    ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "r4_bench_c512_nn_gfstack_ws_summary.json"),
                     help="rocprofv3 PMC summary (tools/run_profile.sh + tools/summarize_rocpd.py) of THIS "
                          "command; supplies roofline.traffic when its configuration matches")
     ap.add_argument("--gf-order", type=int, default=None,
@@ -521,7 +521,7 @@ def main():
             "note": "no cross-chain row reuse: algorithmic bytes = HBM bytes (block order chain-major)"}
         if Bs == 128 and spec.T == 64 and spec.N == 4096:
             attach_traffic(out["roofline_streaming"], os.path.join(ROOT, "profiles",
-                                                                   "r3_bench_c512_nn_gfstack0_summary.json"))
+                                                                   "r4_bench_c512_nn_gfstack0_summary.json"))
     # ---- the same population in larger batches: chain groups of one (target, tile) share an XCD,
     # rows common to several groups come from its L2 (labelled leg; `value` stays the 512-chain batch)
     if world == 1 and not args.no_batch_leg and spec.covariance == "scalar" and B < 2048:
@@ -666,8 +666,18 @@ def main():
                     "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": qa / FP64_VALU_PEAK_TFLOPS,
                     "avg_launch_ms": q_ms / max(q_n, 1), "launches": q_n, "flops_per_launch": qflops,
                     "mfma_loop_ceiling_TFLOPs": 49.4, "frac_of_mfma_loop_ceiling": qa / 49.4,
+                    "traffic": None,
+                    "algorithmic_bytes_per_launch": T * N * N * 4.0 + 2.0 * B * T * N * 8.0,   # W's upper half + R in, once
                     "note": "v_mfma_f64_16x16x4_f64; a register-resident MFMA loop reaches 49.4 TF on this part "
                             "(tools/micro/mfma64.hip), nominal 78.6"}}
+            if B == 512 and T == 64 and N == 4096 and not env_knobs:
+                qsum = os.path.join(ROOT, "profiles", "r4_bench_c512_toeplitz_quadform128_summary.json")
+                if os.path.exists(qsum):
+                    pq = json.load(open(qsum))
+                    rq = out["toeplitz_leg"]["roofline_quadform"]
+                    rq["traffic"] = pq["hbm_read_bytes_per_launch_corrected"] + pq.get("hbm_write_bytes_per_launch", 0.0)
+                    rq["traffic_source"] = os.path.relpath(qsum, ROOT)
+                    rq["traffic_measured_in"] = "builder rocprofv3 --pmc passes of `bench.py --covariance toeplitz` (not this run)"
             if "default_config" in legs:
                 # the configuration a real FFI run uses: the reference's default interpolation (multilinear,
                 # beat/config.py:571-575) TOGETHER with a non-diagonal data covariance (beat/covariance.py:397-427,
