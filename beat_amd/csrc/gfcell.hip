@@ -32,6 +32,7 @@
 #include "kernels.hpp"
 #include "gfcell_asm.inc"
 #include "gfml_asm.inc"
+#include "gfruns_asm.inc"
 
 namespace beatamd {
 
@@ -493,12 +494,19 @@ struct GmTabArgs {
     uint32_t *ucount;             // [(g*T+t)*P+p] row segments the loaders move (statistics)
 };
 
-// one workgroup per (group, target, patch); thread <-> chain slot of the group order
+// one workgroup per (group, target, patch); thread <-> chain slot of the group order.
+// RUNS (k_gfstack_runs): the chains of a wavefront are written in CELL ORDER and every record carries, in the dword of
+// entry GR_PK_LANE, the accumulator offsets (2 x chain slot, 7 bits each) of its four chains and a bit per chain that
+// opens a new cell (the program reads rows only then).
+template <int RUNS>
 __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
 {
     __shared__ uint32_t flags[256];
     __shared__ uint32_t reqs[256];
     __shared__ uint32_t nreq_s;
+    __shared__ uint32_t keys[RUNS ? GC_CG : 1];
+    __shared__ uint8_t srt[RUNS ? GC_CG : 1];
+    __shared__ uint8_t pk8[RUNS ? GC_CG : 1];
     const int tid = threadIdx.x;
     const int64_t gtp = blockIdx.x;
     const int64_t p = gtp % a.P;
@@ -562,21 +570,62 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
         }
         a.ltab[((gt * (a.nsteps + 3) + s) * GC_NLOAD + ll) * 32 + d] = val;
     }
-    if (!slot) return;
     const int w = tid / GC_NCHAIN, j = tid % GC_NCHAIN;
     const uint32_t ring = (uint32_t)((s % 3) * a.nslot);
-    char *rec = a.wtab + ((gt * GC_NCONS + w) * (a.nsteps + 1) + s) * (int64_t)GM_WSTRIDE + (j >> 2) * GM_REC;
-    const int q = j & 3;
     const double sl = live ? a.slips.base[c * a.slips.stride + a.slips.off + p] : 0.0;
-    for (int k = 0; k < 4; k++)
-        *reinterpret_cast<double *>(rec + (4 * q + k) * 16) = fr[k] * sl;     // base.py:676-679 x slip, as k_gfstack
-    // a dead chain slot reads slot 0 of the buffer (its accumulator is never stored)
-    *reinterpret_cast<uint32_t *>(rec + (2 * q) * 16 + 8) = (ring + sa) * 512u;
-    *reinterpret_cast<uint32_t *>(rec + (2 * q + 1) * 16 + 8) = (ring + sb) * 512u;
+    if constexpr (!RUNS) {
+        if (!slot) return;
+        char *rec = a.wtab + ((gt * GC_NCONS + w) * (a.nsteps + 1) + s) * (int64_t)GM_WSTRIDE + (j >> 2) * GM_REC;
+        const int q = j & 3;
+        for (int k = 0; k < 4; k++)
+            *reinterpret_cast<double *>(rec + (4 * q + k) * 16) = fr[k] * sl;     // base.py:676-679 x slip, as k_gfstack
+        // a dead chain slot reads slot 0 of the buffer (its accumulator is never stored)
+        *reinterpret_cast<uint32_t *>(rec + (2 * q) * 16 + 8) = (ring + sa) * 512u;
+        *reinterpret_cast<uint32_t *>(rec + (2 * q + 1) * 16 + 8) = (ring + sb) * 512u;
+    } else {
+        // position of the chain in the cell order of its wavefront (dead slots last)
+        const uint32_t key = live ? ((sb << 16) | sa) : 0xffffffffu;
+        if (slot) keys[tid] = key;
+        __syncthreads();
+        int r = 0;
+        if (slot) {
+            for (int k = 0; k < GC_NCHAIN; k++) {
+                const uint32_t kk = keys[w * GC_NCHAIN + k];
+                r += (kk < key) || (kk == key && k < j);
+            }
+            srt[w * GC_NCHAIN + r] = (uint8_t)j;
+        }
+        __syncthreads();
+        if (slot) {
+            // a chain opens a cell when its key differs from its predecessor's; dead slots ride on the rows in place
+            const bool opens = live && (r == 0 || keys[w * GC_NCHAIN + srt[w * GC_NCHAIN + r - 1]] != key);
+            pk8[w * GC_NCHAIN + r] = (uint8_t)((2 * j) | (opens ? 0x80 : 0));
+            char *rec = a.wtab + ((gt * GC_NCONS + w) * (a.nsteps + 1) + s) * (int64_t)GM_WSTRIDE + (r >> 2) * GM_REC;
+            const int q = r & 3;
+            for (int k = 0; k < 4; k++)
+                *reinterpret_cast<double *>(rec + (4 * q + k) * 16) = fr[k] * sl;
+            *reinterpret_cast<uint32_t *>(rec + (2 * q) * 16 + 8) = (ring + sa) * 512u;
+            *reinterpret_cast<uint32_t *>(rec + (2 * q + 1) * 16 + 8) = (ring + sb) * 512u;
+        }
+        __syncthreads();
+        if (slot && (j & 3) == 0) {
+            // here the thread is record j / 4 of wavefront w: pack its (up to) four chains
+            uint32_t pk = 0;
+            for (int q = 0; q < 4 && j + q < GC_NCHAIN; q++) {
+                const uint32_t v = pk8[w * GC_NCHAIN + j + q];
+                pk |= (v & 0x7fu) << (7 * q);
+                pk |= (v >> 7) << (GR_PK_NEW + q);
+            }
+            char *rec = a.wtab + ((gt * GC_NCONS + w) * (a.nsteps + 1) + s) * (int64_t)GM_WSTRIDE + (j >> 2) * GM_REC;
+            *reinterpret_cast<uint32_t *>(rec + GR_PK_LANE * 16 + 8) = pk;
+        }
+    }
 }
 
-template <int NTH, int VAR>
-__global__ void __launch_bounds__(1024) k_gfstack_ml(GcArgs a)
+// PROG 0: k_gfstack_ml (static chain order, four row reads per chain); PROG 1: k_gfstack_runs (cell order, rows read
+// once per run of chains sharing a cell, accumulators through the VGPR index register)
+template <int NTH, int VAR, int PROG>
+__global__ void __launch_bounds__(1024) k_gfstack_mlr(GcArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t gsm[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -633,6 +682,19 @@ __global__ void __launch_bounds__(1024) k_gfstack_ml(GcArgs a)
     }
     __syncthreads();
     const uint32_t paddr = lds0 + (uint32_t)(wave * 128);
+    if constexpr (PROG == 1) {
+        if constexpr (VAR == 0) {
+            if (wave < GC_NCONS) { GR_CONSUMER_0(paddr); }
+            else if (NTH) { GC_LOADER_0_1(paddr); }
+            else { GC_LOADER_0_0(paddr); }
+        }
+#if GR_NVARIANT > 1
+        if constexpr (VAR == 1) { if (wave < GC_NCONS) { GR_CONSUMER_1(paddr); } else { GC_LOADER_0_1(paddr); } }
+        if constexpr (VAR == 2) { if (wave < GC_NCONS) { GR_CONSUMER_2(paddr); } else { GC_LOADER_0_1(paddr); } }
+        if constexpr (VAR == 3) { if (wave < GC_NCONS) { GR_CONSUMER_3(paddr); } else { GC_LOADER_0_1(paddr); } }
+#endif
+        return;
+    }
     if constexpr (VAR == 0) {
         if (wave < GC_NCONS) { GM_CONSUMER_0(paddr); }
         else if (NTH) { GC_LOADER_0_1(paddr); }
@@ -690,9 +752,12 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
     const int64_t GT = ngroups * Ttab;
     void *p = nullptr;
 
+    const bool runs = env_int("BEATAMD_GS_RUNS", 1) != 0;   // k_gfstack_runs (default) or k_gfstack_ml
     GcOrderArgs oa;
     oa.C = k.C; oa.T = Ttab; oa.P = L.P; oa.S = L.S; oa.rowoff = rowoff;
-    oa.sort = 0;   // the order of the chains does not matter to a static program
+    // k_gfstack_runs: chains that rupture alike share cells patch after patch -> put them into one wavefront
+    // (k_gc_order); the static program does not care
+    oa.sort = runs ? env_int("BEATAMD_GC_SORT", 1) != 0 : 0;
     BA_TRY(ctx->get_scratch(SL_GC_ORDER, (size_t)(ngroups * GC_CG + 64) * sizeof(uint32_t), &p));
     oa.order = (uint32_t *)p;
 
@@ -716,7 +781,8 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
         // the request tables behind the last step stay empty
         BA_HIP(hipMemset2DAsync((char *)ta.ltab + (size_t)nsteps * GC_NLOAD * GC_LTAB, lt_pitch, 0,
                                 (size_t)3 * GC_NLOAD * GC_LTAB, (size_t)GT, ctx->stream));
-        hipLaunchKernelGGL(k_gm_tables, dim3((unsigned)(GT * L.P)), dim3(GC_TB), 0, ctx->stream, ta);
+        if (runs) hipLaunchKernelGGL(k_gm_tables<1>, dim3((unsigned)(GT * L.P)), dim3(GC_TB), 0, ctx->stream, ta);
+        else hipLaunchKernelGGL(k_gm_tables<0>, dim3((unsigned)(GT * L.P)), dim3(GC_TB), 0, ctx->stream, ta);
     }
     BA_HIP(hipGetLastError());
 
@@ -745,21 +811,29 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
     const size_t ring = std::max<size_t>((size_t)3 * nslot * 512, (size_t)GC_NCONS * 16 * GC_TPITCH);
     const size_t lds = GC_PARAM_BYTES + ring;
     BA_CHECK(lds <= 160 * 1024, BEATAMD_EINVAL, "internal: k_gfstack_ml row buffers exceed LDS");
-    snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack_ml<%d,%d>", k.mode, nth);
+    snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "%s<%d,%d>", runs ? "k_gfstack_runs" : "k_gfstack_ml", k.mode, nth);
     ctx->gs_ngtp = GT * L.P;
     ctx->gs_trep = L.T / Ttab;
     ctx->gs_N = L.N;
     ctx->gs_cg = GC_CG;
     {
         ScopedTimer tm(ctx, "gfstack");
-        void (*kern)(GcArgs) = nth ? k_gfstack_ml<1, 0> : k_gfstack_ml<0, 0>;
+        void (*kern)(GcArgs) = runs ? (nth ? k_gfstack_mlr<1, 0, 1> : k_gfstack_mlr<0, 0, 1>)
+                                    : (nth ? k_gfstack_mlr<1, 0, 0> : k_gfstack_mlr<0, 0, 0>);
 #if GM_NVARIANT > 1
-        {
+        if (!runs) {
             const int var = env_int("BEATAMD_GM_VAR", 0);   // timing experiments (GM_ABLATIONS builds; wrong results)
-            void (*vk[])(GcArgs) = {kern, k_gfstack_ml<1, 1>, k_gfstack_ml<1, 2>, k_gfstack_ml<1, 3>, k_gfstack_ml<1, 4>,
-                                    k_gfstack_ml<1, 5>, k_gfstack_ml<1, 6>, k_gfstack_ml<1, 7>, k_gfstack_ml<1, 8>,
-                                    k_gfstack_ml<1, 9>};
+            void (*vk[])(GcArgs) = {kern, k_gfstack_mlr<1, 1, 0>, k_gfstack_mlr<1, 2, 0>, k_gfstack_mlr<1, 3, 0>, k_gfstack_mlr<1, 4, 0>,
+                                    k_gfstack_mlr<1, 5, 0>, k_gfstack_mlr<1, 6, 0>, k_gfstack_mlr<1, 7, 0>, k_gfstack_mlr<1, 8, 0>,
+                                    k_gfstack_mlr<1, 9, 0>};
             if (var >= 1 && var < GM_NVARIANT) kern = vk[var];
+        }
+#endif
+#if GR_NVARIANT > 1
+        if (runs) {
+            const int var = env_int("BEATAMD_GR_VAR", 0);
+            void (*vk[])(GcArgs) = {kern, k_gfstack_mlr<1, 1, 1>, k_gfstack_mlr<1, 2, 1>, k_gfstack_mlr<1, 3, 1>};
+            if (var >= 1 && var < GR_NVARIANT) kern = vk[var];
         }
 #endif
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -352,6 +352,7 @@ def main():
         shared = st["row_bytes"] > 0
         cell = leg["kernel"].startswith("k_gfstack_cell")
         ml_static = leg["kernel"].startswith("k_gfstack_ml")
+        ml_runs = leg["kernel"].startswith("k_gfstack_runs")
         # bytes the kernel has to move from HBM: every distinct row of every (group, target,
         # patch) once (chain-shared kernels) or every chain's rows (streaming kernel), + tables
         tables = n_chains * spec_leg.T * spec_leg.P * 4 * rows_per_patch * 2 + spec_leg.T * spec_leg.N * 8

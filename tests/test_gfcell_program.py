@@ -51,7 +51,7 @@ def _run(T, P, D, S, N, C, Ttab_is_one, mode, sort, nth, seed, static_acc=False,
     order = emu.gc_order(ro, C, Ttab, P, S, sort)
     assert sorted(order[order != emu.DEAD].tolist()) == list(range(C))
     if static_acc:
-        wtab, ltab, ucount = emu.gm_tables(ro, fa, sl, order, C, Ttab, P, D, S)
+        wtab, ltab, ucount = emu.gm_tables(ro, fa, sl, order, C, Ttab, P, D, S, runs=(static_acc == "runs"))
     else:
         wtab, ltab, ucount = emu.gc_tables(ro, fa, [sl], order, C, Ttab, P, DS)
     data = rng.standard_normal((T, N))
@@ -145,6 +145,26 @@ def test_static_program_tables_per_patch_and_two_groups():
     _run(T=1, P=2, D=1, S=1, N=64, C=3, Ttab_is_one=True, mode=0, sort=False, nth=0, seed=4, static_acc=True)
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_runs_program_one_group(mode):
+    """k_gfstack_runs (cell order per patch, rows read once per run of chains sharing a cell, accumulators through
+    the VGPR index register with the offset unpacked on the scalar side): the cases of the static program"""
+    _run(T=2, P=4, D=3, S=6, N=70, C=45, Ttab_is_one=False, mode=mode, sort=bool(mode & 1), nth=mode & 1, seed=5 + mode,
+         static_acc="runs", below_grid=True)
+
+
+def test_runs_program_shares_row_reads():
+    stats, _ = _run(T=2, P=3, D=2, S=5, N=64, C=80, Ttab_is_one=True, mode=0, sort=True, nth=0, seed=11, static_acc="runs")
+    # four FMAs per chain SLOT and step, but far fewer row reads: 80 chains over 2 x 4 cells
+    assert sum(w.fma_count for w in stats[0].waves) == emu.CG * 3 * 4
+    stats, ucount = _run(T=1, P=2, D=2, S=4, N=64, C=519, Ttab_is_one=True, mode=1, sort=True, nth=1, seed=3,
+                         static_acc="runs")
+    assert stats[0].dma_bytes == int(ucount[:2].sum()) * 512
+    _run(T=1, P=2, D=1, S=1, N=64, C=3, Ttab_is_one=True, mode=0, sort=False, nth=0, seed=4, static_acc="runs")
+    # a step of one patch and a wavefront full of one cell
+    _run(T=1, P=1, D=2, S=3, N=64, C=40, Ttab_is_one=True, mode=2, sort=True, nth=0, seed=9, static_acc="runs")
+
+
 def test_register_budget():
     """the programs stay inside the registers the kernel may use: 128 VGPRs (16 wavefronts per
     workgroup = 4 per SIMD) and user SGPRs below s96 (VCC, FLAT_SCRATCH, XNACK_MASK above); SGPR
@@ -152,7 +172,7 @@ def test_register_budget():
     import re
     assert gen.V_LAST < 128 and gen.NCONS + gen.NLOAD == 16 and gen.NQMIN >= 3
     assert emu.genml.V_LAST < 128
-    for prog in (gen.consumer(), gen.loader(0), gen.loader(1), emu.genml.consumer()):
+    for prog in (gen.consumer(), gen.loader(0), gen.loader(1), emu.genml.consumer(), emu.genruns.consumer()):
         for ln in prog:
             for m in re.finditer(r"\b[sv]\[(\d+):(\d+)\]", ln):
                 assert int(m.group(1)) % 2 == 0, ln   # (gfx950: SGPR address pairs and VGPR tuples are 64-bit aligned)
@@ -195,3 +215,14 @@ def test_committed_include_is_the_generators_output(tmp_path, monkeypatch):
     genml.main()
     monkeypatch.undo()
     assert open(str(tmp_path / "gfml_asm.inc")).read() == committed
+    genruns = importlib.import_module("gen_gfruns_asm")
+    committed = open(os.path.join(root, "beat_amd", "csrc", "gfruns_asm.inc")).read()
+    monkeypatch.delenv("GR_ABLATIONS", raising=False)
+
+    def join3(*a):
+        p = real_join(*a)
+        return str(tmp_path / "gfruns_asm.inc") if p.endswith("gfruns_asm.inc") else p
+    monkeypatch.setattr(genruns.os.path, "join", join3)
+    genruns.main()
+    monkeypatch.undo()
+    assert open(str(tmp_path / "gfruns_asm.inc")).read() == committed

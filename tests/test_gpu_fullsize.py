@@ -204,11 +204,17 @@ def test_fullsize_shipped_dma_kernel_at_bench_shape(full, monkeypatch, C):
         assert ctx.last_kernel().startswith("k_gfstack<"), ctx.last_kernel()
         monkeypatch.delenv("BEATAMD_GF_KERNEL")
         assert torch.equal(out, ref), "k_gfstack_dma differs from the streaming kernel (%s)" % interp
-        if nrow == 4:   # the shipped multilinear kernel (static accumulators, dense LDS rows) and the round-3 cell kernel
+        if nrow == 4:   # the shipped multilinear kernel (rows read once per run of chains sharing a cell), the static
+            # kernel and the round-3 cell kernel
             monkeypatch.delenv("BEATAMD_GS_CG")
+            out2 = gf.stack_all_batch(dur_d, st_d, sl_d, interpolation=interp)
+            assert ctx.last_kernel().startswith("k_gfstack_runs<0,"), ctx.last_kernel()
+            assert torch.equal(out2, ref), "k_gfstack_runs differs from the streaming kernel"
+            monkeypatch.setenv("BEATAMD_GS_RUNS", "0")
             out2 = gf.stack_all_batch(dur_d, st_d, sl_d, interpolation=interp)
             assert ctx.last_kernel().startswith("k_gfstack_ml<0,"), ctx.last_kernel()
             assert torch.equal(out2, ref), "k_gfstack_ml differs from the streaming kernel"
+            monkeypatch.delenv("BEATAMD_GS_RUNS")
             monkeypatch.setenv("BEATAMD_GS_ML", "0")
             out2 = gf.stack_all_batch(dur_d, st_d, sl_d, interpolation=interp)
             assert ctx.last_kernel().startswith("k_gfstack_cell<0,"), ctx.last_kernel()
@@ -282,8 +288,9 @@ def test_fullsize_fused_logp_through_dma_kernel(full, monkeypatch, C):
 @pytest.mark.parametrize("cov", ["scalar", "dense"])
 def test_fullsize_fused_logp_multilinear(full, monkeypatch, cov):
     """the kernel the multilinear legs of bench.py time, asserted BY NAME at the bench shape
-    in its fused epilogues -- k_gfstack_ml<1,..> (scalar-covariance misfit) and <2,..> (residual store feeding the
-    dense-W quadratic form) -- against the streaming kernel (1e-12) and the round-3 cell kernel, and on sampled
+    in its fused epilogues -- k_gfstack_runs<1,..> (scalar-covariance misfit) and <2,..> (residual store feeding the
+    dense-W quadratic form) -- against the streaming kernel (1e-12), the static kernel k_gfstack_ml and the round-3 cell
+    kernel, and on sampled
     (chain, target) pairs against the oracle composition (oracle index maps + closed-form rows + oracle MVN) at
     1e-10.  No BEATAMD_GS_CG: that knob selects the lane <-> chain family instead."""
     import torch
@@ -314,11 +321,16 @@ def test_fullsize_fused_logp_multilinear(full, monkeypatch, cov):
     f = pm.compile(ctx)
     Q = _population(full, C, seed_offset=31000)
     Qd = torch.from_numpy(Q).to("cuda:0")
-    for name in ("BEATAMD_GF_KERNEL", "BEATAMD_GS_CG", "BEATAMD_GS_ML", "BEATAMD_GS_CELL"):
+    for name in ("BEATAMD_GF_KERNEL", "BEATAMD_GS_CG", "BEATAMD_GS_ML", "BEATAMD_GS_CELL", "BEATAMD_GS_RUNS"):
         monkeypatch.delenv(name, raising=False)
     mode = 1 if cov == "scalar" else 2
     LM = f.batch(Qd).cpu().numpy()
+    assert ctx.last_kernel().startswith("k_gfstack_runs<%d," % mode), ctx.last_kernel()
+    monkeypatch.setenv("BEATAMD_GS_RUNS", "0")
+    LM2 = f.batch(Qd).cpu().numpy()
     assert ctx.last_kernel().startswith("k_gfstack_ml<%d," % mode), ctx.last_kernel()
+    assert np.array_equal(LM, LM2)
+    monkeypatch.delenv("BEATAMD_GS_RUNS")
     monkeypatch.setenv("BEATAMD_GS_ML", "0")
     LC = f.batch(Qd).cpu().numpy()
     assert ctx.last_kernel().startswith("k_gfstack_cell<%d," % mode), ctx.last_kernel()

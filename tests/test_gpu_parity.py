@@ -210,19 +210,22 @@ def test_shared_row_kernel_equals_streaming_kernel(ctx, orc, monkeypatch, C, int
         ref = orc.stack_all(G, dur[c], st[c], sl[c], 0.5, 0.25, 0.0, 0.5, interp)
         assert np.abs(b[c] - ref).max() <= 1e-11 * np.abs(ref).max()
     if interp == "multilinear":
-        # lane <-> sample kernels of gfcell.hip: static accumulators over dense LDS rows (k_gfstack_ml, the default
-        # from 192 chains on) and rows of a cell in registers with accumulators through the VGPR index
-        # (k_gfstack_cell, round 3); forced below; chain order and non-temporal requests are scheduling only
+        # lane <-> sample kernels of gfcell.hip over dense LDS rows: k_gfstack_runs (cell order per patch, rows read
+        # once per run of chains sharing a cell, accumulators through the VGPR index: the default from 192 chains on),
+        # k_gfstack_ml (static order, four row reads per chain) and round 3's k_gfstack_cell; forced below; chain order
+        # and non-temporal requests are scheduling only
         if C >= 192:
-            assert ctx.last_kernel().startswith("k_gfstack_ml<0,"), ctx.last_kernel()
-        for ml, srt, nth in (("1", "0", "1"), ("1", "0", "0"), ("0", "1", "1"), ("0", "0", "0")):
-            monkeypatch.setenv("BEATAMD_GS_ML", ml)
+            assert ctx.last_kernel().startswith("k_gfstack_runs<0,"), ctx.last_kernel()
+        for kern, srt, nth in (("runs", "1", "1"), ("runs", "0", "0"), ("ml", "0", "1"), ("ml", "0", "0"),
+                               ("cell", "1", "1"), ("cell", "0", "0")):
+            monkeypatch.setenv("BEATAMD_GS_ML", "0" if kern == "cell" else "1")
+            monkeypatch.setenv("BEATAMD_GS_RUNS", "1" if kern == "runs" else "0")
             monkeypatch.setenv("BEATAMD_GS_CELL", "1")
             monkeypatch.setenv("BEATAMD_GC_SORT", srt)
             monkeypatch.setenv("BEATAMD_GS_NTHINT", nth)
-            assert np.array_equal(gf.stack_all_batch(dur, st, sl, interpolation=interp), a), (C, ml, srt, nth)
-            assert ctx.last_kernel() == "k_gfstack_%s<0,%s>" % ("ml" if ml == "1" else "cell", nth), ctx.last_kernel()
-        for name in ("BEATAMD_GS_ML", "BEATAMD_GS_CELL", "BEATAMD_GC_SORT", "BEATAMD_GS_NTHINT"):
+            assert np.array_equal(gf.stack_all_batch(dur, st, sl, interpolation=interp), a), (C, kern, srt, nth)
+            assert ctx.last_kernel() == "k_gfstack_%s<0,%s>" % (kern, nth), ctx.last_kernel()
+        for name in ("BEATAMD_GS_ML", "BEATAMD_GS_RUNS", "BEATAMD_GS_CELL", "BEATAMD_GC_SORT", "BEATAMD_GS_NTHINT"):
             monkeypatch.delenv(name)
     seen = set()
     for cg in ("64", "128", "256", "512", "1024"):
@@ -259,7 +262,7 @@ def test_shared_row_kernel_equals_streaming_kernel(ctx, orc, monkeypatch, C, int
 
 @pytest.mark.parametrize("C", [200, 530])
 def test_ml_kernel_wrapped_floor_nodes(ctx, orc, monkeypatch, C):
-    """k_gfstack_ml keeps a chain's four rows at two LDS addresses (dense rows; slot 0 of a duration line = a copy of
+    """k_gfstack_runs / k_gfstack_ml keep a chain's four rows at two LDS addresses (dense rows; slot 0 of a duration line = a copy of
     its LAST start-time node).  Times exactly on node 0 (floor node wraps with weight 0), times BELOW the first node
     (the reference's python index -1 wraps to the last node WITH weight, base.py:513-517) and one-node axes must come
     out as in the streaming kernel (bitwise) and the oracle"""
@@ -281,10 +284,13 @@ def test_ml_kernel_wrapped_floor_nodes(ctx, orc, monkeypatch, C):
         a = gf.stack_all_batch(dur, st, sl, interpolation="multilinear")
         monkeypatch.delenv("BEATAMD_GF_KERNEL")
         monkeypatch.setenv("BEATAMD_GS_ML", "1")
-        b = gf.stack_all_batch(dur, st, sl, interpolation="multilinear")
-        assert ctx.last_kernel().startswith("k_gfstack_ml<0,"), ctx.last_kernel()
+        for runs in ("1", "0"):
+            monkeypatch.setenv("BEATAMD_GS_RUNS", runs)
+            b = gf.stack_all_batch(dur, st, sl, interpolation="multilinear")
+            assert ctx.last_kernel().startswith("k_gfstack_runs<0," if runs == "1" else "k_gfstack_ml<0,"), ctx.last_kernel()
+            assert np.array_equal(a, b), (T, P, D, S, N, runs)
         monkeypatch.delenv("BEATAMD_GS_ML")
-        assert np.array_equal(a, b), (T, P, D, S, N)
+        monkeypatch.delenv("BEATAMD_GS_RUNS")
         for c in (0, 1, 2, 3, 4, C - 1):
             ref = orc.stack_all(G, dur[c], st[c], sl[c], 0.5, 0.5, 0.0, 0.5, "multilinear")
             assert np.abs(b[c] - ref).max() <= 1e-11 * max(np.abs(ref).max(), 1.0)

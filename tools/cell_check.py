@@ -40,16 +40,17 @@ def main():
         a = gf.stack_all_batch(dur, st, sl, interpolation="multilinear")
         ka = ctx.last_kernel()
         del os.environ["BEATAMD_GF_KERNEL"]
-        for srt, ml in (("1", "0"), ("0", "0"), ("0", "1")):
+        for srt, ml, runs in (("1", "0", "0"), ("0", "0", "0"), ("0", "1", "0"), ("1", "1", "1"), ("0", "1", "1")):
             os.environ["BEATAMD_GC_SORT"] = srt
             os.environ["BEATAMD_GS_CELL"] = "1"
             os.environ["BEATAMD_GS_ML"] = ml
+            os.environ["BEATAMD_GS_RUNS"] = runs
             b = gf.stack_all_batch(dur, st, sl, interpolation="multilinear")
             kb = ctx.last_kernel()
             eq = np.array_equal(a, b)
             print("stack", (T, P, D, S, N, C), "sort", srt, ka, kb, "bitwise", eq,
                   "maxdiff", float(np.abs(a - b).max()), flush=True)
-            ok &= eq and kb.startswith("k_gfstack_ml" if ml == "1" else "k_gfstack_cell")
+            ok &= eq and kb.startswith(("k_gfstack_runs" if runs == "1" else "k_gfstack_ml") if ml == "1" else "k_gfstack_cell")
     # fused model: tables per patch, scalar and dense covariance
     from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
     for cov in ("scalar", "toeplitz"):
@@ -62,14 +63,15 @@ def main():
         A = f.batch(Q)
         ka = ctx.last_kernel()
         del os.environ["BEATAMD_GF_KERNEL"]
-        for ml in ("0", "1"):
+        for ml, runs in (("0", "0"), ("1", "0"), ("1", "1")):
             os.environ["BEATAMD_GS_CELL"] = "1"
             os.environ["BEATAMD_GS_ML"] = ml
+            os.environ["BEATAMD_GS_RUNS"] = runs
             B = f.batch(Q)
             kb = ctx.last_kernel()
             d = float(np.abs(np.asarray(A) - np.asarray(B)).max() / np.abs(np.asarray(A)).max())
             print("model", cov, ka, kb, "rel diff", d, flush=True)
-            ok &= d < 1e-12 and kb.startswith("k_gfstack_ml" if ml == "1" else "k_gfstack_cell")
+            ok &= d < 1e-12 and kb.startswith(("k_gfstack_runs" if runs == "1" else "k_gfstack_ml") if ml == "1" else "k_gfstack_cell")
     print("CELL_CHECK", "OK" if ok else "FAILED", flush=True)
     return 0 if ok else 1
 

@@ -22,6 +22,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import gen_gfcell_asm as gen  # noqa: E402
 import gen_gfml_asm as genml  # noqa: E402
+import gen_gfruns_asm as genruns  # noqa: E402
 
 U32 = np.uint32
 MASK64 = (1 << 64) - 1
@@ -193,8 +194,9 @@ def gc_tables(rowoff, fac, slips, order, C, T, P, DS, nvar=1):
     return wtab, ltab, ucount
 
 
-def gm_tables(rowoff, fac, slips, order, C, T, P, D, S):
-    """numpy twin of k_gm_tables (gfcell.hip): record table, request table and moved-row counts of k_gfstack_ml"""
+def gm_tables(rowoff, fac, slips, order, C, T, P, D, S, runs=False):
+    """numpy twin of k_gm_tables<RUNS> (gfcell.hip): record table, request table and moved-row counts of k_gfstack_ml;
+    runs: the chains of a wavefront in cell order + the packed accumulator offsets / new-cell bits of k_gfstack_runs"""
     ngroups = order.size // CG
     nsteps, GT, DS, S1 = P, ngroups * T, D * S, S + 1
     nslot = D * S1
@@ -247,10 +249,22 @@ def gm_tables(rowoff, fac, slips, order, C, T, P, D, S):
                     h[1:1 + len(mine)] = mine
                 ring = (s % 3) * nslot
                 for w in range(NCONS):
-                    for j in range(NCH):
+                    if runs:
+                        key = np.where(live[w * NCH:(w + 1) * NCH], (sb[w * NCH:(w + 1) * NCH] << 16) | sa[w * NCH:(w + 1) * NCH],
+                                       0xFFFFFFFF)
+                        perm = sorted(range(NCH), key=lambda jj: (int(key[jj]), jj))
+                    else:
+                        perm = list(range(NCH))
+                    for r, j in enumerate(perm):
                         k = w * NCH + j
-                        rec = ((gt * NCONS + w) * (nsteps + 1) + s) * genml.WSTRIDE + (j // 4) * genml.REC
-                        q = j % 4
+                        rec = ((gt * NCONS + w) * (nsteps + 1) + s) * genml.WSTRIDE + (r // 4) * genml.REC
+                        q = r % 4
+                        if runs:
+                            opens = bool(live[k]) and (r == 0 or int(key[perm[r - 1]]) != int(key[j]))
+                            pkw = wtab[rec + genruns.PK_LANE * 16 + 8:rec + genruns.PK_LANE * 16 + 12].view(np.uint32)
+                            if q == 0:
+                                pkw[0] = 0
+                            pkw[0] |= ((2 * j) << (7 * q)) | ((1 if opens else 0) << (genruns.PK_NEW + q))
                         c = int(ids[k]) if live[k] else 0
                         for kk in range(4):
                             wv = (fac[c, t, p, kk] * slips[c, p]) if live[k] else 0.0
@@ -266,7 +280,8 @@ class Barrier(Exception):
 
 
 def _parse_program(kind, nth):
-    lines = gen.consumer() if kind == "consumer" else genml.consumer() if kind == "consumer_ml" else gen.loader(nth)
+    lines = (gen.consumer() if kind == "consumer" else genml.consumer() if kind == "consumer_ml" else
+             genruns.consumer() if kind == "consumer_runs" else gen.loader(nth))
     labels, prog = {}, []
     for ln in lines:
         m = re.match(r"^(\w+)_%=:$", ln)
@@ -497,6 +512,8 @@ class Wave(object):
                 self.m0 = (self.m0 & ~0xF0FF) | (self.get_s32(ops[0]) & 0xFF) | ((int(ops[1], 0) & 0xF) << 12)
             elif op == "s_set_gpr_idx_off":
                 self.idx_en = False
+            elif op == "s_set_gpr_idx_idx":
+                self.m0 = (self.m0 & ~0xFF) | (self.get_s32(ops[0]) & 0xFF)
             elif op.startswith("s_load_dwordx"):
                 n = int(op[len("s_load_dwordx"):])
                 r = self.sreg(ops[0])
@@ -545,7 +562,11 @@ class Wave(object):
                 # D = dpp(S0) * S1 + D ; row_newbcast:k: lane k of the lane's own 16-lane row
                 k = int(re.search(r"row_newbcast:(\d+)", ln).group(1))
                 ops = [o.split()[0] for o in ops]
-                if self.wg.static_acc:
+                if self.wg.static_acc == "runs":
+                    assert self.idx_en and ((self.m0 >> 12) & 0xF) == 0x8, ln
+                    d = self.vreg(ops[0]) + (self.m0 & 0xFF)
+                    assert genml.ACC <= d <= genml.V_LAST - 1 and (d - genml.ACC) % 2 == 0, (ln, d)
+                elif self.wg.static_acc:
                     assert not self.idx_en, ln
                     d = self.vreg(ops[0])
                     assert genml.ACC <= d <= genml.V_LAST - 1 and (d - genml.ACC) % 2 == 0, (ln, d)
@@ -627,8 +648,8 @@ class Wave(object):
                     assert PARAM_BYTES <= dst and dst + 16 <= lds.size, ("LDS-DMA destination", ln, dst)
                     lds[dst:dst + 16] = mem.read(base + int(voff[i]), 16)
                 self.wg.dma_bytes += 16 * int(self.lanes().sum())
-            elif op in ("global_load_dwordx2", "global_load_dword", "global_load_dwordx4"):
-                n = 16 if op.endswith("x4") else 8 if op.endswith("x2") else 4
+            elif op in ("global_load_dwordx2", "global_load_dword", "global_load_dwordx3", "global_load_dwordx4"):
+                n = 16 if op.endswith("x4") else 12 if op.endswith("x3") else 8 if op.endswith("x2") else 4
                 off = imm_off
                 last = ops[2].split()[0]
                 base = self.get_s64(last)
@@ -661,7 +682,8 @@ class Workgroup(object):
         self.lds = np.zeros(lds_bytes, dtype=np.uint8)
         self.max_instr = max_instr
         self.dma_bytes = 0
-        self.programs = {"consumer": _parse_program("consumer_ml" if static_acc else "consumer", nth),
+        self.programs = {"consumer": _parse_program("consumer_runs" if static_acc == "runs" else
+                                                    "consumer_ml" if static_acc else "consumer", nth),
                          "loader": _parse_program("loader", nth)}
         self.waves = []
         for w in range(WAVES):
