@@ -360,7 +360,9 @@ def main():
                       float(n_chains) * spec_leg.T * spec_leg.P * spec_leg.N * 8 * rows_per_patch) + tables
         # LDS operands: one 8-byte operand per FMA and lane for the lane <-> chain kernels; the
         # cell kernel keeps the rows of a cell in registers (its LDS reads are per cell, not per chain)
-        lds_bytes = 0.0 if cell else float(n_chains) * spec_leg.T * spec_leg.P * spec_leg.N * 8 * rows_per_patch
+        # (k_gfstack_runs reads a cell's rows once per run of chains sharing it: its LDS operand bytes depend on the
+        # population; the SQ counters give 3.2 chains per row quartet on this one -> not modelled here)
+        lds_bytes = 0.0 if (cell or ml_runs) else float(n_chains) * spec_leg.T * spec_leg.P * spec_leg.N * 8 * rows_per_patch
         lds_floor_ms = lds_bytes / (LDS_PEAK_GBS * 1e9) * 1e3
         flops = 2.0 * n_chains * spec_leg.T * spec_leg.P * spec_leg.N * rows_per_patch
         t = avg_ms * 1e-3
@@ -368,7 +370,7 @@ def main():
         lds_frac = lds_floor_ms / avg_ms if (gf_n and shared) else 0.0
         valu_frac = flops / t / 1e12 / FP64_VALU_PEAK_TFLOPS if gf_n else 0.0
         bound = "lds" if (shared and lds_frac > hbm_frac) else "hbm"
-        if cell and valu_frac > max(hbm_frac, lds_frac):
+        if (cell or ml_runs) and valu_frac > max(hbm_frac, lds_frac):
             bound = "fp64_valu"   # the largest of its fractions; see `note` for what actually limits it
         roof = {
             "bound": bound,
@@ -394,6 +396,13 @@ def main():
             "distinct_rows_per_patch": {"mean": st["mean_rows"], "max": st["max_rows"],
                                         "of": spec_leg.D * spec_leg.S},
         }
+        if ml_runs:
+            roof["note"] = ("rows of a cell read from LDS once per run of chains sharing it (3.2 chains per row quartet on this population by "
+                            "SQ_INSTS_LDS, LDS 0.28 busy), accumulators through the VGPR index register, offsets unpacked on the scalar side: "
+                            "463 instructions per wavefront and patch step (VALU 184 of them: the FP64 pipe 0.31-0.39 busy with FMAs at the "
+                            "2.1 GHz the part sustains), HBM 0.34; timing-only builds keep the same cycle count with fewer record loads, without "
+                            "LDS-DMA and without the barrier, and two restructurings of the per-wavefront stream (rows one cell ahead, scalar work "
+                            "in the FMA shadows) did not move it either (profiles/r4_variants.md)")
         if ml_static:
             roof["note"] = ("static accumulators, lane <-> sample: every FMA takes its 8-byte row operand from LDS by contiguous "
                             "512-byte ds_read_b64 (no bank conflicts); SQ_LDS_IDX_ACTIVE = 0.77 of the CU cycles from the row reads "
@@ -420,7 +429,11 @@ def main():
         kern = pmc.get("kernel", "").replace("beatamd::", "").split("(")[0].replace(" ", "")
         mine = roof_d["kernel"].replace(" ", "")
         # (the cell kernel reports <epilogue, loader threads>, its symbol is <loader threads, variant>)
-        same = kern == mine or any(kern.startswith(x) and mine.startswith(x) for x in ("k_gfstack_cell<", "k_gfstack_ml<"))
+        # (the cell / static / runs kernels report <epilogue, loader hint>; the symbols are k_gfstack_cell<hint, variant> and
+        # k_gfstack_mlr<hint, variant, program>: program 1 = k_gfstack_runs)
+        same = kern == mine or (kern.startswith("k_gfstack_cell<") and mine.startswith("k_gfstack_cell<")) or \
+            (kern.startswith("k_gfstack_mlr<") and kern.endswith(",1>") and mine.startswith("k_gfstack_runs<")) or \
+            (kern.startswith("k_gfstack_mlr<") and kern.endswith(",0>") and mine.startswith("k_gfstack_ml<"))
         if "hbm_read_bytes_per_launch_corrected" not in pmc or not same:
             return
         tr = pmc["hbm_read_bytes_per_launch_corrected"] + pmc.get("hbm_write_bytes_per_launch", 0.0)
@@ -633,7 +646,7 @@ def main():
             leg = run_leg(spec_ml, f_ml, B, Kl, 2, seed_offset=1000)
             roof_ml = stack_roofline(spec_ml, leg, B)
             if B == 512 and T == 64 and N == 4096 and args.prior == "survey" and not env_knobs:
-                attach_traffic(roof_ml, os.path.join(ROOT, "profiles", "r4_bench_c512_ml_gfstack_ml_summary.json"))
+                attach_traffic(roof_ml, os.path.join(ROOT, "profiles", "r4_bench_c512_ml_gfstack_mlr_summary.json"))
             out["multilinear_leg"] = {
                 "interpolation": "multilinear (4 rows per patch and chain; beat/ffi/base.py:663-704)",
                 "chains": B, "steps": Kl, "chain_steps_per_s": B * Kl / leg["dt"],

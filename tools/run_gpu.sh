@@ -67,9 +67,9 @@ profile)
   timeout 300 rocprofv3 --kernel-trace --stats -d $O/geometry/stats -o bench -- python $R/tools/geo_app.py 1024 200 > $O/geometry/stats_run.log 2>&1
   S="python $R/tools/summarize_rocpd2.py"
   $S $O/c512_nn $O/out ${tag}_bench_c512_nn k_gfstack_ws "k_gfstack<0" k_fast_sweep k_accept > $O/sum_c512_nn.log 2>&1
-  $S $O/c512_ml $O/out ${tag}_bench_c512_ml k_gfstack_ml k_gm_tables > $O/sum_c512_ml.log 2>&1
+  $S $O/c512_ml $O/out ${tag}_bench_c512_ml k_gfstack_mlr k_gm_tables > $O/sum_c512_ml.log 2>&1
   $S $O/c512_toeplitz $O/out ${tag}_bench_c512_toeplitz "k_quadform<128>" k_gfstack_ws > $O/sum_c512_toeplitz.log 2>&1
-  $S $O/default $O/out ${tag}_bench_default "k_quadform<128>" k_gfstack_ml "k_gemm_f64<0>" k_gfstack_ws > $O/sum_default.log 2>&1
+  $S $O/default $O/out ${tag}_bench_default "k_quadform<128>" k_gfstack_mlr "k_gemm_f64<0>" k_gfstack_ws > $O/sum_default.log 2>&1
   $S $O/geometry $O/out ${tag}_geometry_c1024 k_geom_los k_quadform_small k_draw_propose k_accept > $O/sum_geometry.log 2>&1
   grep -h "^{\"metric" $O/*/stats_run.log > $O/out/${tag}_bench_lines_under_profiler.jsonl
   tail -3 $O/default/stats_run.log $O/geometry/stats_run.log | cut -c1-300
