@@ -95,7 +95,7 @@ class BatchedMetropolis(object):
     def run(self, Q, L, beta, n_steps, n_acc, use_graph=False):
         """n_steps steps of every chain, in place on Q, L; accepted moves are added to the 0-d int64
         tensor n_acc.  On the device a step is ONE C call (beatamd_ffi_mstep_batch: draws, proposal,
-        forward model, accept, acceptance counters).  use_graph (CUDA only): the step is captured
+        forward model, accept, acceptance counters).  use_graph (CUDA only): a chunk of steps is captured
         ONCE per call in a HIP graph and replayed, with the Philox step counter resident on the
         device (beatamd_ctx_set_step_counter), so the draws are exactly those of the eager loop;
         the step-size tuning runs between replays."""
@@ -109,16 +109,29 @@ class BatchedMetropolis(object):
         ctx = self.ops.ctx
         counter = torch.tensor([self.n_steps_total], dtype=torch.int32, device=Q.device)
         torch.cuda.synchronize(Q.device)
+        # one graph holds a CHUNK of steps (a replay costs ~10-16 us of host / front-end time whatever it contains:
+        # with one 60 us step per replay the graph was slower than the eager loop it was built to beat); the step-size
+        # tuning falls between chunks
+        chunk = max(1, min(16, self.tune_interval if self.tune else 16, n_steps - 1))
         graph = torch.cuda.CUDAGraph()
         ctx.set_step_counter(counter)
         try:
             with torch.cuda.graph(graph):
-                self._draw_and_astep(Q, L, beta, n_acc)
-            for _ in range(n_steps - 1):
+                for _ in range(chunk):
+                    self._draw_and_astep(Q, L, beta, n_acc)
+            remaining = n_steps - 1
+            while remaining > 0:
                 self._tune_if_due()
-                graph.replay()
-                self.steps_until_tune -= 1
-                self.n_steps_total += 1
+                room = self.steps_until_tune if self.tune else remaining
+                if remaining >= chunk and room >= chunk:
+                    graph.replay()
+                    done = chunk
+                else:
+                    self._draw_and_astep(Q, L, beta, n_acc)     # (eager, same device-resident step counter)
+                    done = 1
+                self.steps_until_tune -= done
+                self.n_steps_total += done
+                remaining -= done
         finally:
             ctx.set_step_counter(None)
         if int(counter.item()) != self.n_steps_total & 0x7fffffff:

@@ -175,27 +175,58 @@ def _dump_stage(step, homepath, layout, out_names, backend):
     st = step.stepper.state_dict()
     sc = parallel.allgather_rows(step.stepper.scaling[:, None])[:, 0].cpu().numpy()
     ac = parallel.allgather_rows(step.stepper.accepted_since_tune[:, None])[:, 0].cpu().numpy()
+    _join_stage_writer(step)          # (at most one stage is being written at a time)
     if step.rank != 0:
         return
-    from ..backend import write_population
-    pop, lp = step.array_population, step.array_lpoints
-    path = write_population(homepath, step.stage, layout, out_names, pop, lp, backend) \
-        if layout is not None else None
-    if path is None:
-        from ..backend import stage_path
-        path = stage_path(homepath, step.stage)
-        os.makedirs(path, exist_ok=True)
+    # everything the files hold is copied to the host HERE; the writing itself (one NumpyChain / TextChain file per
+    # chain + the state archive: ~0.5 ms per chain) runs in a thread beside the next stage's sampling, whose host
+    # side sits in GIL-free C calls
+    pop, lp = np.array(step.array_population, copy=True), np.array(step.array_lpoints, copy=True)   # (host tensors are views)
+    sc, ac = np.array(sc, copy=True), np.array(ac, copy=True)
     rs = step.rng.get_state()
-    extra = {}
+    state = dict(beta=step.beta, old_beta=step.old_beta, stage=step.stage, population=pop, lpoints=lp, scaling=sc,
+                 accepted_since_tune=ac, n_steps_total=st["n_steps_total"], steps_until_tune=st["steps_until_tune"],
+                 seed=st["seed"], rng_keys=rs[1], rng_pos=rs[2], rng_has_gauss=rs[3], rng_cached=rs[4])
     if getattr(step, "update_map_point", None) is not None:
         # the point the weights of this stage were estimated at (smc.py:492-503): a resumed run re-derives the
         # weights from it -- the saved lpoints belong to THOSE weights (the reference pickles update.get_weights()
         # in save_sampler_state; 8.6 GB of operators per wavemap here, a parameter vector does the same)
-        extra["update_map_point"] = np.asarray(step.update_map_point, dtype=np.float64)
-    np.savez(os.path.join(path, "sampler_state.npz"), beta=step.beta, old_beta=step.old_beta,
-             stage=step.stage, population=pop, lpoints=lp, scaling=sc, accepted_since_tune=ac,
-             n_steps_total=st["n_steps_total"], steps_until_tune=st["steps_until_tune"], seed=st["seed"],
-             rng_keys=rs[1], rng_pos=rs[2], rng_has_gauss=rs[3], rng_cached=rs[4], **extra)
+        state["update_map_point"] = np.asarray(step.update_map_point, dtype=np.float64)
+    stage = step.stage
+
+    def write():
+        from ..backend import stage_path, write_population
+        path = write_population(homepath, stage, layout, out_names, pop, lp, backend) if layout is not None else None
+        if path is None:
+            path = stage_path(homepath, stage)
+            os.makedirs(path, exist_ok=True)
+        np.savez(os.path.join(path, "sampler_state.npz"), **state)
+
+    if not getattr(step, "async_stage_files", True):
+        return write()
+    import threading
+    box = {}
+
+    def guarded():
+        try:
+            write()
+        except BaseException as exc:      # re-raised in the sampling thread by _join_stage_writer
+            box["error"] = exc
+    th = threading.Thread(target=guarded, name="beatamd-stage-writer", daemon=False)
+    th.start()
+    step._stage_writer = (th, box)
+
+
+def _join_stage_writer(step):
+    """wait for the stage files in flight (before the next ones are written, before a resume reads them, at the end
+    of smc_sample) and surface a failure of the writer"""
+    w = getattr(step, "_stage_writer", None)
+    if w is None:
+        return
+    step._stage_writer = None
+    w[0].join()
+    if "error" in w[1]:
+        raise w[1]["error"]
 
 
 def load_stage(step, homepath, stage):
@@ -315,6 +346,7 @@ def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, 
             on_stage(step)
     if not final_stage and step.beta < 1.0:
         step.stage_betas = betas
+        timed("io_s", _join_stage_writer, step)
         return step.array_population, step.array_lpoints, betas
     # final stage at beta = 1 (smc.py:526-543)
     step.stage = -1
@@ -324,6 +356,7 @@ def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, 
     timed("gather_s", step.select_end_points, Q, L)
     betas.append(1.0)
     timed("io_s", _dump_stage, step, homepath, layout, out_names, backend)
+    timed("io_s", _join_stage_writer, step)
     step.stage_betas = betas
     return step.array_population, step.array_lpoints, betas
 
