@@ -348,6 +348,10 @@ __global__ void __launch_bounds__(1024) k_gfstack_cell(GcArgs a)
             pb[GC_PL_BUFB] = (uint32_t)(a.ucap * 512);
             pb[GC_PL_NSTEP] = (uint32_t)a.nsteps;
             pb[GC_PL_NLANES] = (uint32_t)min((int64_t)32, (a.N - n0 + 1) / 2);
+            // steps cycle through the slip variables' libraries patch by patch (one variable: the same base thrice)
+            pb[GC_PL_NVAR] = (uint32_t)a.nvar;
+            put64(GC_PL_G1, (uint64_t)(uintptr_t)(a.G[a.nvar > 1 ? 1 : 0] + (t * a.rows_per_target) * a.N + n0));
+            put64(GC_PL_G2, (uint64_t)(uintptr_t)(a.G[a.nvar > 2 ? 2 : 0] + (t * a.rows_per_target) * a.N + n0));
         }
     }
     __syncthreads();
@@ -485,9 +489,10 @@ int launch_gfstack_cell(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *
 struct GmTabArgs {
     int64_t C, T, P, D, S, DS, nslot;   // T: targets the tables are built for (1 or all)
     int64_t nsteps;
+    int nvar;                     // slip variables: step = patch * nvar + variable (same rows, the variable's slips)
     const uint32_t *rowoff;       // [C,T,P,4] global row ids (k_gf_tables: cc, fc, cf, ff)
     const double *fac;            // [C,T,P,4]
-    ChainVec slips;
+    ChainVec slips[4];
     const uint32_t *order;        // [ngroups*GC_CG]
     char *wtab;                   // [(g*T+t)][consumer][step 0..nsteps][GM_NREC] records of 16 entries {weight, dword, pad}
     uint32_t *ltab;               // [(g*T+t)][step 0..nsteps+2][loader][32 dwords]: count, row requests
@@ -559,36 +564,17 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
     }
     __syncthreads();
     const int nreq = (int)nreq_s;   // <= 2 * GC_LPAIR (launcher: (nslot + 1) / 2 + D)
-    const int64_t s = p;            // one slip variable: step = patch
-    for (int i = tid; i < GC_NLOAD * 32; i += GC_TB) {
-        const int ll = i / 32, d = i % 32;
-        uint32_t val;
-        if (d == 0) val = (nreq > ll) ? (uint32_t)((nreq - ll + GC_NLOAD - 1) / GC_NLOAD) : 0u;
-        else {
-            const int r = ll + GC_NLOAD * (d - 1);
-            val = r < nreq ? reqs[r] : 0u;
-        }
-        a.ltab[((gt * (a.nsteps + 3) + s) * GC_NLOAD + ll) * 32 + d] = val;
-    }
     const int w = tid / GC_NCHAIN, j = tid % GC_NCHAIN;
-    const uint32_t ring = (uint32_t)((s % 3) * a.nslot);
-    const double sl = live ? a.slips.base[c * a.slips.stride + a.slips.off + p] : 0.0;
-    if constexpr (!RUNS) {
-        if (!slot) return;
-        char *rec = a.wtab + ((gt * GC_NCONS + w) * (a.nsteps + 1) + s) * (int64_t)GM_WSTRIDE + (j >> 2) * GM_REC;
-        const int q = j & 3;
-        for (int k = 0; k < 4; k++)
-            *reinterpret_cast<double *>(rec + (4 * q + k) * 16) = fr[k] * sl;     // base.py:676-679 x slip, as k_gfstack
-        // a dead chain slot reads slot 0 of the buffer (its accumulator is never stored)
-        *reinterpret_cast<uint32_t *>(rec + (2 * q) * 16 + 8) = (ring + sa) * 512u;
-        *reinterpret_cast<uint32_t *>(rec + (2 * q + 1) * 16 + 8) = (ring + sb) * 512u;
-    } else {
-        // position of the chain in the cell order of its wavefront (dead slots last)
-        const uint32_t key = live ? ((sb << 16) | sa) : 0xffffffffu;
+    // cell order of the wavefront's chains (RUNS): the same for every slip variable of the patch
+    uint32_t key = 0;
+    int r = j;
+    bool opens = false;
+    if constexpr (RUNS) {
+        key = live ? ((sb << 16) | sa) : 0xffffffffu;
         if (slot) keys[tid] = key;
         __syncthreads();
-        int r = 0;
         if (slot) {
+            r = 0;
             for (int k = 0; k < GC_NCHAIN; k++) {
                 const uint32_t kk = keys[w * GC_NCHAIN + k];
                 r += (kk < key) || (kk == key && k < j);
@@ -598,32 +584,49 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
         __syncthreads();
         if (slot) {
             // a chain opens a cell when its key differs from its predecessor's; dead slots ride on the rows in place
-            const bool opens = live && (r == 0 || keys[w * GC_NCHAIN + srt[w * GC_NCHAIN + r - 1]] != key);
+            opens = live && (r == 0 || keys[w * GC_NCHAIN + srt[w * GC_NCHAIN + r - 1]] != key);
             pk8[w * GC_NCHAIN + r] = (uint8_t)((2 * j) | (opens ? 0x80 : 0));
-            char *rec = a.wtab + ((gt * GC_NCONS + w) * (a.nsteps + 1) + s) * (int64_t)GM_WSTRIDE + (r >> 2) * GM_REC;
-            const int q = r & 3;
-            for (int k = 0; k < 4; k++)
-                *reinterpret_cast<double *>(rec + (4 * q + k) * 16) = fr[k] * sl;
-            *reinterpret_cast<uint32_t *>(rec + (2 * q) * 16 + 8) = (ring + sa) * 512u;
-            *reinterpret_cast<uint32_t *>(rec + (2 * q + 1) * 16 + 8) = (ring + sb) * 512u;
         }
         __syncthreads();
-        if (slot && (j & 3) == 0) {
-            // here the thread is record j / 4 of wavefront w: pack its (up to) four chains
-            uint32_t pk = 0;
-            for (int q = 0; q < 4 && j + q < GC_NCHAIN; q++) {
-                const uint32_t v = pk8[w * GC_NCHAIN + j + q];
-                pk |= (v & 0x7fu) << (7 * q);
-                pk |= (v >> 7) << (GR_PK_NEW + q);
+    }
+    for (int iv = 0; iv < a.nvar; iv++) {
+        const int64_t s = p * a.nvar + iv;
+        for (int i = tid; i < GC_NLOAD * 32; i += GC_TB) {
+            const int ll = i / 32, d = i % 32;
+            uint32_t val;
+            if (d == 0) val = (nreq > ll) ? (uint32_t)((nreq - ll + GC_NLOAD - 1) / GC_NLOAD) : 0u;
+            else {
+                const int rq = ll + GC_NLOAD * (d - 1);
+                val = rq < nreq ? reqs[rq] : 0u;
             }
-            char *rec = a.wtab + ((gt * GC_NCONS + w) * (a.nsteps + 1) + s) * (int64_t)GM_WSTRIDE + (j >> 2) * GM_REC;
-            *reinterpret_cast<uint32_t *>(rec + GR_PK_LANE * 16 + 8) = pk;
+            a.ltab[((gt * (a.nsteps + 3) + s) * GC_NLOAD + ll) * 32 + d] = val;
+        }
+        if (!slot) continue;
+        const uint32_t ring = (uint32_t)((s % 3) * a.nslot);
+        const double sl = live ? a.slips[iv].base[c * a.slips[iv].stride + a.slips[iv].off + p] : 0.0;
+        // a dead chain slot reads slot 0 of the buffer (its accumulator is never stored)
+        char *rec = a.wtab + ((gt * GC_NCONS + w) * (a.nsteps + 1) + s) * (int64_t)GM_WSTRIDE + (r >> 2) * GM_REC;
+        const int q = r & 3;
+        for (int k = 0; k < 4; k++)
+            *reinterpret_cast<double *>(rec + (4 * q + k) * 16) = fr[k] * sl;     // base.py:676-679 x slip, as k_gfstack
+        *reinterpret_cast<uint32_t *>(rec + (2 * q) * 16 + 8) = (ring + sa) * 512u;
+        *reinterpret_cast<uint32_t *>(rec + (2 * q + 1) * 16 + 8) = (ring + sb) * 512u;
+        if constexpr (RUNS) {
+            if ((j & 3) == 0) {
+                // here the thread is record j / 4 of wavefront w: pack its (up to) four chains
+                uint32_t pk = 0;
+                for (int qq = 0; qq < 4 && j + qq < GC_NCHAIN; qq++) {
+                    const uint32_t v = pk8[w * GC_NCHAIN + j + qq];
+                    pk |= (v & 0x7fu) << (7 * qq);
+                    pk |= (v >> 7) << (GR_PK_NEW + qq);
+                }
+                char *rec2 = a.wtab + ((gt * GC_NCONS + w) * (a.nsteps + 1) + s) * (int64_t)GM_WSTRIDE + (j >> 2) * GM_REC;
+                *reinterpret_cast<uint32_t *>(rec2 + GR_PK_LANE * 16 + 8) = pk;
+            }
         }
     }
 }
 
-// PROG 0: k_gfstack_ml (static chain order, four row reads per chain); PROG 1: k_gfstack_runs (cell order, rows read
-// once per run of chains sharing a cell, accumulators through the VGPR index register)
 template <int NTH, int VAR, int PROG>
 __global__ void __launch_bounds__(1024) k_gfstack_mlr(GcArgs a)
 {
@@ -678,6 +681,10 @@ __global__ void __launch_bounds__(1024) k_gfstack_mlr(GcArgs a)
             pb[GC_PL_BUFB] = (uint32_t)(a.ucap * 512);      // ucap: slots of a step's row buffer
             pb[GC_PL_NSTEP] = (uint32_t)a.nsteps;
             pb[GC_PL_NLANES] = (uint32_t)min((int64_t)32, (a.N - n0 + 1) / 2);
+            // steps cycle through the slip variables' libraries patch by patch (one variable: the same base thrice)
+            pb[GC_PL_NVAR] = (uint32_t)a.nvar;
+            put64(GC_PL_G1, (uint64_t)(uintptr_t)(a.G[a.nvar > 1 ? 1 : 0] + (t * a.rows_per_target) * a.N + n0));
+            put64(GC_PL_G2, (uint64_t)(uintptr_t)(a.G[a.nvar > 2 ? 2 : 0] + (t * a.rows_per_target) * a.N + n0));
         }
     }
     __syncthreads();
@@ -730,7 +737,7 @@ bool gfstack_ml_applicable(const GfStackCall &k)
     const bool cg_fixed = getenv("BEATAMD_GS_CG") != nullptr;
     const SeisLib &L = *k.libs[0];
     if (knob == 0 || gfk == 0) return false;
-    if (k.interp != BEATAMD_MULTILINEAR || k.nvar != 1) return false;
+    if (k.interp != BEATAMD_MULTILINEAR || k.nvar < 1 || k.nvar > 3) return false;
     if (L.N % 2 != 0) return false;
     const int64_t DS = L.D * L.S, nslot = L.D * (L.S + 1);
     // three dense row buffers in LDS; request table of the two loaders; 8-bit row / slot fields of a request
@@ -748,7 +755,7 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
     const SeisLib &L = *k.libs[0];
     const int64_t DS = L.D * L.S, nslot = L.D * (L.S + 1);
     const int64_t ngroups = (k.C + GC_CG - 1) / GC_CG;
-    const int64_t nsteps = L.P;
+    const int64_t nsteps = L.P * k.nvar;
     const int64_t GT = ngroups * Ttab;
     void *p = nullptr;
 
@@ -765,8 +772,9 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
     memset(&ta, 0, sizeof(ta));
     ta.C = k.C; ta.T = Ttab; ta.P = L.P; ta.D = L.D; ta.S = L.S; ta.DS = DS; ta.nslot = nslot;
     ta.nsteps = nsteps;
+    ta.nvar = k.nvar;
     ta.rowoff = rowoff; ta.fac = fac;
-    ta.slips = k.slips[0];
+    for (int v = 0; v < k.nvar; v++) ta.slips[v] = k.slips[v];
     ta.order = oa.order;
     BA_TRY(ctx->get_scratch(SL_GC_STREAM, (size_t)GT * GC_NCONS * (nsteps + 1) * GM_WSTRIDE + 8192, &p));
     ta.wtab = (char *)p;
@@ -788,8 +796,8 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
 
     GcArgs a;
     memset(&a, 0, sizeof(a));
-    a.G[0] = L.g;
-    a.nvar = 1; a.ucap = (int)nslot;
+    for (int v = 0; v < k.nvar; v++) a.G[v] = k.libs[v]->g;
+    a.nvar = k.nvar; a.ucap = (int)nslot;
     a.ntile = (int)((L.N + 63) / 64);
     a.mode = k.mode;
     a.C = k.C; a.T = L.T; a.P = L.P; a.N = L.N; a.DS = DS;

@@ -17,24 +17,28 @@ import gen_gfcell_asm as gen  # noqa: E402
 import gfcell_emu as emu  # noqa: E402
 
 
-def _reference(G, ro, fa, sl, T, P, N):
-    """acc = a*b + c in the kernel's order: patches ascending, rows k = 0..3"""
+def _reference(G, ro, fa, sl, T, P, N, Gx=(), slx=()):
+    """acc = a*b + c in the kernel's order: patches ascending, slip variables, rows k = 0..3"""
     C = sl.shape[0]
-    Gr = G.reshape(-1, N)
+    Grs = [g.reshape(-1, N) for g in (G,) + tuple(Gx)]
+    sls = (sl,) + tuple(slx)
     out = np.zeros((C, T, N))
     for c in range(C):
         for t in range(T):
             acc = np.zeros(N)
             for p in range(P):
-                for k in range(4):
-                    acc = Gr[ro[c, t, p, k]] * (fa[c, t, p, k] * sl[c, p]) + acc
+                for Gr, s_ in zip(Grs, sls):
+                    for k in range(4):
+                        acc = Gr[ro[c, t, p, k]] * (fa[c, t, p, k] * s_[c, p]) + acc
             out[c, t] = acc
     return out
 
 
-def _run(T, P, D, S, N, C, Ttab_is_one, mode, sort, nth, seed, static_acc=False, below_grid=False):
+def _run(T, P, D, S, N, C, Ttab_is_one, mode, sort, nth, seed, static_acc=False, below_grid=False, nvar=1):
     rng = np.random.default_rng(seed)
     G = rng.standard_normal((T, P, D, S, N))
+    Gx = [rng.standard_normal((T, P, D, S, N)) for _ in range(nvar - 1)]     # libraries of further slip variables
+    slx = [rng.uniform(-1, 1, (C, P)) for _ in range(nvar - 1)]
     du = rng.uniform(0.5, 0.5 + 0.5 * (D - 1), (C, P))
     st = rng.uniform(0.0, max(0.5 * (S - 1) - 0.01, 0.0), (C, 1 if Ttab_is_one else T, P))
     st[0, 0, 0] = 0.0        # exactly on node 0: the floor node wraps to the last one with factor 0
@@ -51,15 +55,17 @@ def _run(T, P, D, S, N, C, Ttab_is_one, mode, sort, nth, seed, static_acc=False,
     order = emu.gc_order(ro, C, Ttab, P, S, sort)
     assert sorted(order[order != emu.DEAD].tolist()) == list(range(C))
     if static_acc:
-        wtab, ltab, ucount = emu.gm_tables(ro, fa, sl, order, C, Ttab, P, D, S, runs=(static_acc == "runs"))
+        wtab, ltab, ucount = emu.gm_tables(ro, fa, [sl] + slx, order, C, Ttab, P, D, S, runs=(static_acc == "runs"), nvar=nvar)
     else:
         wtab, ltab, ucount = emu.gc_tables(ro, fa, [sl], order, C, Ttab, P, DS)
     data = rng.standard_normal((T, N))
     wsc = rng.uniform(0.5, 2.0, T)
     ntile = (N + 63) // 64
     mem = emu.Memory()
-    a = dict(T=T, P=P, N=N, DS=DS, Ttab=Ttab, rows_per_target=P * DS, nsteps=P, mode=mode, ntile=ntile,
-             wscalar=wsc)
+    a = dict(T=T, P=P, N=N, DS=DS, Ttab=Ttab, rows_per_target=P * DS, nsteps=P * nvar, mode=mode, ntile=ntile,
+             wscalar=wsc, nvar=nvar)
+    for i, gx in enumerate(Gx):
+        a["G%d" % (i + 1)] = mem.alloc(gx.nbytes, gx)
     if static_acc:
         a["wstride"], a["ucap"] = emu.genml.WSTRIDE, D * (S + 1)
     a["G"] = mem.alloc(G.nbytes, G)
@@ -78,12 +84,12 @@ def _run(T, P, D, S, N, C, Ttab_is_one, mode, sort, nth, seed, static_acc=False,
                 nlds = emu.lds_bytes_ml(D * (S + 1)) if static_acc else emu.lds_bytes(DS)
                 wg = emu.Workgroup(mem, nth, nlds, params, static_acc=static_acc).run()
                 assert all(w.done and not w.idx_en and w.exec == emu.MASK64 for w in wg.waves)
-                assert {w.nbarrier for w in wg.waves} == {P + 1}
+                assert {w.nbarrier for w in wg.waves} == {P * nvar + 1}
                 stats.append(wg)
     # full rows for the reference: with tables per patch the row ids are those of target 0
     rof = ro if Ttab == T else np.stack([ro[:, 0] + t * P * DS for t in range(T)], 1)
     faf = fa if Ttab == T else np.repeat(fa, T, axis=1)
-    ref = _reference(G, rof, faf, sl, T, P, N)
+    ref = _reference(G, rof, faf, sl, T, P, N, Gx, slx)
     out = mem.array(a["out"], np.float64, C * T * N).reshape(C, T, N)
     if mode == 0:
         assert np.array_equal(out, ref)
@@ -163,6 +169,14 @@ def test_runs_program_shares_row_reads():
     _run(T=1, P=2, D=1, S=1, N=64, C=3, Ttab_is_one=True, mode=0, sort=False, nth=0, seed=4, static_acc="runs")
     # a step of one patch and a wavefront full of one cell
     _run(T=1, P=1, D=2, S=3, N=64, C=40, Ttab_is_one=True, mode=2, sort=True, nth=0, seed=9, static_acc="runs")
+
+
+@pytest.mark.parametrize("kind,nvar", [("runs", 2), ("runs", 3), (True, 2)])
+def test_programs_with_several_slip_variables(kind, nvar):
+    """steps cycle through the slip variables' libraries patch by patch (loader: base of the step's variable + rows of
+    the patch; records: the variable's slips on the same cells)"""
+    _run(T=2, P=3, D=2, S=5, N=70, C=45, Ttab_is_one=(nvar == 2), mode=nvar % 3, sort=True, nth=0, seed=21 + nvar,
+         static_acc=kind, nvar=nvar)
 
 
 def test_register_budget():

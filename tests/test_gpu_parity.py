@@ -442,6 +442,40 @@ def test_fused_model_512_chain_groups(ctx, monkeypatch, name):
         np.testing.assert_allclose(B[c], ref, rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("nvar,cov,shifts", [(2, "scalar", False), (2, "toeplitz", True), (3, "scalar", True)])
+def test_multilinear_with_several_slip_variables_through_the_runs_kernel(ctx, monkeypatch, nvar, cov, shifts):
+    """BEAT's usual FFI set-up samples uparr AND uperp (static_dist_vars, beat/config.py:83) with the default
+    multilinear interpolation: 530 chains run through k_gfstack_runs (steps cycle through the variables' libraries
+    patch by patch) -- against the static kernel (bitwise: same order), the streaming kernel (another summation
+    order over the variables: 1e-12) and the oracle on sampled chains"""
+    from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
+    from oracle import problem_oracle
+    spec = SyntheticSpec((5,), (6,), (1.0,), T=3, N=136, D=3, S=25, slip_varnames=("uparr", "uperp", "utens")[:nvar],
+                         covariance=cov, station_shifts=shifts, interpolation="multilinear")
+    prob, host = build_problem(spec)
+    f = prob.compile(ctx)
+    Q = draw_population(spec, host["layout"], host["lower"], host["upper"], 530)
+    mode = 1 if cov == "scalar" else 2
+    for name in ("BEATAMD_GF_KERNEL", "BEATAMD_GS_CG", "BEATAMD_GS_ML", "BEATAMD_GS_RUNS"):
+        monkeypatch.delenv(name, raising=False)
+    B = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack_runs<%d," % mode), ctx.last_kernel()
+    monkeypatch.setenv("BEATAMD_GS_RUNS", "0")
+    B2 = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack_ml<%d," % mode), ctx.last_kernel()
+    assert np.array_equal(B, B2)
+    monkeypatch.delenv("BEATAMD_GS_RUNS")
+    monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
+    A = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack<1,%d," % nvar), ctx.last_kernel()
+    monkeypatch.delenv("BEATAMD_GF_KERNEL")
+    np.testing.assert_allclose(B, A, rtol=1e-11)
+    for c in (0, 511, 512, 529):
+        ref, _ = problem_oracle.forward(host, Q[c])
+        np.testing.assert_allclose(B[c], ref, rtol=RTOL)
+        np.testing.assert_allclose(B[c], ref, rtol=1e-9, atol=1e-9)
+
+
 def test_stack_closed_form_and_linearity(ctx):
     """reference test/test_ffi.py:22-89 recipe: out[t,n] = t*n*sum(slips); plus linearity"""
     T, P, D, S, N = 30, 40, 11, 31, 10

@@ -88,6 +88,7 @@ P_WP, P_RB0, P_NSTEP, P_BNC = 0, 4, 5, 6
 P_OUT, P_CTN, P_MODE, P_DATA, P_W, P_CID, P_PART, P_PCS, P_NVALID, P_TRB = 16, 18, 19, 20, 22, 24, 26, 28, 29, 30
 # parameter block of a loader wavefront
 PL_LT, PL_GROW, PL_DSRB, PL_ROWB, PL_RB0, PL_BUFB, PL_NSTEP, PL_NLANES = 0, 2, 4, 5, 6, 7, 8, 9
+PL_NVAR, PL_G1, PL_G2 = 10, 12, 14   # slip variables (steps cycle through their libraries patch by patch), bases 2 and 3
 
 L = []
 ABL = set()   # timing experiments: 'nofma', 'nox', 'nobar', 'now' (results are wrong with any of them)
@@ -402,6 +403,7 @@ def consumer():
 LV_DMA, LV_HI, LV_OFF, LV_T0, LV_PAR = 1, 2, 4, 3, 46
 LS_LT, LS_GROW, LS_DSRB, LS_ROWB, LS_RB0, LS_BUFB, LS_RBREQ, LS_NSTEP, LS_CNT = 4, 6, 8, 9, 10, 11, 12, 13, 14
 LS_MP, LS_MS = 20, 22   # exec masks of a row pair / of a single row
+LS_G0, LS_G1, LS_G2, LS_IV, LS_NVAR, LS_ROWOFF = 24, 26, 28, 30, 31, 15   # library bases, variable of the step, rows of the patch
 LS_TAB = 32      # [32:63] request table of a step: count, requests
 # request: rowA | (rowB - rowA) << 8 | slotA << 16 | single << 24  (rows relative to the step's first row;
 # the two rows of a pair land in adjacent LDS slots: lanes 0-31 move rowA, lanes 32-63 rowB)
@@ -447,7 +449,19 @@ def issue_requests(tag, nth):
             e("global_load_lds_dwordx4 v%d, %s%s" % (LV_OFF, sp(T2), " nt" if nth else ""))
     lab("RQD_%s" % tag)
     e("s_mov_b64 exec, -1")
-    e("s_add_u32 s%d, s%d, s%d" % (LS_GROW, LS_GROW, LS_DSRB))
+    # the next step: the next slip variable's library at the same patch, or the first one at the next patch
+    e("s_add_u32 s%d, s%d, 1" % (LS_IV, LS_IV))
+    e("s_cmp_lt_u32 s%d, s%d" % (LS_IV, LS_NVAR))
+    br("s_cbranch_scc1", "SAMEP_%s" % tag)
+    e("s_mov_b32 s%d, 0" % LS_IV)
+    e("s_add_u32 s%d, s%d, s%d" % (LS_ROWOFF, LS_ROWOFF, LS_DSRB))
+    lab("SAMEP_%s" % tag)
+    e("s_mov_b64 %s, %s" % (sp(LS_GROW), sp(LS_G0)))
+    e("s_cmp_eq_u32 s%d, 1" % LS_IV)
+    e("s_cselect_b64 %s, %s, %s" % (sp(LS_GROW), sp(LS_G1), sp(LS_GROW)))
+    e("s_cmp_eq_u32 s%d, 2" % LS_IV)
+    e("s_cselect_b64 %s, %s, %s" % (sp(LS_GROW), sp(LS_G2), sp(LS_GROW)))
+    e("s_add_u32 s%d, s%d, s%d" % (LS_GROW, LS_GROW, LS_ROWOFF))
     e("s_addc_u32 s%d, s%d, 0" % (LS_GROW + 1, LS_GROW + 1))
     e("s_add_u32 s%d, s%d, s%d" % (LS_RBREQ, LS_RBREQ, LS_BUFB))
     e("s_mul_i32 s%d, s%d, 3" % (T0, LS_BUFB))
@@ -476,9 +490,13 @@ def loader(nth):
     e("s_waitcnt lgkmcnt(0)")
     for sreg, k in ((LS_LT, PL_LT), (LS_LT + 1, PL_LT + 1), (LS_GROW, PL_GROW), (LS_GROW + 1, PL_GROW + 1),
                     (LS_DSRB, PL_DSRB), (LS_ROWB, PL_ROWB), (LS_RB0, PL_RB0), (LS_BUFB, PL_BUFB),
-                    (LS_NSTEP, PL_NSTEP), (T0, PL_NLANES)):
+                    (LS_NSTEP, PL_NSTEP), (T0, PL_NLANES), (LS_NVAR, PL_NVAR), (LS_G1, PL_G1), (LS_G1 + 1, PL_G1 + 1),
+                    (LS_G2, PL_G2), (LS_G2 + 1, PL_G2 + 1)):
         e("v_readlane_b32 s%d, v%d, %d" % (sreg, LV_PAR, k))
     e("s_nop 4")
+    e("s_mov_b64 %s, %s" % (sp(LS_G0), sp(LS_GROW)))
+    e("s_mov_b32 s%d, 0" % LS_IV)
+    e("s_mov_b32 s%d, 0" % LS_ROWOFF)
     # lanes that move 16 bytes of a row segment: the first NLANES of each half (pair) / of the low half (single row)
     e("s_bfm_b64 %s, s%d, 0" % (sp(LS_MS), T0))
     e("s_lshl_b64 %s, %s, 32" % (sp(LS_MP), sp(LS_MS)))
@@ -538,7 +556,8 @@ def main():
                           ("CID", P_CID), ("PART", P_PART), ("PCS", P_PCS), ("NVALID", P_NVALID), ("TRB", P_TRB)):
             f.write("#define GC_P_%s %d\n" % (name, val))
         for name, val in (("LT", PL_LT), ("GROW", PL_GROW), ("DSRB", PL_DSRB), ("ROWB", PL_ROWB), ("RB0", PL_RB0),
-                          ("BUFB", PL_BUFB), ("NSTEP", PL_NSTEP), ("NLANES", PL_NLANES)):
+                          ("BUFB", PL_BUFB), ("NSTEP", PL_NSTEP), ("NLANES", PL_NLANES), ("NVAR", PL_NVAR),
+                          ("G1", PL_G1), ("G2", PL_G2)):
             f.write("#define GC_PL_%s %d\n" % (name, val))
         variants = [set()] + ([{"nobar"}, {"nodma"}] if os.environ.get("GC_ABLATIONS") else [])
         f.write("#define GC_NVARIANT %d\n" % len(variants))

@@ -194,12 +194,13 @@ def gc_tables(rowoff, fac, slips, order, C, T, P, DS, nvar=1):
     return wtab, ltab, ucount
 
 
-def gm_tables(rowoff, fac, slips, order, C, T, P, D, S, runs=False):
+def gm_tables(rowoff, fac, slips, order, C, T, P, D, S, runs=False, nvar=1):
     """numpy twin of k_gm_tables<RUNS> (gfcell.hip): record table, request table and moved-row counts of k_gfstack_ml;
     runs: the chains of a wavefront in cell order + the packed accumulator offsets / new-cell bits of k_gfstack_runs"""
     ngroups = order.size // CG
-    nsteps, GT, DS, S1 = P, ngroups * T, D * S, S + 1
+    nsteps, GT, DS, S1 = P * nvar, ngroups * T, D * S, S + 1
     nslot = D * S1
+    slips = [slips] if nvar == 1 and not isinstance(slips, (list, tuple)) else list(slips)
     wtab = np.zeros(GT * NCONS * (nsteps + 1) * genml.WSTRIDE + 8192, dtype=np.uint8)
     ltab = np.zeros(GT * (nsteps + 3) * NLOAD * 32, dtype=np.uint32)
     ucount = np.zeros(GT * P, dtype=np.uint32)
@@ -240,37 +241,38 @@ def gm_tables(rowoff, fac, slips, order, C, T, P, D, S, runs=False):
                     sl += 1
                     moved += 1
                 ucount[gt * P + p] = moved
-                s = p
-                for ll in range(NLOAD):
-                    h = ltab[((gt * (nsteps + 3) + s) * NLOAD + ll) * 32:][:32]
-                    mine = reqs[ll::NLOAD]
-                    assert len(mine) <= 31
-                    h[0] = len(mine)
-                    h[1:1 + len(mine)] = mine
-                ring = (s % 3) * nslot
-                for w in range(NCONS):
-                    if runs:
-                        key = np.where(live[w * NCH:(w + 1) * NCH], (sb[w * NCH:(w + 1) * NCH] << 16) | sa[w * NCH:(w + 1) * NCH],
-                                       0xFFFFFFFF)
-                        perm = sorted(range(NCH), key=lambda jj: (int(key[jj]), jj))
-                    else:
-                        perm = list(range(NCH))
-                    for r, j in enumerate(perm):
-                        k = w * NCH + j
-                        rec = ((gt * NCONS + w) * (nsteps + 1) + s) * genml.WSTRIDE + (r // 4) * genml.REC
-                        q = r % 4
-                        if runs:
-                            opens = bool(live[k]) and (r == 0 or int(key[perm[r - 1]]) != int(key[j]))
-                            pkw = wtab[rec + genruns.PK_LANE * 16 + 8:rec + genruns.PK_LANE * 16 + 12].view(np.uint32)
-                            if q == 0:
-                                pkw[0] = 0
-                            pkw[0] |= ((2 * j) << (7 * q)) | ((1 if opens else 0) << (genruns.PK_NEW + q))
-                        c = int(ids[k]) if live[k] else 0
-                        for kk in range(4):
-                            wv = (fac[c, t, p, kk] * slips[c, p]) if live[k] else 0.0
-                            wtab[rec + (4 * q + kk) * 16:rec + (4 * q + kk) * 16 + 8].view(np.float64)[0] = wv
-                        wtab[rec + (2 * q) * 16 + 8:rec + (2 * q) * 16 + 12].view(np.uint32)[0] = (ring + sa[k]) * 512
-                        wtab[rec + (2 * q + 1) * 16 + 8:rec + (2 * q + 1) * 16 + 12].view(np.uint32)[0] = (ring + sb[k]) * 512
+                for iv in range(nvar):
+                  s = p * nvar + iv
+                  for ll in range(NLOAD):
+                      h = ltab[((gt * (nsteps + 3) + s) * NLOAD + ll) * 32:][:32]
+                      mine = reqs[ll::NLOAD]
+                      assert len(mine) <= 31
+                      h[0] = len(mine)
+                      h[1:1 + len(mine)] = mine
+                  ring = (s % 3) * nslot
+                  for w in range(NCONS):
+                      if runs:
+                          key = np.where(live[w * NCH:(w + 1) * NCH], (sb[w * NCH:(w + 1) * NCH] << 16) | sa[w * NCH:(w + 1) * NCH],
+                                         0xFFFFFFFF)
+                          perm = sorted(range(NCH), key=lambda jj: (int(key[jj]), jj))
+                      else:
+                          perm = list(range(NCH))
+                      for r, j in enumerate(perm):
+                          k = w * NCH + j
+                          rec = ((gt * NCONS + w) * (nsteps + 1) + s) * genml.WSTRIDE + (r // 4) * genml.REC
+                          q = r % 4
+                          if runs:
+                              opens = bool(live[k]) and (r == 0 or int(key[perm[r - 1]]) != int(key[j]))
+                              pkw = wtab[rec + genruns.PK_LANE * 16 + 8:rec + genruns.PK_LANE * 16 + 12].view(np.uint32)
+                              if q == 0:
+                                  pkw[0] = 0
+                              pkw[0] |= ((2 * j) << (7 * q)) | ((1 if opens else 0) << (genruns.PK_NEW + q))
+                          c = int(ids[k]) if live[k] else 0
+                          for kk in range(4):
+                              wv = (fac[c, t, p, kk] * slips[iv][c, p]) if live[k] else 0.0
+                              wtab[rec + (4 * q + kk) * 16:rec + (4 * q + kk) * 16 + 8].view(np.float64)[0] = wv
+                          wtab[rec + (2 * q) * 16 + 8:rec + (2 * q) * 16 + 12].view(np.uint32)[0] = (ring + sa[k]) * 512
+                          wtab[rec + (2 * q + 1) * 16 + 8:rec + (2 * q + 1) * 16 + 12].view(np.uint32)[0] = (ring + sb[k]) * 512
     return wtab, ltab, ucount
 
 
@@ -743,6 +745,9 @@ def wave_params(w, g, t, tile, a):
         P[gen.PL_BUFB] = a.get("ucap", a["DS"]) * 512
         P[gen.PL_NSTEP] = a["nsteps"]
         P[gen.PL_NLANES] = min(32, (N - n0 + 1) // 2)
+        P[gen.PL_NVAR] = a.get("nvar", 1)
+        put64(gen.PL_G1, a.get("G1", a["G"]) + ((t * a["rows_per_target"]) * N + n0) * 8)
+        put64(gen.PL_G2, a.get("G2", a["G"]) + ((t * a["rows_per_target"]) * N + n0) * 8)
     return P
 
 
