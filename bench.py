@@ -600,45 +600,6 @@ def main():
             host_of[sp] = host
             return sp
 
-        if "smc" in legs:
-            # the sampler a user runs, end to end (beat/sampler/smc.py:333-546): smc_sample on this problem -- initial
-            # stage + 3 tempering stages of 50 Metropolis steps each through the one-call step
-            # (beatamd_ffi_mstep_batch: Philox proposals from the population factor, forward model, accept), stage
-            # transitions on the device, with and without the stage directories (NumpyChain one-draw traces + state)
-            import shutil
-            import tempfile
-
-            from beat_amd.sampler import smc_sample
-            n_smc = 50
-            smc_out = {}
-            for nch, with_files in ((B, False), (B, True), (2048, False)):
-                if nch == 2048 and B >= 2048:
-                    continue
-                st = SMC(f, lo, up, n_chains=nch, device=dev, random_seed=11, tune_interval=25)
-                home = tempfile.mkdtemp(prefix="beatamd_smc_") if with_files else None
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                pop_s, lp_s, betas_s = smc_sample(n_smc, st, max_stages=3, homepath=home, final_stage=False,
-                                                  layout=lay if with_files else None,
-                                                  out_names=prob.out_names if with_files else None)
-                torch.cuda.synchronize()
-                dt_s = time.perf_counter() - t0
-                if home:
-                    shutil.rmtree(home, ignore_errors=True)
-                tmg = dict(st.timings)
-                nsteps_s = tmg.pop("steps")
-                smc_out["%d_chains%s" % (nch, "_with_stage_files" if with_files else "")] = {
-                    "chains": nch, "stages": len(betas_s) - 1, "steps_per_stage": n_smc, "metropolis_steps": nsteps_s,
-                    "wall_s": dt_s, "chain_steps_per_s_whole_call": nch * nsteps_s / dt_s,
-                    "chain_steps_per_s_sampling_only": nch * nsteps_s / tmg["sample_s"],
-                    "split_s": tmg, "betas": [float(b_) for b_ in betas_s],
-                    "acceptance_per_stage": [float(a_) for a_ in st.stage_acceptance], "finite": bool(np.isfinite(lp_s).all())}
-                del st
-            smc_out["note"] = ("whole call incl. the initial evaluation of the prior population, transitions, all-gathers and "
-                               "(where stated) stage files; `value` above is the same step with torch-drawn proposal rows "
-                               "handed in (beatamd_ffi_astep_batch) on the prior population -- later stages concentrate the "
-                               "population (fewer distinct rows per patch), which is why sampling-only can exceed `value`")
-            out["smc_leg"] = smc_out
         if "multilinear" in legs:
             # the reference's default interpolation (beat/config.py:571-575)
             spec_ml = spec_with(interp="multilinear")
@@ -658,7 +619,49 @@ def main():
                 out["multilinear_leg"]["batch_2048"] = {
                     "chains": 2048, "chain_steps_per_s": 2048 * 3 / leg2["dt"], "kernel": leg2["kernel"],
                     "gfstack_avg_launch_ms": ms2 / max(n2, 1), "gfstack_ms_per_512_chains": ms2 / max(n2, 1) / 4.0}
-            del f_ml
+        if "smc" in legs:
+            # the sampler a user runs, end to end (beat/sampler/smc.py:333-546): smc_sample on this problem -- initial
+            # stage + 3 tempering stages of 50 Metropolis steps each through the one-call step
+            # (beatamd_ffi_mstep_batch: Philox proposals from the population factor, forward model, accept), stage
+            # transitions on the device, with and without the stage directories (NumpyChain one-draw traces + state)
+            import shutil
+            import tempfile
+
+            from beat_amd.sampler import smc_sample
+            n_smc = 50
+            smc_out = {}
+            runs_ = [(B, False, f, ""), (B, True, f, ""), (2048, False, f, "")]
+            if "multilinear" in legs:
+                runs_.append((B, False, f_ml, "_multilinear"))      # the reference's default interpolation, end to end
+            for nch, with_files, f_smc, tag_ in runs_:
+                if nch == 2048 and B >= 2048:
+                    continue
+                st = SMC(f_smc, lo, up, n_chains=nch, device=dev, random_seed=11, tune_interval=25)
+                home = tempfile.mkdtemp(prefix="beatamd_smc_") if with_files else None
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                pop_s, lp_s, betas_s = smc_sample(n_smc, st, max_stages=3, homepath=home, final_stage=False,
+                                                  layout=lay if with_files else None,
+                                                  out_names=prob.out_names if with_files else None)
+                torch.cuda.synchronize()
+                dt_s = time.perf_counter() - t0
+                if home:
+                    shutil.rmtree(home, ignore_errors=True)
+                tmg = dict(st.timings)
+                nsteps_s = tmg.pop("steps")
+                smc_out["%d_chains%s%s" % (nch, "_with_stage_files" if with_files else "", tag_)] = {
+                    "chains": nch, "stages": len(betas_s) - 1, "steps_per_stage": n_smc, "metropolis_steps": nsteps_s,
+                    "wall_s": dt_s, "chain_steps_per_s_whole_call": nch * nsteps_s / dt_s,
+                    "chain_steps_per_s_sampling_only": nch * nsteps_s / tmg["sample_s"],
+                    "split_s": tmg, "betas": [float(b_) for b_ in betas_s],
+                    "acceptance_per_stage": [float(a_) for a_ in st.stage_acceptance], "finite": bool(np.isfinite(lp_s).all())}
+                del st
+            smc_out["note"] = ("whole call incl. the initial evaluation of the prior population, transitions, all-gathers and "
+                               "(where stated) stage files; `value` above is the same step with torch-drawn proposal rows "
+                               "handed in (beatamd_ffi_astep_batch) on the prior population -- later stages concentrate the "
+                               "population (fewer distinct rows per patch), which is why sampling-only can exceed `value`")
+            out["smc_leg"] = smc_out
+        f_ml = None
         f_tp = None
         if legs & {"toeplitz", "pt", "prewhitened"}:
             Wd, slog_d = dense_weights()
