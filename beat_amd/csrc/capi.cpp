@@ -120,6 +120,8 @@ int ffi_logp_device(beatamd_ctx *ctx, FfiModel &m, int64_t C, const double *Q, d
             k.st.starttimes0 = st0;
             k.st.Q = Q;
             k.st.nparams = np;
+            k.order_key[0] = ChainVec{Q, np, m.layout.nuc_strike_off};   // (scheduling hint of k_gfstack_runs)
+            k.order_key[1] = ChainVec{Q, np, m.layout.nuc_dip_off};
             k.st.shift_off = wm.shift_off;
             k.st.chain_bad = chain_bad;
             k.interp = wm.interp;
@@ -906,6 +908,8 @@ int beatamd_ffi_synthetics_batch(beatamd_ctx *ctx, int32_t model_id, int32_t wav
     k.st.starttimes0 = st0;
     k.st.Q = Qd;
     k.st.nparams = np;
+    k.order_key[0] = ChainVec{Qd, np, m->layout.nuc_strike_off};
+    k.order_key[1] = ChainVec{Qd, np, m->layout.nuc_dip_off};
     k.st.shift_off = wm.shift_off;
     k.st.chain_bad = chain_bad;
     k.interp = wm.interp;

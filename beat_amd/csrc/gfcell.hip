@@ -43,21 +43,32 @@ constexpr int GC_TPITCH = 65 * 8;               // transposed misfit tile: row p
 constexpr int GC_PARAM_BYTES = GC_WAVES * 128;
 constexpr uint32_t GC_DEAD = 0xffffffffu;
 
+static int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 // ---------------------------------------------------------------------------- chain order
-// Chains that rupture alike choose the same cells patch after patch; a wavefront that holds
-// alike chains needs fewer row reads.  Order of a group: eight bands by the start-time index at
-// the first patch, inside a band by the start-time index at patch P/2 (both from the row ids of
-// k_gf_tables; no fault geometry needed).  Scheduling only: results do not depend on it.
+// Chains that rupture alike choose the same cells patch after patch; a wavefront that holds alike chains needs
+// fewer row reads.  Two sort keys per chain: bands of whole wavefronts by the first key, inside a band by the
+// second.  The keys are the hypocentre coordinates (strike, dip) when the caller has them (GfStackCall::order_key:
+// the fused model path points them at the nucleation variables of q) -- 121 distinct cells per patch and 512 prior
+// chains instead of 160 with the round-3 order (tests/order_experiment.py) -- and otherwise the start-time indices at
+// the first patch and at patch P/2 (from the row ids of k_gf_tables; no fault geometry needed; 140).  Scheduling
+// only: results do not depend on it.
 struct GcOrderArgs {
     int64_t C, T, P, S;
     const uint32_t *rowoff;   // [C,T,P,4]
     int sort;
+    ChainVec key[2];          // optional caller keys (base == nullptr: start-time indices)
     uint32_t *order;          // [ngroups*GC_CG]: chain id or GC_DEAD
 };
 
 __global__ void __launch_bounds__(GC_TB) k_gc_order(GcOrderArgs a)
 {
-    __shared__ uint32_t ka[GC_CG], kb[GC_CG];
+    __shared__ double ka[GC_CG], kb[GC_CG];
+    __shared__ int bnd[GC_CG];
     const int tid = threadIdx.x;
     const int64_t c = (int64_t)blockIdx.x * GC_CG + tid;
     const bool slot = tid < GC_CG;
@@ -66,24 +77,38 @@ __global__ void __launch_bounds__(GC_TB) k_gc_order(GcOrderArgs a)
         if (slot) a.order[c] = live ? (uint32_t)c : GC_DEAD;
         return;
     }
-    uint32_t s0 = 0xffffu, s1 = 0xffffu;
+    double f0 = 0.0, f1 = 0.0;
     if (live) {
-        const int64_t pm = a.P / 2;
-        s0 = a.rowoff[((c * a.T) * a.P) * 4 + 3] % (uint32_t)a.S;
-        s1 = a.rowoff[((c * a.T) * a.P + pm) * 4 + 3] % (uint32_t)a.S;
+        if (a.key[0].base && a.key[1].base) {
+            f0 = a.key[0].base[c * a.key[0].stride + a.key[0].off];
+            f1 = a.key[1].base[c * a.key[1].stride + a.key[1].off];
+            if (!(fabs(f0) <= 1.79e308)) f0 = 0.0;    // (NaN / inf proposals: any place will do, but a total order)
+            if (!(fabs(f1) <= 1.79e308)) f1 = 0.0;
+        } else {
+            const int64_t pm = a.P / 2;
+            f0 = (double)(a.rowoff[((c * a.T) * a.P) * 4 + 3] % (uint32_t)a.S);
+            f1 = (double)(a.rowoff[((c * a.T) * a.P + pm) * 4 + 3] % (uint32_t)a.S);
+        }
     }
-    if (slot) ka[tid] = live ? ((s0 << 10) | (uint32_t)tid) : (0xffff0000u | (uint32_t)tid);
+    if (slot) { ka[tid] = f0; kb[tid] = f1; }
     __syncthreads();
-    const int64_t nlive = min((int64_t)GC_CG, a.C - (int64_t)blockIdx.x * GC_CG);
+    const int nlive = (int)min((int64_t)GC_CG, a.C - (int64_t)blockIdx.x * GC_CG);
+    // dead slots sort behind the live ones (tid >= nlive for all of them)
     int r0 = 0;
-    if (slot)
-        for (int k = 0; k < GC_CG; k++) r0 += ka[k] < ka[tid];
-    const uint32_t band = live ? (uint32_t)((int64_t)r0 * 8 / nlive) : 15u;
-    if (slot) kb[tid] = (band << 28) | (s1 << 10) | (uint32_t)tid;
+    if (live)
+        for (int k = 0; k < nlive; k++) r0 += (ka[k] < f0) || (ka[k] == f0 && k < tid);
+    const int nw = (nlive + GC_NCHAIN - 1) / GC_NCHAIN;
+    const int nb = a.key[0].base ? 4 : 5;
+    if (slot) bnd[tid] = live ? (r0 / GC_NCHAIN) * nb / nw : nb;
     __syncthreads();
     if (!slot) return;
-    int r1 = 0;
-    for (int k = 0; k < GC_CG; k++) r1 += kb[k] < kb[tid];
+    int r1 = tid;
+    if (live) {
+        const int b = bnd[tid];
+        r1 = 0;
+        for (int k = 0; k < nlive; k++)
+            r1 += (bnd[k] < b) || (bnd[k] == b && ((kb[k] < f1) || (kb[k] == f1 && k < tid)));
+    }
     a.order[(int64_t)blockIdx.x * GC_CG + r1] = live ? (uint32_t)c : GC_DEAD;
 }
 
@@ -399,6 +424,7 @@ int launch_gfstack_cell(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *
     GcOrderArgs oa;
     oa.C = k.C; oa.T = Ttab; oa.P = L.P; oa.S = L.S; oa.rowoff = rowoff;
     oa.sort = !(getenv("BEATAMD_GC_SORT") && atoi(getenv("BEATAMD_GC_SORT")) == 0);
+    if (env_int("BEATAMD_GC_KEYS", 1)) { oa.key[0] = k.order_key[0]; oa.key[1] = k.order_key[1]; }
     BA_TRY(ctx->get_scratch(SL_GC_ORDER, (size_t)(ngroups * GC_CG + 64) * sizeof(uint32_t), &p));
     oa.order = (uint32_t *)p;
 
@@ -722,11 +748,6 @@ __global__ void __launch_bounds__(1024) k_gfstack_mlr(GcArgs a)
 #endif
 }
 
-static int env_int(const char *name, int dflt)
-{
-    const char *e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
 
 bool gfstack_ml_applicable(const GfStackCall &k)
 {
@@ -765,6 +786,7 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
     // k_gfstack_runs: chains that rupture alike share cells patch after patch -> put them into one wavefront
     // (k_gc_order); the static program does not care
     oa.sort = runs ? env_int("BEATAMD_GC_SORT", 1) != 0 : 0;
+    if (env_int("BEATAMD_GC_KEYS", 1)) { oa.key[0] = k.order_key[0]; oa.key[1] = k.order_key[1]; }
     BA_TRY(ctx->get_scratch(SL_GC_ORDER, (size_t)(ngroups * GC_CG + 64) * sizeof(uint32_t), &p));
     oa.order = (uint32_t *)p;
 

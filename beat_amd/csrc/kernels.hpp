@@ -53,6 +53,9 @@ struct GfStackCall {
     double *out = nullptr;            // [C,T,N] (modes 0,2)
     double *quad = nullptr;           // [C,T]   (mode 1) sum over tiles, fixed order
     bool f32 = false;                 // rows from the libraries' float copies where the kernel supports it
+    // optional scheduling hint: two per-chain sort keys that put chains which rupture alike next to each other
+    // (the fused model path: hypocentre strike / dip of the first subfault).  Never changes a result.
+    ChainVec order_key[2];
 };
 int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &call);
 int launch_sum_tiles(beatamd_ctx *ctx, const double *partial, int64_t n, int ntile, double *quad);
