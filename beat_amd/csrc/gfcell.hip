@@ -314,6 +314,7 @@ struct GcArgs {
     const uint32_t *ltab, *order;
     const double *data, *wscalar;
     double *out, *partial;
+    const uint32_t *dtab;         // k_gfstack_runs: chain descriptors, [(g*T+t)][consumer][step 0..nsteps][GR_DLINE]
 };
 
 // VAR > 0: timing experiments of tools/gen_gfcell_asm.py (GC_ABLATIONS builds only; wrong results)
@@ -463,7 +464,7 @@ int launch_gfstack_cell(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *
     a.C = k.C; a.T = L.T; a.P = L.P; a.N = L.N; a.DS = DS;
     a.Ttab = Ttab; a.rows_per_target = L.P * DS;
     a.ngroups = ngroups; a.nsteps = nsteps;
-    a.wtab = ta.wtab; a.ltab = ta.ltab; a.order = oa.order;
+    a.wtab = ta.wtab; a.ltab = ta.ltab; a.order = oa.order; a.dtab = nullptr;
     a.data = k.data; a.wscalar = k.wscalar; a.out = k.out;
     if (k.mode == GF_RESID_SCALAR) {
         BA_TRY(ctx->get_scratch(SL_PARTIAL, (size_t)k.C * L.T * a.ntile * sizeof(double), &p));
@@ -523,12 +524,14 @@ struct GmTabArgs {
     char *wtab;                   // [(g*T+t)][consumer][step 0..nsteps][GM_NREC] records of 16 entries {weight, dword, pad}
     uint32_t *ltab;               // [(g*T+t)][step 0..nsteps+2][loader][32 dwords]: count, row requests
     uint32_t *ucount;             // [(g*T+t)*P+p] row segments the loaders move (statistics)
+    uint32_t *dtab;               // RUNS: [(g*T+t)][consumer][step 0..nsteps][GR_DLINE] chain descriptors (scalar loads)
 };
 
 // one workgroup per (group, target, patch); thread <-> chain slot of the group order.
-// RUNS (k_gfstack_runs): the chains of a wavefront are written in CELL ORDER and every record carries, in the dword of
-// entry GR_PK_LANE, the accumulator offsets (2 x chain slot, 7 bits each) of its four chains and a bit per chain that
-// opens a new cell (the program reads rows only then).
+// RUNS (k_gfstack_runs): the chains of a wavefront are written in CELL ORDER; records hold the weights only (GR_REC
+// bytes per four chains) and the descriptor line of the (wavefront, step) two dwords per sorted position:
+// GR_D_BASE | chain slot | "the next position opens a new cell" << 31 (the program reads rows only then), and the
+// LDS slots of the chain's row pairs, A | B << 16 (tools/gen_gfruns_asm.py).
 template <int RUNS>
 __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
 {
@@ -631,24 +634,23 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
         const uint32_t ring = (uint32_t)((s % 3) * a.nslot);
         const double sl = live ? a.slips[iv].base[c * a.slips[iv].stride + a.slips[iv].off + p] : 0.0;
         // a dead chain slot reads slot 0 of the buffer (its accumulator is never stored)
-        char *rec = a.wtab + ((gt * GC_NCONS + w) * (a.nsteps + 1) + s) * (int64_t)GM_WSTRIDE + (r >> 2) * GM_REC;
         const int q = r & 3;
-        for (int k = 0; k < 4; k++)
-            *reinterpret_cast<double *>(rec + (4 * q + k) * 16) = fr[k] * sl;     // base.py:676-679 x slip, as k_gfstack
-        *reinterpret_cast<uint32_t *>(rec + (2 * q) * 16 + 8) = (ring + sa) * 512u;
-        *reinterpret_cast<uint32_t *>(rec + (2 * q + 1) * 16 + 8) = (ring + sb) * 512u;
         if constexpr (RUNS) {
-            if ((j & 3) == 0) {
-                // here the thread is record j / 4 of wavefront w: pack its (up to) four chains
-                uint32_t pk = 0;
-                for (int qq = 0; qq < 4 && j + qq < GC_NCHAIN; qq++) {
-                    const uint32_t v = pk8[w * GC_NCHAIN + j + qq];
-                    pk |= (v & 0x7fu) << (7 * qq);
-                    pk |= (v >> 7) << (GR_PK_NEW + qq);
-                }
-                char *rec2 = a.wtab + ((gt * GC_NCONS + w) * (a.nsteps + 1) + s) * (int64_t)GM_WSTRIDE + (j >> 2) * GM_REC;
-                *reinterpret_cast<uint32_t *>(rec2 + GR_PK_LANE * 16 + 8) = pk;
-            }
+            // weights only (16 x f64 per four chains); slots and accumulator in the descriptor line
+            char *rec = a.wtab + ((gt * GC_NCONS + w) * (a.nsteps + 1) + s) * (int64_t)GR_WSTRIDE + (r >> 2) * GR_REC;
+            for (int k = 0; k < 4; k++)
+                *reinterpret_cast<double *>(rec + (4 * q + k) * 8) = fr[k] * sl;      // base.py:676-679 x slip, as k_gfstack
+            const uint32_t next_opens = (r + 1 < GC_NCHAIN) ? (uint32_t)(pk8[w * GC_NCHAIN + r + 1] >> 7) : 0u;
+            uint32_t *dl = a.dtab + ((gt * GC_NCONS + w) * (a.nsteps + 1) + s) * GR_DLINE +
+                           (r < GR_NHALF ? 2 * r : GR_DHALF + 2 * (r - GR_NHALF));
+            dl[0] = (uint32_t)GR_D_BASE | (uint32_t)j | (next_opens << 31);
+            dl[1] = (ring + sa) | ((ring + sb) << 16);
+        } else {
+            char *rec = a.wtab + ((gt * GC_NCONS + w) * (a.nsteps + 1) + s) * (int64_t)GM_WSTRIDE + (r >> 2) * GM_REC;
+            for (int k = 0; k < 4; k++)
+                *reinterpret_cast<double *>(rec + (4 * q + k) * 16) = fr[k] * sl;     // base.py:676-679 x slip, as k_gfstack
+            *reinterpret_cast<uint32_t *>(rec + (2 * q) * 16 + 8) = (ring + sa) * 512u;
+            *reinterpret_cast<uint32_t *>(rec + (2 * q + 1) * 16 + 8) = (ring + sb) * 512u;
         }
     }
 }
@@ -683,7 +685,9 @@ __global__ void __launch_bounds__(1024) k_gfstack_mlr(GcArgs a)
         uint32_t *pb = gsm + wave * 32;
         auto put64 = [&](int k, uint64_t x) { pb[k] = (uint32_t)x; pb[k + 1] = (uint32_t)(x >> 32); };
         if (wave < GC_NCONS) {
-            put64(GC_P_WP, (uint64_t)(uintptr_t)(a.wtab + ((gt * GC_NCONS + wave) * (a.nsteps + 1)) * (int64_t)GM_WSTRIDE));
+            put64(GC_P_WP, (uint64_t)(uintptr_t)(a.wtab + ((gt * GC_NCONS + wave) * (a.nsteps + 1)) *
+                                                 (int64_t)(PROG == 1 ? GR_WSTRIDE : GM_WSTRIDE)));
+            put64(GC_P_DP, (uint64_t)(uintptr_t)(a.dtab + ((gt * GC_NCONS + wave) * (a.nsteps + 1)) * (int64_t)GR_DLINE));
             pb[GC_P_RB0] = rb0;
             pb[GC_P_NSTEP] = (uint32_t)a.nsteps;
             put64(GC_P_OUT, (uint64_t)(uintptr_t)(a.out + t * a.N + n0));
@@ -725,6 +729,11 @@ __global__ void __launch_bounds__(1024) k_gfstack_mlr(GcArgs a)
         if constexpr (VAR == 1) { if (wave < GC_NCONS) { GR_CONSUMER_1(paddr); } else { GC_LOADER_0_1(paddr); } }
         if constexpr (VAR == 2) { if (wave < GC_NCONS) { GR_CONSUMER_2(paddr); } else { GC_LOADER_0_1(paddr); } }
         if constexpr (VAR == 3) { if (wave < GC_NCONS) { GR_CONSUMER_3(paddr); } else { GC_LOADER_0_1(paddr); } }
+        if constexpr (VAR == 4) { if (wave < GC_NCONS) { GR_CONSUMER_4(paddr); } else { GC_LOADER_0_1(paddr); } }
+        if constexpr (VAR == 5) { if (wave < GC_NCONS) { GR_CONSUMER_5(paddr); } else { GC_LOADER_0_1(paddr); } }
+        if constexpr (VAR == 6) { if (wave < GC_NCONS) { GR_CONSUMER_6(paddr); } else { GC_LOADER_0_1(paddr); } }
+        if constexpr (VAR == 7) { if (wave < GC_NCONS) { GR_CONSUMER_7(paddr); } else { GC_LOADER_0_1(paddr); } }
+        if constexpr (VAR == 8) { if (wave < GC_NCONS) { GR_CONSUMER_8(paddr); } else { GC_LOADER_0_1(paddr); } }
 #endif
         return;
     }
@@ -805,6 +814,9 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
     ta.ltab = (uint32_t *)p;
     BA_TRY(ctx->get_scratch(SL_GS_UCOUNT, (size_t)GT * L.P * sizeof(uint32_t), &p));
     ta.ucount = (uint32_t *)p;
+    // (the line behind the last step is read ahead, never used)
+    BA_TRY(ctx->get_scratch(SL_GC_META, (size_t)GT * GC_NCONS * (nsteps + 1) * GR_DLINE * sizeof(uint32_t) + 256, &p));
+    ta.dtab = (uint32_t *)p;
     {
         ScopedTimer tm(ctx, "grouptables");
         hipLaunchKernelGGL(k_gc_order, dim3((unsigned)ngroups), dim3(GC_TB), 0, ctx->stream, oa);
@@ -825,7 +837,7 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
     a.C = k.C; a.T = L.T; a.P = L.P; a.N = L.N; a.DS = DS;
     a.Ttab = Ttab; a.rows_per_target = L.P * DS;
     a.ngroups = ngroups; a.nsteps = nsteps;
-    a.wtab = ta.wtab; a.ltab = ta.ltab; a.order = oa.order;
+    a.wtab = ta.wtab; a.ltab = ta.ltab; a.order = oa.order; a.dtab = ta.dtab;
     a.data = k.data; a.wscalar = k.wscalar; a.out = k.out;
     if (k.mode == GF_RESID_SCALAR) {
         BA_TRY(ctx->get_scratch(SL_PARTIAL, (size_t)k.C * L.T * a.ntile * sizeof(double), &p));
@@ -862,7 +874,8 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
 #if GR_NVARIANT > 1
         if (runs) {
             const int var = env_int("BEATAMD_GR_VAR", 0);
-            void (*vk[])(GcArgs) = {kern, k_gfstack_mlr<1, 1, 1>, k_gfstack_mlr<1, 2, 1>, k_gfstack_mlr<1, 3, 1>};
+            void (*vk[])(GcArgs) = {kern, k_gfstack_mlr<1, 1, 1>, k_gfstack_mlr<1, 2, 1>, k_gfstack_mlr<1, 3, 1>, k_gfstack_mlr<1, 4, 1>, k_gfstack_mlr<1, 5, 1>,
+                                    k_gfstack_mlr<1, 6, 1>, k_gfstack_mlr<1, 7, 1>, k_gfstack_mlr<1, 8, 1>};
             if (var >= 1 && var < GR_NVARIANT) kern = vk[var];
         }
 #endif

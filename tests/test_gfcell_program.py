@@ -55,7 +55,9 @@ def _run(T, P, D, S, N, C, Ttab_is_one, mode, sort, nth, seed, static_acc=False,
     order = emu.gc_order(ro, C, Ttab, P, S, sort)
     assert sorted(order[order != emu.DEAD].tolist()) == list(range(C))
     if static_acc:
-        wtab, ltab, ucount = emu.gm_tables(ro, fa, [sl] + slx, order, C, Ttab, P, D, S, runs=(static_acc == "runs"), nvar=nvar)
+        tabs = emu.gm_tables(ro, fa, [sl] + slx, order, C, Ttab, P, D, S, runs=(static_acc == "runs"), nvar=nvar)
+        wtab, ltab, ucount = tabs[:3]
+        dtab = tabs[3] if static_acc == "runs" else None
     else:
         wtab, ltab, ucount = emu.gc_tables(ro, fa, [sl], order, C, Ttab, P, DS)
     data = rng.standard_normal((T, N))
@@ -67,11 +69,13 @@ def _run(T, P, D, S, N, C, Ttab_is_one, mode, sort, nth, seed, static_acc=False,
     for i, gx in enumerate(Gx):
         a["G%d" % (i + 1)] = mem.alloc(gx.nbytes, gx)
     if static_acc:
-        a["wstride"], a["ucap"] = emu.genml.WSTRIDE, D * (S + 1)
+        a["wstride"], a["ucap"] = (emu.genruns if static_acc == "runs" else emu.genml).WSTRIDE, D * (S + 1)
     a["G"] = mem.alloc(G.nbytes, G)
     a["wtab"] = mem.alloc(wtab.nbytes, wtab)
     a["ltab"] = mem.alloc(ltab.nbytes, ltab)
     a["order"] = mem.alloc(order.nbytes + 256, order)
+    if static_acc == "runs":
+        a["dtab"] = mem.alloc(dtab.nbytes, dtab)
     a["data"] = mem.alloc(data.nbytes, data)
     a["out"] = mem.alloc(C * T * N * 8)
     a["partial"] = mem.alloc(C * T * ntile * 8)

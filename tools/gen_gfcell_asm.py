@@ -85,6 +85,7 @@ S_LAST = 95      # user SGPRs stop here: VCC, FLAT_SCRATCH and XNACK_MASK take t
 
 # parameter block of a consumer wavefront (dwords)
 P_WP, P_RB0, P_NSTEP, P_BNC = 0, 4, 5, 6
+P_DP = 8         # k_gfstack_runs: the wavefront's chain descriptors (scalar loads)
 P_OUT, P_CTN, P_MODE, P_DATA, P_W, P_CID, P_PART, P_PCS, P_NVALID, P_TRB = 16, 18, 19, 20, 22, 24, 26, 28, 29, 30
 # parameter block of a loader wavefront
 PL_LT, PL_GROW, PL_DSRB, PL_ROWB, PL_RB0, PL_BUFB, PL_NSTEP, PL_NLANES = 0, 2, 4, 5, 6, 7, 8, 9
@@ -551,7 +552,7 @@ def main():
                           ("A_XN", A_XN), ("A_ACC01", A_ACC01), ("A_CF", A_CF), ("A_ACC23", A_ACC23), ("A_XO", A_XO),
                           ("LPAIR", LPAIR), ("LTAB", LTAB), ("NVGPR", V_LAST + 1)):
             f.write("#define GC_%s %d\n" % (name, val))
-        for name, val in (("WP", P_WP), ("RB0", P_RB0), ("NSTEP", P_NSTEP), ("BNC", P_BNC),
+        for name, val in (("WP", P_WP), ("RB0", P_RB0), ("NSTEP", P_NSTEP), ("BNC", P_BNC), ("DP", P_DP),
                           ("OUT", P_OUT), ("CTN", P_CTN), ("MODE", P_MODE), ("DATA", P_DATA), ("W", P_W),
                           ("CID", P_CID), ("PART", P_PART), ("PCS", P_PCS), ("NVALID", P_NVALID), ("TRB", P_TRB)):
             f.write("#define GC_P_%s %d\n" % (name, val))

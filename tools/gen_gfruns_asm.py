@@ -14,15 +14,27 @@ sustains; profiles/r4_variants.md).  k_gfstack_cell (round 3) shares row reads b
 instructions of control per batch record.  tools/micro/m0cost.hip showed that the index register itself is cheap
 when the index comes from the SCALAR side (~2 cycles next to four FMAs, nothing at four waves per SIMD).  So:
 
-  * per patch the chains of a wavefront are visited in CELL ORDER (k_gr_tables sorts them); the record stream keeps
-    the static shape of k_gfstack_ml -- one 16-lane-replicated vector load per four chains: sixteen weights, the two
-    LDS addresses (A, B) of each chain, and ONE packed dword per record: four 7-bit accumulator offsets + four
-    "this chain opens a new cell" bits, fetched by one v_readlane per four chains and unpacked by the scalar unit;
-  * the accumulator of a chain is v[ACC + M0] (s_set_gpr_idx mode, DST_REL; M0 by s_bfe_u32 + s_set_gpr_idx_idx);
+  * per patch the chains of a wavefront are visited in CELL ORDER (k_gm_tables<1> sorts them);
+  * the record stream carries ONLY the weights: one 16-lane-replicated global_load_dwordx2 per four chains (sixteen
+    weights, what row_newbcast needs), in a ring of TEN register pairs, nine records = a whole step ahead.  The
+    records come from the far side of the L2 (14 MB per call, read by 4096 workgroups) while the loaders pull
+    3 TB/s through it: with four records ahead the kernel took 13.1 ms, with two 14.6 ms (profiles/r4_variants.md);
+  * TWO DWORDS PER CHAIN in scalar registers (scalar loads from a second table, one 80-dword line per wavefront and
+    step): d = 0x4000 | accumulator slot | "the NEXT chain opens a new cell" << 31 and the LDS slots of the chain's two
+    row pairs (A | B << 16).  A single scalar instruction, s_add_u32 m0, d, d, both selects the accumulator
+    (M0 = 0x8000 | 2 x slot: s_set_gpr_idx mode, DST_REL, v_fmac_f64_dpp v[ACC + M0[7:0]]) and puts the new-cell bit
+    into SCC.  tools/micro/chaincost.hip: with four wavefronts per SIMD a chain that stays in its cell costs 8.3 ns
+    per SIMD as four bare FMAs, 10.2 ns with the three scalar instructions of the first version (s_bitcmp1 on a
+    packed dword fetched by v_readlane, s_bfe_u32, s_set_gpr_idx_idx) and 9.3-9.7 ns with this one;
   * rows are read only when the NEXT chain opens a new cell: two copies of the chain loop ("streams") differ in
     which row register set holds the current cell; a chain that opens a cell sends the wavefront through an
-    out-of-line block (two address adds, four ds_read_b64 into the other set, one chain ahead of their use) and
-    into the other stream -- one untaken scalar branch per chain that stays in its cell, two taken per new cell.
+    out-of-line block (two scalar unpacks, two v_lshl_add_u32, four ds_read_b64 into the other set, issued before
+    the FMAs of the chain in hand, waited for behind them) and into the other stream -- one untaken scalar branch per
+    chain that stays in its cell, two taken per new cell.  No s_waitcnt on the path of a chain that stays in its cell;
+  * the descriptor registers are reloaded in two halves for the next step as soon as the chains that own them are
+    done (chains 0-18 at chain 19; chains 19-36 right behind the barrier of the next step); s_waitcnt lgkmcnt(0)
+    in every new-cell block, at the end of a step and at chain 12 keeps every consumer behind its load on every
+    path (scalar loads return out of order: only a full wait counts).
 LDS row layout, loader wavefronts, row ring, barrier per patch and epilogues are those of k_gfstack_ml.
 
     python tools/gen_gfruns_asm.py        # rewrites beat_amd/csrc/gfruns_asm.inc
@@ -36,21 +48,42 @@ import gen_gfml_asm as ml  # noqa: E402
 
 e, lab, br, vp, sp, readlane = base.e, base.lab, base.br, base.vp, base.sp, base.readlane
 
-NCHAIN, NREC, REC, WSTRIDE, NRING, AHEAD = ml.NCHAIN, ml.NREC, ml.REC, ml.WSTRIDE, ml.NRING, ml.AHEAD
+NCHAIN, NREC = ml.NCHAIN, ml.NREC
+REC = 128             # bytes per record: the sixteen weights of four chains
+WSTRIDE = NREC * REC  # bytes per (wavefront, step) in the record table
+NRING = NREC          # register pairs of the record ring (ring position = record index: static)
+AHEAD = NRING - 1     # records requested ahead: a whole step
+assert (NREC + AHEAD) * REC < 4096      # 13-bit immediate offsets of global_load
 V_RING, V_T0, V_PAR, V_AD, V_L16, XA, XB, RREC, ACC, V_LAST = (ml.V_RING, ml.V_T0, ml.V_PAR, ml.V_AD, ml.V_L16, ml.XA,
                                                                ml.XB, ml.RREC, ml.ACC, ml.V_LAST)
+assert RREC + 2 * NRING <= ACC
 S_NSTEP, S_WP, S_RB0 = ml.S_NSTEP, ml.S_WP, ml.S_RB0
+T0, T1 = base.T0, base.T1
 S_ZERO = 3            # 0: accumulator offset of every instruction that is not a chain's FMA
-S_PK = 8              # [8:9] packed dword of the record in use / of the next record (record i -> s[8 + i % 2])
-S_IDX = 16            # scratch: the accumulator offset on its way to M0
-PK_LANE = 8           # entry of a record whose dword holds the packed accumulator offsets / new-cell bits
-PK_NEW = 28           # bit 28 + q: chain q of the record opens a new cell; bits [7q, 7q + 7): 2 x accumulator slot
+S_DP = 6              # [6:7] the wavefront's descriptor line of the step in hand
+# chain descriptors, two dwords per chain: chains 0..NHALF-1 in s[D_A ..], the rest in s[D_B ..]
+NHALF = 19
+D_A, D_B = 20, 60
+DLINE = 80            # dwords per (wavefront, step) of the descriptor table: chain r at dwords 2r, 2r+1 (r < NHALF) or
+DHALF = 40            # DHALF + 2(r - NHALF), +1
+DSTRIDE = DLINE * 4
+D_BASE = 0x4000       # d = D_BASE | slot | new << 31;  d + d = 0x8000 (DST_REL) | 2 * slot, carry = new
+FORCE_WAIT = 12       # chain whose block waits for everything in flight (the second half of the descriptors)
+assert D_A + 2 * NHALF <= D_B and D_B + 2 * (NCHAIN - NHALF) - 1 <= base.S_LAST
 
-ABL = set()           # timing experiments: 'nofma', 'nox'
+ABL = set()           # timing experiments: 'nofma', 'nox', 'nonew', 'norec', 'ahead2', 'ahead4' (wrong results except ahead*)
 
 
 def rec_w(i):
-    return RREC + 4 * (i % NRING)
+    return RREC + 2 * (i % NRING)
+
+
+def dreg(r):
+    return D_A + 2 * r if r < NHALF else D_B + 2 * (r - NHALF)
+
+
+def ddword(r):
+    return 2 * r if r < NHALF else DHALF + 2 * (r - NHALF)
 
 
 def idx0():
@@ -59,19 +92,29 @@ def idx0():
 
 def request_record(i):
     r = rec_w(i)
-    e("global_load_dwordx3 v[%d:%d], v%d, %s offset:%d" % (r, r + 2, V_L16, sp(S_WP), i * REC))
+    if 'norec' in ABL and base._in_loop[0]:
+        return
+    e("global_load_dwordx2 v[%d:%d], v%d, %s offset:%d" % (r, r + 1, V_L16, sp(S_WP), i * REC))
 
 
-def fetch_packed(i):
-    """packed dword of record i -> its scalar register (index 0 must be in force)"""
-    e("v_readlane_b32 s%d, v%d, %d" % (S_PK + i % 2, rec_w(i) + 2, PK_LANE))
+def load_descriptors(first, count, byte_off):
+    """scalar loads of the descriptor dwords of `count` chains from chain `first` on"""
+    reg, dw, n_left = dreg(first), ddword(first), 2 * count
+    while n_left:
+        n = 16
+        while n > n_left or reg % min(n, 4):
+            n //= 2
+        dst = "s%d" % reg if n == 1 else "s[%d:%d]" % (reg, reg + n - 1)
+        e("s_load_dword%s %s, %s, 0x%x" % ("" if n == 1 else "x%d" % n, dst, sp(S_DP), byte_off + 4 * dw))
+        reg, dw, n_left = reg + n, dw + n, n_left - n
 
 
 def addresses(j, xset):
-    i, q = j // 4, j % 4
-    for h in range(2):
-        e("v_add_u32_dpp v%d, v%d, v%d row_newbcast:%d row_mask:0xf bank_mask:0xf"
-          % (V_AD + 2 * xset + h, rec_w(i) + 2, V_RING, 2 * q + h))
+    """LDS addresses of the two row pairs of the chain at sorted position j (index 0 must be in force)"""
+    e("s_and_b32 s%d, s%d, 0xffff" % (T0, dreg(j) + 1))
+    e("s_lshr_b32 s%d, s%d, 16" % (T1, dreg(j) + 1))
+    e("v_lshl_add_u32 v%d, s%d, 9, v%d" % (V_AD + 2 * xset, T0, V_RING))
+    e("v_lshl_add_u32 v%d, s%d, 9, v%d" % (V_AD + 2 * xset + 1, T1, V_RING))
 
 
 def reads(xset):
@@ -85,13 +128,20 @@ def reads(xset):
     e("ds_read_b64 %s, v%d" % (vp(x + 6), a))
 
 
-def fmas(j, xset):
-    """chain at sorted position j: accumulator through M0, rows from set xset"""
-    i, q = j // 4, j % 4
-    e("s_bfe_u32 s%d, s%d, 0x%x" % (S_IDX, S_PK + i % 2, (7 << 16) | (7 * q)))
-    e("s_set_gpr_idx_idx s%d" % S_IDX)
+def lgkm0():
+    if 'nox' not in ABL:
+        e("s_waitcnt lgkmcnt(0)")
+
+
+def select(r):
+    """accumulator of the chain at sorted position r -> M0; SCC = the next chain opens a cell"""
+    e("s_add_u32 m0, s%d, s%d" % (dreg(r), dreg(r)))
+
+
+def fma4(r, xset):
     if 'nofma' in ABL:
         return
+    i, q = r // 4, r % 4
     x = XA if xset == 0 else XB
     for k in range(4):
         e("v_fmac_f64_dpp %s, %s, %s row_newbcast:%d row_mask:0xf bank_mask:0xf"
@@ -99,24 +149,24 @@ def fmas(j, xset):
 
 
 def block(r, p, out_of_line):
-    """chain at sorted position r with its cell's rows in set p"""
+    """chain at sorted position r with its cell's rows (landed) in set p"""
     i, q = r // 4, r % 4
     lab("B%d_%d" % (r, p))
     if q == 0:
-        idx0()                                  # (vector memory instructions are issued with offset 0 as well)
+        idx0()                                  # (vector memory instructions take the index as well)
         request_record(i + AHEAD)
+    if r == FORCE_WAIT:
+        e("s_waitcnt lgkmcnt(0)")               # descriptors of chains NHALF.. (requested at the step's start)
+    if r == NHALF:
+        load_descriptors(0, NHALF, DSTRIDE)     # chains 0..NHALF-1 of the NEXT step: their registers are free
     if r < NCHAIN - 1:
         rn = r + 1
         if rn % 4 == 0:
-            e("s_waitcnt vmcnt(%d)" % (AHEAD - 1))
-            if q != 0:
-                idx0()
-            fetch_packed(rn // 4)
-        e("s_bitcmp1_b32 s%d, %d" % (S_PK + (rn // 4) % 2, PK_NEW + rn % 4))
-        br("s_cbranch_scc1", "N%d_%d" % (r, p))
-        if 'nox' not in ABL:
-            e("s_waitcnt lgkmcnt(0)")               # (reads of this cell may still be in flight right after it opened)
-        fmas(r, p)
+            e("s_waitcnt vmcnt(%d)" % (AHEAD - 1))     # record of chain rn
+        select(r)
+        if 'nonew' not in ABL:
+            br("s_cbranch_scc1", "N%d_%d" % (r, p))
+        fma4(r, p)
         # falls through into B{r+1}_{p}
 
         def new_arm():
@@ -124,9 +174,9 @@ def block(r, p, out_of_line):
             idx0()
             addresses(rn, 1 - p)
             reads(1 - p)
-            if 'nox' not in ABL:
-                e("s_waitcnt lgkmcnt(4)")
-            fmas(r, p)
+            select(r)
+            fma4(r, p)
+            lgkm0()                              # the new rows (and whatever scalar load is in flight)
             br("s_branch", "B%d_%d" % (rn, 1 - p))
         out_of_line.append(new_arm)
     else:
@@ -137,16 +187,17 @@ def block(r, p, out_of_line):
         e("s_waitcnt vmcnt(%d)" % (AHEAD - 1))       # record 0 of the next step
         e("s_add_u32 s%d, s%d, %d" % (S_WP, S_WP, WSTRIDE))
         e("s_addc_u32 s%d, s%d, 0" % (S_WP + 1, S_WP + 1))
-        if q != 0:
-            idx0()
-        fetch_packed(NREC)                           # = record 0 of the next step (NREC even: same scalar register)
-        addresses(0, 1 - p)
-        if 'nox' not in ABL:
-            e("s_waitcnt lgkmcnt(0)")
-        fmas(r, p)
+        e("s_add_u32 s%d, s%d, %d" % (S_DP, S_DP, DSTRIDE))
+        e("s_addc_u32 s%d, s%d, 0" % (S_DP + 1, S_DP + 1))
+        select(r)
+        fma4(r, p)
+        e("s_waitcnt lgkmcnt(0)")                    # descriptors of chains 0..NHALF-1 of the next step
         idx0()
+        addresses(0, 1 - p)
         e("s_barrier")                               # rows of the next step published by the loaders
         reads(1 - p)
+        lgkm0()
+        load_descriptors(NHALF, NCHAIN - NHALF, 0)   # chains NHALF.. of the step that starts (S_DP has moved on)
         br("s_branch", "B0_%d" % (1 - p))
 
 
@@ -156,12 +207,15 @@ def consumer():
     base.lane_setup()
     e("v_lshlrev_b32 v%d, 3, v%d" % (V_RING, V_T0))
     e("v_and_b32 v%d, 15, v%d" % (V_L16, V_T0))
-    e("v_lshlrev_b32 v%d, 4, v%d" % (V_L16, V_L16))
+    e("v_lshlrev_b32 v%d, 3, v%d" % (V_L16, V_L16))    # (lane % 16) * 8: a lane's weight of a record
     base.read_params()
-    for sreg, k in ((S_WP, base.P_WP), (S_WP + 1, base.P_WP + 1), (S_RB0, base.P_RB0), (S_NSTEP, base.P_NSTEP)):
+    for sreg, k in ((S_WP, base.P_WP), (S_WP + 1, base.P_WP + 1), (S_RB0, base.P_RB0), (S_NSTEP, base.P_NSTEP),
+                    (S_DP, base.P_DP), (S_DP + 1, base.P_DP + 1)):
         readlane(sreg, k)
     e("s_nop 4")
     e("v_add_u32 v%d, s%d, v%d" % (V_RING, S_RB0, V_RING))
+    load_descriptors(0, NHALF, 0)
+    load_descriptors(NHALF, NCHAIN - NHALF, 0)
     for r in range(AHEAD):
         request_record(r)
     for j in range(NCHAIN):
@@ -171,12 +225,11 @@ def consumer():
     e("s_barrier")                                     # rows of steps 0..2 in LDS
     # VGPR index mode (DST_REL) for the whole loop: v_fmac_f64_dpp v[ACC + M0[7:0]]; everything else runs with M0[7:0] = 0
     e("s_set_gpr_idx_on s%d, 0x8" % S_ZERO)
-    e("s_waitcnt vmcnt(%d)" % (AHEAD - 1))             # record 0
-    fetch_packed(0)
+    e("s_waitcnt vmcnt(%d) lgkmcnt(0)" % (AHEAD - 1))  # record 0, the descriptors of step 0
     addresses(0, 0)
     reads(0)
+    e("s_waitcnt lgkmcnt(0)")                          # rows of chain 0
     base._in_loop[0] = True
-    assert NREC % 2 == 0
     ool = []
     for p in (0, 1):
         for r in range(NCHAIN):
@@ -186,15 +239,15 @@ def consumer():
     base._in_loop[0] = False
     for p in (0, 1):
         lab("LAST_%d" % p)
-        if 'nox' not in ABL:
-            e("s_waitcnt lgkmcnt(0)")
-        fmas(NCHAIN - 1, p)
+        select(NCHAIN - 1)
+        fma4(NCHAIN - 1, p)
+        e("s_waitcnt lgkmcnt(0)")                      # the descriptor load ahead must not land in the epilogue's registers
         br("s_branch", "EPI")
     base.epilogue(XA, XB, ACC, NCHAIN, True)
     return list(L)
 
 
-VARIANTS = [set(), {"nofma"}, {"nox"}, {"nofma", "nox"}]
+VARIANTS = [set(), {"nofma"}, {"nox"}, {"nonew"}, {"norec"}, {"nonew", "norec"}, {"nonew", "norec", "nofma"}, {"ahead2"}, {"ahead4"}]
 
 
 def main():
@@ -202,7 +255,8 @@ def main():
     with open(out, "w") as f:
         f.write("// generated by tools/gen_gfruns_asm.py -- do not edit\n")
         f.write("// the consumer wavefront program of k_gfstack_runs (see gfcell.hip and the generator)\n")
-        for name, val in (("PK_LANE", PK_LANE), ("PK_NEW", PK_NEW)):
+        for name, val in (("REC", REC), ("WSTRIDE", WSTRIDE), ("NHALF", NHALF), ("DLINE", DLINE), ("DHALF", DHALF),
+                          ("D_BASE", D_BASE)):
             f.write("#define GR_%s %d\n" % (name, val))
         variants = VARIANTS if os.environ.get("GR_ABLATIONS") else VARIANTS[:1]
         f.write("#define GR_NVARIANT %d\n" % len(variants))
@@ -210,6 +264,8 @@ def main():
         for vi, abl in enumerate(variants):
             ABL.clear()
             ABL.update(abl)
+            global AHEAD
+            AHEAD = 2 if "ahead2" in abl else 4 if "ahead4" in abl else NRING - 1
             f.write("#define GR_CONSUMER_%d(PARAM_VGPR) asm volatile( \\\n" % vi)
             for line in consumer():
                 f.write('    "%s\\n\\t" \\\n' % line)

@@ -87,7 +87,9 @@ def gf_tables_ml(st, du, st_min, st_dt, du_min, du_dt, D, S, T, P):
     return ro.astype(np.uint32), fa
 
 
-def gc_order(rowoff, C, T, P, S, sort=True):
+def gc_order(rowoff, C, T, P, S, sort=True, keys=None):
+    """numpy twin of k_gc_order (gfcell.hip): bands of whole wavefronts by the first key, inside a band by the second;
+    keys: optional (k0[C], k1[C]) of the caller (hypocentre strike / dip), else start-time indices at patches 0, P/2"""
     ngroups = (C + CG - 1) // CG
     order = np.full(ngroups * CG, DEAD, dtype=np.uint32)
     for g in range(ngroups):
@@ -96,12 +98,17 @@ def gc_order(rowoff, C, T, P, S, sort=True):
             order[g * CG:g * CG + cs.size] = cs
             continue
         tid = cs - g * CG
-        s0 = rowoff[cs, 0, 0, 3] % S
-        s1 = rowoff[cs, 0, P // 2, 3] % S
-        r0 = np.argsort(np.argsort((s0.astype(np.int64) << 10) | tid))
-        band = r0 * 8 // cs.size
-        kb = (band.astype(np.int64) << 28) | (s1.astype(np.int64) << 10) | tid
-        r1 = np.argsort(np.argsort(kb))
+        if keys is not None:
+            f0, f1 = [np.where(np.abs(k[cs]) <= 1.79e308, k[cs], 0.0) for k in keys]
+            nb = 4
+        else:
+            f0 = (rowoff[cs, 0, 0, 3] % S).astype(np.float64)
+            f1 = (rowoff[cs, 0, P // 2, 3] % S).astype(np.float64)
+            nb = 5
+        r0 = np.argsort(np.lexsort((tid, f0)))
+        nw = (cs.size + NCH - 1) // NCH
+        band = (r0 // NCH) * nb // nw
+        r1 = np.argsort(np.lexsort((tid, f1, band)))
         order[g * CG + r1] = cs
     return order
 
@@ -196,7 +203,7 @@ def gc_tables(rowoff, fac, slips, order, C, T, P, DS, nvar=1):
 
 def gm_tables(rowoff, fac, slips, order, C, T, P, D, S, runs=False, nvar=1):
     """numpy twin of k_gm_tables<RUNS> (gfcell.hip): record table, request table and moved-row counts of k_gfstack_ml;
-    runs: the chains of a wavefront in cell order + the packed accumulator offsets / new-cell bits of k_gfstack_runs"""
+    runs: the chains of a wavefront in cell order, weights-only records and the descriptor lines of k_gfstack_runs"""
     ngroups = order.size // CG
     nsteps, GT, DS, S1 = P * nvar, ngroups * T, D * S, S + 1
     nslot = D * S1
@@ -204,6 +211,7 @@ def gm_tables(rowoff, fac, slips, order, C, T, P, D, S, runs=False, nvar=1):
     wtab = np.zeros(GT * NCONS * (nsteps + 1) * genml.WSTRIDE + 8192, dtype=np.uint8)
     ltab = np.zeros(GT * (nsteps + 3) * NLOAD * 32, dtype=np.uint32)
     ucount = np.zeros(GT * P, dtype=np.uint32)
+    dtab = np.zeros(GT * NCONS * (nsteps + 1) * genruns.DLINE + 64, dtype=np.uint32)
 
     def row_of(sl):
         d, s1 = divmod(sl, S1)
@@ -257,22 +265,30 @@ def gm_tables(rowoff, fac, slips, order, C, T, P, D, S, runs=False, nvar=1):
                           perm = sorted(range(NCH), key=lambda jj: (int(key[jj]), jj))
                       else:
                           perm = list(range(NCH))
+                      def opens_at(r):
+                          j = perm[r]
+                          return bool(live[w * NCH + j]) and (r == 0 or int(key[perm[r - 1]]) != int(key[j]))
                       for r, j in enumerate(perm):
                           k = w * NCH + j
-                          rec = ((gt * NCONS + w) * (nsteps + 1) + s) * genml.WSTRIDE + (r // 4) * genml.REC
                           q = r % 4
-                          if runs:
-                              opens = bool(live[k]) and (r == 0 or int(key[perm[r - 1]]) != int(key[j]))
-                              pkw = wtab[rec + genruns.PK_LANE * 16 + 8:rec + genruns.PK_LANE * 16 + 12].view(np.uint32)
-                              if q == 0:
-                                  pkw[0] = 0
-                              pkw[0] |= ((2 * j) << (7 * q)) | ((1 if opens else 0) << (genruns.PK_NEW + q))
                           c = int(ids[k]) if live[k] else 0
+                          wv = [(fac[c, t, p, kk] * slips[iv][c, p]) if live[k] else 0.0 for kk in range(4)]
+                          if runs:
+                              rec = ((gt * NCONS + w) * (nsteps + 1) + s) * genruns.WSTRIDE + (r // 4) * genruns.REC
+                              for kk in range(4):
+                                  wtab[rec + (4 * q + kk) * 8:rec + (4 * q + kk) * 8 + 8].view(np.float64)[0] = wv[kk]
+                              nxt = 1 if (r + 1 < NCH and opens_at(r + 1)) else 0
+                              dl = ((gt * NCONS + w) * (nsteps + 1) + s) * genruns.DLINE + genruns.ddword(r)
+                              dtab[dl] = genruns.D_BASE | j | (nxt << 31)
+                              dtab[dl + 1] = int(ring + sa[k]) | (int(ring + sb[k]) << 16)
+                              continue
+                          rec = ((gt * NCONS + w) * (nsteps + 1) + s) * genml.WSTRIDE + (r // 4) * genml.REC
                           for kk in range(4):
-                              wv = (fac[c, t, p, kk] * slips[iv][c, p]) if live[k] else 0.0
-                              wtab[rec + (4 * q + kk) * 16:rec + (4 * q + kk) * 16 + 8].view(np.float64)[0] = wv
+                              wtab[rec + (4 * q + kk) * 16:rec + (4 * q + kk) * 16 + 8].view(np.float64)[0] = wv[kk]
                           wtab[rec + (2 * q) * 16 + 8:rec + (2 * q) * 16 + 12].view(np.uint32)[0] = (ring + sa[k]) * 512
                           wtab[rec + (2 * q + 1) * 16 + 8:rec + (2 * q + 1) * 16 + 12].view(np.uint32)[0] = (ring + sb[k]) * 512
+    if runs:
+        return wtab, ltab, ucount, dtab
     return wtab, ltab, ucount
 
 
@@ -516,8 +532,8 @@ class Wave(object):
                 self.idx_en = False
             elif op == "s_set_gpr_idx_idx":
                 self.m0 = (self.m0 & ~0xFF) | (self.get_s32(ops[0]) & 0xFF)
-            elif op.startswith("s_load_dwordx"):
-                n = int(op[len("s_load_dwordx"):])
+            elif op.startswith("s_load_dword"):
+                n = int(op[len("s_load_dwordx"):] or 1)
                 r = self.sreg(ops[0])
                 assert r[2] == n and r[1] % min(n, 4) == 0, ln
                 base = self.sreg(ops[1])
@@ -725,6 +741,8 @@ def wave_params(w, g, t, tile, a):
         P[gen.P_RB0] = PARAM_BYTES
         P[gen.P_NSTEP] = a["nsteps"]
         P[gen.P_BNC] = PARAM_BYTES + 3 * a["DS"] * 512 + w * BOUNCE
+        if "dtab" in a:
+            put64(gen.P_DP, a["dtab"] + ((gt * NCONS + w) * (a["nsteps"] + 1)) * genruns.DLINE * 4)
         put64(gen.P_OUT, a["out"] + (t * N + n0) * 8)
         P[gen.P_CTN] = T * N * 8
         P[gen.P_MODE] = a["mode"]
