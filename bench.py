@@ -361,7 +361,7 @@ def main():
         # LDS operands: one 8-byte operand per FMA and lane for the lane <-> chain kernels; the
         # cell kernel keeps the rows of a cell in registers (its LDS reads are per cell, not per chain)
         # (k_gfstack_runs reads a cell's rows once per run of chains sharing it: its LDS operand bytes depend on the
-        # population; the SQ counters give 3.2 chains per row quartet on this one -> not modelled here)
+        # population; 4.2 chains per row quartet on this one -> not modelled here)
         lds_bytes = 0.0 if (cell or ml_runs) else float(n_chains) * spec_leg.T * spec_leg.P * spec_leg.N * 8 * rows_per_patch
         lds_floor_ms = lds_bytes / (LDS_PEAK_GBS * 1e9) * 1e3
         flops = 2.0 * n_chains * spec_leg.T * spec_leg.P * spec_leg.N * rows_per_patch
@@ -397,12 +397,13 @@ def main():
                                         "of": spec_leg.D * spec_leg.S},
         }
         if ml_runs:
-            roof["note"] = ("rows of a cell read from LDS once per run of chains sharing it (3.2 chains per row quartet on this population by "
-                            "SQ_INSTS_LDS, LDS 0.28 busy), accumulators through the VGPR index register, offsets unpacked on the scalar side: "
-                            "463 instructions per wavefront and patch step (VALU 184 of them: the FP64 pipe 0.31-0.39 busy with FMAs at the "
-                            "2.1 GHz the part sustains), HBM 0.34; timing-only builds keep the same cycle count with fewer record loads, without "
-                            "LDS-DMA and without the barrier, and two restructurings of the per-wavefront stream (rows one cell ahead, scalar work "
-                            "in the FMA shadows) did not move it either (profiles/r4_variants.md)")
+            roof["note"] = ("rows of a cell read from LDS once per run of chains sharing it (4.2 chains per cell on this population with "
+                            "the hypocentre chain order), accumulators through the VGPR index register with ONE scalar instruction per "
+                            "chain (s_add_u32 m0, d, d: accumulator and new-cell bit), descriptors by scalar loads, weights-only record "
+                            "ring a step ahead.  Timing-only builds on one box (profiles/r4_variants.md): 13.7 ms as shipped, 11.1 without "
+                            "new-cell blocks, 10.0 also without record loads, 6.3 also without the FMAs (= the 38 GB of row traffic at "
+                            "6.1 TB/s); the FMAs alone are 7.8 ms at the 2 GHz the part sustains -- what is left is per-wavefront "
+                            "instruction latency at four wavefronts per SIMD (128-VGPR budget)")
         if ml_static:
             roof["note"] = ("static accumulators, lane <-> sample: every FMA takes its 8-byte row operand from LDS by contiguous "
                             "512-byte ds_read_b64 (no bank conflicts); SQ_LDS_IDX_ACTIVE = 0.77 of the CU cycles from the row reads "
