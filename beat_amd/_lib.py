@@ -18,7 +18,7 @@ W_SCALAR, W_DENSE = 0, 1
 INTERPOLATIONS = {"nearest_neighbor": NEAREST_NEIGHBOR, "multilinear": MULTILINEAR}
 
 OK, EINVAL, EHIP, EINDEX, ENOMEM, ENAN, ENOTPSD, EBADCOV = 0, -1, -2, -3, -4, -5, -6, -7
-ABI_VERSION = 113   # include/beat_amd.h BEATAMD_VERSION this module was written against
+ABI_VERSION = 114   # include/beat_amd.h BEATAMD_VERSION this module was written against
 
 
 class BeatAmdError(RuntimeError):
@@ -105,6 +105,7 @@ _PROTOS = {
     "beatamd_chol_inverse_batch": [_vp, _i64, _i64, _vp, _vp, _vp],
     "beatamd_chol_inverse_batch_flags": [_vp, _i64, _i64, _vp, _vp, _vp, _vp],
     "beatamd_whitening_ratio_batch": [_vp, _i64, _i64, _vp, _vp, _vp],
+    "beatamd_unwhiten_traces": [_vp, _i64, _i64, _vp, _vp],
     "beatamd_factor_compact": [_vp, _i64, _i64, _vp, _vp],
     "beatamd_ffi_model_update_data": [_vp, _i32, _i32, _vp],
     "beatamd_halfspace_displacements_batch": [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _f64, _vp],

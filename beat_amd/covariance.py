@@ -133,21 +133,13 @@ class NoiseCovarianceUpdate(object):
         coeffs = f.ctx.autocovariance_batch((res / stds).contiguous())
         return f.ctx.scaled_toeplitz_batch(coeffs, stds.contiguous()), res
 
-    def _unwhiten(self, res, w_old, dev, chunk=8):
-        """rows r_t = inv(W_t) res_t for upper-triangular W [T, n, n] (host or device); the inverses come from the
-        library's own triangular solve (``beatamd_whitening_ratio_batch`` with the identity as numerator), a few
-        datasets at a time, the products from ``beatamd_whiten_rows`` (res_t^T . inv(W_t)^T)"""
+    def _unwhiten(self, res, w_old, dev):
+        """rows r_t = inv(W_t) res_t for upper-triangular W [T, n, n] (host or device): one back substitution per
+        dataset on the device (``beatamd_unwhiten_traces``; the first version formed the 64 inverses for this)"""
         import torch
-        T, n = res.shape
-        out = res.clone()
-        eye = torch.eye(n, dtype=torch.float64, device=dev)
-        for t0 in range(0, T, chunk):
-            t1 = min(T, t0 + chunk)
-            wo = w_old[t0:t1]
-            wo = wo.to(dev) if torch.is_tensor(wo) else torch.from_numpy(np.ascontiguousarray(wo)).to(dev)
-            inv = self.f.ctx.whitening_ratio_batch(eye.expand(t1 - t0, n, n).contiguous(), wo.contiguous())
-            for t in range(t0, t1):
-                self.f.ctx.whiten_rows(out[t:t + 1], inv[t - t0])
+        out = res.clone().contiguous()
+        wo = w_old.to(dev) if torch.is_tensor(w_old) else torch.from_numpy(np.ascontiguousarray(w_old)).to(dev)
+        self.f.ctx.unwhiten_traces(wo.contiguous(), out)
         return out
 
     def update_weights(self, q_map):

@@ -1384,6 +1384,21 @@ int beatamd_whitening_ratio_batch(beatamd_ctx *ctx, int64_t nd, int64_t n, const
     return finish_out(ctx, &rec, 1);
 }
 
+int beatamd_unwhiten_traces(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *W, double *X)
+{
+    ENTER(ctx);
+    BA_CHECK(W && X && nd >= 0 && n > 0, BEATAMD_EINVAL, "unwhiten_traces: bad argument");
+    if (nd == 0) return BEATAMD_OK;
+    const void *d_w;
+    void *d_o;
+    Arg rec;
+    BA_TRY(stage_in(ctx, SL_IN0, W, (size_t)nd * n * n * 8, &d_w));
+    BA_TRY(stage_out(ctx, SL_OUT0, X, (size_t)nd * n * 8, &d_o, &rec, true));   // in place: host traces go up first
+    BA_TRY(launch_triu_solve_vec(ctx, nd, n, (const double *)d_w, (double *)d_o));
+    BA_TRY(ctx->check_status());
+    return finish_out(ctx, &rec, 1);
+}
+
 int beatamd_ffi_model_update_data(beatamd_ctx *ctx, int32_t model_id, int32_t wavemap_index, const double *data)
 {
     ENTER(ctx);

@@ -375,6 +375,77 @@ int launch_triu_ratio(beatamd_ctx *ctx, int64_t nbatch, int64_t n, const double 
     return BEATAMD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// x_b = inv(W_b) . x_b for upper-triangular W_b [n x n] and ONE vector per matrix (back substitution):
+// the residual traces of a pre-whitened model are W_old (d - s); the covariance update needs d - s
+// (covariance.py, BatchedCovarianceUpdater).  One workgroup of 1024 threads per matrix; 64-row blocks from the
+// bottom up: sixteen wavefronts form the dot products of the block's rows with the part of x already solved
+// (W rows are contiguous: coalesced, every element of the triangle read once = 67 MB at n = 4096), one wavefront
+// then solves the 64 x 64 diagonal block from LDS.  A zero on the diagonal raises BEATAMD_ENOTPSD.
+constexpr int TS_B = 64;
+
+__global__ void __launch_bounds__(1024) k_triu_solve_vec(const double *W, int64_t n, double *X, int *status)
+{
+    extern __shared__ double ts_x[];            // [n] the solution so far, then [TS_B] partial sums, [TS_B*TS_B] block
+    double *part = ts_x + n;
+    double *blk = part + TS_B;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double *Wb = W + (int64_t)blockIdx.x * n * n;
+    double *xb = X + (int64_t)blockIdx.x * n;
+    for (int64_t i = tid; i < n; i += 1024) ts_x[i] = xb[i];
+    __syncthreads();
+    const int64_t nblk = (n + TS_B - 1) / TS_B;
+    for (int64_t kb = nblk - 1; kb >= 0; kb--) {
+        const int64_t i0 = kb * TS_B, i1 = min(n, i0 + TS_B), j0 = i1;
+        // (1) part[r] = sum_{j >= j0} W[i0 + r, j] x[j]; wavefront w takes rows w, w + 16, ...
+        for (int r = wave; r < (int)(i1 - i0); r += 16) {
+            const double *row = Wb + (i0 + r) * n;
+            double acc = 0.0;
+            for (int64_t j = j0 + lane; j < n; j += 64) acc = fma(row[j], ts_x[j], acc);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (lane == 0) part[r] = acc;
+        }
+        // the diagonal block into LDS
+        for (int e = tid; e < TS_B * TS_B; e += 1024) {
+            const int r = e / TS_B, c = e % TS_B;
+            blk[e] = (i0 + r < n && i0 + c < n) ? Wb[(i0 + r) * n + i0 + c] : (r == c ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        // (2) back substitution inside the block by wavefront 0: lane <-> column
+        if (wave == 0) {
+            const int m = (int)(i1 - i0);
+            double xl = 0.0;                         // x of column `lane` once solved
+            for (int r = m - 1; r >= 0; r--) {
+                double t = (lane > r && lane < m) ? blk[r * TS_B + lane] * xl : 0.0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+                const double d = blk[r * TS_B + r];
+                if (!(fabs(d) > 0.0) && lane == 0) atomicOr(status, ST_NOT_PSD);   // (zero or NaN pivot)
+                const double xr = (ts_x[i0 + r] - part[r] - t) / d;
+                if (lane == r) xl = xr;
+            }
+            if (lane < m) ts_x[i0 + lane] = xl;
+        }
+        __syncthreads();
+    }
+    for (int64_t i = tid; i < n; i += 1024) xb[i] = ts_x[i];
+}
+
+int launch_triu_solve_vec(beatamd_ctx *ctx, int64_t nbatch, int64_t n, const double *W, double *X)
+{
+    if (nbatch == 0 || n == 0) return BEATAMD_OK;
+    BA_CHECK(W && X && nbatch > 0 && n > 0, BEATAMD_EINVAL, "triu_solve: bad argument");
+    const size_t lds = (size_t)(n + TS_B + TS_B * TS_B) * sizeof(double);
+    BA_CHECK(lds <= 160 * 1024, BEATAMD_EINVAL, "triu_solve: n = %lld does not fit the LDS (max %d)", (long long)n,
+             (int)(160 * 1024 / 8 - TS_B - TS_B * TS_B));
+    ScopedTimer tm(ctx, "triu_solve");
+    (void)hipFuncSetAttribute((const void *)k_triu_solve_vec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_triu_solve_vec, dim3((unsigned)nbatch), dim3(1024), lds, ctx->stream, W, n, X, ctx->d_status);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
 }  // namespace beatamd
 
 // ---------------------------------------------------------------------------------------------

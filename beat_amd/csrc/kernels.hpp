@@ -197,6 +197,8 @@ int launch_chol_inverse(beatamd_ctx *ctx, int64_t nbatch, int64_t n, const doubl
 int launch_gram_cholesky(beatamd_ctx *ctx, int64_t K, int64_t n, const double *F, double *R);
 // M = Wn . inv(Wo) for stacks of upper-triangular matrices (device pointers)
 int launch_triu_ratio(beatamd_ctx *ctx, int64_t nbatch, int64_t n, const double *Wn, const double *Wo, double *M);
+// X[b, :] = inv(W[b]) . X[b, :] for upper-triangular W (one vector per matrix, back substitution)
+int launch_triu_solve_vec(beatamd_ctx *ctx, int64_t nbatch, int64_t n, const double *W, double *X);
 
 // ---- smc.hip: sampler steps on the device
 int launch_smc_calc_beta(beatamd_ctx *ctx, int64_t n, const double *lik, int64_t stride, double beta,

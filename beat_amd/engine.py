@@ -569,6 +569,16 @@ class Context(object):
                                                       ptr(Wo), ptr(M)))
         return M
 
+    def unwhiten_traces(self, W, X):
+        """X (nd, n) <- inv(W[t]) . X[t] for upper-triangular W (nd, n, n), in place (back substitution)"""
+        Wd = f64(W)
+        if Wd.ndim != 3 or Wd.shape[1] != Wd.shape[2] or tuple(X.shape) != (Wd.shape[0], Wd.shape[1]):
+            raise ValueError("W must be (nd, n, n) and X (nd, n)")
+        if f64(X) is not X:
+            raise ValueError("X must be a contiguous float64 array / tensor (updated in place)")
+        check(self._lib.beatamd_unwhiten_traces(self._h, int(Wd.shape[0]), int(Wd.shape[1]), ptr(Wd), ptr(X)))
+        return X
+
     def ffi_model_update_data(self, model_id, wavemap_index, data):
         d = f64(data)
         check(self._lib.beatamd_ffi_model_update_data(self._h, int(model_id), int(wavemap_index), ptr(d)))

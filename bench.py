@@ -800,7 +800,7 @@ def main():
                         t_re = time.perf_counter() - t0
                     wflops = float(spec.T) * spec.P * spec.D * spec.S * N * N
                     out.setdefault("stage_update_leg", {})["prewhitened"] = {
-                        "what": "the same update on the pre-whitened model: residuals un-whitened, covariances, factorisation, "
+                        "what": "the same update on the pre-whitened model: residuals un-whitened (one back substitution per dataset), covariances, factorisation, "
                                 "M = W_new inv(W_old), all %.1f GB of library rows re-whitened in place (beatamd_whiten_rows_batch), "
                                 "end points evaluated again" % (spec.lib_bytes / 1e9),
                         "stage_update_s": upd.last_ms * 1e-3 + t_re, "update_weights_s": upd.last_ms * 1e-3,

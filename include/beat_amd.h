@@ -42,7 +42,7 @@ extern "C" {
 /* ABI revision: bumped whenever an entry point changes its signature or an error code is added
  * (1.1: beatamd_weights_update gained kind/count in round 2; BEATAMD_EBADCOV).  beat_amd/_lib.py
  * refuses a library whose revision differs from the header it was written against. */
-#define BEATAMD_VERSION 113
+#define BEATAMD_VERSION 114
 
 #define BEATAMD_NEAREST_NEIGHBOR 0 /* interpolation="nearest_neighbor" */
 #define BEATAMD_MULTILINEAR 1      /* interpolation="multilinear"      */
@@ -414,6 +414,11 @@ int beatamd_factor_compact(beatamd_ctx *ctx, int64_t K, int64_t n, const double 
  *   place.  A singular W_old is BEATAMD_ENOTPSD. */
 int beatamd_whitening_ratio_batch(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *W_new,
                                   const double *W_old, double *M);
+/* replaces: nothing in the reference; the covariance update (covariance.py:307-325 estimates the noise on
+ *           d - s) on a pre-whitened model, whose residual traces are W_old (d - s):
+ *   X [nd,n] <- inv(W_t) . X[t] for upper-triangular W [nd,n,n] (back substitution, one trace per
+ *   dataset; in place, host or device pointers).  A zero on a diagonal is BEATAMD_ENOTPSD. */
+int beatamd_unwhiten_traces(beatamd_ctx *ctx, int64_t nd, int64_t n, const double *W, double *X);
 /* replaces: the data half of update_weights on a pre-whitened wavemap: new observed data
  *   [T,N] (already whitened) of wavemap `wavemap_index` of a compiled model */
 int beatamd_ffi_model_update_data(beatamd_ctx *ctx, int32_t model_id, int32_t wavemap_index, const double *data);

@@ -200,6 +200,35 @@ def test_whiten_rows_batch_in_place_vs_numpy(ctx, B, R, N):
         ctx.whiten_rows_batch(torch.zeros((2, 3, 8), dtype=torch.float64, device=dev), np.zeros((3, 8, 8)))
 
 
+@pytest.mark.parametrize("B,N", [(1, 1), (3, 63), (2, 64), (4, 100), (5, 513), (2, 4096)])
+def test_unwhiten_traces_vs_numpy(ctx, B, N):
+    """beatamd_unwhiten_traces: X[t] <- inv(W[t]) . X[t] by back substitution (the residuals of a pre-whitened model are
+    W_old (d - s), the covariance update wants d - s): sizes around the 64-row blocks, host and device arrays, against
+    numpy's solve; a zero on the diagonal is a LinAlgError."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(7 * B + N)
+    W = np.triu(rng.standard_normal((B, N, N)) / np.sqrt(N)) + 2.0 * np.eye(N)
+    x = rng.standard_normal((B, N))
+    ref = np.stack([np.linalg.solve(W[b], x[b]) for b in range(B)])
+    tol = dict(rtol=1e-10, atol=1e-11 * np.abs(ref).max())
+    h = x.copy()
+    ctx.unwhiten_traces(W, h)
+    np.testing.assert_allclose(h, ref, **tol)
+    d = torch.from_numpy(x.copy()).to(dev)
+    ctx.unwhiten_traces(torch.from_numpy(W).to(dev), d)
+    np.testing.assert_allclose(d.cpu().numpy(), ref, **tol)
+    # back through the whitening product: W . inv(W) x = x
+    np.testing.assert_allclose(np.einsum("bij,bj->bi", W, h), x, rtol=1e-9, atol=1e-10)
+    if N > 1:
+        Ws = W.copy()
+        Ws[B - 1, N // 2, N // 2] = 0.0
+        with pytest.raises(np.linalg.LinAlgError):
+            ctx.unwhiten_traces(Ws, x.copy())
+    with pytest.raises(ValueError):
+        ctx.unwhiten_traces(W, np.zeros((B, N + 1)))
+
+
 # ----------------------------------------------------------------------------- failure behaviour
 def _small_model(ctx, **kw):
     from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
