@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--reps", type=int, default=6)
     ap.add_argument("--targets", type=int, default=64)
     ap.add_argument("--samples", type=int, default=4096)
+    ap.add_argument("--sort-chains", action="store_true", help="order the population by hypocentre (strike bands, then dip) first")
     ap.add_argument("--envs", default="", help="semicolon separated VAR=VALUE sets (comma separated inside a set) to time in turn")
     args = ap.parse_args()
     import torch
@@ -30,6 +31,13 @@ def main():
     prob, host = build_problem(spec, device_library=True, ctx=ctx)
     f = prob.compile(ctx)
     Q = torch.from_numpy(draw_population(spec, host["layout"], host["lower"], host["upper"], args.chains)).to("cuda")
+    if args.sort_chains:
+        lay = host["layout"]
+        qs = Q.cpu().numpy()
+        ks = qs[:, lay.offset("nucleation_strike")]
+        kd = qs[:, lay.offset("nucleation_dip")]
+        band = np.argsort(np.argsort(ks)) * 8 // len(ks)
+        Q = Q[torch.from_numpy(np.lexsort((kd, band))).to(Q.device)].contiguous()
     sets = [s for s in args.envs.split(";")] if args.envs else [""]
     ref = None
     for es in sets:

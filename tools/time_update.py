@@ -41,7 +41,10 @@ for rep in range(3):
     upd.update_weights(q_map)
     torch.cuda.synchronize()
     wms, wn = ctx.kernel_time("whiten")
+    parts = ["%s %.1f ms (%d)" % ((nm,) + ctx.kernel_time(nm)) for nm in ("chol_inverse", "triu_ratio", "triu_solve", "gfstack",
+                                                                        "stage") if ctx.kernel_time(nm)[1]]
     ctx.enable_timing(False)
+    print("  device timers: " + ", ".join(parts))
     if wn:
         flops = 64 * 400 * 3 * 25 * 4096.0 * 4096.0     # rows x N x N (upper-triangular operators: half of 2 N^2)
         print("  re-whitening: %d launches, %.1f ms, %.1f TFLOP/s" % (wn, wms, flops / (wms * 1e-3) / 1e12))
