@@ -58,9 +58,80 @@ __device__ __forceinline__ double upwind(const double *t, int i, int j, const do
     return (v < old) ? v : old;
 }
 
+// lane l receives x of lane l - 1 (DPP wave_shr:1, a VALU move; lane 0: its own x).  Must run with every lane of the
+// wavefront enabled: a DPP read from a disabled lane does not deliver.
+__device__ __forceinline__ double from_lane_below(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// One sweep of fast_sweep_ext.c:141-196 by anti-diagonals with the UPWIND operands in registers (grids of at most 64
+// rows; round 4).  In sweep order lane ip owns row ip and walks it one cell per diagonal: the upwind neighbour in its
+// own row, (ip, jp-1), is the value the lane computed on the previous diagonal, the upwind neighbour in the row below,
+// (ip-1, jp), is what lane ip-1 computed on the previous diagonal (one DPP move).  The other operands -- the cell's own
+// old value, the two DOWNWIND neighbours (diagonals d+1: not written yet in this sweep) and the slowness -- do not depend
+// on anything this sweep has written before diagonal d+1, so they are read from LDS one diagonal ahead.  The dependent
+// chain of a diagonal is then DPP -> min -> eq_solve -> min instead of LDS write -> LDS read -> ... (the first version:
+// sweep_wave below, kept for grids with more than 64 rows).  Same operands, same operations, same order per cell:
+// bitwise the same times.
+__device__ __forceinline__ void sweep_diag64(double *t, const double *slow, int ni, int nj, double h, bool irev,
+                                              bool jrev, int lane)
+{
+    const bool row = lane < ni;
+    const int i = row ? (irev ? ni - 1 - lane : lane) : 0;
+    // true row of sweep row ip + 1; beyond the grid the reference clamps to the cell's own row (its old value)
+    const int idn = (lane + 1 < ni) ? (irev ? i - 1 : i + 1) : i;
+    double *trow = t + i * nj;
+    const double *drow = t + idn * nj, *srow = slow + i * nj;
+    // (S, S2: the two slowness terms of eq_solve, f*h and 2*f*f*h*h, formed ahead as well: same expressions, same values.
+    // Everything is straight-line: reads go to clamped, always valid cells, both arms of eq_solve are evaluated and
+    // selected -- a wavefront that runs alone on its SIMD pays for every branch.)
+    double O = 0.0, S = 0.0, S2 = 0.0, Di = 0.0, Dj = 0.0, vprev = 0.0;
+    auto fetch = [&](int d, double &o, double &fh, double &c2, double &di, double &dj) {
+        const int jc = min(max(d - lane, 0), nj - 1);
+        const int j = jrev ? nj - 1 - jc : jc;
+        const int jd = (jc + 1 < nj) ? (jrev ? j - 1 : j + 1) : j;    // beyond the row: the cell itself (its old value)
+        o = trow[j];
+        const double f = srow[j];
+        fh = f * h;
+        c2 = 2.0 * f * f * h * h;
+        di = drow[j];
+        dj = trow[jd];
+    };
+    fetch(0, O, S, S2, Di, Dj);
+    for (int d = 0; d < ni + nj - 1; d++) {
+        const double below = from_lane_below(vprev);       // (ip-1, jp) of this sweep
+        double On, Sn, S2n, Din, Djn;
+        fetch(d + 1, On, Sn, S2n, Din, Djn);
+        const int jp = d - lane;
+        const bool act = row && jp >= 0 && jp < nj;
+        const double ui = (lane >= 1) ? below : O;
+        const double uj = (jp >= 1) ? vprev : O;
+        // fast_sweep_ext.c:77-118 upwind(): a1 = t[i-1][j], a2 = t[i+1][j], b1 = t[i][j-1], b2 = t[i][j+1]
+        const double a1 = irev ? Di : ui, a2 = irev ? ui : Di;
+        const double b1 = jrev ? Dj : uj, b2 = jrev ? uj : Dj;
+        const double uxmin = (a1 < a2) ? a1 : a2;
+        const double uymin = (b1 < b2) ? b1 : b2;
+        // eq_solve (fast_sweep_ext.c:65-75)
+        const double dab = uxmin - uymin;
+        const double vlin = ((uxmin < uymin) ? uxmin : uymin) + S;
+        const double vsq = (uxmin + uymin + sqrt(S2 - dab * dab)) / 2.0;
+        double v = (fabs(dab) >= S) ? vlin : vsq;
+        v = (v < O) ? v : O;
+        if (act) {
+            trow[jrev ? nj - 1 - jp : jp] = v;
+            vprev = v;
+        }
+        O = On; S = Sn; S2 = S2n; Di = Din; Dj = Djn;
+    }
+}
+
 // fast_sweep_ext.c:120-206, one wavefront.  t/told/slow are this wave's LDS arrays.
 __device__ void sweep_wave(double *t, double *told, const double *slow, int ni, int nj, double h,
-                           int hi, int hj, int lane)
+                           int hi, int hj, int lane, bool a_first_version)
 {
     const int n = ni * nj;
     for (int k = lane; k < n; k += 64) t[k] = __builtin_inf();
@@ -76,6 +147,11 @@ __device__ void sweep_wave(double *t, double *told, const double *slow, int ni, 
         for (int sw = 0; sw < 4; sw++) {
             const bool irev = (sw == 1) || (sw == 2);
             const bool jrev = (sw == 2) || (sw == 3);
+            if (ni <= 64 && !a_first_version) {
+                sweep_diag64(t, slow, ni, nj, h, irev, jrev, lane);
+                wave_lds_sync();
+                continue;
+            }
             for (int d = 0; d < ni + nj - 1; d++) {
                 for (int base = 0; base < ni; base += 64) {
                     const int ip = base + lane;
@@ -131,6 +207,7 @@ struct SweepParams {
     int *status;
     int32_t *chain_bad;  // mode 1, nullable: chain flagged when its hypocentre index is off the grid
     int32_t nmax;  // LDS doubles reserved per array per wave
+    int32_t first_version;   // BEATAMD_SWEEP_V1=1: the LDS-only diagonal loop also for grids of <= 64 rows (A/B, tests)
 };
 
 template <int WAVES>
@@ -184,7 +261,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_fast_sweep(SweepParams a)
         hj = min(max(hj, 0), nj - 1);
     }
     wave_lds_sync();
-    sweep_wave(t, told, slow, ni, nj, h, hi, hj, lane);
+    sweep_wave(t, told, slow, ni, nj, h, hi, hj, lane, a.first_version != 0);
     wave_lds_sync();
     // seismic.py:1268: starttimes_tmp += time[index]
     for (int k = lane; k < ni * nj; k += 64) out[k] = (a.mode == 0) ? t[k] : (t[k] + tadd);
@@ -197,6 +274,10 @@ static int launch_sweep(beatamd_ctx *ctx, SweepParams &p, int nmax_cells)
              nmax_cells);
     p.nmax = (nmax_cells + 1) & ~1;
     p.status = ctx->d_status;
+    {
+        const char *e = getenv("BEATAMD_SWEEP_V1");
+        p.first_version = (e && atoi(e) != 0) ? 1 : 0;
+    }
     ScopedTimer tm(ctx, "sweep");
     if (p.nmax <= 1600) {
         const int W = 4;

@@ -99,6 +99,29 @@ def test_sweep_batch_random_vs_oracle(ctx, orc):
             assert np.array_equal(orc.time2idx(out[c], 0.0, 0.5)[0], orc.time2idx(ref, 0.0, 0.5)[0])
 
 
+def test_sweep_register_upwind_is_bitwise_the_lds_version(ctx, monkeypatch):
+    """round 4: grids of at most 64 rows keep the upwind operands of a diagonal in registers (own previous cell, the
+    lane below by DPP) and read the rest one diagonal ahead; BEATAMD_SWEEP_V1=1 runs the first, LDS-only loop.  Same
+    operands and operations per cell: the times must be equal bit for bit -- all four sweep directions, one-row /
+    one-column grids, 64 rows (the limit), hypocentres in corners and on edges, infinitely slow patches."""
+    rng = np.random.default_rng(11)
+    for nd, ns in [(20, 20), (1, 1), (1, 17), (17, 1), (2, 2), (64, 5), (5, 64), (64, 64), (33, 48), (65, 4)]:
+        C = 40
+        slow = 1.0 / rng.uniform(0.3, 8.0, (C, nd * ns))
+        if nd * ns > 8:
+            slow[3, rng.integers(0, nd * ns, 3)] = np.inf
+        hd = rng.integers(0, nd, C).astype(np.int32)
+        hs = rng.integers(0, ns, C).astype(np.int32)
+        hd[:4] = [0, nd - 1, 0, nd - 1]
+        hs[:4] = [0, ns - 1, ns - 1, 0]
+        monkeypatch.delenv("BEATAMD_SWEEP_V1", raising=False)
+        new = ctx.fast_sweep_batch(slow, 1.3, hd, hs, nd, ns)
+        monkeypatch.setenv("BEATAMD_SWEEP_V1", "1")
+        old = ctx.fast_sweep_batch(slow, 1.3, hd, hs, nd, ns)
+        monkeypatch.delenv("BEATAMD_SWEEP_V1", raising=False)
+        assert np.array_equal(new, old, equal_nan=True), (nd, ns)
+
+
 def test_sweep_bad_hypocentre_raises(ctx):
     with pytest.raises(ValueError):
         ctx.fast_sweep_batch(np.ones((1, 12)), 1.0, [3], [0], 3, 4)
