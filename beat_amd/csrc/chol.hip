@@ -352,22 +352,42 @@ int launch_triu_ratio(beatamd_ctx *ctx, int64_t nbatch, int64_t n, const double 
     hipLaunchKernelGGL(k_triu_diag_inv, dim3((unsigned)nblk, (unsigned)nbatch), dim3(256), 0, ctx->stream,
                        (const double *)A, np, nblk, Dinv, ctx->d_status);
     const int64_t sM = np * np;
-    for (int kb = 0; kb < nblk; kb++) {
-        const int64_t kc = (int64_t)kb * CH_NB, rows = kc + CH_NB;   // M[:, kb] is nonzero in rows < rows
-        if (kb > 0) {
-            GemmCall g;   // X[:rows, kb] -= M[:rows, :kc] . Wo[:kc, kb]
-            g.A = X; g.lda = np; g.sA = sM;
-            g.B = A + kc; g.ldb = np; g.sB = sM;
-            g.O = X + kc; g.ldo = np; g.sO = sM;
-            g.M = rows; g.N = CH_NB; g.K = kc; g.b_kn = 1; g.alpha = -1.0; g.accumulate = 1; g.nbatch = (int)nbatch;
-            BA_TRY(launch_gemm_f64(ctx, g));
-        }
-        GemmCall h;       // M[:rows, kb] = X[:rows, kb] . inv(Wo[kb, kb])   (in place: one column block)
+    // Two blocking levels (round 4): the update of a block column by everything to its left is done for TWO block
+    // columns at a time -- a 128-column product, the full width of the GEMM tile (the 64-column products of the first
+    // version left half of every MFMA tile empty) --, then the pair is finished with 64 x 64 steps.
+    auto finish_block = [&](int kb) -> int {   // M[:rows, kb] = X[:rows, kb] . inv(Wo[kb, kb])   (in place: one column block)
+        const int64_t kc = (int64_t)kb * CH_NB, rows = kc + CH_NB;
+        GemmCall h;
         h.A = X + kc; h.lda = np; h.sA = sM;
         h.B = Dinv + (int64_t)kb * CH_NB * CH_NB; h.ldb = CH_NB; h.sB = (int64_t)nblk * CH_NB * CH_NB;
         h.O = X + kc; h.ldo = np; h.sO = sM;
         h.M = rows; h.N = CH_NB; h.K = CH_NB; h.b_kn = 1; h.nbatch = (int)nbatch;
-        BA_TRY(launch_gemm_f64(ctx, h));
+        return launch_gemm_f64(ctx, h);
+    };
+    for (int pb = 0; pb < nblk; pb += 2) {
+        const int64_t pc = (int64_t)pb * CH_NB;
+        const int ncol = (pb + 1 < nblk) ? 2 : 1;               // block columns of this panel
+        if (pb > 0) {
+            GemmCall g;   // X[:rows, panel] -= M[:rows, :pc] . Wo[:pc, panel]   (rows >= pc of M[:, :pc] are zero)
+            g.A = X; g.lda = np; g.sA = sM;
+            g.B = A + pc; g.ldb = np; g.sB = sM;
+            g.O = X + pc; g.ldo = np; g.sO = sM;
+            g.M = pc + ncol * CH_NB; g.N = ncol * CH_NB; g.K = pc; g.b_kn = 1; g.alpha = -1.0; g.accumulate = 1;
+            g.nbatch = (int)nbatch;
+            BA_TRY(launch_gemm_f64(ctx, g));
+        }
+        BA_TRY(finish_block(pb));
+        if (ncol == 2) {
+            const int64_t kc2 = pc + CH_NB;
+            GemmCall g;   // X[:rows, second] -= M[:rows, first] . Wo[first, second]
+            g.A = X + pc; g.lda = np; g.sA = sM;
+            g.B = A + pc * np + kc2; g.ldb = np; g.sB = sM;
+            g.O = X + kc2; g.ldo = np; g.sO = sM;
+            g.M = kc2 + CH_NB; g.N = CH_NB; g.K = CH_NB; g.b_kn = 1; g.alpha = -1.0; g.accumulate = 1;
+            g.nbatch = (int)nbatch;
+            BA_TRY(launch_gemm_f64(ctx, g));
+            BA_TRY(finish_block(pb + 1));
+        }
     }
     const dim3 gu((unsigned)((n * n + 255) / 256), (unsigned)nbatch);
     hipLaunchKernelGGL(k_unpad, gu, dim3(256), 0, ctx->stream, (const double *)X, n, np, M);

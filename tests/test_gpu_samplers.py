@@ -329,10 +329,10 @@ def test_compact_proposal_factor(ctx, K, n):
     np.testing.assert_allclose(Pcn.T @ Pcn, np.cov(Xc, rowvar=0), rtol=1e-9, atol=1e-9 * np.abs(cov).max())
 
 
-@pytest.mark.parametrize("n", [5, 64, 100, 200])
+@pytest.mark.parametrize("n", [5, 64, 100, 150, 200, 330])
 def test_whitening_ratio_kernel(ctx, n):
     """M = W_new . inv(W_old) for upper-triangular whitening operators (blocked right-side triangular
-    solve on the FP64 matrix cores) against numpy"""
+    solve on the FP64 matrix cores, block columns in pairs: 1, 2, 3, 4 and 6 block columns) against numpy"""
     rng = np.random.default_rng(n)
     t = np.arange(n)
     def op(scale, corr):
