@@ -522,6 +522,7 @@ struct GmTabArgs {
     ChainVec slips[4];
     const uint32_t *order;        // [ngroups*GC_CG]
     char *wtab;                   // [(g*T+t)][consumer][step 0..nsteps][GM_NREC] records of 16 entries {weight, dword, pad}
+                                  // (RUNS: GR_REC-byte records of 16 weights)
     uint32_t *ltab;               // [(g*T+t)][step 0..nsteps+2][loader][32 dwords]: count, row requests
     uint32_t *ucount;             // [(g*T+t)*P+p] row segments the loaders move (statistics)
     uint32_t *dtab;               // RUNS: [(g*T+t)][consumer][step 0..nsteps][GR_DLINE] chain descriptors (scalar loads)
