@@ -338,8 +338,9 @@ def test_whitening_ratio_kernel(ctx, n):
     def op(scale, corr):
         Cm = scale * np.exp(-np.abs(t[:, None] - t[None, :]) / corr) + 1e-3 * np.eye(n)
         return np.linalg.cholesky(np.linalg.inv(Cm)).T
-    Wo = np.stack([op(0.7, 5.0), op(1.3, 2.0), np.triu(rng.standard_normal((n, n))) + 4.0 * np.eye(n)])
-    Wn = np.stack([op(0.9, 4.0), op(0.4, 7.0), np.triu(rng.standard_normal((n, n))) + 3.0 * np.eye(n)])
+    off = 1.0 if n <= 200 else 0.2      # (a random triangular matrix with unit entries is ill-conditioned beyond that)
+    Wo = np.stack([op(0.7, 5.0), op(1.3, 2.0), off * np.triu(rng.standard_normal((n, n))) + 4.0 * np.eye(n)])
+    Wn = np.stack([op(0.9, 4.0), op(0.4, 7.0), off * np.triu(rng.standard_normal((n, n))) + 3.0 * np.eye(n)])
     M = ctx.whitening_ratio_batch(Wn, Wo)
     for i in range(3):
         ref = Wn[i] @ np.linalg.inv(Wo[i])
