@@ -53,7 +53,7 @@ print('value %.0f ms/step %.3f' % (d['value'], d['ms_per_step']), d['roofline'][
 profile)
   tag=$1; O=$R/gpurun_out/prof_$tag
   rm -rf $O; mkdir -p $O; cd /tmp
-  B="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-variant-legs --no-narrow-leg --no-batch-leg"
+  B="python $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-variant-legs --no-narrow-leg --no-batch-leg"
   prof() { t=$1; shift; mkdir -p $O/$t
     timeout 600 rocprofv3 --kernel-trace --stats -d $O/$t/stats -o bench -- "$@" > $O/$t/stats_run.log 2>&1
     timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/$t/fetch -o bench -- "$@" > $O/$t/fetch_run.log 2>&1

@@ -40,7 +40,7 @@ def main(src, dst, tag, *kernels):
             w.writerow([short(r[0]), r[1], "%.3f" % r[2], "%.3f" % r[3], "%.3f" % r[4]])
     for kn in kernels:
         disp = list(db.execute("select name, duration, grid_x, workgroup_x, vgpr_count, accum_vgpr_count, "
-                               "sgpr_count, lds_size from kernels where name like ?", ("%" + kn + "%",)))
+                               "sgpr_count, lds_size from kernels where name like ? order by start", ("%" + kn + "%",)))
         if not disp:
             print("no dispatch of", kn)
             continue
@@ -57,6 +57,9 @@ def main(src, dst, tag, *kernels):
         summary = dict(kernel=disp[0][0].replace("void ", ""), dispatches=len(disp),
                        avg_us=sum(durs) / len(durs) / 1e3, median_us=sorted(durs)[len(durs) // 2] / 1e3,
                        min_us=min(durs) / 1e3, max_us=max(durs) / 1e3,
+                       # the timed launches of bench.py are the LAST `steps` ones of a run; the first few (initial
+                       # evaluation, warm-up) run on cold tables and clocks
+                       avg_us_after_first_4=(sum(durs[4:]) / len(durs[4:]) / 1e3) if len(durs) > 8 else None,
                        grid=disp[0][2], workgroup=disp[0][3], vgpr=disp[0][4], agpr=disp[0][5],
                        sgpr=disp[0][6], lds=disp[0][7])
         for sub, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
