@@ -26,11 +26,13 @@ when the index comes from the SCALAR side (~2 cycles next to four FMAs, nothing 
     into SCC.  tools/micro/chaincost.hip: with four wavefronts per SIMD a chain that stays in its cell costs 8.3 ns
     per SIMD as four bare FMAs, 10.2 ns with the three scalar instructions of the first version (s_bitcmp1 on a
     packed dword fetched by v_readlane, s_bfe_u32, s_set_gpr_idx_idx) and 9.3-9.7 ns with this one;
-  * rows are read only when the NEXT chain opens a new cell: two copies of the chain loop ("streams") differ in
-    which row register set holds the current cell; a chain that opens a cell sends the wavefront through an
-    out-of-line block (two scalar unpacks, two v_lshl_add_u32, four ds_read_b64 into the other set, issued before
-    the FMAs of the chain in hand, waited for behind them) and into the other stream -- one untaken scalar branch per
-    chain that stays in its cell, two taken per new cell.  No s_waitcnt on the path of a chain that stays in its cell;
+  * rows are read only when the NEXT chain opens a new cell: behind the chain's own FMAs, into the SAME eight row
+    registers (two scalar unpacks, two v_lshl_add_u32, four ds_read_b64, s_waitcnt) -- one short scalar branch per chain
+    that stays in its cell, nothing out of line.  (The first versions kept two row sets and two copies of the loop, so
+    that the reads could be issued before the FMAs and waited for behind them: ablation 'two'.  It is 0-2.5 % slower:
+    what counts is instructions and branches per wavefront, not the cover of an LDS round trip;
+    tools/micro/chaincost.hip: a taken short branch costs what an untaken one costs.)  No s_waitcnt on the path of a
+    chain that stays in its cell;
   * the descriptor registers are reloaded in two halves for the next step as soon as the chains that own them are
     done (chains 0-18 at chain 19; chains 19-36 right behind the barrier of the next step); s_waitcnt lgkmcnt(0)
     in every new-cell block, at the end of a step and at chain 12 keeps every consumer behind its load on every
@@ -201,6 +203,53 @@ def block(r, p, out_of_line):
         br("s_branch", "B0_%d" % (1 - p))
 
 
+def block_one(r):
+    """chain at sorted position r; ONE copy of the chain loop and one row set: a chain whose successor opens a cell
+    reads the new rows into the same registers right behind its own FMAs and waits for them (no cover for the LDS round
+    trip, but no out-of-line block, no taken far branches, half the code: 1-2.5 % faster than the two-copy version,
+    ablation 'two')"""
+    i, q = r // 4, r % 4
+    lab("B%d_0" % r)
+    if q == 0:
+        # (the VGPR index applies to vector ALU destinations only: a build with s_set_gpr_idx_idx 0 in front of this
+        # load gives the same bits and is 0.8 % slower)
+        request_record(i + AHEAD)
+    if r == FORCE_WAIT:
+        e("s_waitcnt lgkmcnt(0)")               # descriptors of chains NHALF.. (requested at the step's start)
+    if r == NHALF:
+        load_descriptors(0, NHALF, DSTRIDE)     # chains 0..NHALF-1 of the NEXT step: their registers are free
+    if r < NCHAIN - 1:
+        rn = r + 1
+        if rn % 4 == 0:
+            e("s_waitcnt vmcnt(%d)" % (AHEAD - 1))     # record of chain rn
+        select(r)
+        fma4(r, 0)
+        br("s_cbranch_scc0", "B%d_0" % rn)          # the next chain stays in the cell
+        idx0()
+        addresses(rn, 0)
+        reads(0)
+        lgkm0()
+    else:
+        e("s_sub_u32 s%d, s%d, 1" % (S_NSTEP, S_NSTEP))
+        e("s_cmp_eq_u32 s%d, 0" % S_NSTEP)
+        br("s_cbranch_scc1", "LAST_0")
+        e("s_waitcnt vmcnt(%d)" % (AHEAD - 1))
+        e("s_add_u32 s%d, s%d, %d" % (S_WP, S_WP, WSTRIDE))
+        e("s_addc_u32 s%d, s%d, 0" % (S_WP + 1, S_WP + 1))
+        e("s_add_u32 s%d, s%d, %d" % (S_DP, S_DP, DSTRIDE))
+        e("s_addc_u32 s%d, s%d, 0" % (S_DP + 1, S_DP + 1))
+        select(r)
+        fma4(r, 0)
+        e("s_waitcnt lgkmcnt(0)")
+        idx0()
+        addresses(0, 0)
+        e("s_barrier")
+        reads(0)
+        lgkm0()
+        load_descriptors(NHALF, NCHAIN - NHALF, 0)
+        br("s_branch", "B0_0")
+
+
 def consumer():
     L = base.L
     del L[:]
@@ -231,13 +280,16 @@ def consumer():
     e("s_waitcnt lgkmcnt(0)")                          # rows of chain 0
     base._in_loop[0] = True
     ool = []
-    for p in (0, 1):
+    for p in ((0,) if 'two' not in ABL else (0, 1)):
         for r in range(NCHAIN):
-            block(r, p, ool)
+            if 'two' not in ABL:
+                block_one(r)
+            else:
+                block(r, p, ool)
     for fn in ool:
         fn()
     base._in_loop[0] = False
-    for p in (0, 1):
+    for p in ((0,) if 'two' not in ABL else (0, 1)):
         lab("LAST_%d" % p)
         select(NCHAIN - 1)
         fma4(NCHAIN - 1, p)
@@ -247,7 +299,7 @@ def consumer():
     return list(L)
 
 
-VARIANTS = [set(), {"nofma"}, {"nox"}, {"nonew"}, {"norec"}, {"nonew", "norec"}, {"nonew", "norec", "nofma"}, {"ahead2"}, {"ahead4"}]
+VARIANTS = [set(), {"nofma"}, {"nox"}, {"nonew"}, {"norec"}, {"nonew", "norec"}, {"nonew", "norec", "nofma"}, {"ahead2"}, {"ahead4"}, {"two"}]
 
 
 def main():

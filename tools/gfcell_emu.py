@@ -456,8 +456,11 @@ class Wave(object):
                 imm_off = int(mo.group(1), 0)
                 rest = rest.replace(mo.group(0), "")
             ops = _split_ops(rest)
+            # the VGPR index applies to vector ALU operands only (vector memory loads are issued under a non-zero index by
+            # k_gfstack_runs and land in the registers named: bitwise-correct on the GPU); LDS instructions are kept
+            # behind index 0 by the programs
             if self.idx_en and (self.m0 & 0xFF) and (op.startswith("v_") and op != "v_fmac_f64_dpp"
-                                                      or op.startswith("ds_") or op.startswith("global_")):
+                                                      or op.startswith("ds_")):
                 raise RuntimeError("%s executed with a non-zero VGPR index" % op)
             # ------------------------------------------------ scalar
             if op in ("s_nop", "s_waitcnt"):

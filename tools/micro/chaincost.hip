@@ -69,6 +69,14 @@ __global__ void __launch_bounds__(1024) k_rate(double *out, const double *w, int
                          "s_mov_b32 s24, 0x4000\n\ts_mov_b32 s25, 0x4003\n\ts_mov_b32 s26, 0x4001\n\ts_mov_b32 s27, 0x4006\n\t"
                          ONEB(24) ONEB(25) ONEB(26) ONEB(27) ONEB(24) ONEB(25) ONEB(26) ONEB(27) EPI
                          : : "v"(wv), "v"(xv), "s"(packed) : CLOB, "s24", "s25", "s26", "s27");
+        } else if (WHICH == 9) {
+            // taken short forward branch per chain: the new-cell block inline behind the FMAs, skipped by the chains that stay
+#define SKIPPED "s_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\t"
+#define ONET(R, L) "s_add_u32 m0, s" #R ", s" #R "\n\t" FMA4 "s_cbranch_scc0 T" #L "%=\n\t" SKIPPED "T" #L "%=:\n\t"
+            asm volatile("s_mov_b32 s20, 0\n\ts_set_gpr_idx_on s20, 0x8\n\t"
+                         "s_mov_b32 s24, 0x4000\n\ts_mov_b32 s25, 0x4003\n\ts_mov_b32 s26, 0x4001\n\ts_mov_b32 s27, 0x4006\n\t"
+                         ONET(24, a) ONET(25, b) ONET(26, c) ONET(27, d) ONET(24, e) ONET(25, f) ONET(26, g) ONET(27, h) EPI
+                         : : "v"(wv), "v"(xv), "s"(packed) : CLOB, "s24", "s25", "s26", "s27");
         } else if (WHICH == 7) {
 #define ONEV(L) "v_readlane_b32 s21, %2, " #L "\n\ts_add_u32 m0, s21, s21\n\ts_cbranch_scc1 OUT%=\n\ts_waitcnt lgkmcnt(0)\n\t" FMA4
             asm volatile("s_mov_b32 s20, 0\n\ts_set_gpr_idx_on s20, 0x8\n\t"
@@ -136,6 +144,7 @@ int main()
     run<3>("shipped path without the FMAs", out, w, cyc, packed);
     run<6>("s_add_u32 m0 (+SCC) + cbranch + wait + 4 FMA", out, w, cyc, packed);
     run<8>("s_add_u32 m0 + 4 FMA back to back", out, w, cyc, packed);
+    run<9>("s_add_u32 m0 + 4 FMA + TAKEN branch over 12 instr", out, w, cyc, packed);
     run<7>("v_readlane + s_add_u32 m0 + cbranch + wait + 4 FMA", out, w, cyc, packed);
     return 0;
 }
