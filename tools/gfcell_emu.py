@@ -640,6 +640,20 @@ class Wave(object):
                 for i in np.nonzero(self.lanes())[0]:
                     assert 0 <= addr[i] and addr[i] + 16 <= lds.size and addr[i] % 16 == 0, ("LDS write", ln, addr[i])
                     lds[addr[i]:addr[i] + 16].view(np.uint32)[:] = [self.v[d + kk][i] for kk in range(4)]
+            elif op == "ds_read2_b64":
+                # two 8-byte reads at addr + offset0 * 8 and addr + offset1 * 8 -> v[d:d+1], v[d+2:d+3]
+                o0 = int(re.search(r"offset0:(\d+)", ln).group(1)) if "offset0:" in ln else 0
+                o1 = int(re.search(r"offset1:(\d+)", ln).group(1)) if "offset1:" in ln else 0
+                d = int(re.match(r"v\[(\d+):(\d+)\]", ops[0]).group(1))
+                areg = re.sub(r"\s+offset[01]:\d+", "", ops[1]).strip()
+                base_a = self.v[self.vreg(areg)].astype(np.int64)
+                for half, o in enumerate((o0, o1)):
+                    addr = base_a + 8 * o
+                    for i in np.nonzero(self.lanes())[0]:
+                        if not (0 <= addr[i] and addr[i] + 8 <= lds.size):
+                            raise IndexError("LDS read out of range: %s lane %d addr %d" % (ln, i, addr[i]))
+                        w = lds[addr[i]:addr[i] + 8].view(np.uint32)
+                        self.v[d + 2 * half][i], self.v[d + 2 * half + 1][i] = w[0], w[1]
             elif op in ("ds_read_b32", "ds_read_b64", "ds_write_b64"):
                 off = imm_off
                 m = self.lanes()
