@@ -488,6 +488,22 @@ def test_multilinear_with_several_slip_variables_through_the_runs_kernel(ctx, mo
     assert ctx.last_kernel().startswith("k_gfstack_ml<%d," % mode), ctx.last_kernel()
     assert np.array_equal(B, B2)
     monkeypatch.delenv("BEATAMD_GS_RUNS")
+    # the chain order is scheduling only: hypocentre keys of the model path (default), start-time index keys, input order
+    for knob, val in (("BEATAMD_GC_KEYS", "0"), ("BEATAMD_GC_SORT", "0")):
+        monkeypatch.setenv(knob, val)
+        B3 = f.batch(Q)
+        assert ctx.last_kernel().startswith("k_gfstack_runs<%d," % mode), ctx.last_kernel()
+        assert np.array_equal(B, B3), knob
+        monkeypatch.delenv(knob)
+    # ... also when the keys are NaN / inf for some chains (proposals outside everything): any place will do
+    Qn = Q.copy()
+    lay = host["layout"]
+    Qn[7, lay.offset("nucleation_strike")] = np.nan
+    Qn[500, lay.offset("nucleation_dip")] = np.inf
+    Bn = f.batch(Qn)
+    keep = np.ones(len(Q), dtype=bool)
+    keep[[7, 500]] = False
+    assert np.array_equal(Bn[keep], B[keep])
     monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
     A = f.batch(Q)
     assert ctx.last_kernel().startswith("k_gfstack<1,%d," % nvar), ctx.last_kernel()
