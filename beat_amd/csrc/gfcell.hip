@@ -736,6 +736,7 @@ __global__ void __launch_bounds__(1024) k_gfstack_mlr(GcArgs a)
         if constexpr (VAR == 7) { if (wave < GC_NCONS) { GR_CONSUMER_7(paddr); } else { GC_LOADER_0_1(paddr); } }
         if constexpr (VAR == 8) { if (wave < GC_NCONS) { GR_CONSUMER_8(paddr); } else { GC_LOADER_0_1(paddr); } }
         if constexpr (VAR == 9) { if (wave < GC_NCONS) { GR_CONSUMER_9(paddr); } else { GC_LOADER_0_1(paddr); } }
+        if constexpr (VAR == 10) { if (wave < GC_NCONS) { GR_CONSUMER_10(paddr); } else { GC_LOADER_0_1(paddr); } }
 #endif
         return;
     }
@@ -877,7 +878,7 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
         if (runs) {
             const int var = env_int("BEATAMD_GR_VAR", 0);
             void (*vk[])(GcArgs) = {kern, k_gfstack_mlr<1, 1, 1>, k_gfstack_mlr<1, 2, 1>, k_gfstack_mlr<1, 3, 1>, k_gfstack_mlr<1, 4, 1>, k_gfstack_mlr<1, 5, 1>,
-                                    k_gfstack_mlr<1, 6, 1>, k_gfstack_mlr<1, 7, 1>, k_gfstack_mlr<1, 8, 1>, k_gfstack_mlr<1, 9, 1>};
+                                    k_gfstack_mlr<1, 6, 1>, k_gfstack_mlr<1, 7, 1>, k_gfstack_mlr<1, 8, 1>, k_gfstack_mlr<1, 9, 1>, k_gfstack_mlr<1, 10, 1>};
             if (var >= 1 && var < GR_NVARIANT) kern = vk[var];
         }
 #endif

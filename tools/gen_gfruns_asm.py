@@ -96,6 +96,12 @@ def request_record(i):
     r = rec_w(i)
     if 'norec' in ABL and base._in_loop[0]:
         return
+    if 'rec16' in ABL and base._in_loop[0]:
+        # timing only: 16 lanes fetch (a quarter of the bytes through the texture path; rows 1-3 of the weights stale)
+        e("s_mov_b64 exec, 0xffff")
+        e("global_load_dwordx2 v[%d:%d], v%d, %s offset:%d" % (r, r + 1, V_L16, sp(S_WP), i * REC))
+        e("s_mov_b64 exec, -1")
+        return
     e("global_load_dwordx2 v[%d:%d], v%d, %s offset:%d" % (r, r + 1, V_L16, sp(S_WP), i * REC))
 
 
@@ -301,7 +307,7 @@ def consumer():
     return list(L)
 
 
-VARIANTS = [set(), {"nofma"}, {"nox"}, {"nonew"}, {"norec"}, {"nonew", "norec"}, {"nonew", "norec", "nofma"}, {"ahead2"}, {"ahead4"}, {"two"}]
+VARIANTS = [set(), {"nofma"}, {"nox"}, {"nonew"}, {"norec"}, {"nonew", "norec"}, {"nonew", "norec", "nofma"}, {"ahead2"}, {"ahead4"}, {"two"}, {"rec16"}]
 
 
 def main():
