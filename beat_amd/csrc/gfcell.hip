@@ -522,15 +522,15 @@ struct GmTabArgs {
     ChainVec slips[4];
     const uint32_t *order;        // [ngroups*GC_CG]
     char *wtab;                   // [(g*T+t)][consumer][step 0..nsteps][GM_NREC] records of 16 entries {weight, dword, pad}
-                                  // (RUNS: GR_REC-byte records of 16 weights)
+                                  // (RUNS: GR_PAIR-byte record pairs of 2 x 16 weights)
     uint32_t *ltab;               // [(g*T+t)][step 0..nsteps+2][loader][32 dwords]: count, row requests
     uint32_t *ucount;             // [(g*T+t)*P+p] row segments the loaders move (statistics)
     uint32_t *dtab;               // RUNS: [(g*T+t)][consumer][step 0..nsteps][GR_DLINE] chain descriptors (scalar loads)
 };
 
 // one workgroup per (group, target, patch); thread <-> chain slot of the group order.
-// RUNS (k_gfstack_runs): the chains of a wavefront are written in CELL ORDER; records hold the weights only (GR_REC
-// bytes per four chains) and the descriptor line of the (wavefront, step) two dwords per sorted position:
+// RUNS (k_gfstack_runs): the chains of a wavefront are written in CELL ORDER; records hold the weights only (GR_PAIR
+// bytes per eight chains) and the descriptor line of the (wavefront, step) two dwords per sorted position:
 // GR_D_BASE | chain slot | "the next position opens a new cell" << 31 (the program reads rows only then), and the
 // LDS slots of the chain's row pairs, A | B << 16 (tools/gen_gfruns_asm.py).
 template <int RUNS>
@@ -637,10 +637,12 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
         // a dead chain slot reads slot 0 of the buffer (its accumulator is never stored)
         const int q = r & 3;
         if constexpr (RUNS) {
-            // weights only (16 x f64 per four chains); slots and accumulator in the descriptor line
-            char *rec = a.wtab + ((gt * GC_NCONS + w) * (a.nsteps + 1) + s) * (int64_t)GR_WSTRIDE + (r >> 2) * GR_REC;
+            // weights only: a 256-byte record pair serves eight chains, entry e = {weight e of record 2p, of record 2p + 1};
+            // slots and accumulator in the descriptor line
+            char *rec = a.wtab + ((gt * GC_NCONS + w) * (a.nsteps + 1) + s) * (int64_t)GR_WSTRIDE + (r >> 3) * GR_PAIR +
+                        ((r >> 2) & 1) * 8;
             for (int k = 0; k < 4; k++)
-                *reinterpret_cast<double *>(rec + (4 * q + k) * 8) = fr[k] * sl;      // base.py:676-679 x slip, as k_gfstack
+                *reinterpret_cast<double *>(rec + (4 * q + k) * 16) = fr[k] * sl;     // base.py:676-679 x slip, as k_gfstack
             const uint32_t next_opens = (r + 1 < GC_NCHAIN) ? (uint32_t)(pk8[w * GC_NCHAIN + r + 1] >> 7) : 0u;
             uint32_t *dl = a.dtab + ((gt * GC_NCONS + w) * (a.nsteps + 1) + s) * GR_DLINE +
                            (r < GR_NHALF ? 2 * r : GR_DHALF + 2 * (r - GR_NHALF));

@@ -15,10 +15,13 @@ instructions of control per batch record.  tools/micro/m0cost.hip showed that th
 when the index comes from the SCALAR side (~2 cycles next to four FMAs, nothing at four waves per SIMD).  So:
 
   * per patch the chains of a wavefront are visited in CELL ORDER (k_gm_tables<1> sorts them);
-  * the record stream carries ONLY the weights: one 16-lane-replicated global_load_dwordx2 per four chains (sixteen
-    weights, what row_newbcast needs), in a ring of TEN register pairs, nine records = a whole step ahead.  The
-    records come from the far side of the L2 (14 MB per call, read by 4096 workgroups) while the loaders pull
-    3 TB/s through it: with four records ahead the kernel took 13.1 ms, with two 14.6 ms (profiles/r4_variants.md);
+  * the record stream carries ONLY the weights: one 16-lane-replicated global_load_dwordx4 per EIGHT chains (entry
+    l mod 16 of a 256-byte record pair = {weight l mod 16 of the first four chains, of the second four}: what
+    row_newbcast needs), in a ring of five register quads, four pairs = 32 chains ahead.  The records come from the
+    far side of the L2 (7 MB per call, read by 4096 workgroups) while the loaders pull 3 TB/s through it: with 16
+    chains ahead the kernel took 13.1 ms, with 8 ahead 14.6 ms (profiles/r4_variants.md).  What the records cost is
+    their instructions (a load and a wait), not their bytes (a build fetching with 16 lanes is not faster): hence
+    eight chains per load;
   * TWO DWORDS PER CHAIN in scalar registers (scalar loads from a second table, one 80-dword line per wavefront and
     step): d = 0x4000 | accumulator slot | "the NEXT chain opens a new cell" << 31 and the LDS slots of the chain's two
     row pairs (A | B << 16).  A single scalar instruction, s_add_u32 m0, d, d, both selects the accumulator
@@ -51,14 +54,15 @@ import gen_gfml_asm as ml  # noqa: E402
 e, lab, br, vp, sp, readlane = base.e, base.lab, base.br, base.vp, base.sp, base.readlane
 
 NCHAIN, NREC = ml.NCHAIN, ml.NREC
-REC = 128             # bytes per record: the sixteen weights of four chains
-WSTRIDE = NREC * REC  # bytes per (wavefront, step) in the record table
-NRING = NREC          # register pairs of the record ring (ring position = record index: static)
-AHEAD = NRING - 1     # records requested ahead: a whole step
-assert (NREC + AHEAD) * REC < 4096      # 13-bit immediate offsets of global_load
+NPAIR = NREC // 2     # a vector load brings the weights of EIGHT chains (two records of four): half the loads and waits
+PAIR = 256            # bytes per record pair: sixteen entries {weight of record 2p, weight of record 2p + 1}
+WSTRIDE = NPAIR * PAIR  # bytes per (wavefront, step) in the record table
+NRING = NPAIR         # register quads of the record ring (ring position = pair index: static)
+AHEAD = NRING - 1     # record pairs requested ahead (32 chains)
+assert NREC % 2 == 0 and (NPAIR + AHEAD) * PAIR < 4096      # 13-bit immediate offsets of global_load
 V_RING, V_T0, V_PAR, V_AD, V_L16, XA, XB, RREC, ACC, V_LAST = (ml.V_RING, ml.V_T0, ml.V_PAR, ml.V_AD, ml.V_L16, ml.XA,
                                                                ml.XB, ml.RREC, ml.ACC, ml.V_LAST)
-assert RREC + 2 * NRING <= ACC
+assert RREC + 4 * NRING <= ACC
 S_NSTEP, S_WP, S_RB0 = ml.S_NSTEP, ml.S_WP, ml.S_RB0
 T0, T1 = base.T0, base.T1
 S_ZERO = 3            # 0: accumulator offset of every instruction that is not a chain's FMA
@@ -77,7 +81,8 @@ ABL = set()           # timing experiments: 'nofma', 'nox', 'nonew', 'norec', 'a
 
 
 def rec_w(i):
-    return RREC + 2 * (i % NRING)
+    """register pair with the sixteen weights of record i (four chains)"""
+    return RREC + 4 * ((i // 2) % NRING) + 2 * (i % 2)
 
 
 def dreg(r):
@@ -92,17 +97,17 @@ def idx0():
     e("s_set_gpr_idx_idx s%d" % S_ZERO)
 
 
-def request_record(i):
-    r = rec_w(i)
+def request_pair(p):
+    r = RREC + 4 * (p % NRING)
     if 'norec' in ABL and base._in_loop[0]:
         return
     if 'rec16' in ABL and base._in_loop[0]:
         # timing only: 16 lanes fetch (a quarter of the bytes through the texture path; rows 1-3 of the weights stale)
         e("s_mov_b64 exec, 0xffff")
-        e("global_load_dwordx2 v[%d:%d], v%d, %s offset:%d" % (r, r + 1, V_L16, sp(S_WP), i * REC))
+        e("global_load_dwordx4 v[%d:%d], v%d, %s offset:%d" % (r, r + 3, V_L16, sp(S_WP), p * PAIR))
         e("s_mov_b64 exec, -1")
         return
-    e("global_load_dwordx2 v[%d:%d], v%d, %s offset:%d" % (r, r + 1, V_L16, sp(S_WP), i * REC))
+    e("global_load_dwordx4 v[%d:%d], v%d, %s offset:%d" % (r, r + 3, V_L16, sp(S_WP), p * PAIR))
 
 
 def load_descriptors(first, count, byte_off):
@@ -162,17 +167,16 @@ def block(r, p, out_of_line):
     """chain at sorted position r with its cell's rows (landed) in set p"""
     i, q = r // 4, r % 4
     lab("B%d_%d" % (r, p))
-    if q == 0:
-        idx0()                                  # (vector memory instructions take the index as well)
-        request_record(i + AHEAD)
+    if r % 8 == 0:
+        request_pair(r // 8 + AHEAD)
     if r == FORCE_WAIT:
         e("s_waitcnt lgkmcnt(0)")               # descriptors of chains NHALF.. (requested at the step's start)
     if r == NHALF:
         load_descriptors(0, NHALF, DSTRIDE)     # chains 0..NHALF-1 of the NEXT step: their registers are free
     if r < NCHAIN - 1:
         rn = r + 1
-        if rn % 4 == 0:
-            e("s_waitcnt vmcnt(%d)" % (AHEAD - 1))     # record of chain rn
+        if rn % 8 == 0:
+            e("s_waitcnt vmcnt(%d)" % (AHEAD - 1))     # record pair of chain rn
         select(r)
         if 'nonew' not in ABL:
             br("s_cbranch_scc1", "N%d_%d" % (r, p))
@@ -218,18 +222,18 @@ def block_one(r):
     ablation 'two')"""
     i, q = r // 4, r % 4
     lab("B%d_0" % r)
-    if q == 0:
+    if r % 8 == 0:
         # (the VGPR index applies to vector ALU destinations only: a build with s_set_gpr_idx_idx 0 in front of this
         # load gives the same bits and is 0.8 % slower)
-        request_record(i + AHEAD)
+        request_pair(r // 8 + AHEAD)
     if r == FORCE_WAIT:
         e("s_waitcnt lgkmcnt(0)")               # descriptors of chains NHALF.. (requested at the step's start)
     if r == NHALF:
         load_descriptors(0, NHALF, DSTRIDE)     # chains 0..NHALF-1 of the NEXT step: their registers are free
     if r < NCHAIN - 1:
         rn = r + 1
-        if rn % 4 == 0:
-            e("s_waitcnt vmcnt(%d)" % (AHEAD - 1))     # record of chain rn
+        if rn % 8 == 0:
+            e("s_waitcnt vmcnt(%d)" % (AHEAD - 1))     # record pair of chain rn
         select(r)
         fma4(r, 0)
         br("s_cbranch_scc0", "B%d_0" % rn)          # the next chain stays in the cell
@@ -264,7 +268,7 @@ def consumer():
     base.lane_setup()
     e("v_lshlrev_b32 v%d, 3, v%d" % (V_RING, V_T0))
     e("v_and_b32 v%d, 15, v%d" % (V_L16, V_T0))
-    e("v_lshlrev_b32 v%d, 3, v%d" % (V_L16, V_L16))    # (lane % 16) * 8: a lane's weight of a record
+    e("v_lshlrev_b32 v%d, 4, v%d" % (V_L16, V_L16))    # (lane % 16) * 16: a lane's entry of a record pair
     base.read_params()
     for sreg, k in ((S_WP, base.P_WP), (S_WP + 1, base.P_WP + 1), (S_RB0, base.P_RB0), (S_NSTEP, base.P_NSTEP),
                     (S_DP, base.P_DP), (S_DP + 1, base.P_DP + 1)):
@@ -274,7 +278,7 @@ def consumer():
     load_descriptors(0, NHALF, 0)
     load_descriptors(NHALF, NCHAIN - NHALF, 0)
     for r in range(AHEAD):
-        request_record(r)
+        request_pair(r)
     for j in range(NCHAIN):
         e("v_mov_b32 v%d, 0" % (ACC + 2 * j))
         e("v_mov_b32 v%d, 0" % (ACC + 2 * j + 1))
@@ -307,7 +311,7 @@ def consumer():
     return list(L)
 
 
-VARIANTS = [set(), {"nofma"}, {"nox"}, {"nonew"}, {"norec"}, {"nonew", "norec"}, {"nonew", "norec", "nofma"}, {"ahead2"}, {"ahead4"}, {"two"}, {"rec16"}]
+VARIANTS = [set(), {"nofma"}, {"nox"}, {"nonew"}, {"norec"}, {"nonew", "norec"}, {"nonew", "norec", "nofma"}, {"ahead2"}, {"two"}, {"rec16"}]
 
 
 def main():
@@ -315,7 +319,7 @@ def main():
     with open(out, "w") as f:
         f.write("// generated by tools/gen_gfruns_asm.py -- do not edit\n")
         f.write("// the consumer wavefront program of k_gfstack_runs (see gfcell.hip and the generator)\n")
-        for name, val in (("REC", REC), ("WSTRIDE", WSTRIDE), ("NHALF", NHALF), ("DLINE", DLINE), ("DHALF", DHALF),
+        for name, val in (("PAIR", PAIR), ("WSTRIDE", WSTRIDE), ("NHALF", NHALF), ("DLINE", DLINE), ("DHALF", DHALF),
                           ("D_BASE", D_BASE)):
             f.write("#define GR_%s %d\n" % (name, val))
         variants = VARIANTS if os.environ.get("GR_ABLATIONS") else VARIANTS[:1]
@@ -325,7 +329,7 @@ def main():
             ABL.clear()
             ABL.update(abl)
             global AHEAD
-            AHEAD = 2 if "ahead2" in abl else 4 if "ahead4" in abl else NRING - 1
+            AHEAD = 2 if "ahead2" in abl else NRING - 1
             f.write("#define GR_CONSUMER_%d(PARAM_VGPR) asm volatile( \\\n" % vi)
             for line in consumer():
                 f.write('    "%s\\n\\t" \\\n' % line)

@@ -274,9 +274,10 @@ def gm_tables(rowoff, fac, slips, order, C, T, P, D, S, runs=False, nvar=1):
                           c = int(ids[k]) if live[k] else 0
                           wv = [(fac[c, t, p, kk] * slips[iv][c, p]) if live[k] else 0.0 for kk in range(4)]
                           if runs:
-                              rec = ((gt * NCONS + w) * (nsteps + 1) + s) * genruns.WSTRIDE + (r // 4) * genruns.REC
+                              rec = (((gt * NCONS + w) * (nsteps + 1) + s) * genruns.WSTRIDE + (r // 8) * genruns.PAIR +
+                                     ((r // 4) % 2) * 8)
                               for kk in range(4):
-                                  wtab[rec + (4 * q + kk) * 8:rec + (4 * q + kk) * 8 + 8].view(np.float64)[0] = wv[kk]
+                                  wtab[rec + (4 * q + kk) * 16:rec + (4 * q + kk) * 16 + 8].view(np.float64)[0] = wv[kk]
                               nxt = 1 if (r + 1 < NCH and opens_at(r + 1)) else 0
                               dl = ((gt * NCONS + w) * (nsteps + 1) + s) * genruns.DLINE + genruns.ddword(r)
                               dtab[dl] = genruns.D_BASE | j | (nxt << 31)
