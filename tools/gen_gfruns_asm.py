@@ -30,7 +30,7 @@ when the index comes from the SCALAR side (~2 cycles next to four FMAs, nothing 
     per SIMD as four bare FMAs, 10.2 ns with the three scalar instructions of the first version (s_bitcmp1 on a
     packed dword fetched by v_readlane, s_bfe_u32, s_set_gpr_idx_idx) and 9.3-9.7 ns with this one;
   * rows are read only when the NEXT chain opens a new cell: behind the chain's own FMAs, into the SAME eight row
-    registers (two scalar unpacks, two v_lshl_add_u32, four ds_read_b64, s_waitcnt) -- one short scalar branch per chain
+    registers (two v_mad_u32_u16 on the halves of the slot dword, four ds_read_b64, s_waitcnt) -- one short scalar branch per chain
     that stays in its cell, nothing out of line.  (The first versions kept two row sets and two copies of the loop, so
     that the reads could be issued before the FMAs and waited for behind them: ablation 'two'.  It is 0-2.5 % slower:
     what counts is instructions and branches per wavefront, not the cover of an LDS round trip;
@@ -122,12 +122,15 @@ def load_descriptors(first, count, byte_off):
         reg, dw, n_left = reg + n, dw + n, n_left - n
 
 
+V_C512 = 2            # 512: bytes per LDS row slot (v_mad_u32_u16 takes one scalar operand only)
+
+
 def addresses(j, xset):
-    """LDS addresses of the two row pairs of the chain at sorted position j (index 0 must be in force)"""
-    e("s_and_b32 s%d, s%d, 0xffff" % (T0, dreg(j) + 1))
-    e("s_lshr_b32 s%d, s%d, 16" % (T1, dreg(j) + 1))
-    e("v_lshl_add_u32 v%d, s%d, 9, v%d" % (V_AD + 2 * xset, T0, V_RING))
-    e("v_lshl_add_u32 v%d, s%d, 9, v%d" % (V_AD + 2 * xset + 1, T1, V_RING))
+    """LDS addresses of the two row pairs of the chain at sorted position j (index 0 must be in force): slot halves of
+    the chain's second descriptor dword x 512 + the lane's address in the row ring -- v_mad_u32_u16 picks the half
+    itself (no scalar unpacking)"""
+    e("v_mad_u32_u16 v%d, s%d, v%d, v%d" % (V_AD + 2 * xset, dreg(j) + 1, V_C512, V_RING))
+    e("v_mad_u32_u16 v%d, s%d, v%d, v%d op_sel:[1,0,0,0]" % (V_AD + 2 * xset + 1, dreg(j) + 1, V_C512, V_RING))
 
 
 def reads(xset):
@@ -275,6 +278,7 @@ def consumer():
         readlane(sreg, k)
     e("s_nop 4")
     e("v_add_u32 v%d, s%d, v%d" % (V_RING, S_RB0, V_RING))
+    e("v_mov_b32 v%d, 0x200" % V_C512)
     load_descriptors(0, NHALF, 0)
     load_descriptors(NHALF, NCHAIN - NHALF, 0)
     for r in range(AHEAD):

@@ -558,6 +558,14 @@ class Wave(object):
             elif op == "v_lshl_add_u32":
                 self.wr32(self.vreg(ops[0]), (self.src32(ops[1]).astype(np.uint64) << np.uint64(self.get_s32(ops[2])))
                           + self.src32(ops[3]))
+            elif op == "v_mad_u32_u16":
+                # D = S0.u16 * S1.u16 + S2.u32; op_sel:[a,b,c,d]: high halves of src0 / src1
+                sel = re.search(r"op_sel:\[(\d),(\d),(\d),(\d)\]", ln)
+                o3 = re.sub(r"\s+op_sel:\[[\d,]+\]", "", ops[3]).strip()
+                h0, h1 = (int(sel.group(1)), int(sel.group(2))) if sel else (0, 0)
+                a_ = (self.src32(ops[1]).astype(np.uint64) >> (16 * h0)) & 0xFFFF
+                b_ = (self.src32(ops[2]).astype(np.uint64) >> (16 * h1)) & 0xFFFF
+                self.wr32(self.vreg(ops[0]), (a_ * b_ + self.src32(o3).astype(np.uint64)) & 0xFFFFFFFF)
             elif op == "v_mad_u32_u24":
                 self.wr32(self.vreg(ops[0]), (self.src32(ops[1]).astype(np.uint64) & np.uint64(0xFFFFFF))
                           * (self.src32(ops[2]).astype(np.uint64) & np.uint64(0xFFFFFF)) + self.src32(ops[3]))
