@@ -1398,14 +1398,21 @@ k_gfstack_ws(GsArgs a)
     __builtin_amdgcn_sched_barrier(0);
     fetch_tabs(tab_slot(p1), tab_w(p1, iv1));
     advance(p1, iv1);
+    // The tables of step s+2 as RUNNING pointers (round 4).  The loop is sensitive to every scalar instruction -- 28
+    // dummy s_add_u32 per step cost 5 % -- and rebuilding both pointers from (patch, variable) with the clamp at the last
+    // step took ~25 of them.  Now: five scalar instructions pick the increments (hand-written: hipcc turns the same
+    // selects into a dozen), four add them, behind the fetch at the end of the step.  No clamp: the pointers run up to two
+    // steps past the last one, into padding the launcher allocates (values fetched there are never used).
+    const char *ps_run = tab_slot(p1), *pw_run = tab_w(p1, iv1);
+    int iv_run = iv1;                                                                     // variable the pointers stand at
+    const int64_t dw_next = (nvar == 1) ? (int64_t)w_step : w_var_bytes;                  // next variable of the patch
+    const int64_t dw_wrap = (int64_t)w_step - (int64_t)(nvar - 1) * w_var_bytes;          // first variable, next patch
 #pragma clang loop unroll(disable)
     for (int s = 0; s < nsteps; s++) {
         // all scalar bookkeeping of the step first: hipcc sinks FMAs into any block that follows the
         // gather, so nothing below may branch
         int gnext = gbuf + bufsz;
         if (gnext == ring) gnext = 0;
-        const char *const ps2 = tab_slot(p1), *const pw2 = tab_w(p1, iv1);   // tables of step s+2
-        advance(p1, iv1);
         __builtin_amdgcn_sched_barrier(0);
         // One asm statement per gather group: wait for the group's reads, its 8 FMAs, and the reads
         // of the group after next into the registers just consumed (v_fmac_f64 d, x, w = fma(x, w, d)).
@@ -1471,7 +1478,20 @@ k_gfstack_ws(GsArgs a)
 #undef BA_ACC8
 #undef BA_RD8
 #undef BA_FMA8
-        fetch_tabs(ps2, pw2);           // slot / weight of step s+2
+        fetch_tabs(ps_run, pw_run);     // slot / weight of step s+2
+        {
+            // patch-major over (patch, variable): the slot table moves on with the patch, the weight table every step
+            uint32_t ds;
+            int64_t dw;
+            asm("s_add_i32 %0, %0, 1\n\t"
+                "s_cmp_eq_u32 %0, %3\n\t"
+                "s_cselect_b32 %0, 0, %0\n\t"
+                "s_cselect_b32 %1, %4, 0\n\t"
+                "s_cselect_b64 %2, %5, %6"
+                : "+s"(iv_run), "=s"(ds), "=s"(dw) : "s"(nvar), "s"(slot_step), "s"(dw_wrap), "s"(dw_next) : "scc");
+            ps_run += ds;
+            pw_run += dw;
+        }
     }
     // drain the reads issued for the step after the last (their registers stay reserved until here)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
@@ -2040,10 +2060,11 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     ga.uent = (uint32_t *)p;
     BA_TRY(ctx->get_scratch(SL_GS_UCOUNT, (size_t)GTP * sizeof(uint32_t), &p));
     ga.ucount = (uint32_t *)p;
-    BA_TRY(ctx->get_scratch(SL_GS_SLOT, (size_t)GTP * nrow * CG * sizeof(uint16_t), &p));
+    // (+ 3 steps of padding behind both tables: k_gfstack_ws runs its table pointers past the last step)
+    BA_TRY(ctx->get_scratch(SL_GS_SLOT, (size_t)(GTP + 3) * nrow * CG * sizeof(uint16_t), &p));
     ga.slot = (uint16_t *)p;
     ga.w_var_stride = (nrow == 1) ? ngroups * L.P * CG : GTP * 4 * CG;
-    BA_TRY(ctx->get_scratch(SL_GS_W, (size_t)ga.w_var_stride * k.nvar * sizeof(double), &p));
+    BA_TRY(ctx->get_scratch(SL_GS_W, ((size_t)ga.w_var_stride * k.nvar + (size_t)3 * 4 * CG) * sizeof(double), &p));
     ga.w = (double *)p;
     const bool fit_lds = CG <= 128 && !(getenv("BEATAMD_GS_FIT") && atoi(getenv("BEATAMD_GS_FIT")) == 0);
     ga.umax = nullptr;
