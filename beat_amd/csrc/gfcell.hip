@@ -541,7 +541,7 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
     __shared__ uint32_t nreq_s;
     __shared__ uint32_t keys[RUNS ? GC_CG : 1];
     __shared__ uint8_t srt[RUNS ? GC_CG : 1];
-    __shared__ uint8_t pk8[RUNS ? GC_CG : 1];
+    __shared__ uint8_t opens_at[RUNS ? GC_CG : 1];   // sorted position -> the chain there opens a new cell
     const int tid = threadIdx.x;
     const int64_t gtp = blockIdx.x;
     const int64_t p = gtp % a.P;
@@ -615,7 +615,7 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
         if (slot) {
             // a chain opens a cell when its key differs from its predecessor's; dead slots ride on the rows in place
             opens = live && (r == 0 || keys[w * GC_NCHAIN + srt[w * GC_NCHAIN + r - 1]] != key);
-            pk8[w * GC_NCHAIN + r] = (uint8_t)((2 * j) | (opens ? 0x80 : 0));
+            opens_at[w * GC_NCHAIN + r] = opens ? 1 : 0;
         }
         __syncthreads();
     }
@@ -643,7 +643,7 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
                         ((r >> 2) & 1) * 8;
             for (int k = 0; k < 4; k++)
                 *reinterpret_cast<double *>(rec + (4 * q + k) * 16) = fr[k] * sl;     // base.py:676-679 x slip, as k_gfstack
-            const uint32_t next_opens = (r + 1 < GC_NCHAIN) ? (uint32_t)(pk8[w * GC_NCHAIN + r + 1] >> 7) : 0u;
+            const uint32_t next_opens = (r + 1 < GC_NCHAIN) ? (uint32_t)opens_at[w * GC_NCHAIN + r + 1] : 0u;
             uint32_t *dl = a.dtab + ((gt * GC_NCONS + w) * (a.nsteps + 1) + s) * GR_DLINE +
                            (r < GR_NHALF ? 2 * r : GR_DHALF + 2 * (r - GR_NHALF));
             dl[0] = (uint32_t)GR_D_BASE | (uint32_t)j | (next_opens << 31);
