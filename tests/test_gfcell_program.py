@@ -244,3 +244,38 @@ def test_committed_include_is_the_generators_output(tmp_path, monkeypatch):
     genruns.main()
     monkeypatch.undo()
     assert open(str(tmp_path / "gfruns_asm.inc")).read() == committed
+
+
+def test_chain_order_twin_is_a_permutation_whatever_the_keys():
+    """gc_order (numpy twin of k_gc_order): every chain exactly once per group, with caller keys (hypocentre), with
+    start-index keys, with NaN / inf keys (proposals outside everything), for full, partial and single-chain groups; with
+    keys the first key ascends from band to band and the second inside a band"""
+    rng = np.random.default_rng(3)
+    T, P, D, S = 1, 6, 3, 9
+    for C in (1, 36, 37, 518, 519, 1100):
+        st = rng.uniform(0.0, 0.5 * (S - 1) - 0.01, (C, T, P))
+        du = rng.uniform(0.5, 0.5 + 0.5 * (D - 1), (C, P))
+        ro, _ = emu.gf_tables_ml(st, du, 0.0, 0.5, 0.5, 0.5, D, S, T, P)
+        k0, k1 = rng.uniform(0, 20, C), rng.uniform(0, 20, C)
+        for keys in (None, (k0, k1)):
+            if keys is not None and C > 5:
+                keys[0][3], keys[1][4] = np.nan, np.inf
+            order = emu.gc_order(ro, C, T, P, S, True, keys=keys)
+            assert order.size == ((C + emu.CG - 1) // emu.CG) * emu.CG
+            assert sorted(order[order != emu.DEAD].tolist()) == list(range(C))
+            for g in range(order.size // emu.CG):
+                ids = order[g * emu.CG:(g + 1) * emu.CG]
+                live = ids[ids != emu.DEAD]
+                assert np.all(live // emu.CG == g)                      # chains stay in their group
+                assert np.all(ids[:live.size] != emu.DEAD)              # dead slots behind the live ones
+        if C >= 518:
+            order = emu.gc_order(ro, C, T, P, S, True, keys=(k0, k1))
+            ids = order[:emu.CG]
+            nw = emu.CG // emu.NCH
+            band = (np.arange(emu.CG) // emu.NCH) * 4 // nw
+            f0 = np.where(np.abs(k0[ids]) <= 1.79e308, k0[ids], 0.0)
+            f1 = np.where(np.abs(k1[ids]) <= 1.79e308, k1[ids], 0.0)
+            for b in range(3):
+                assert f0[band == b].max() <= f0[band == b + 1].min()
+            for b in range(4):
+                assert np.all(np.diff(f1[band == b]) >= 0)
