@@ -63,33 +63,69 @@ struct GcOrderArgs {
     int sort;
     ChainVec key[2];          // optional caller keys (base == nullptr: start-time indices)
     uint32_t *order;          // [ngroups*GC_CG]: chain id or GC_DEAD
+    // batches of several groups: the chains of the whole batch in the order of the first key (k_gc_members); group g takes
+    // members[g*GC_CG ..] -- a slice of the fault per group: fewer distinct rows to stage, fewer cells per wavefront.
+    // nullptr: group g = chains g*GC_CG .. as they come
+    uint32_t *members;
+    double *key0;             // [C] first keys (scratch of k_gc_members)
 };
+
+__device__ __forceinline__ void gc_keys(const GcOrderArgs &a, int64_t c, double &f0, double &f1)
+{
+    if (a.key[0].base && a.key[1].base) {
+        f0 = a.key[0].base[c * a.key[0].stride + a.key[0].off];
+        f1 = a.key[1].base[c * a.key[1].stride + a.key[1].off];
+        if (!(fabs(f0) <= 1.79e308)) f0 = 0.0;    // (NaN / inf proposals: any place will do, but a total order)
+        if (!(fabs(f1) <= 1.79e308)) f1 = 0.0;
+    } else {
+        const int64_t pm = a.P / 2;
+        f0 = (double)(a.rowoff[((c * a.T) * a.P) * 4 + 3] % (uint32_t)a.S);
+        f1 = (double)(a.rowoff[((c * a.T) * a.P + pm) * 4 + 3] % (uint32_t)a.S);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_gc_key0(GcOrderArgs a)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.C) return;
+    double f0, f1;
+    gc_keys(a, c, f0, f1);
+    a.key0[c] = f0;
+}
+
+// members[rank of chain c by (first key, c)] = c   (C <= GC_MEMBERS_MAX: C*C comparisons)
+constexpr int64_t GC_MEMBERS_MAX = 4096;
+__global__ void __launch_bounds__(256) k_gc_members(GcOrderArgs a)
+{
+    __shared__ double tile[256];
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const double f = c < a.C ? a.key0[c] : 0.0;
+    int64_t rank = 0;
+    for (int64_t k0 = 0; k0 < a.C; k0 += 256) {
+        __syncthreads();
+        tile[threadIdx.x] = (k0 + threadIdx.x < a.C) ? a.key0[k0 + threadIdx.x] : 0.0;
+        __syncthreads();
+        const int n = (int)min((int64_t)256, a.C - k0);
+        for (int k = 0; k < n; k++) rank += (tile[k] < f) || (tile[k] == f && k0 + k < c);
+    }
+    if (c < a.C) a.members[rank] = (uint32_t)c;
+}
 
 __global__ void __launch_bounds__(GC_TB) k_gc_order(GcOrderArgs a)
 {
     __shared__ double ka[GC_CG], kb[GC_CG];
     __shared__ int bnd[GC_CG];
     const int tid = threadIdx.x;
-    const int64_t c = (int64_t)blockIdx.x * GC_CG + tid;
+    const int64_t pos = (int64_t)blockIdx.x * GC_CG + tid;
     const bool slot = tid < GC_CG;
-    const bool live = slot && c < a.C;
+    const bool live = slot && pos < a.C;
     if (!a.sort) {
-        if (slot) a.order[c] = live ? (uint32_t)c : GC_DEAD;
+        if (slot) a.order[pos] = live ? (uint32_t)pos : GC_DEAD;
         return;
     }
+    const int64_t c = (live && a.members) ? (int64_t)a.members[pos] : pos;
     double f0 = 0.0, f1 = 0.0;
-    if (live) {
-        if (a.key[0].base && a.key[1].base) {
-            f0 = a.key[0].base[c * a.key[0].stride + a.key[0].off];
-            f1 = a.key[1].base[c * a.key[1].stride + a.key[1].off];
-            if (!(fabs(f0) <= 1.79e308)) f0 = 0.0;    // (NaN / inf proposals: any place will do, but a total order)
-            if (!(fabs(f1) <= 1.79e308)) f1 = 0.0;
-        } else {
-            const int64_t pm = a.P / 2;
-            f0 = (double)(a.rowoff[((c * a.T) * a.P) * 4 + 3] % (uint32_t)a.S);
-            f1 = (double)(a.rowoff[((c * a.T) * a.P + pm) * 4 + 3] % (uint32_t)a.S);
-        }
-    }
+    if (live) gc_keys(a, c, f0, f1);
     if (slot) { ka[tid] = f0; kb[tid] = f1; }
     __syncthreads();
     const int nlive = (int)min((int64_t)GC_CG, a.C - (int64_t)blockIdx.x * GC_CG);
@@ -110,6 +146,27 @@ __global__ void __launch_bounds__(GC_TB) k_gc_order(GcOrderArgs a)
             r1 += (bnd[k] < b) || (bnd[k] == b && ((kb[k] < f1) || (kb[k] == f1 && k < tid)));
     }
     a.order[(int64_t)blockIdx.x * GC_CG + r1] = live ? (uint32_t)c : GC_DEAD;
+}
+
+// launches the chain order of a batch into oa.order (scratch for members / keys behind it)
+static int launch_gc_order(beatamd_ctx *ctx, GcOrderArgs &oa, int64_t ngroups)
+{
+    void *p = nullptr;
+    const size_t norder = (size_t)(ngroups * GC_CG + 64);
+    const bool global = oa.sort && ngroups > 1 && oa.C <= GC_MEMBERS_MAX && env_int("BEATAMD_GC_GLOBAL", 1) != 0;
+    BA_TRY(ctx->get_scratch(SL_GC_ORDER, norder * sizeof(uint32_t) + (global ? (size_t)oa.C * 12 + 64 : 0), &p));
+    oa.order = (uint32_t *)p;
+    oa.members = nullptr;
+    oa.key0 = nullptr;
+    if (global) {
+        oa.key0 = reinterpret_cast<double *>(((uintptr_t)(oa.order + norder) + 7) & ~(uintptr_t)7);
+        oa.members = reinterpret_cast<uint32_t *>(oa.key0 + oa.C);
+        const unsigned nb = (unsigned)((oa.C + 255) / 256);
+        hipLaunchKernelGGL(k_gc_key0, dim3(nb), dim3(256), 0, ctx->stream, oa);
+        hipLaunchKernelGGL(k_gc_members, dim3(nb), dim3(256), 0, ctx->stream, oa);
+    }
+    hipLaunchKernelGGL(k_gc_order, dim3((unsigned)ngroups), dim3(GC_TB), 0, ctx->stream, oa);
+    return BEATAMD_OK;
 }
 
 // ---------------------------------------------------------------------------- tables
@@ -426,8 +483,7 @@ int launch_gfstack_cell(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *
     oa.C = k.C; oa.T = Ttab; oa.P = L.P; oa.S = L.S; oa.rowoff = rowoff;
     oa.sort = !(getenv("BEATAMD_GC_SORT") && atoi(getenv("BEATAMD_GC_SORT")) == 0);
     if (env_int("BEATAMD_GC_KEYS", 1)) { oa.key[0] = k.order_key[0]; oa.key[1] = k.order_key[1]; }
-    BA_TRY(ctx->get_scratch(SL_GC_ORDER, (size_t)(ngroups * GC_CG + 64) * sizeof(uint32_t), &p));
-    oa.order = (uint32_t *)p;
+    BA_TRY(launch_gc_order(ctx, oa, ngroups));   // (reads the row ids of k_gf_tables, launched before this call)
 
     GcTabArgs ta;
     memset(&ta, 0, sizeof(ta));
@@ -446,7 +502,6 @@ int launch_gfstack_cell(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *
     ta.ucount = (uint32_t *)p;
     {
         ScopedTimer tm(ctx, "grouptables");
-        hipLaunchKernelGGL(k_gc_order, dim3((unsigned)ngroups), dim3(GC_TB), 0, ctx->stream, oa);
         // the request tables behind the last step stay empty
         BA_HIP(hipMemset2DAsync((char *)ta.ltab + (size_t)nsteps * GC_NLOAD * GC_LTAB, lt_pitch, 0,
                                 (size_t)3 * GC_NLOAD * GC_LTAB, (size_t)GT, ctx->stream));
@@ -801,8 +856,7 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
     // (k_gc_order); the static program does not care
     oa.sort = runs ? env_int("BEATAMD_GC_SORT", 1) != 0 : 0;
     if (env_int("BEATAMD_GC_KEYS", 1)) { oa.key[0] = k.order_key[0]; oa.key[1] = k.order_key[1]; }
-    BA_TRY(ctx->get_scratch(SL_GC_ORDER, (size_t)(ngroups * GC_CG + 64) * sizeof(uint32_t), &p));
-    oa.order = (uint32_t *)p;
+    BA_TRY(launch_gc_order(ctx, oa, ngroups));   // (reads the row ids of k_gf_tables, launched before this call)
 
     GmTabArgs ta;
     memset(&ta, 0, sizeof(ta));
@@ -824,7 +878,6 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
     ta.dtab = (uint32_t *)p;
     {
         ScopedTimer tm(ctx, "grouptables");
-        hipLaunchKernelGGL(k_gc_order, dim3((unsigned)ngroups), dim3(GC_TB), 0, ctx->stream, oa);
         // the request tables behind the last step stay empty
         BA_HIP(hipMemset2DAsync((char *)ta.ltab + (size_t)nsteps * GC_NLOAD * GC_LTAB, lt_pitch, 0,
                                 (size_t)3 * GC_NLOAD * GC_LTAB, (size_t)GT, ctx->stream));

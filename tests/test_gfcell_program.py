@@ -263,11 +263,20 @@ def test_chain_order_twin_is_a_permutation_whatever_the_keys():
             order = emu.gc_order(ro, C, T, P, S, True, keys=keys)
             assert order.size == ((C + emu.CG - 1) // emu.CG) * emu.CG
             assert sorted(order[order != emu.DEAD].tolist()) == list(range(C))
-            for g in range(order.size // emu.CG):
+            ngr = order.size // emu.CG
+            for g in range(ngr):
                 ids = order[g * emu.CG:(g + 1) * emu.CG]
                 live = ids[ids != emu.DEAD]
-                assert np.all(live // emu.CG == g)                      # chains stay in their group
+                assert live.size == min(emu.CG, C - g * emu.CG)         # full groups first
                 assert np.all(ids[:live.size] != emu.DEAD)              # dead slots behind the live ones
+            if ngr > 1:
+                # several groups: the batch is cut in the order of the first key (a slice of the fault per group)
+                f0 = (ro[:, 0, 0, 3] % S).astype(float) if keys is None else np.where(np.abs(keys[0]) <= 1.79e308, keys[0], 0.0)
+                for g in range(ngr - 1):
+                    a_, b_ = order[g * emu.CG:(g + 1) * emu.CG], order[(g + 1) * emu.CG:(g + 2) * emu.CG]
+                    assert f0[a_[a_ != emu.DEAD]].max() <= f0[b_[b_ != emu.DEAD]].min()
+                plain = emu.gc_order(ro, C, T, P, S, True, keys=keys, global_members=False)
+                assert all(np.all(plain[g * emu.CG:(g + 1) * emu.CG][:min(emu.CG, C - g * emu.CG)] // emu.CG == g) for g in range(ngr))
         if C >= 518:
             order = emu.gc_order(ro, C, T, P, S, True, keys=(k0, k1))
             ids = order[:emu.CG]

@@ -87,24 +87,31 @@ def gf_tables_ml(st, du, st_min, st_dt, du_min, du_dt, D, S, T, P):
     return ro.astype(np.uint32), fa
 
 
-def gc_order(rowoff, C, T, P, S, sort=True, keys=None):
-    """numpy twin of k_gc_order (gfcell.hip): bands of whole wavefronts by the first key, inside a band by the second;
-    keys: optional (k0[C], k1[C]) of the caller (hypocentre strike / dip), else start-time indices at patches 0, P/2"""
+def gc_order(rowoff, C, T, P, S, sort=True, keys=None, global_members=True):
+    """numpy twin of k_gc_key0 / k_gc_members / k_gc_order (gfcell.hip): batches of several groups are cut into groups in
+    the order of the first key (C <= 4096), then inside a group: bands of whole wavefronts by the first key, inside a
+    band by the second; keys: optional (k0[C], k1[C]) of the caller (hypocentre strike / dip), else start-time indices
+    at patches 0, P/2"""
     ngroups = (C + CG - 1) // CG
     order = np.full(ngroups * CG, DEAD, dtype=np.uint32)
+    allc = np.arange(C)
+    if keys is not None:
+        F0, F1 = [np.where(np.abs(k) <= 1.79e308, k, 0.0) for k in keys]
+        nb = 4
+    else:
+        F0 = (rowoff[allc, 0, 0, 3] % S).astype(np.float64)
+        F1 = (rowoff[allc, 0, P // 2, 3] % S).astype(np.float64)
+        nb = 5
+    members = allc
+    if sort and global_members and ngroups > 1 and C <= 4096:
+        members = np.lexsort((allc, F0))
     for g in range(ngroups):
-        cs = np.arange(g * CG, min(C, (g + 1) * CG))
+        cs = members[g * CG:min(C, (g + 1) * CG)]
         if not sort:
             order[g * CG:g * CG + cs.size] = cs
             continue
-        tid = cs - g * CG
-        if keys is not None:
-            f0, f1 = [np.where(np.abs(k[cs]) <= 1.79e308, k[cs], 0.0) for k in keys]
-            nb = 4
-        else:
-            f0 = (rowoff[cs, 0, 0, 3] % S).astype(np.float64)
-            f1 = (rowoff[cs, 0, P // 2, 3] % S).astype(np.float64)
-            nb = 5
+        tid = np.arange(cs.size)
+        f0, f1 = F0[cs], F1[cs]
         r0 = np.argsort(np.lexsort((tid, f0)))
         nw = (cs.size + NCH - 1) // NCH
         band = (r0 // NCH) * nb // nw
