@@ -1139,7 +1139,30 @@ int beatamd_ctx_gf_group_stats(beatamd_ctx *ctx, int64_t *chains_per_group, doub
     }
     *mean_rows = (double)tot / (double)uc.size();
     *max_rows = mx;
-    *row_bytes = tot * ctx->gs_trep * ctx->gs_N * 8;   // every distinct row is staged once per (group, target)
+    // every distinct row is staged once per (group, target) and slip variable
+    *row_bytes = tot * ctx->gs_trep * ctx->gs_N * 8 * ctx->gs_nvar;
+    return BEATAMD_OK;
+}
+
+int beatamd_ctx_gf_plan(beatamd_ctx *ctx, char *buf, int64_t buflen, double *mean_passes, int64_t *max_passes)
+{
+    ENTER(ctx);
+    BA_CHECK(buf && buflen > 0, BEATAMD_EINVAL, "gf_plan: bad argument");
+    snprintf(buf, (size_t)buflen, "%s", ctx->gf_plan);
+    if (mean_passes) *mean_passes = ctx->gs_ngtp ? 1.0 : 0.0;
+    if (max_passes) *max_passes = ctx->gs_ngtp ? 1 : 0;
+    if (!ctx->gs_has_passes || ctx->gs_ngtp == 0 || (!mean_passes && !max_passes)) return BEATAMD_OK;
+    BA_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<uint32_t> np((size_t)ctx->gs_ngtp);
+    BA_HIP(hipMemcpy(np.data(), (const uint32_t *)ctx->scratch[SL_GS_UCOUNT].p + ctx->gs_ngtp, np.size() * sizeof(uint32_t),
+                     hipMemcpyDeviceToHost));
+    int64_t tot = 0, mx = 0;
+    for (uint32_t u : np) {
+        tot += u;
+        mx = std::max<int64_t>(mx, u);
+    }
+    if (mean_passes) *mean_passes = (double)tot / (double)np.size();
+    if (max_passes) *max_passes = mx;
     return BEATAMD_OK;
 }
 

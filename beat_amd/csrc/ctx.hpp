@@ -154,6 +154,10 @@ struct beatamd_ctx {
     char last_gf_kernel[96] = "";
     // distinct-row statistics of the most recent chain-shared launch (bench.py roofline leg)
     int64_t gs_ngtp = 0, gs_N = 0, gs_trep = 1;   // trep: targets served by one table cell
+    int gs_nvar = 1;                // slip variables: every distinct row is staged once per variable
+    bool gs_has_passes = false;     // the statistics slot holds [rows per patch][passes per patch]
+    // what the selection chose for the most recent stacking launch and why (beatamd_ctx_gf_plan)
+    char gf_plan[384] = "";
     // largest distinct-row count of the previous small-group launch, read back asynchronously
     // (pinned mailbox + event; never waited for): sizes the next launch's row buffers
     uint32_t *h_umax = nullptr;

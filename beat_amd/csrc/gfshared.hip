@@ -238,6 +238,10 @@ struct GsArgs {
     // *guard_umax is <= guard_fit (mode 1) / > guard_fit (mode 2); mode 0: always
     const uint32_t *guard_umax;
     int guard_mode, guard_fit;
+    // k_gfstack_ws / _wsp: the tables list vsteps (row passes, k_ws_tables): nv[gt] of them per (group, target)
+    // (nullptr: P, one per patch), vmax apart
+    const uint32_t *nv;
+    int64_t vmax;
     const uint32_t *urows, *uent, *ucount;
     const uint16_t *slot;
     const double *w;
@@ -1185,8 +1189,11 @@ k_gfstack_ws(GsArgs a)
     const int64_t N = a.N;
     const int64_t n0 = (int64_t)tile * GS_NT;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)xbuf;
-    const int bufsz = a.ucap * GS_PITCH;                          // doubles per buffer
-    const int P = (int)a.P, nvar = a.nvar;
+    const int bufsz = (a.ucap + 1) * GS_PITCH;                    // doubles per buffer: ucap row slots + the zero row
+    // the workgroup's list of vsteps: (patch, row pass) pairs, k_ws_tables -- one per patch unless a patch touches more
+    // distinct rows than a buffer holds
+    const int P = a.nv ? (int)__builtin_amdgcn_readfirstlane((int)a.nv[gt]) : (int)a.P;
+    const int nvar = a.nvar;
     const int nsteps = P * nvar;
     auto advance = [&](int &p, int &iv) {
         if (++iv == nvar) { iv = 0; ++p; }
@@ -1218,8 +1225,8 @@ k_gfstack_ws(GsArgs a)
                     : "+s"(tk) : "v"(voff), "s"(rowp), "s"(dst));
         };
         const int kstr = a.ustride / LW;
-        const char *const cnt_base = reinterpret_cast<const char *>(a.ucount + gt * a.P);
-        const char *const ent_base = reinterpret_cast<const char *>(a.uent + ((gt * a.P) * LW + lw) * kstr * 2);
+        const char *const cnt_base = reinterpret_cast<const char *>(a.ucount + gt * a.vmax);
+        const char *const ent_base = reinterpret_cast<const char *>(a.uent + ((gt * a.vmax) * LW + lw) * kstr * 2);
         const uint32_t ent_step = (uint32_t)(a.ustride * 8);
         int U_a;
         uint32_t rid[KPRE], rsl[KPRE];
@@ -1334,6 +1341,10 @@ k_gfstack_ws(GsArgs a)
     // ==================================== consumer ====================================
     static_assert(NROW == 1, "the loader / consumer kernel exists for single-row interpolation");
     const int64_t c = g * CG + tid;
+    // the zero row of every buffer (slot index ucap; the loaders never write it): what a lane reads, with weight 0, in
+    // the row passes of a patch that do not hold its chain's row
+    for (int i = tid; i < NB * GS_PITCH; i += CG) xbuf[(i / GS_PITCH) * bufsz + a.ucap * GS_PITCH + (i % GS_PITCH)] = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (visible behind the barrier of step 0)
     double acc[GS_NT];
 #pragma unroll
     for (int i = 0; i < GS_NT; i++) acc[i] = 0.0;
@@ -1343,8 +1354,8 @@ k_gfstack_ws(GsArgs a)
     // scalar base + 32-bit lane offset: no 64-bit pointers in VGPRs
     const uint32_t voff_s = (uint32_t)tid * 2u;   // (the weight's offset is rebuilt from it per load: one
                                                    // register less is what keeps the step loop free of spills)
-    const char *const slot_base = reinterpret_cast<const char *>(a.slot + (gt * a.P) * CG);
-    const char *const w_base = reinterpret_cast<const char *>(a.w + (g * a.P) * CG);
+    const char *const slot_base = reinterpret_cast<const char *>(a.slot + (gt * a.vmax) * CG);
+    const char *const w_base = reinterpret_cast<const char *>(a.w + (gt * a.vmax) * CG);
     const uint32_t slot_step = (uint32_t)(CG * 2);
     const uint32_t w_step = (uint32_t)(CG * 8);
     const int64_t w_var_bytes = a.w_var_stride * 8;
@@ -1587,8 +1598,11 @@ k_gfstack_wsp(GsArgs a)
     const int64_t N = a.N;
     const int64_t n0 = (int64_t)tile * GS_NT;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)xbuf;
-    const int bufsz = a.ucap * GS_PITCH;                          // floats per buffer
-    const int P = (int)a.P, nvar = a.nvar;
+    const int bufsz = (a.ucap + 1) * GS_PITCH;                    // elements per buffer: ucap row slots + the zero row
+    // the workgroup's list of vsteps: (patch, row pass) pairs, k_ws_tables -- one per patch unless a patch touches more
+    // distinct rows than a buffer holds
+    const int P = a.nv ? (int)__builtin_amdgcn_readfirstlane((int)a.nv[gt]) : (int)a.P;
+    const int nvar = a.nvar;
     const int nsteps = P * nvar;
     auto advance = [&](int &p, int &iv) {
         if (++iv == nvar) { iv = 0; ++p; }
@@ -1630,8 +1644,8 @@ k_gfstack_wsp(GsArgs a)
                     : "+s"(tk) : "v"(voff), "s"(rowp), "s"(dst));
         };
         const int kstr = a.ustride / LW;
-        const char *const cnt_base = reinterpret_cast<const char *>(a.ucount + gt * a.P);
-        const char *const ent_base = reinterpret_cast<const char *>(a.uent + ((gt * a.P) * LW + lw) * kstr * 2);
+        const char *const cnt_base = reinterpret_cast<const char *>(a.ucount + gt * a.vmax);
+        const char *const ent_base = reinterpret_cast<const char *>(a.uent + ((gt * a.vmax) * LW + lw) * kstr * 2);
         const uint32_t ent_step = (uint32_t)(a.ustride * 8);
         int U_a;
         uint32_t rid[KPRE], rsl[KPRE];
@@ -1745,6 +1759,10 @@ k_gfstack_wsp(GsArgs a)
 
     // ==================================== consumer ====================================
     const int64_t c = g * CG + tid;
+    // the zero row of every buffer (slot index ucap): see k_gfstack_ws
+    for (int i = tid; i < NB * GS_PITCH; i += CG)
+        reinterpret_cast<elem_t *>(xbuf)[(i / GS_PITCH) * bufsz + a.ucap * GS_PITCH + (i % GS_PITCH)] = (elem_t)0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     double acc[GS_NT];
 #pragma unroll
     for (int i = 0; i < GS_NT; i++) acc[i] = 0.0;
@@ -1752,8 +1770,8 @@ k_gfstack_wsp(GsArgs a)
     uint32_t sl_n;
     double wl_n;
     const uint32_t voff_s = (uint32_t)tid * 2u;
-    const char *const slot_base = reinterpret_cast<const char *>(a.slot + (gt * a.P) * CG);
-    const char *const w_base = reinterpret_cast<const char *>(a.w + (g * a.P) * CG);
+    const char *const slot_base = reinterpret_cast<const char *>(a.slot + (gt * a.vmax) * CG);
+    const char *const w_base = reinterpret_cast<const char *>(a.w + (gt * a.vmax) * CG);
     const uint32_t slot_step = (uint32_t)(CG * 2);
     const uint32_t w_step = (uint32_t)(CG * 8);
     const int64_t w_var_bytes = a.w_var_stride * 8;
@@ -1963,6 +1981,206 @@ static int launch_ws(int mode, dim3 grid, size_t lds, hipStream_t s, const GsArg
     return BEATAMD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tables of k_gfstack_ws / k_gfstack_wsp (round 5): ROW PASSES.  The kernel walks a list of "vsteps"; a vstep
+// stages at most `cap` (32, 64 or 96) distinct rows in one LDS row buffer.  A (chain group, target, patch) whose
+// chains touch U <= cap distinct rows is one vstep, as before; one that touches more -- a library on a fine
+// (duration x start-time) grid: the reference's tutorial grid gives 178 rows per patch for 512 prior chains -- is
+// cut into ceil(U / cap) PASSES of equal size over the rows in ascending order.  A chain takes part in the pass
+// that holds its row; in the other passes of the patch its lane reads the buffer's ZERO ROW (slot index `cap`,
+// written once by the kernel) with weight 0: fma(0, 0, acc) = acc exactly, and since every chain still sees its
+// rows in ascending patch order the kernel stays bitwise equal to k_gfstack.  Nothing is sized by the library's
+// D * S any more: the distinct rows are found by ranking the 512 row ids of the group against each other.
+//   k_ws_tables<0>  per (group, target, patch): U -> number of passes            (only when passes can occur)
+//   k_ws_scan       per (group, target): first vstep of every patch, total
+//   k_ws_tables<1>  per (group, target, patch): row lists, LDS slots (by bank window, as k_gf_group_tables),
+//                   per-lane slot and weight of every pass
+constexpr int WS_CG = 512;        // chains per group (8 consumer wavefronts)
+constexpr int WS_LW = 4;          // loader wavefronts
+constexpr int WS_USTRIDE = 128;   // list entries per vstep in the row-request table (cap <= 96)
+constexpr int WS_CAP_MAX = 96;    // three buffers of 96 + 1 slots x 520 B = 151 KB of the CU's 160 KB
+constexpr int WS_MAXPASS = (WS_CG + WS_CAP_MAX - 1) / WS_CAP_MAX;
+static bool ws_wanted(const GfStackCall &k, int CG);
+
+struct WsTabArgs {
+    int nvar, cap;
+    int64_t C, T, P;          // T: targets the tables are built for (1 or all)
+    int64_t vmax;             // vsteps per (group, target) the tables are strided by
+    const uint32_t *rowoff;   // [C,T,P] global row ids (k_gf_tables)
+    ChainVec slips[4];
+    uint32_t *npass;          // [gtp] passes of the patch (phase 0 out)
+    const uint32_t *voff;     // [gtp] first vstep of the patch; nullptr: one pass per patch, vstep = patch
+    uint32_t *utotal;         // [gtp] distinct rows (statistics)
+    uint32_t *ucount;         // [gt*vmax + v] rows of the vstep
+    uint32_t *uent;           // [gt*vmax + v][loader][WS_USTRIDE / WS_LW][2] = (row id, LDS slot)
+    uint16_t *slot;           // [gt*vmax + v][WS_CG]
+    double *w;                // [variable][gt*vmax + v][WS_CG]
+    int64_t w_var_stride;
+};
+
+__global__ void __launch_bounds__(256) k_ws_scan(const uint32_t *npass, uint32_t *voff, uint32_t *nv, int64_t P)
+{
+    __shared__ uint32_t part[256];
+    const int tid = threadIdx.x;
+    const int64_t gt = blockIdx.x;
+    uint32_t run = 0;
+    for (int64_t base = 0; base < P; base += 256) {
+        const int64_t p = base + tid;
+        const uint32_t x = p < P ? npass[gt * P + p] : 0u;
+        part[tid] = x;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (int k = 0; k < 256; k++) {
+            const uint32_t y = part[k];
+            if (k < tid) before += y;
+            total += y;
+        }
+        if (p < P) voff[gt * P + p] = run + before;
+        run += total;
+        __syncthreads();
+    }
+    if (tid == 0) nv[gt] = run;
+}
+
+template <int FILL>
+__global__ void __launch_bounds__(WS_CG) k_ws_tables(WsTabArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t vals[WS_CG];   // the lanes' row ids (dead lanes: ~0)
+    __shared__ __attribute__((aligned(16))) uint32_t firstv[WS_CG]; // the row id where the lane is the first to name it, else ~0
+    __shared__ uint32_t lst[WS_CG];     // distinct rows, ascending
+    __shared__ uint32_t gm[WS_CG];      // 32-lane groups of the workgroup that use distinct row i
+    __shared__ uint16_t slt[WS_CG];     // LDS slot of distinct row i inside its pass
+    __shared__ uint8_t rk2i[WS_MAXPASS][128];   // per pass: popularity rank -> row of the pass
+    __shared__ uint32_t wsum[WS_CG / 64 + 1];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int64_t gtp = blockIdx.x;       // (g*T + t)*P + p
+    const int64_t p = gtp % a.P;
+    const int64_t gt = gtp / a.P;
+    const int64_t t = gt % a.T;
+    const int64_t g = gt / a.T;
+    const int64_t c = g * WS_CG + tid;
+    const bool live = c < a.C;
+    const uint32_t v = live ? a.rowoff[(c * a.T + t) * a.P + p] : 0xffffffffu;
+    vals[tid] = v;
+    gm[tid] = 0;
+    __syncthreads();
+    // first lane to name its row
+    bool first = live;
+    {
+        const uint4 *v4 = reinterpret_cast<const uint4 *>(vals);
+        for (int k4 = 0; k4 < WS_CG / 4; k4++) {
+            const uint4 x = v4[k4];
+            const int k = 4 * k4;
+            first = first && !((x.x == v && k < tid) || (x.y == v && k + 1 < tid) || (x.z == v && k + 2 < tid) ||
+                               (x.w == v && k + 3 < tid));
+        }
+    }
+    firstv[tid] = first ? v : 0xffffffffu;
+    {
+        const uint64_t m = __ballot(first);
+        if (lane == 0) wsum[wv] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    // position of the lane's row among the distinct rows in ascending order
+    uint32_t pos = 0;
+    if (live) {
+        const uint4 *f4 = reinterpret_cast<const uint4 *>(firstv);
+        for (int k4 = 0; k4 < WS_CG / 4; k4++) {
+            const uint4 x = f4[k4];
+            pos += (x.x < v) + (x.y < v) + (x.z < v) + (x.w < v);
+        }
+    }
+    uint32_t U = 0;
+    for (int q = 0; q < WS_CG / 64; q++) U += wsum[q];
+    const int npass = (int)((U + (uint32_t)a.cap - 1) / (uint32_t)a.cap);
+    if constexpr (!FILL) {
+        if (tid == 0) {
+            a.npass[gtp] = (uint32_t)npass;
+            a.utotal[gtp] = U;
+        }
+        return;
+    }
+    if (tid == 0) a.utotal[gtp] = U;
+    const int per = ((int)U + npass - 1) / npass;       // rows of a pass (the last may hold fewer)
+    if (first) lst[pos] = v;
+    if (live) atomicOr(&gm[pos], 1u << (tid >> 5));
+    __syncthreads();
+    const int mypass = live ? (int)pos / per : -1;
+    // ---- LDS slots of the rows of pass k: wavefront k.  k_gfstack_ws reads row `slot` of a lane at slot * 65 doubles
+    // with ds_read_b64: the 32 lanes of a lane group hit the two-bank window (slot + sample) mod 32, so rows whose slots
+    // differ by 32 collide when ONE lane group reads both.  Rows in order of decreasing number of lane groups using
+    // them; the first 32 take a window each, every further row the window whose occupants share the fewest lane groups
+    // with it (then the emptiest, then the lowest).  Results never depend on the slots, only the LDS read timing does.
+    if (wv < npass) {
+        const int base = wv * per;
+        const int n = min(per, (int)U - base);
+        if (n <= 32) {
+            if (lane < n) slt[base + lane] = (uint16_t)lane;
+        } else {
+            const int depth = a.cap / 32;
+            const int r0 = lane, r1 = lane + 64;
+            const uint32_t m0 = r0 < n ? gm[base + r0] : 0u, m1 = r1 < n ? gm[base + r1] : 0u;
+            const int key0 = r0 < n ? ((__popc(m0) << 8) | (255 - r0)) : -1;
+            const int key1 = r1 < n ? ((__popc(m1) << 8) | (255 - r1)) : -1;
+            int rank0 = 0, rank1 = 0;
+            for (int j = 0; j < n; j++) {
+                const int kj = (__popc(gm[base + j]) << 8) | (255 - j);
+                rank0 += kj > key0;
+                rank1 += kj > key1;
+            }
+            if (r0 < n && rank0 < 32) slt[base + r0] = (uint16_t)rank0;
+            if (r1 < n && rank1 < 32) slt[base + r1] = (uint16_t)rank1;
+            if (r0 < n) rk2i[wv][rank0] = (uint8_t)r0;
+            if (r1 < n) rk2i[wv][rank1] = (uint8_t)r1;
+            wave_lds_fence();
+            uint32_t wmask = 0;
+            int wcnt = 0;
+            if (lane < 32) {
+                wmask = gm[base + rk2i[wv][lane]];
+                wcnt = 1;
+            }
+            for (int rk = 32; rk < n; rk++) {
+                const int ridx = (int)rk2i[wv][rk];
+                const uint32_t mm = gm[base + ridx];
+                int cost = (lane < 32 && wcnt < depth) ? ((__popc(wmask & mm) << 12) | (wcnt << 6) | lane) : 0x7fffffff;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) cost = min(cost, __shfl_xor(cost, off, 64));
+                const int w = cost & 63;
+                if (lane == w) {
+                    slt[base + ridx] = (uint16_t)(w + 32 * wcnt);
+                    wmask |= mm;
+                    wcnt++;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int64_t v0 = gt * a.vmax + (a.voff ? (int64_t)a.voff[gtp] : p);
+    const uint16_t myslot = live ? slt[pos] : (uint16_t)0;
+    double sl[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int iv = 0; iv < a.nvar; iv++)
+        if (live) sl[iv] = a.slips[iv].base[c * a.slips[iv].stride + a.slips[iv].off + p];
+    constexpr int kstr = WS_USTRIDE / WS_LW;
+    for (int k = 0; k < npass; k++) {
+        const int64_t vs = v0 + k;
+        const int base = k * per;
+        const int n = min(per, (int)U - base);
+        const bool mine = mypass == k;
+        a.slot[vs * WS_CG + tid] = mine ? myslot : (uint16_t)a.cap;     // (not in this pass / no chain: the zero row)
+        for (int iv = 0; iv < a.nvar; iv++) a.w[(int64_t)iv * a.w_var_stride + vs * WS_CG + tid] = mine ? sl[iv] : 0.0;
+        if (tid == 0) a.ucount[vs] = (uint32_t)n;
+        if (tid < WS_USTRIDE) {
+            // (row id, LDS slot) of list entry j, grouped by the loader that stages it (entry j: loader j mod 4);
+            // padded with the last id: the loaders fetch entries ahead of the count
+            const int j = tid;
+            uint32_t *e = a.uent + ((vs * WS_LW + (j % WS_LW)) * kstr + (j / WS_LW)) * 2;
+            e[0] = lst[base + (j < n ? j : n - 1)];
+            e[1] = j < n ? (uint32_t)slt[base + j] : 0u;
+        }
+    }
+}
+
 // chains per group for a batch of C chains: the group size that minimises
 // (number of groups) x (cost of one group's launch share).  Relative costs measured on config 3
 // (ms per single-group launch: 64 chains 2.4, 128 2.9, 256 3.6, 512 6.2): a larger group is much
@@ -1989,6 +2207,10 @@ static bool shared_fit(const GfStackCall &k, int cg, int *ucap_out)
     const int nrow = k.interp == BEATAMD_MULTILINEAR ? 4 : 1;
     const int64_t DS = L.D * L.S;
     const int64_t ucap = std::min<int64_t>((int64_t)cg * nrow, DS);
+    if (ws_wanted(k, cg)) {   // row passes: any library
+        *ucap_out = (int)std::max<int64_t>(ucap, 2);
+        return true;
+    }
     if (ucap * (GS_NT_MAX + 2) * 8 > 150 * 1024) return false;
     if (2 * DS * 4 + cg * 4 + 2048 > 60 * 1024) return false;
     *ucap_out = (int)std::max<int64_t>(ucap, 2);
@@ -2024,6 +2246,11 @@ bool gfstack_shared_applicable(const GfStackCall &k, int *cg_out, int *ucap_out)
                atoi(gq) == 1024)) cg = atoi(gq);
     const int64_t DS = L.D * L.S;
     int64_t ucap = std::min<int64_t>((int64_t)cg * nrow, DS);
+    if (ws_wanted(k, cg)) {
+        *cg_out = cg;
+        *ucap_out = (int)std::max<int64_t>(ucap, 2);
+        return true;
+    }
     // the distinct rows of one step must fit in LDS; prefer >= 2 workgroups per CU
     const int GS_PITCH = GS_NT_MAX + 2;
     while (ucap * GS_PITCH * 8 > 72 * 1024 && cg > 64) {
@@ -2037,9 +2264,133 @@ bool gfstack_shared_applicable(const GfStackCall &k, int *cg_out, int *ucap_out)
     return true;
 }
 
+// 512-chain groups with one row per chain and patch: the loader / consumer kernel, whatever the library's
+// (duration x start-time) grid (row passes, k_ws_tables)
+static bool ws_wanted(const GfStackCall &k, int CG)
+{
+    const char *e = getenv("BEATAMD_GS_WS"), *ed = getenv("BEATAMD_GS_DMA"), *en = getenv("BEATAMD_GS_NT");
+    const bool want = e ? atoi(e) != 0 : (GS_WS_DEFAULT != 0);
+    return want && CG == WS_CG && k.interp != BEATAMD_MULTILINEAR && k.libs[0]->N % 2 == 0 && !(ed && atoi(ed) != 2) &&
+           !(en && atoi(en) != 64);
+}
+
+static int launch_gfstack_ws(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *rowoff, int64_t Ttab)
+{
+    const SeisLib &L = *k.libs[0];
+    const int64_t ngroups = (k.C + WS_CG - 1) / WS_CG;
+    const int64_t GT = ngroups * Ttab, GTP = GT * L.P;
+    // row slots of an LDS buffer: what a patch can touch at most, in whole bank windows, up to the 96 that three
+    // buffers leave room for; a patch that touches more is staged in passes
+    const int64_t bound = std::min<int64_t>(WS_CG, L.D * L.S);
+    const int cap = bound <= 32 ? 32 : bound <= 64 ? 64 : WS_CAP_MAX;
+    const int maxpass = (int)((bound + cap - 1) / cap);
+    const int64_t vmax = L.P * maxpass;
+    void *p = nullptr;
+
+    WsTabArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.nvar = k.nvar; ta.cap = cap;
+    ta.C = k.C; ta.T = Ttab; ta.P = L.P; ta.vmax = vmax;
+    ta.rowoff = rowoff;
+    for (int v = 0; v < k.nvar; v++) ta.slips[v] = k.slips[v];
+    // [utotal GTP][npass GTP][voff GTP][nv GT]
+    BA_TRY(ctx->get_scratch(SL_GS_UCOUNT, (size_t)(3 * GTP + GT) * sizeof(uint32_t), &p));
+    ta.utotal = (uint32_t *)p;
+    ta.npass = ta.utotal + GTP;
+    uint32_t *voff = ta.npass + GTP, *nv = voff + GTP;
+    // (+ 3 vsteps of padding behind the tables: the kernel runs its table pointers past the last step)
+    const size_t nvs = (size_t)GT * vmax + 3;
+    BA_TRY(ctx->get_scratch(SL_GS_UROWS, nvs * sizeof(uint32_t), &p));
+    ta.ucount = (uint32_t *)p;
+    BA_TRY(ctx->get_scratch(SL_GS_USLOT, nvs * WS_USTRIDE * 2 * sizeof(uint32_t), &p));
+    ta.uent = (uint32_t *)p;
+    BA_TRY(ctx->get_scratch(SL_GS_SLOT, nvs * WS_CG * sizeof(uint16_t), &p));
+    ta.slot = (uint16_t *)p;
+    ta.w_var_stride = (int64_t)GT * vmax * WS_CG;
+    BA_TRY(ctx->get_scratch(SL_GS_W, ((size_t)ta.w_var_stride * k.nvar + (size_t)3 * WS_CG) * sizeof(double), &p));
+    ta.w = (double *)p;
+    {
+        ScopedTimer tm(ctx, "grouptables");
+        if (maxpass > 1) {
+            hipLaunchKernelGGL(k_ws_tables<0>, dim3((unsigned)GTP), dim3(WS_CG), 0, ctx->stream, ta);
+            hipLaunchKernelGGL(k_ws_scan, dim3((unsigned)GT), dim3(256), 0, ctx->stream, ta.npass, voff, nv, L.P);
+            ta.voff = voff;
+        }
+        hipLaunchKernelGGL(k_ws_tables<1>, dim3((unsigned)GTP), dim3(WS_CG), 0, ctx->stream, ta);
+    }
+    BA_HIP(hipGetLastError());
+
+    GsArgs a;
+    memset(&a, 0, sizeof(a));
+    bool f32 = k.f32;   // float copies: the pair gather of k_gfstack_wsp<1>
+    const bool pair64 = getenv("BEATAMD_GS_PAIR") && atoi(getenv("BEATAMD_GS_PAIR")) == 1;   // A/B: ds_read_b128 pairs
+    for (int v = 0; v < k.nvar; v++) {
+        a.G[v] = k.libs[v]->g;
+        a.G32[v] = k.libs[v]->g32;
+        f32 = f32 && a.G32[v] != nullptr;
+    }
+    a.nvar = k.nvar; a.nrow = 1;
+    a.C = k.C; a.T = L.T; a.P = L.P; a.N = L.N;
+    a.Ttab = Ttab; a.rows_per_target = L.P * L.D * L.S;
+    a.CG = WS_CG; a.ucap = cap; a.ustride = WS_USTRIDE;
+    a.nt = 64; a.dma = 2; a.ws = 3;
+    a.ngroups = ngroups;
+    a.ntile = (int)((L.N + 63) / 64);
+    a.nv = maxpass > 1 ? nv : nullptr;
+    a.vmax = vmax;
+    a.uent = ta.uent; a.ucount = ta.ucount; a.slot = ta.slot; a.w = ta.w;
+    a.w_var_stride = ta.w_var_stride;
+    a.data = k.data; a.wscalar = k.wscalar; a.out = k.out;
+    if (k.mode == GF_RESID_SCALAR) {
+        BA_TRY(ctx->get_scratch(SL_PARTIAL, (size_t)k.C * L.T * a.ntile * sizeof(double), &p));
+        a.partial = (double *)p;
+    }
+    {
+        const char *e = getenv("BEATAMD_GS_NTHINT");
+        a.nthint = e ? (atoi(e) != 0) : (GS_NTHINT_DEFAULT && ngroups == 1);
+    }
+    int64_t nblocks = ngroups * L.T * a.ntile;
+    {
+        // chain groups of one (target, tile) on one XCD (several groups only)
+        const char *e = getenv("BEATAMD_GS_ORDER");
+        a.xcd_order = (ngroups > 1 && !(e && atoi(e) == 0)) ? 1 : 0;
+        if (e && atoi(e) == 1) a.xcd_order = 1;
+        if (a.xcd_order) nblocks = ((L.T * a.ntile + 7) / 8) * 8 * ngroups;
+    }
+    BA_CHECK(nblocks < (int64_t)0x7fffffff, BEATAMD_EINVAL, "gfstack: batch too large");
+    // three row buffers of cap slots + the zero row each
+    size_t lds = f32 ? (size_t)(cap + 1) * (64 + 2) * sizeof(float) * 3
+                     : (size_t)(cap + 1) * (64 + (pair64 ? 2 : 1)) * sizeof(double) * 3;
+    lds = std::max<size_t>(lds, 64 * sizeof(double));   // the epilogue's data tile
+    BA_CHECK(lds <= 160 * 1024, BEATAMD_EINVAL, "internal: k_gfstack_ws row buffers exceed LDS");
+    if (f32 || pair64)
+        snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack_ws%s<%d,%d,%d>", f32 ? "32" : "p64", k.mode, a.ws,
+                 a.nthint);
+    else
+        snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack_ws<%d,%d,%d,%d>", 1, k.mode, a.ws, a.nthint);
+    snprintf(ctx->gf_plan, sizeof(ctx->gf_plan),
+             "loader/consumer kernel: 512-chain groups, nearest neighbour; %d row slots per LDS buffer (a patch can touch min(512, "
+             "D*S = %lld) rows), %s", cap, (long long)(L.D * L.S),
+             maxpass > 1 ? "patches that touch more are staged in passes of equal size" : "one pass per patch");
+    ctx->gs_ngtp = GTP;
+    ctx->gs_trep = L.T / Ttab;
+    ctx->gs_N = L.N;
+    ctx->gs_cg = WS_CG;
+    ctx->gs_nvar = k.nvar;
+    ctx->gs_has_passes = maxpass > 1;
+    {
+        ScopedTimer tm(ctx, "gfstack");
+        BA_TRY(launch_ws(k.mode, dim3((unsigned)nblocks), lds, ctx->stream, a, f32 ? 1 : (pair64 ? 2 : 0)));
+    }
+    BA_HIP(hipGetLastError());
+    if (k.mode == GF_RESID_SCALAR) BA_TRY(launch_sum_tiles(ctx, a.partial, k.C * L.T, a.ntile, k.quad));
+    return BEATAMD_OK;
+}
+
 int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *rowoff,
                           const double *fac, int CG, int ucap, int64_t Ttab)
 {
+    if (ws_wanted(k, CG)) return launch_gfstack_ws(ctx, k, rowoff, Ttab);
     const SeisLib &L = *k.libs[0];
     const int nrow = k.interp == BEATAMD_MULTILINEAR ? 4 : 1;
     const int64_t ngroups = (k.C + CG - 1) / CG;
@@ -2073,17 +2424,7 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         ga.umax = (uint32_t *)p;
         BA_HIP(hipMemsetAsync(ga.umax, 0, sizeof(uint32_t), ctx->stream));
     }
-    // wave-specialised kernel: 512-chain groups whose three row buffers fit LDS
-    bool use_ws = false;
-    const int ws_nb = 3;   // row buffers (four of 64 slots measured the same as three of 96)
-    {
-        const char *e = getenv("BEATAMD_GS_WS"), *ed = getenv("BEATAMD_GS_DMA"), *en = getenv("BEATAMD_GS_NT");
-        const int depth = (ucap + 31) / 32;
-        const bool want = e ? atoi(e) != 0 : (GS_WS_DEFAULT != 0);
-        use_ws = want && CG == 512 && nrow == 1 && L.N % 2 == 0 && !(ed && atoi(ed) != 2) && !(en && atoi(en) != 64) &&
-                 ucap <= 128 && (size_t)3 * 32 * depth * (GS_NT_MAX + 1) * 8 <= 158 * 1024;
-    }
-    ga.nissue = use_ws ? 4 : CG / 64;
+    ga.nissue = CG / 64;
     // LDS slots by bank window for the ds_read_b64 LDS-DMA kernel with large chain groups (the
     // small groups size their LDS by the measured row count and keep dense slots): the row
     // buffers then hold 32 * depth slots
@@ -2098,7 +2439,7 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         ga.windowed = (CG >= 512 && nrow == 1 && dma2 && ucap > 32 && ucap <= 128 && !(ew && atoi(ew) == 0) &&
                        (size_t)2 * 32 * depth * (GS_NT_MAX + 2) * 8 <= 158 * 1024) ? 1 : 0;
         ga.depth = depth;
-        if (ga.windowed || use_ws) ucap = 32 * depth;
+        if (ga.windowed) ucap = 32 * depth;
     }
     {
         ScopedTimer tm(ctx, "grouptables");
@@ -2109,10 +2450,7 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
 
     GsArgs a;
     memset(&a, 0, sizeof(a));
-    bool f32 = k.f32;   // float copies: the loader/consumer pair gather (512-chain groups, one row per chain)
-                        // or k_gfstack_dmaf (LDS-DMA kernel, 64-sample tiles, groups up to 512 chains)
-    // A/B: the float64 kernel with the pair gather (ds_read_b128)
-    const bool pair64 = use_ws && getenv("BEATAMD_GS_PAIR") && atoi(getenv("BEATAMD_GS_PAIR")) == 1;
+    bool f32 = k.f32;   // float copies: k_gfstack_dmaf (LDS-DMA kernel, 64-sample tiles, groups up to 512 chains)
     for (int v = 0; v < k.nvar; v++) {
         a.G[v] = k.libs[v]->g;
         a.G32[v] = k.libs[v]->g32;
@@ -2194,17 +2532,13 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
                                         lds = (size_t)ucap * (a.nt + 2) * sizeof(double); a.dma = 0; }
         BA_CHECK(CG != 1024 || a.dma == 2, BEATAMD_EINVAL, "gfstack: 1024-chain groups need the LDS-DMA kernel");
         BA_CHECK(!ga.windowed || a.dma == 2, BEATAMD_EINVAL, "internal: window slots need the ds_read_b64 kernel");
-        a.ws = (use_ws && a.dma == 2) ? ws_nb : 0;
+        a.ws = 0;
         {
             const char *e = getenv("BEATAMD_GS_NTHINT");
             a.nthint = e ? (atoi(e) != 0) : (GS_NTHINT_DEFAULT && ngroups == 1);
         }
         a.f32pair = 0;
-        if (a.ws) {
-            lds = f32 ? (size_t)ucap * (a.nt + 2) * sizeof(float) * a.ws
-                      : (size_t)ucap * (a.nt + (pair64 ? 2 : 1)) * sizeof(double) * a.ws;
-            lds = std::max<size_t>(lds, 64 * sizeof(double));   // the epilogue's data tile
-        } else if (a.dma == 2 && a.nt == 64 && CG <= 512 && f32) {
+        if (a.dma == 2 && a.nt == 64 && CG <= 512 && f32) {
             a.f32pair = 1;
             lds = std::max<size_t>((size_t)ucap * (a.nt + 2) * sizeof(float) * 2, 64 * sizeof(double));
         } else if (a.dma) {
@@ -2220,11 +2554,6 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     }
     if (a.f32pair)
         snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack_dmaf<%d,%d,%d>", CG / 64, nrow, k.mode);
-    else if (a.ws && (f32 || pair64))
-        snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack_ws%s<%d,%d,%d>", f32 ? "32" : "p64", k.mode,
-                 a.ws, a.nthint);
-    else if (a.ws)
-        snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack_ws<%d,%d,%d,%d>", nrow, k.mode, a.ws, a.nthint);
     else
         snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "%s<%d,%d,%d,%d,%d>",
                  a.dma ? "k_gfstack_dma" : "k_gfstack_shared", CG / 64, nrow, k.mode, a.nt, a.dma == 2 ? 1 : 0);
@@ -2232,10 +2561,15 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     ctx->gs_trep = L.T / Ttab;
     ctx->gs_N = L.N;
     ctx->gs_cg = CG;
+    ctx->gs_nvar = k.nvar;
+    ctx->gs_has_passes = false;
+    snprintf(ctx->gf_plan, sizeof(ctx->gf_plan),
+             "lane <-> chain kernel with %d-chain groups (%s): row buffers of %d slots%s", CG,
+             k.C < 384 ? "small batch" : nrow == 4 ? "multilinear below 192 chains or an odd sample count" : "group size measured fastest",
+             ucap, twin ? " sized by the previous launch's distinct-row count" : "");
     {
         dim3 grid((unsigned)nblocks);
-        if (a.ws) BA_TRY(launch_ws(k.mode, grid, lds, ctx->stream, a, f32 ? 1 : (pair64 ? 2 : 0)));
-        else if (CG == 1024) launch_shared_nrow<16>(nrow, k.mode, grid, lds, ctx->stream, a);
+        if (CG == 1024) launch_shared_nrow<16>(nrow, k.mode, grid, lds, ctx->stream, a);
         else if (CG == 512) launch_shared_nrow<8>(nrow, k.mode, grid, lds, ctx->stream, a);
         else if (CG == 256) launch_shared_nrow<4>(nrow, k.mode, grid, lds, ctx->stream, a);
         else if (CG == 128) launch_shared_nrow<2>(nrow, k.mode, grid, lds, ctx->stream, a);

@@ -415,6 +415,18 @@ class Context(object):
         return dict(chains_per_group=cg.value, mean_rows=mean.value, max_rows=mx.value,
                     row_bytes=rb.value)
 
+    def gf_plan(self, passes=True):
+        """-> dict(plan=<what the kernel selection chose for the last stacking launch and why>, mean_passes, max_passes:
+        row passes per (chain group, target, patch); 1 unless a patch touched more rows than an LDS buffer holds)"""
+        buf = C.create_string_buffer(512)
+        mean, mx = C.c_double(), C.c_int64()
+        check(self._lib.beatamd_ctx_gf_plan(self._h, buf, 512, C.byref(mean) if passes else None,
+                                            C.byref(mx) if passes else None))
+        out = dict(plan=buf.value.decode())
+        if passes:
+            out.update(mean_passes=mean.value, max_passes=mx.value)
+        return out
+
     # -- sampler steps on the device (SMC stage transition, proposals, exchange)
     def smc_calc_beta(self, likelihoods, beta, coef_variation, stride=1, n=None):
         """smc.py:133-165 -> (beta_new, weights); likelihoods: (C,) array or a strided view

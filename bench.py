@@ -179,7 +179,7 @@ def main():
                     help="skip the labelled legs of the other configurations: multilinear (the reference's "
                          "default interpolation), dense Toeplitz covariance, pre-whitened library, parallel "
                          "tempering, geometry mode")
-    ap.add_argument("--variant-legs", default="multilinear,toeplitz,default_config,stage_update,smc,pt,prewhitened,geometry,fp32",
+    ap.add_argument("--variant-legs", default="multilinear,toeplitz,default_config,stage_update,smc,pt,prewhitened,geometry,fp32,config4,realistic_grid",
                     help="which of the labelled configuration legs to run (comma separated)")
     ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "r4_bench_c512_nn_gfstack_ws_summary.json"),
                     help="rocprofv3 PMC summary (tools/run_profile.sh + tools/summarize_rocpd.py) of THIS "
@@ -264,8 +264,8 @@ def main():
     def run_leg(spec_leg, f_leg, n_chains, n_steps, n_warm, seed_offset, beta=2e-6):
         """n_steps timed astep batches of n_chains chains; everything resident in HBM beforehand.
         -> dict(dt, kernel times, in-box fraction, acceptance)"""
-        lay_l = lay   # the legs share the parameter layout; only the prior box differs
         box = host_of[spec_leg]
+        lay_l = box.get("layout", lay)   # the legs of the main library share its parameter layout; only the prior box differs
         Q0 = torch.from_numpy(draw_population(spec_leg, lay_l, box["lower"], box["upper"], n_chains,
                                               seed_offset=seed_offset)).to(dev)
         lo_h, up_h = lay_l.bounds(box["lower"], box["upper"])
@@ -880,6 +880,101 @@ def main():
                 "launches_per_step": 4,
                 "us_per_step_eager": gleg["eager"], "us_per_step_hip_graph": gleg["graph"],
                 "chain_steps_per_s": 1024 / (min(gleg.values()) * 1e-6)}
+        if legs & {"config4", "realistic_grid"}:
+            # legs with libraries of their own: the main problem's weights and models are not needed any more
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+
+        def own_library_leg(spec_l, chains_list, interps, n_steps, fix_problem=None):
+            """build a problem with its own device library, time `chains_list` x `interps` on it, free it"""
+            res = {}
+            t0 = time.perf_counter()
+            prob_l, host_l = build_problem(spec_l, device_library=True, ctx=ctx)
+            if fix_problem is not None:
+                fix_problem(prob_l, host_l)
+            host_of[spec_l] = host_l
+            nvar_l = len(spec_l.slip_varnames)
+            f_first = None
+            for interp in interps:
+                import copy as _copy
+                sp_i = _copy.copy(spec_l)
+                sp_i.interpolation = interp
+                host_of[sp_i] = host_l
+                for wm in prob_l.wavemaps:
+                    wm.interpolation = interp
+                f_i = prob_l.compile(ctx)      # (the libraries are uploaded / adopted once: init_optimization keeps lib_id)
+                f_first = f_first or f_i
+                torch.cuda.synchronize()
+                for nch in chains_list:
+                    leg = run_leg(sp_i, f_i, nch, n_steps, 2, seed_offset=1000)
+                    roof_l = stack_roofline(sp_i, leg, nch)
+                    plan = ctx.gf_plan() if hasattr(ctx, "gf_plan") else None
+                    res["%s_%d_chains" % ("nn" if interp == "nearest_neighbor" else "multilinear", nch)] = {
+                        "chains": nch, "steps": n_steps, "chain_steps_per_s": nch * n_steps / leg["dt"],
+                        "ms_per_step": leg["dt"] / n_steps * 1e3, "kernel": leg["kernel"], "plan": plan,
+                        "gfstack_avg_launch_ms": roof_l["avg_launch_ms"],
+                        "gfstack_ms_per_512_chains": roof_l["avg_launch_ms"] * 512.0 / nch,
+                        "kernel_ms_per_step": {k: (v[0] / n_steps) for k, v in leg["times"].items() if v[1]},
+                        "roofline": roof_l}
+                    del leg
+                del f_i
+            res["setup_s"] = time.perf_counter() - t0
+            res["library"] = "%d slip variable(s) x (%d,%d,%d,%d,%d) f64 = %.1f GB each" % (
+                nvar_l, spec_l.T, spec_l.P, spec_l.D, spec_l.S, spec_l.N, spec_l.lib_bytes / 1e9)
+            del prob_l, host_l, f_first
+            gc.collect()
+            torch.cuda.empty_cache()
+            return res
+
+        if "config4" in legs:
+            # BASELINE configs[3] (SURVEY 8(d) "config 4", reference test/test_ffi_gfstacking_multifault.py:16-122):
+            # 2 subfaults of 10 x 20 patches (2 km), 35 targets, two slip components, station time shifts, joint with
+            # the geodetic composite (the Laquila SAR scenes: 2 x 214 points, full covariances), Toeplitz data
+            # covariance (dense W); 512 chains = the per-GPU share of 4096 chains over 8 GPUs
+            from beat_amd.heart import whitening
+            from beat_amd.models.problem import GeodeticData
+            from beat_amd.synthetic import SyntheticSpec
+            gold = os.path.join(ROOT, "tests", "golden", "laquila_geodetic.npz")
+            out["config4_leg"] = {}
+            for N4 in (4096, 120):
+                if os.path.exists(gold):
+                    gz = np.load(gold)
+                    sizes4 = tuple(int(gz["d%d_displacement" % i].size) for i in range(int(gz["n"])))
+                else:
+                    gz, sizes4 = None, (214, 214)
+                sp4 = SyntheticSpec((10, 10), (20, 20), (2.0, 2.0), T=35, N=N4, D=2, S=60, st_dt=0.5,
+                                    slip_varnames=("uparr", "uperp"), covariance="toeplitz", station_shifts=True,
+                                    geodetic_nobs=sizes4, vel_bounds=(3.0, 4.0), time_bounds=(0.0, 2.0))
+
+                def laquila(prob_l, host_l, gz=gz, sizes4=sizes4):
+                    if gz is None:
+                        return
+                    gd = prob_l.geodetic
+                    d4 = np.concatenate([gz["d%d_displacement" % i] for i in range(len(sizes4))])
+                    o4 = np.concatenate([gz["d%d_odw" % i] for i in range(len(sizes4))])
+                    ws = [whitening(gz["d%d_C" % i]) for i in range(len(sizes4))]
+                    prob_l.geodetic = GeodeticData(gd.gfs, d4, o4, sizes4, [w_[0] for w_ in ws], [w_[1] for w_ in ws],
+                                                   gd.hypers)
+                r4 = own_library_leg(sp4, (512,), ("multilinear", "nearest_neighbor"), max(Kl // 2, 3), laquila)
+                r4["workload"] = ("BASELINE configs[3]: joint seismic + geodetic FFI, 2 subfaults x (10 x 20) patches of 2 km, 35 "
+                                  "targets x %d samples, slip components uparr + uperp, station time shifts, Toeplitz data "
+                                  "covariance (dense W), %s; 512 chains = the per-GPU share of 4096 over 8 GPUs"
+                                  % (N4, "Laquila SAR scenes (2 x 214 points, full covariances)" if gz is not None
+                                     else "synthetic geodetic scenes"))
+                out["config4_leg"]["N%d" % N4] = r4
+        if "realistic_grid" in legs:
+            # a library on the (duration x start-time) grid of the reference's own tutorial and defaults: durations 0-4 s every
+            # 0.25 s (docs/examples/FFI_kinematic.rst:185-195), start times 0-20 s every 0.5 s (beat/config.py:1906-1909);
+            # the prior spans the duration axis (the library is built from the prior bounds, beat/ffi/base.py:1005-1254)
+            from beat_amd.synthetic import SyntheticSpec
+            spr = SyntheticSpec((20,), (20,), (1.0,), T=64, N=512, D=17, S=41, st_min=0.0, st_dt=0.5, du_min=0.0, du_dt=0.25,
+                                nuc_margin=0.0, time_bounds=(0.0, 0.0))
+            rr = own_library_leg(spr, (512, 2048), ("nearest_neighbor", "multilinear"), max(Kl // 2, 3))
+            rr["workload"] = ("one 20 x 20 subfault, 64 targets x 512 samples, durations 0-4 s @ 0.25 s (D=17) x start times 0-20 s "
+                              "@ 0.5 s (S=41): library (64,400,17,41,512) f64 = %.1f GB; SURVEY 8(d) population with the duration "
+                              "prior spanning the library axis (U(0,4) s)" % (spr.lib_bytes / 1e9))
+            out["realistic_grid_leg"] = rr
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec)

@@ -42,7 +42,7 @@ extern "C" {
 /* ABI revision: bumped whenever an entry point changes its signature or an error code is added
  * (1.1: beatamd_weights_update gained kind/count in round 2; BEATAMD_EBADCOV).  beat_amd/_lib.py
  * refuses a library whose revision differs from the header it was written against. */
-#define BEATAMD_VERSION 114
+#define BEATAMD_VERSION 115
 
 #define BEATAMD_NEAREST_NEIGHBOR 0 /* interpolation="nearest_neighbor" */
 #define BEATAMD_MULTILINEAR 1      /* interpolation="multilinear"      */
@@ -86,6 +86,12 @@ int beatamd_ctx_last_kernel(beatamd_ctx *ctx, char *buf, int64_t buflen);
  * chains_per_group = 0 / row_bytes = 0 when the streaming kernel ran.  Synchronises. */
 int beatamd_ctx_gf_group_stats(beatamd_ctx *ctx, int64_t *chains_per_group, double *mean_rows,
                                int64_t *max_rows, int64_t *row_bytes);
+/* which stacking kernel the selection chose for the most recent launch and why, in words (chains per group, LDS row
+ * slots, whether patches are staged in several row passes), and -- when asked for (non-NULL; synchronises) -- the row
+ * passes per (chain group, target, patch) of that launch: 1 everywhere unless a patch touched more distinct library
+ * rows than an LDS row buffer holds.  No reference counterpart: the reference gathers one chain's rows by fancy
+ * indexing (beat/ffi/base.py:651-704); this reports how the batch shares them. */
+int beatamd_ctx_gf_plan(beatamd_ctx *ctx, char *buf, int64_t buflen, double *mean_passes, int64_t *max_passes);
 
 /* ---------------------------------------------------------------- fast sweep -------
  * replaces: fast_sweep_ext.fast_sweep(slowness, patch_size, h_strk, h_dip, num_strk,

@@ -1,0 +1,120 @@
+"""Row passes (round 5): libraries on fine (duration x start-time) grids -- the reference's tutorial uses durations
+0-4 s every 0.25 s (D = 17, docs/examples/FFI_kinematic.rst:185-195) and start times every 0.5 s over tens of seconds
+(beat/config.py:1906-1909) -- where a chain group touches more distinct library rows per patch than an LDS row
+buffer holds.  The loader/consumer kernel (nearest neighbour) and the runs kernel (multilinear) then stage a patch
+in several passes; results stay bitwise those of the streaming kernel (reference arithmetic beat/ffi/base.py:607-709)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import beat_amd
+    return beat_amd.get_context(0)
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def _lib(ctx, G, st_dt=0.5, du_dt=0.25, du_min=0.0):
+    from beat_amd.ffi import SeismicGFLibrary, SeismicGFLibraryConfig
+    T, P, D, S, N = G.shape
+    gf = SeismicGFLibrary(SeismicGFLibraryConfig(dimensions=G.shape, starttime_sampling=st_dt, duration_sampling=du_dt,
+                                                 starttime_min=0.0, duration_min=du_min))
+    gf.setup(T, P, D, S, N, allocate=True)
+    gf._gfmatrix[:] = G
+    gf.init_optimization(ctx)
+    return gf
+
+
+@pytest.mark.parametrize("C", [512, 530, 1100])
+def test_nn_row_passes_equal_streaming_kernel(ctx, orc, monkeypatch, C):
+    """tutorial grid (17 x 41 = 697 rows per patch), chains spread over all of it: ~360 distinct rows per 512-chain
+    group and patch = 4 passes of <= 96 rows through k_gfstack_ws; partial sample tile (N = 130), several groups"""
+    T, P, D, S, N = 2, 7, 17, 41, 130
+    rng = np.random.default_rng(C)
+    G = rng.standard_normal((T, P, D, S, N))
+    gf = _lib(ctx, G)
+    dur = rng.uniform(0.0, 4.0, (C, P))
+    st = rng.uniform(0.0, 19.9, (C, T, P))
+    sl = rng.uniform(-1, 5, (C, P))
+    # one patch with few rows (a single pass between patches of several) and one whose chains all agree
+    st[:, :, 2] = rng.uniform(3.0, 4.9, (C, T))
+    dur[:, 2] = rng.uniform(1.0, 1.2, C)
+    st[:, :, 5] = 7.3
+    dur[:, 5] = 2.1
+    monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
+    a = gf.stack_all_batch(dur, st, sl)
+    assert ctx.last_kernel().startswith("k_gfstack<0,"), ctx.last_kernel()
+    monkeypatch.delenv("BEATAMD_GF_KERNEL")
+    monkeypatch.setenv("BEATAMD_GS_CG", "512")
+    for order in ("1", "0"):
+        monkeypatch.setenv("BEATAMD_GS_ORDER", order)
+        monkeypatch.setenv("BEATAMD_GS_NTHINT", order)
+        b = gf.stack_all_batch(dur, st, sl)
+        assert ctx.last_kernel() == "k_gfstack_ws<1,0,3,%s>" % order, ctx.last_kernel()
+        st_ = ctx.gf_group_stats()
+        plan = ctx.gf_plan()
+        assert st_["max_rows"] > 192 and plan["max_passes"] >= 3 and 1.0 < plan["mean_passes"] < plan["max_passes"], (st_, plan)
+        assert "passes" in plan["plan"]
+        assert np.array_equal(a, b), (C, order)
+    for c in (0, 511, C - 1):
+        ref = orc.stack_all(G, dur[c], st[c], sl[c], 0.0, 0.25, 0.0, 0.5)
+        assert np.abs(a[c] - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("nvar,cov,shifts", [(1, "scalar", False), (2, "toeplitz", True), (2, "scalar", True)])
+def test_fused_model_on_a_fine_grid_nn(ctx, monkeypatch, nvar, cov, shifts):
+    """the fused log-likelihood (scalar-weight epilogue / residual store for dense W) through row passes: 600 chains of a
+    model whose library has 17 durations x 41 start times; against the streaming kernel (1e-11: two slip variables
+    accumulate in another order there only if the kernels differed -- they must not) and, bitwise, a sub-batch"""
+    from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
+    spec = SyntheticSpec((5,), (6,), (1.0,), T=3, N=96, D=17, S=41, du_min=0.0, du_dt=0.25, covariance=cov,
+                         slip_varnames=("uparr", "uperp")[:nvar], station_shifts=shifts, time_bounds=(0.0, 12.0))
+    prob, host = build_problem(spec)
+    f = prob.compile(ctx)
+    C = 600
+    Q = draw_population(spec, host["layout"], host["lower"], host["upper"], C)
+    monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
+    A = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack<0,"), ctx.last_kernel()
+    monkeypatch.delenv("BEATAMD_GF_KERNEL")
+    monkeypatch.setenv("BEATAMD_GS_CG", "512")
+    B = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack_ws<1,%d,3," % (1 if cov == "scalar" else 2)), ctx.last_kernel()
+    assert ctx.gf_plan()["max_passes"] >= 2, ctx.gf_plan()
+    assert np.isfinite(B).all()
+    # (the streaming kernel sums the misfit over 512-sample tiles, the chain-shared kernels over 64-sample tiles)
+    np.testing.assert_allclose(A, B, rtol=1e-11, atol=1e-9)
+    assert np.array_equal(f.batch(Q[:512]), B[:512])
+    # the lane <-> chain kernel with 128-chain groups (its row buffers hold a group's whole bound) has the same epilogue
+    monkeypatch.setenv("BEATAMD_GS_CG", "128")
+    B2 = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack_dma<2,1,"), ctx.last_kernel()
+    assert np.array_equal(B2, B)
+
+
+def test_float_storage_kernel_with_row_passes(ctx, monkeypatch):
+    """k_gfstack_ws32 (float copy of the library, pair gather) walks the same pass tables"""
+    from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
+    spec = SyntheticSpec((5,), (6,), (1.0,), T=3, N=100, D=17, S=41, du_min=0.0, du_dt=0.25, time_bounds=(0.0, 12.0))
+    prob, host = build_problem(spec)
+    f = prob.compile(ctx)
+    Q = draw_population(spec, host["layout"], host["lower"], host["upper"], 700)
+    f.round_libraries_to_f32()
+    monkeypatch.setenv("BEATAMD_GS_CG", "512")
+    B = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack_ws32<1,3,"), ctx.last_kernel()
+    assert ctx.gf_plan()["max_passes"] >= 2
+    f.set_f32(False)
+    A = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack_ws<1,1,3,"), ctx.last_kernel()
+    monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
+    A0 = f.batch(Q)
+    assert np.array_equal(A, B)
+    np.testing.assert_allclose(A0, A, rtol=1e-11, atol=1e-9)
