@@ -210,7 +210,7 @@ struct ScopedTimer {
 enum Slot : int {
     SL_IN0 = 0, SL_IN1, SL_IN2, SL_IN3, SL_IN4, SL_IN5, SL_IN6, SL_IN7,
     SL_OUT0, SL_OUT1, SL_OUT2,
-    SL_ROWOFF, SL_WEIGHTS, SL_ST0, SL_RESID, SL_PARTIAL, SL_QUAD, SL_MU, SL_SLIPS,
+    SL_ROWOFF, SL_WEIGHTS, SL_ST0, SL_RESID, SL_PARTIAL, SL_PARTIAL2, SL_QUAD, SL_MU, SL_SLIPS,
     SL_QPROP, SL_LPROP, SL_MISC, SL_GS_UROWS, SL_GS_UCOUNT, SL_GS_SLOT, SL_GS_W, SL_GS_UMAX, SL_GS_USLOT,
     SL_CHAINBAD, SL_Z, SL_ROWSCALE, SL_CUM, SL_STAGE2, SL_WHITEN,
     SL_CHOL_A, SL_CHOL_X, SL_CHOL_D, SL_CHOL_T, SL_CHOL_L,

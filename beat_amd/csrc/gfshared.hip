@@ -14,12 +14,14 @@
 //   LDS; each lane then reads ITS row from LDS (per-lane address) and does 64 fp64 FMAs with
 //   its own weight.  No cross-lane traffic, no dynamic register indexing, no atomics.
 //
-// Two kernels share this mapping:
-//   k_gfstack_dma     (shipped) rows by LDS-DMA into two LDS buffers one step ahead, one barrier
-//                     per step, hand-issued conflict-free ds_read_b64 (row pitch 65 doubles) or
+// Kernels of this mapping:
+//   k_gfstack_ws      (512-chain groups, one row per chain: the bench kernel) 8 consumer + 4 loader wavefronts, ring of three
+//                     LDS row buffers, row passes for patches that touch more than 96 distinct rows (k_ws_tables)
+//   k_gfstack_dma     (groups of 64 .. 1024 chains, one or four rows per chain) rows by LDS-DMA into two LDS buffers one
+//                     step ahead, one barrier per step, hand-issued conflict-free ds_read_b64 (row pitch 65 doubles) or
 //                     ds_read_b128 (pitch 66); all global accesses of its loop are asm statements
-//   k_gfstack_shared  single LDS buffer filled through registers, two barriers per step; used
-//                     when two row buffers do not fit LDS, and as A/B (BEATAMD_GS_DMA=0)
+// (round 1's single-buffer k_gfstack_shared was retired in round 5: what does not fit two row buffers is stacked by the
+// row-pass kernels or by k_gfstack)
 //
 // HBM bytes per batch drop from C x T x P x N x 8 to (distinct rows) x N x 8; the on-chip work
 // (LDS reads = algorithmic bytes, fp64 FMAs) is unchanged: the LDS gather is what bounds these
@@ -249,199 +251,6 @@ struct GsArgs {
     const double *data, *wscalar;
     double *out, *partial;
 };
-
-// Staging: per (patch, variable) step the distinct rows of the group are loaded 16 B per lane
-// (half a wavefront per row) through registers into one LDS buffer; two barriers per step.  A
-// workgroup keeps ~10 KB in flight per step, three workgroups fit per CU (166 VGPRs, 40 KB LDS).
-//
-// Measured alternatives on config 3 / 256 chains (same box, ms per launch): this form 6.2;
-// double-buffered with the next step's loads issued before the FMAs 7.8; the same plus 4-byte
-// LDS-DMA touches six steps ahead as an L2 prefetch 10.1 (the fabric fetches 32/64 B sectors, the
-// touches doubled the traffic); 6-8 steps staged per barrier interval with 16 B LDS-DMA 9.1, of
-// which 6.4 is the LDS-read + FMA phase alone (ablation) -- the kernel is bound by the per-lane
-// LDS gather (34 % of its LDS cycles are bank conflicts: 20 distinct rows vs 16 b128 windows), not
-// by HBM latency, so the deeper load pipelines only cost occupancy.
-template <int WAVES, int NROW, int MODE, int NT>
-__global__ void __launch_bounds__(WAVES * 64) k_gfstack_shared(GsArgs a)
-{
-    constexpr int GS_NT = NT;           // samples per tile = accumulators per lane
-    constexpr int GS_PITCH = NT + 2;    // doubles; row starts step through 16 distinct 4-bank
-                                        // windows for NT = 32, 40, 48, 64 (2*NT+4 dwords)
-    constexpr int LPR = NT / 2;         // lanes moving one row segment (16 B each)
-    constexpr int RPI = 64 / LPR;       // rows per load instruction (lanes >= RPI*LPR idle)
-    static_assert(RPI == 2, "two row segments per load instruction (NT = 64 or 48)");
-    extern __shared__ __attribute__((aligned(16))) double xbuf[];  // [ucap][GS_PITCH]
-    constexpr int CG = WAVES * 64;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row ids via s_load
-    const int tile = blockIdx.x % a.ntile;
-    if (a.guard_mode && ((a.guard_mode == 1) == (*a.guard_umax > (uint32_t)a.guard_fit))) return;
-    const int64_t gt0 = blockIdx.x / a.ntile;  // g*T + t
-    const int64_t t = gt0 % a.T;
-    const int64_t g = gt0 / a.T;
-    const int64_t gt = g * a.Ttab + (a.Ttab == 1 ? 0 : t);                       // table cell
-    const int64_t tbase = (a.Ttab == 1) ? t * a.rows_per_target * a.N : 0;      // doubles
-    const int64_t c = g * CG + tid;
-    const int64_t N = a.N;
-    const int64_t n0 = (int64_t)tile * GS_NT;
-    // LPR lanes per row segment, 16 B per lane: RPI rows per load instruction
-    const int hl = lane % LPR, hsel = lane / LPR;
-    int64_t nload = n0 + hl * 2;
-    const bool lane_ok = hsel < RPI;
-    const bool load_ok = nload < N;      // N even: a pair is never split (launcher guarantees)
-    if (!load_ok) nload = 0;
-
-    double acc[GS_NT];
-#pragma unroll
-    for (int i = 0; i < GS_NT; i++) acc[i] = 0.0;
-
-    // A step = (patch p, slip variable iv).  Everything a step needs besides the row data --
-    // the lane's slot and weight (vector loads), the group's distinct-row count and this
-    // wavefront's first row ids (scalar loads) -- is fetched ONE STEP AHEAD, right after the
-    // current step's row loads have been issued: a step's critical path is then one row-load
-    // latency + the LDS phase instead of table latency + row-id latency + row-load latency.
-    // (urows is padded with its last id up to a multiple of 64, so ids are read unclamped.)
-    const int P = (int)a.P;
-    constexpr int SPAN = WAVES * RPI * 4;  // rows staged per pass of the workgroup
-    int sl_n[NROW];
-    double wl_n[NROW];
-    int U_n = 0;
-    uint32_t ra_n[4], rb_n[4];
-    auto fetch_tabs = [&](int p, int iv) {
-        const int64_t gtq = gt * a.P + p;
-#pragma unroll
-        for (int k = 0; k < NROW; k++) {
-            sl_n[k] = a.slot[(gtq * NROW + k) * CG + tid];
-            wl_n[k] = (NROW == 1)
-                ? a.w[(int64_t)iv * a.w_var_stride + (g * a.P + p) * CG + tid]
-                : a.w[(int64_t)iv * a.w_var_stride + (gtq * 4 + k) * CG + tid];
-        }
-        U_n = __builtin_amdgcn_readfirstlane((int)a.ucount[gtq]);
-        const uint32_t *uq = a.urows + gtq * a.ustride + wave * RPI;   // wave-uniform: scalar loads
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            ra_n[u] = uq[u * WAVES * RPI];
-            rb_n[u] = uq[u * WAVES * RPI + (RPI == 2 ? 1 : 0)];
-        }
-    };
-    fetch_tabs(0, 0);
-    for (int p = 0; p < P; p++) {
-        const int64_t gtp = gt * a.P + p;
-        const uint32_t *ur = a.urows + gtp * a.ustride;
-        for (int iv = 0; iv < a.nvar; iv++) {
-            int sl[NROW];
-            double wl[NROW];
-#pragma unroll
-            for (int k = 0; k < NROW; k++) { sl[k] = sl_n[k]; wl[k] = wl_n[k]; }
-            const int U = U_n;
-            uint32_t ra[4], rb[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { ra[u] = ra_n[u]; rb[u] = rb_n[u]; }
-            const double *Gv = a.G[iv] + tbase;
-            __syncthreads();  // everyone finished reading the previous rows
-            // ---- stage the distinct rows of this (group, target, patch) in LDS
-            {
-                double2 x[4];
-                int ju[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t r = (RPI == 2) ? (hsel ? rb[u] : ra[u]) : ra[u];
-                    ju[u] = wave * RPI + u * WAVES * RPI + hsel;
-                    x[u] = *reinterpret_cast<const double2 *>(Gv + (int64_t)r * N + nload);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // next step's tables, younger than the row loads above
-                {
-                    int pn = p, ivn = iv + 1;
-                    if (ivn == a.nvar) { ivn = 0; pn = p + 1; }
-                    if (pn == P) { pn = p; ivn = iv; }
-                    fetch_tabs(pn, ivn);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (ju[u] < U && lane_ok)
-                        *reinterpret_cast<double2 *>(xbuf + ju[u] * GS_PITCH + hl * 2) =
-                            load_ok ? x[u] : double2{0.0, 0.0};
-            }
-            for (int j0 = wave * RPI + SPAN; j0 < U; j0 += SPAN) {
-                double2 x[4];
-                int ju[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int j = j0 + u * WAVES * RPI;
-                    const uint32_t qa = ur[j], qb = ur[j + (RPI == 2 ? 1 : 0)];
-                    const uint32_t r = (RPI == 2) ? (hsel ? qb : qa) : qa;
-                    ju[u] = j + hsel;
-                    x[u] = *reinterpret_cast<const double2 *>(Gv + (int64_t)r * N + nload);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (ju[u] < U && lane_ok)
-                        *reinterpret_cast<double2 *>(xbuf + ju[u] * GS_PITCH + hl * 2) =
-                            load_ok ? x[u] : double2{0.0, 0.0};
-            }
-            __syncthreads();
-            // ---- every lane applies ITS rows with ITS weights
-#pragma unroll
-            for (int k = 0; k < NROW; k++) {
-                const double *xs = xbuf + sl[k] * GS_PITCH;
-                const double w = wl[k];
-#pragma unroll
-                for (int i = 0; i < GS_NT; i += 2) {
-                    const double2 xv = *reinterpret_cast<const double2 *>(xs + i);
-                    acc[i] = fma(xv.x, w, acc[i]);
-                    acc[i + 1] = fma(xv.y, w, acc[i + 1]);
-                }
-            }
-        }
-    }
-
-    // ---- epilogue: lane = chain c, acc[i] = synthetics[c, t, n0 + i]
-    const bool live = c < a.C;
-    const int nvalid = (int)min((int64_t)GS_NT, N - n0);
-    if (MODE == GF_STORE_SYN) {
-        if (live) {
-            double *o = a.out + (c * a.T + t) * N + n0;
-#pragma unroll
-            for (int i = 0; i < GS_NT; i++)
-                if (i < nvalid) o[i] = acc[i];
-        }
-        return;
-    }
-    // data of this tile, broadcast through LDS
-    __syncthreads();
-    if (tid < GS_NT) xbuf[tid] = (tid < nvalid) ? a.data[t * N + n0 + tid] : 0.0;
-    __syncthreads();
-    // (processed 8 samples at a time with scheduling fences: hoisting all 64 LDS reads next
-    // to the 64 live accumulators would exceed the register budget and spill)
-    if (MODE == GF_RESID_STORE) {
-        double *o = a.out + (c * a.T + t) * N + n0;
-#pragma unroll
-        for (int i0 = 0; i0 < GS_NT; i0 += 8) {
-#pragma unroll
-            for (int i = i0; i < i0 + 8; i++)
-                if (live && i < nvalid) o[i] = xbuf[i] - acc[i];  // seismic.py:1332
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else {
-        // distributions.py:128-136 with W = w I, summed in sample order
-        const double w = a.wscalar[t];
-        double q = 0.0;
-#pragma unroll
-        for (int i0 = 0; i0 < GS_NT; i0 += 8) {
-#pragma unroll
-            for (int i = i0; i < i0 + 8; i++)
-                if (i < nvalid) {
-                    const double tt = w * (xbuf[i] - acc[i]);
-                    q = fma(tt, tt, q);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (live) a.partial[(c * a.T + t) * a.ntile + tile] = q;
-    }
-}
-
 
 typedef double v2d __attribute__((ext_vector_type(2)));
 
@@ -1933,9 +1742,7 @@ static void launch_shared_one(dim3 grid, size_t lds, hipStream_t s, const GsArgs
     } else {
         kern = (a.dma == 2 && a.nt == 32) ? k_gfstack_dma<WAVES, NROW, MODE, 32, 1>
              : (a.dma == 2) ? k_gfstack_dma<WAVES, NROW, MODE, 64, 1>
-             : a.dma ? k_gfstack_dma<WAVES, NROW, MODE, 64, 0>
-             : (a.nt == 48) ? k_gfstack_shared<WAVES, NROW, MODE, 48>
-                            : k_gfstack_shared<WAVES, NROW, MODE, 64>;
+                            : k_gfstack_dma<WAVES, NROW, MODE, 64, 0>;
     }
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2004,7 +1811,7 @@ static bool ws_wanted(const GfStackCall &k, int CG);
 
 struct WsTabArgs {
     int nvar, cap;
-    int64_t C, T, P;          // T: targets the tables are built for (1 or all)
+    int64_t C, T, P, DS;      // T: targets the tables are built for (1 or all); DS: library rows per (target, patch)
     int64_t vmax;             // vsteps per (group, target) the tables are strided by
     const uint32_t *rowoff;   // [C,T,P] global row ids (k_gf_tables)
     ChainVec slips[4];
@@ -2042,9 +1849,13 @@ __global__ void __launch_bounds__(256) k_ws_scan(const uint32_t *npass, uint32_t
     if (tid == 0) nv[gt] = run;
 }
 
-template <int FILL>
+// MAP: the distinct rows through a presence map over the D * S rows of the patch in LDS (libraries up to WS_MAP_MAX rows
+// per patch: every one so far); else by ranking the 512 row ids against each other (no bound, ~20 x the LDS traffic)
+constexpr int64_t WS_MAP_MAX = 16384;
+template <int FILL, int MAP>
 __global__ void __launch_bounds__(WS_CG) k_ws_tables(WsTabArgs a)
 {
+    extern __shared__ __attribute__((aligned(16))) uint16_t rowmap[];   // MAP: [DS] presence -> position
     __shared__ __attribute__((aligned(16))) uint32_t vals[WS_CG];   // the lanes' row ids (dead lanes: ~0)
     __shared__ __attribute__((aligned(16))) uint32_t firstv[WS_CG]; // the row id where the lane is the first to name it, else ~0
     __shared__ uint32_t lst[WS_CG];     // distinct rows, ascending
@@ -2062,37 +1873,69 @@ __global__ void __launch_bounds__(WS_CG) k_ws_tables(WsTabArgs a)
     const int64_t c = g * WS_CG + tid;
     const bool live = c < a.C;
     const uint32_t v = live ? a.rowoff[(c * a.T + t) * a.P + p] : 0xffffffffu;
-    vals[tid] = v;
     gm[tid] = 0;
-    __syncthreads();
-    // first lane to name its row
-    bool first = live;
-    {
-        const uint4 *v4 = reinterpret_cast<const uint4 *>(vals);
-        for (int k4 = 0; k4 < WS_CG / 4; k4++) {
-            const uint4 x = v4[k4];
-            const int k = 4 * k4;
-            first = first && !((x.x == v && k < tid) || (x.y == v && k + 1 < tid) || (x.z == v && k + 2 < tid) ||
-                               (x.w == v && k + 3 < tid));
+    uint32_t pos = 0, U = 0;
+    bool first = false;
+    if constexpr (MAP) {
+        const uint32_t row0 = (uint32_t)((t * a.P + p) * a.DS);
+        for (int64_t i = tid; i < a.DS; i += WS_CG) rowmap[i] = 0;
+        __syncthreads();
+        if (live) rowmap[v - row0] = 1;   // benign race: every writer stores 1
+        __syncthreads();
+        // exclusive scan of the map in row order: chunks of 512 flags, rank inside a wavefront by ballot / popcount
+        uint32_t run = 0;
+        for (int64_t base = 0; base < a.DS; base += WS_CG) {
+            const int64_t i = base + tid;
+            const uint32_t f = (i < a.DS) ? rowmap[i] : 0u;
+            const uint64_t m = __ballot(f != 0);
+            if (lane == 0) wsum[wv] = (uint32_t)__popcll(m);
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+            for (int q = 0; q < WS_CG / 64; q++) {
+                const uint32_t x = wsum[q];
+                if (q < wv) before += x;
+                total += x;
+            }
+            if (f) {
+                const uint32_t ps = run + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                rowmap[i] = (uint16_t)ps;
+                if constexpr (FILL) lst[ps] = row0 + (uint32_t)i;
+            }
+            run += total;
+            __syncthreads();
         }
-    }
-    firstv[tid] = first ? v : 0xffffffffu;
-    {
-        const uint64_t m = __ballot(first);
-        if (lane == 0) wsum[wv] = (uint32_t)__popcll(m);
-    }
-    __syncthreads();
-    // position of the lane's row among the distinct rows in ascending order
-    uint32_t pos = 0;
-    if (live) {
-        const uint4 *f4 = reinterpret_cast<const uint4 *>(firstv);
-        for (int k4 = 0; k4 < WS_CG / 4; k4++) {
-            const uint4 x = f4[k4];
-            pos += (x.x < v) + (x.y < v) + (x.z < v) + (x.w < v);
+        U = run;
+        if (live) pos = rowmap[v - row0];
+    } else {
+        vals[tid] = v;
+        __syncthreads();
+        // first lane to name its row
+        first = live;
+        {
+            const uint4 *v4 = reinterpret_cast<const uint4 *>(vals);
+            for (int k4 = 0; k4 < WS_CG / 4; k4++) {
+                const uint4 x = v4[k4];
+                const int k = 4 * k4;
+                first = first && !((x.x == v && k < tid) || (x.y == v && k + 1 < tid) || (x.z == v && k + 2 < tid) ||
+                                   (x.w == v && k + 3 < tid));
+            }
         }
+        firstv[tid] = first ? v : 0xffffffffu;
+        {
+            const uint64_t m = __ballot(first);
+            if (lane == 0) wsum[wv] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        // position of the lane's row among the distinct rows in ascending order
+        if (live) {
+            const uint4 *f4 = reinterpret_cast<const uint4 *>(firstv);
+            for (int k4 = 0; k4 < WS_CG / 4; k4++) {
+                const uint4 x = f4[k4];
+                pos += (x.x < v) + (x.y < v) + (x.z < v) + (x.w < v);
+            }
+        }
+        for (int q = 0; q < WS_CG / 64; q++) U += wsum[q];
     }
-    uint32_t U = 0;
-    for (int q = 0; q < WS_CG / 64; q++) U += wsum[q];
     const int npass = (int)((U + (uint32_t)a.cap - 1) / (uint32_t)a.cap);
     if constexpr (!FILL) {
         if (tid == 0) {
@@ -2103,7 +1946,9 @@ __global__ void __launch_bounds__(WS_CG) k_ws_tables(WsTabArgs a)
     }
     if (tid == 0) a.utotal[gtp] = U;
     const int per = ((int)U + npass - 1) / npass;       // rows of a pass (the last may hold fewer)
-    if (first) lst[pos] = v;
+    if constexpr (!MAP) {
+        if (first) lst[pos] = v;
+    }
     if (live) atomicOr(&gm[pos], 1u << (tid >> 5));
     __syncthreads();
     const int mypass = live ? (int)pos / per : -1;
@@ -2211,8 +2056,8 @@ static bool shared_fit(const GfStackCall &k, int cg, int *ucap_out)
         *ucap_out = (int)std::max<int64_t>(ucap, 2);
         return true;
     }
-    if (ucap * (GS_NT_MAX + 2) * 8 > 150 * 1024) return false;
-    if (2 * DS * 4 + cg * 4 + 2048 > 60 * 1024) return false;
+    if (2 * ucap * (GS_NT_MAX + 2) * 8 > 158 * 1024) return false;   // two row buffers of the bound
+    if (2 * DS * 4 + cg * 4 + 2048 > 60 * 1024) return false;         // presence map + group masks of k_gf_group_tables
     *ucap_out = (int)std::max<int64_t>(ucap, 2);
     return true;
 }
@@ -2251,13 +2096,14 @@ bool gfstack_shared_applicable(const GfStackCall &k, int *cg_out, int *ucap_out)
         *ucap_out = (int)std::max<int64_t>(ucap, 2);
         return true;
     }
-    // the distinct rows of one step must fit in LDS; prefer >= 2 workgroups per CU
+    // two row buffers of the group's distinct-row bound must fit LDS (prefer >= 2 workgroups per CU): halve the group
+    // until they do
     const int GS_PITCH = GS_NT_MAX + 2;
     while (ucap * GS_PITCH * 8 > 72 * 1024 && cg > 64) {
         cg /= 2;
         ucap = std::min<int64_t>((int64_t)cg * nrow, DS);
     }
-    if (ucap * GS_PITCH * 8 > 150 * 1024) return false;
+    if (2 * ucap * GS_PITCH * 8 > 158 * 1024) return false;
     if (2 * DS * 4 + cg * 4 + 2048 > 60 * 1024) return false;  // presence map + group masks of k_gf_group_tables
     *cg_out = cg;
     *ucap_out = (int)std::max<int64_t>(ucap, 2);
@@ -2290,7 +2136,7 @@ static int launch_gfstack_ws(beatamd_ctx *ctx, const GfStackCall &k, const uint3
     WsTabArgs ta;
     memset(&ta, 0, sizeof(ta));
     ta.nvar = k.nvar; ta.cap = cap;
-    ta.C = k.C; ta.T = Ttab; ta.P = L.P; ta.vmax = vmax;
+    ta.C = k.C; ta.T = Ttab; ta.P = L.P; ta.DS = L.D * L.S; ta.vmax = vmax;
     ta.rowoff = rowoff;
     for (int v = 0; v < k.nvar; v++) ta.slips[v] = k.slips[v];
     // [utotal GTP][npass GTP][voff GTP][nv GT]
@@ -2311,12 +2157,16 @@ static int launch_gfstack_ws(beatamd_ctx *ctx, const GfStackCall &k, const uint3
     ta.w = (double *)p;
     {
         ScopedTimer tm(ctx, "grouptables");
+        const bool map = ta.DS <= WS_MAP_MAX && !(getenv("BEATAMD_WS_MAP") && atoi(getenv("BEATAMD_WS_MAP")) == 0);   // (0: tests of the ranking path)
+        const size_t mlds = map ? (size_t)ta.DS * sizeof(uint16_t) : 0;
         if (maxpass > 1) {
-            hipLaunchKernelGGL(k_ws_tables<0>, dim3((unsigned)GTP), dim3(WS_CG), 0, ctx->stream, ta);
+            if (map) hipLaunchKernelGGL((k_ws_tables<0, 1>), dim3((unsigned)GTP), dim3(WS_CG), mlds, ctx->stream, ta);
+            else hipLaunchKernelGGL((k_ws_tables<0, 0>), dim3((unsigned)GTP), dim3(WS_CG), 0, ctx->stream, ta);
             hipLaunchKernelGGL(k_ws_scan, dim3((unsigned)GT), dim3(256), 0, ctx->stream, ta.npass, voff, nv, L.P);
             ta.voff = voff;
         }
-        hipLaunchKernelGGL(k_ws_tables<1>, dim3((unsigned)GTP), dim3(WS_CG), 0, ctx->stream, ta);
+        if (map) hipLaunchKernelGGL((k_ws_tables<1, 1>), dim3((unsigned)GTP), dim3(WS_CG), mlds, ctx->stream, ta);
+        else hipLaunchKernelGGL((k_ws_tables<1, 0>), dim3((unsigned)GTP), dim3(WS_CG), 0, ctx->stream, ta);
     }
     BA_HIP(hipGetLastError());
 
@@ -2524,12 +2374,12 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     a.guard_umax = ga.umax;
     size_t lds = (size_t)ucap * (a.nt + 2) * sizeof(double);
     {
-        // two row buffers when they fit (BEATAMD_GS_DMA=0 forces the single-buffer kernel)
+        // two row buffers (the candidates were chosen so that they fit); BEATAMD_GS_DMA=1: the ds_read_b128 layout (A/B)
         const char *e = getenv("BEATAMD_GS_DMA");
-        a.dma = ((a.nt == 64 || a.nt == 32) && 2 * lds <= 158 * 1024 && !(e && atoi(e) == 0)) ? 1 : 0;
-        if (a.dma && !(e && atoi(e) == 1)) a.dma = 2;   // ds_read_b64 / pitch NT+1 (default); 1 = b128 / pitch NT+2
+        BA_CHECK(2 * lds <= 158 * 1024, BEATAMD_EINVAL, "internal: k_gfstack_dma row buffers exceed LDS");
+        a.dma = (e && atoi(e) == 1) ? 1 : 2;   // 2: ds_read_b64 / pitch NT+1 (default); 1: b128 / pitch NT+2
         if (a.nt == 32 && a.dma != 2) { a.nt = 64; a.ntile = (int)((L.N + 63) / 64); nblocks = ngroups * L.T * a.ntile;
-                                        lds = (size_t)ucap * (a.nt + 2) * sizeof(double); a.dma = 0; }
+                                        lds = (size_t)ucap * (a.nt + 2) * sizeof(double); }
         BA_CHECK(CG != 1024 || a.dma == 2, BEATAMD_EINVAL, "gfstack: 1024-chain groups need the LDS-DMA kernel");
         BA_CHECK(!ga.windowed || a.dma == 2, BEATAMD_EINVAL, "internal: window slots need the ds_read_b64 kernel");
         a.ws = 0;
@@ -2541,22 +2391,22 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         if (a.dma == 2 && a.nt == 64 && CG <= 512 && f32) {
             a.f32pair = 1;
             lds = std::max<size_t>((size_t)ucap * (a.nt + 2) * sizeof(float) * 2, 64 * sizeof(double));
-        } else if (a.dma) {
+        } else {
             lds *= 2;
         }
     }
     {
         // chain groups of one (target, tile) on one XCD (several groups only)
         const char *e = getenv("BEATAMD_GS_ORDER");
-        a.xcd_order = (a.dma && ngroups > 1 && !(e && atoi(e) == 0)) ? 1 : 0;
-        if (e && atoi(e) == 1 && a.dma) a.xcd_order = 1;
+        a.xcd_order = (ngroups > 1 && !(e && atoi(e) == 0)) ? 1 : 0;
+        if (e && atoi(e) == 1) a.xcd_order = 1;
         if (a.xcd_order) nblocks = ((L.T * a.ntile + 7) / 8) * 8 * ngroups;
     }
     if (a.f32pair)
         snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack_dmaf<%d,%d,%d>", CG / 64, nrow, k.mode);
     else
         snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "%s<%d,%d,%d,%d,%d>",
-                 a.dma ? "k_gfstack_dma" : "k_gfstack_shared", CG / 64, nrow, k.mode, a.nt, a.dma == 2 ? 1 : 0);
+                 "k_gfstack_dma", CG / 64, nrow, k.mode, a.nt, a.dma == 2 ? 1 : 0);
     ctx->gs_ngtp = GTP;
     ctx->gs_trep = L.T / Ttab;
     ctx->gs_N = L.N;

@@ -122,6 +122,8 @@ struct GfArgs {
     int64_t C;
     int cgroup;       // order 1: chains per group
     int64_t Ttab, rows_per_target;   // tables per (chain, target, patch) or, Ttab = 1, per (chain, patch)
+    // stand-in launch behind k_gfstack_runs: works only when *guard != 0 (the runs kernel's tables overflowed)
+    const int *guard;
 };
 
 template <int W> struct VecT;
@@ -151,6 +153,7 @@ __global__ void __launch_bounds__(256) k_gfstack(GfArgs a)
     // rows of V in flight per lane ~ 8
     constexpr int U = (8 / (NROW * NVAR * VEC)) > 0 ? (8 / (NROW * NVAR * VEC)) : 1;
 
+    if (a.guard && *a.guard == 0) return;
     const int tile = blockIdx.x % a.ntile;
     const int64_t bq = blockIdx.x / a.ntile;
     int64_t c, t;
@@ -299,20 +302,23 @@ int launch_round_to_f32(beatamd_ctx *ctx, double *g, float *g32, int64_t n)
     return BEATAMD_OK;
 }
 
+// guard (nullable): the launch works only when (*guard != 0) == (want != 0) -- the two producers of a misfit, the runs
+// kernel and its stand-in, each bring their own tile sums
 __global__ void __launch_bounds__(256) k_sum_tiles(const double *partial, int64_t n, int ntile,
-                                                  double *quad)
+                                                  double *quad, const int *guard, int want)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    if (guard && (*guard != 0) != (want != 0)) return;
     double s = 0.0;
     for (int k = 0; k < ntile; k++) s += partial[i * ntile + k];  // fixed order: deterministic
     quad[i] = s;
 }
 
-int launch_sum_tiles(beatamd_ctx *ctx, const double *partial, int64_t n, int ntile, double *quad)
+int launch_sum_tiles(beatamd_ctx *ctx, const double *partial, int64_t n, int ntile, double *quad, const int *guard, int want)
 {
     hipLaunchKernelGGL(k_sum_tiles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       partial, n, ntile, quad);
+                       partial, n, ntile, quad, guard, want);
     BA_HIP(hipGetLastError());
     return BEATAMD_OK;
 }
@@ -385,9 +391,14 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &k)
     // cell kernel works on the float64 rows)
     bool f32_all = k.f32;
     for (int v = 0; v < k.nvar; v++) f32_all = f32_all && k.libs[v]->g32 != nullptr;
-    if (!f32_all && gfstack_ml_applicable(k)) return launch_gfstack_ml(ctx, k, ta.rowoff, ta.fac, Ttab);
-    if (!f32_all && gfstack_cell_applicable(k)) return launch_gfstack_cell(ctx, k, ta.rowoff, ta.fac, Ttab);
-    {
+    // multilinear from 192 chains on: the runs kernel (gfcell.hip).  When its tables can overflow (more row passes than they
+    // are sized for) the streaming kernel below is enqueued behind it as a stand-in that works only if they did.
+    const int *standin = nullptr;
+    if (!f32_all && gfstack_ml_applicable(k)) {
+        BA_TRY(launch_gfstack_ml(ctx, k, ta.rowoff, ta.fac, Ttab, &standin));
+        if (!standin) return BEATAMD_OK;
+    }
+    if (!standin) {
         int cg = 0, ucap = 0;
         if (gfstack_shared_applicable(k, &cg, &ucap)) {
             // Chains per workgroup: which size is fastest depends on the library (distinct rows a
@@ -454,23 +465,29 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &k)
     a.data = k.data;
     a.wscalar = k.wscalar;
     a.out = k.out;
+    a.guard = standin;
     const int W = (L.N % 2 == 0) ? 2 : 1;
     const int VEC = 1;
     const int64_t tile_w = (int64_t)256 * W * VEC;
     a.ntile = (int)((L.N + tile_w - 1) / tile_w);
     if (k.mode == GF_RESID_SCALAR) {
-        BA_TRY(ctx->get_scratch(SL_PARTIAL, (size_t)k.C * L.T * a.ntile * sizeof(double), &p));
+        // (a stand-in keeps its tile sums apart from those of the kernel it stands in for)
+        BA_TRY(ctx->get_scratch(standin ? SL_PARTIAL2 : SL_PARTIAL, (size_t)k.C * L.T * a.ntile * sizeof(double), &p));
         a.partial = (double *)p;
     }
     const int64_t nblocks = k.C * L.T * a.ntile;
     BA_CHECK(nblocks < (int64_t)0x7fffffff, BEATAMD_EINVAL, "gfstack: batch too large (%lld blocks)",
              (long long)nblocks);
     dim3 grid((unsigned)nblocks);
-    snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack<%d,%d,%d,%d,%d>",
-             k.interp == BEATAMD_MULTILINEAR ? 1 : 0, k.nvar, VEC, W, k.mode);
-    ctx->gs_ngtp = 0;
+    if (!standin) {
+        snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack<%d,%d,%d,%d,%d>",
+                 k.interp == BEATAMD_MULTILINEAR ? 1 : 0, k.nvar, VEC, W, k.mode);
+        snprintf(ctx->gf_plan, sizeof(ctx->gf_plan), "streaming kernel: %s", k.C < 48 ? "fewer than 48 chains share too few rows" :
+                 L.N % 2 ? "odd sample count (the chain-shared kernels move 16-byte lanes)" : "chosen by BEATAMD_GF_KERNEL or no chain-shared kernel fits this library");
+        ctx->gs_ngtp = 0;
+    }
     {
-        ScopedTimer tm(ctx, "gfstack");
+        ScopedTimer tm(ctx, standin ? "gfstack_standin" : "gfstack");
         if (k.interp == BEATAMD_NEAREST_NEIGHBOR) {
             if (W == 2) launch_nvar<0, 1, 2>(k.nvar, k.mode, grid, ctx->stream, a);
             else launch_nvar<0, 1, 1>(k.nvar, k.mode, grid, ctx->stream, a);
@@ -480,7 +497,7 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &k)
         }
     }
     BA_HIP(hipGetLastError());
-    if (k.mode == GF_RESID_SCALAR) BA_TRY(launch_sum_tiles(ctx, a.partial, k.C * L.T, a.ntile, k.quad));
+    if (k.mode == GF_RESID_SCALAR) BA_TRY(launch_sum_tiles(ctx, a.partial, k.C * L.T, a.ntile, k.quad, standin, 1));
     return BEATAMD_OK;
 }
 

@@ -58,7 +58,8 @@ struct GfStackCall {
     ChainVec order_key[2];
 };
 int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &call);
-int launch_sum_tiles(beatamd_ctx *ctx, const double *partial, int64_t n, int ntile, double *quad);
+int launch_sum_tiles(beatamd_ctx *ctx, const double *partial, int64_t n, int ntile, double *quad,
+                     const int *guard = nullptr, int want = 0);
 // g[i] = (double)(float)g[i]; g32[i] = (float)g[i]  (float-storage copy of a GF library)
 int launch_round_to_f32(beatamd_ctx *ctx, double *g, float *g32, int64_t n);
 // gfshared.hip: chain-shared variant (distinct rows staged once per chain group)
@@ -67,14 +68,12 @@ int gfstack_shared_candidates(const GfStackCall &call, int *cgs, int *ucaps);
 int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &call, const uint32_t *rowoff,
                           const double *fac, int CG, int ucap, int64_t Ttab);
 
-// gfcell.hip: multilinear stacking with the rows of a cell in registers (512-chain groups)
-bool gfstack_cell_applicable(const GfStackCall &call);
-int launch_gfstack_cell(beatamd_ctx *ctx, const GfStackCall &call, const uint32_t *rowoff,
-                        const double *fac, int64_t Ttab);
-// gfcell.hip: multilinear stacking with static accumulators and a dense LDS row layout (round 4)
+// gfcell.hip: multilinear stacking with the rows of a cell in registers (518-chain groups, row passes): k_gfstack_runs.
+// *ovf (device, nullable on return): nonzero after the launch = the tables overflowed and nothing was stacked -- the
+// caller enqueues k_gfstack behind it as a stand-in guarded by the same flag
 bool gfstack_ml_applicable(const GfStackCall &call);
 int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &call, const uint32_t *rowoff,
-                      const double *fac, int64_t Ttab);
+                      const double *fac, int64_t Ttab, const int **ovf);
 
 // ---- quadform.hip ----------------------------------------------------------------
 // quad[c,d] = || A_d x_{c,d} ||^2 ; A [nd or 1, M, M] row-major ; x(c,d,k) = X[c*xs_c + d*xs_d + k]

@@ -1,10 +1,10 @@
-"""CPU check of the k_gfstack_cell wavefront program (beat_amd/csrc/gfcell_asm.inc).
+"""CPU check of the k_gfstack_runs wavefront programs (beat_amd/csrc/gfruns_asm.inc).
 
-tools/gfcell_emu.py interprets the instruction list that tools/gen_gfcell_asm.py emits -- all 16
-wavefronts of a workgroup with their barriers, the ring of LDS row buffers, the command stream --
-and a numpy twin of the table builder; the result is compared with a direct multilinear stack
-(reference beat/ffi/base.py:663-704).  Timing / hazards are not modelled; the -m gpu tests run the
-real kernel against k_gfstack and the oracle."""
+tools/gfcell_emu.py interprets the instruction lists that tools/gen_gfruns_asm.py emits -- all 16 wavefronts of a
+workgroup with their barriers, the ring of LDS row buffers, the VGPR index register, the scalar descriptor loads --
+and a numpy twin of the table builders (chain order, row passes, request / descriptor / weight tables); the result
+is compared with a direct multilinear stack (reference beat/ffi/base.py:663-704).  Timing / hazards are not
+modelled; the -m gpu tests run the real kernel against k_gfstack and the oracle."""
 import os
 import sys
 
@@ -13,7 +13,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-import gen_gfcell_asm as gen  # noqa: E402
+import gen_gfruns_asm as gen  # noqa: E402
 import gfcell_emu as emu  # noqa: E402
 
 
@@ -34,7 +34,7 @@ def _reference(G, ro, fa, sl, T, P, N, Gx=(), slx=()):
     return out
 
 
-def _run(T, P, D, S, N, C, Ttab_is_one, mode, sort, nth, seed, static_acc=False, below_grid=False, nvar=1):
+def _run(T, P, D, S, N, C, Ttab_is_one, mode, sort, nth, seed, below_grid=False, nvar=1, cap=None, du_span=None):
     rng = np.random.default_rng(seed)
     G = rng.standard_normal((T, P, D, S, N))
     Gx = [rng.standard_normal((T, P, D, S, N)) for _ in range(nvar - 1)]     # libraries of further slip variables
@@ -54,28 +54,19 @@ def _run(T, P, D, S, N, C, Ttab_is_one, mode, sort, nth, seed, static_acc=False,
     DS = D * S
     order = emu.gc_order(ro, C, Ttab, P, S, sort)
     assert sorted(order[order != emu.DEAD].tolist()) == list(range(C))
-    if static_acc:
-        tabs = emu.gm_tables(ro, fa, [sl] + slx, order, C, Ttab, P, D, S, runs=(static_acc == "runs"), nvar=nvar)
-        wtab, ltab, ucount = tabs[:3]
-        dtab = tabs[3] if static_acc == "runs" else None
-    else:
-        wtab, ltab, ucount = emu.gc_tables(ro, fa, [sl], order, C, Ttab, P, DS)
+    tabs = emu.gm_tables(ro, fa, [sl] + slx, order, C, Ttab, P, D, S, nvar=nvar, cap=cap)
     data = rng.standard_normal((T, N))
     wsc = rng.uniform(0.5, 2.0, T)
     ntile = (N + 63) // 64
     mem = emu.Memory()
-    a = dict(T=T, P=P, N=N, DS=DS, Ttab=Ttab, rows_per_target=P * DS, nsteps=P * nvar, mode=mode, ntile=ntile,
-             wscalar=wsc, nvar=nvar)
+    a = dict(T=T, P=P, N=N, DS=DS, Ttab=Ttab, rows_per_target=P * DS, mode=mode, ntile=ntile, wscalar=wsc, nvar=nvar,
+             nv=tabs["nv"], smax=tabs["smax"], cap=tabs["cap"])
     for i, gx in enumerate(Gx):
         a["G%d" % (i + 1)] = mem.alloc(gx.nbytes, gx)
-    if static_acc:
-        a["wstride"], a["ucap"] = (emu.genruns if static_acc == "runs" else emu.genml).WSTRIDE, D * (S + 1)
     a["G"] = mem.alloc(G.nbytes, G)
-    a["wtab"] = mem.alloc(wtab.nbytes, wtab)
-    a["ltab"] = mem.alloc(ltab.nbytes, ltab)
+    for name in ("wtab", "ltab", "dtab"):
+        a[name] = mem.alloc(tabs[name].nbytes, tabs[name])
     a["order"] = mem.alloc(order.nbytes + 256, order)
-    if static_acc == "runs":
-        a["dtab"] = mem.alloc(dtab.nbytes, dtab)
     a["data"] = mem.alloc(data.nbytes, data)
     a["out"] = mem.alloc(C * T * N * 8)
     a["partial"] = mem.alloc(C * T * ntile * 8)
@@ -85,10 +76,10 @@ def _run(T, P, D, S, N, C, Ttab_is_one, mode, sort, nth, seed, static_acc=False,
         for t in range(T):
             for tile in range(ntile):
                 params = [emu.wave_params(w, g, t, tile, a) for w in range(emu.WAVES)]
-                nlds = emu.lds_bytes_ml(D * (S + 1)) if static_acc else emu.lds_bytes(DS)
-                wg = emu.Workgroup(mem, nth, nlds, params, static_acc=static_acc).run()
+                wg = emu.Workgroup(mem, nth, emu.lds_bytes(tabs["cap"]), params).run()
                 assert all(w.done and not w.idx_en and w.exec == emu.MASK64 for w in wg.waves)
-                assert {w.nbarrier for w in wg.waves} == {P * nvar + 1}
+                gt = g * Ttab + (0 if Ttab == 1 else t)
+                assert {w.nbarrier for w in wg.waves} == {int(tabs["nv"][gt]) * nvar + 1}
                 stats.append(wg)
     # full rows for the reference: with tables per patch the row ids are those of target 0
     rof = ro if Ttab == T else np.stack([ro[:, 0] + t * P * DS for t in range(T)], 1)
@@ -111,86 +102,68 @@ def _run(T, P, D, S, N, C, Ttab_is_one, mode, sort, nth, seed, static_acc=False,
                         q = tt * tt + q
                     exp[c, t, tl] = q
         assert np.array_equal(part, exp)
-    return stats, ucount
-
-
-@pytest.mark.parametrize("mode", [0, 1, 2])
-def test_program_one_group(mode):
-    """45 chains (one full consumer wavefront, one partly filled, twelve empty), two tiles (64 + 6
-    samples), tables per target, node-0 wrap and exact-grid durations included"""
-    _run(T=2, P=4, D=3, S=6, N=70, C=45, Ttab_is_one=False, mode=mode, sort=True, nth=mode & 1, seed=5 + mode)
-
-
-def test_program_tables_per_patch_and_order():
-    """tables built once per (chain, patch); results do not depend on the chain order"""
-    for sort in (True, False):
-        stats, _ = _run(T=2, P=3, D=2, S=5, N=64, C=80, Ttab_is_one=True, mode=0, sort=sort, nth=0, seed=11)
-    # every chain of a step costs exactly four indexed FMAs, whatever the batching
-    assert sum(w.fma_count for w in stats[0].waves) == 80 * 3 * 4
-
-
-def test_program_two_groups():
-    """519 chains: a full group and a group of one chain"""
-    stats, ucount = _run(T=1, P=2, D=2, S=4, N=64, C=519, Ttab_is_one=True, mode=1, sort=True, nth=1, seed=3)
-    # LDS-DMA moved every distinct row segment of the group once (plus the three-step prologue overlap)
-    assert stats[0].dma_bytes == int(ucount[:2].sum()) * 512
-
-
-@pytest.mark.parametrize("mode", [0, 1, 2])
-def test_static_program_one_group(mode):
-    """k_gfstack_ml (static accumulators, dense LDS rows with a wrap slot per duration line): same cases as above
-    plus start times / durations BELOW the first grid node, where the wrapped floor node carries weight"""
-    _run(T=2, P=4, D=3, S=6, N=70, C=45, Ttab_is_one=False, mode=mode, sort=False, nth=mode & 1, seed=5 + mode,
-         static_acc=True, below_grid=True)
-
-
-def test_static_program_tables_per_patch_and_two_groups():
-    stats, _ = _run(T=2, P=3, D=2, S=5, N=64, C=80, Ttab_is_one=True, mode=0, sort=False, nth=0, seed=11, static_acc=True)
-    # four FMAs per chain SLOT of a step (dead slots run with zero weights): nothing depends on the data
-    assert sum(w.fma_count for w in stats[0].waves) == emu.CG * 3 * 4
-    stats, ucount = _run(T=1, P=2, D=2, S=4, N=64, C=519, Ttab_is_one=True, mode=1, sort=False, nth=1, seed=3,
-                         static_acc=True)
-    assert stats[0].dma_bytes == int(ucount[:2].sum()) * 512
-    # D = S = 1: one node, every index wraps onto it
-    _run(T=1, P=2, D=1, S=1, N=64, C=3, Ttab_is_one=True, mode=0, sort=False, nth=0, seed=4, static_acc=True)
+    return stats, tabs
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_runs_program_one_group(mode):
-    """k_gfstack_runs (cell order per patch, rows read once per run of chains sharing a cell, accumulators through
-    the VGPR index register with the offset unpacked on the scalar side): the cases of the static program"""
+    """45 chains (one full consumer wavefront, one partly filled, twelve empty), two tiles (64 + 6 samples), tables per
+    target, node-0 wrap, exact-grid durations and start times / durations BELOW the first grid node (the wrapped floor
+    node carries weight)"""
     _run(T=2, P=4, D=3, S=6, N=70, C=45, Ttab_is_one=False, mode=mode, sort=bool(mode & 1), nth=mode & 1, seed=5 + mode,
-         static_acc="runs", below_grid=True)
+         below_grid=True)
 
 
 def test_runs_program_shares_row_reads():
-    stats, _ = _run(T=2, P=3, D=2, S=5, N=64, C=80, Ttab_is_one=True, mode=0, sort=True, nth=0, seed=11, static_acc="runs")
-    # four FMAs per chain SLOT and step, but far fewer row reads: 80 chains over 2 x 4 cells
+    stats, tabs = _run(T=2, P=3, D=2, S=5, N=64, C=80, Ttab_is_one=True, mode=0, sort=True, nth=0, seed=11)
+    # four FMAs per POSITION and step (pads and empty chain slots go to the scratch accumulator): nothing depends on the data
     assert sum(w.fma_count for w in stats[0].waves) == emu.CG * 3 * 4
-    stats, ucount = _run(T=1, P=2, D=2, S=4, N=64, C=519, Ttab_is_one=True, mode=1, sort=True, nth=1, seed=3,
-                         static_acc="runs")
-    assert stats[0].dma_bytes == int(ucount[:2].sum()) * 512
-    _run(T=1, P=2, D=1, S=1, N=64, C=3, Ttab_is_one=True, mode=0, sort=False, nth=0, seed=4, static_acc="runs")
+    assert sum(w.pad_fma_count for w in stats[0].waves) == (emu.CG - 80) * 3 * 4
+    stats, tabs = _run(T=1, P=2, D=2, S=4, N=64, C=519, Ttab_is_one=True, mode=1, sort=True, nth=1, seed=3)
+    # LDS-DMA moved every distinct row segment of the group once
+    assert stats[0].dma_bytes == int(tabs["ucount"][:2].sum()) * 512
+    # D = S = 1: one node, every index wraps onto it
+    _run(T=1, P=2, D=1, S=1, N=64, C=3, Ttab_is_one=True, mode=0, sort=False, nth=0, seed=4)
     # a step of one patch and a wavefront full of one cell
-    _run(T=1, P=1, D=2, S=3, N=64, C=40, Ttab_is_one=True, mode=2, sort=True, nth=0, seed=9, static_acc="runs")
+    _run(T=1, P=1, D=2, S=3, N=64, C=40, Ttab_is_one=True, mode=2, sort=True, nth=0, seed=9)
 
 
-@pytest.mark.parametrize("kind,nvar", [("runs", 2), ("runs", 3), (True, 2)])
-def test_programs_with_several_slip_variables(kind, nvar):
-    """steps cycle through the slip variables' libraries patch by patch (loader: base of the step's variable + rows of
-    the patch; records: the variable's slips on the same cells)"""
-    _run(T=2, P=3, D=2, S=5, N=70, C=45, Ttab_is_one=(nvar == 2), mode=nvar % 3, sort=True, nth=0, seed=21 + nvar,
-         static_acc=kind, nvar=nvar)
+@pytest.mark.parametrize("nvar", [2, 3])
+def test_programs_with_several_slip_variables(nvar):
+    """steps cycle through the slip variables' libraries (loader: base of the step's variable + rows of the patch;
+    records: the variable's slips on the same cells)"""
+    _run(T=2, P=3, D=2, S=5, N=70, C=45, Ttab_is_one=(nvar == 2), mode=nvar % 3, sort=True, nth=0, seed=21 + nvar, nvar=nvar)
+
+
+@pytest.mark.parametrize("mode,nvar,ttab1", [(0, 1, True), (1, 2, False), (2, 1, False)])
+def test_row_passes(mode, nvar, ttab1):
+    """a library with more rows per patch than a row buffer holds (here: buffers of 12 slots, 6 x 9 = 54 rows per patch):
+    a patch is staged in several passes, a chain takes part in the pass that holds its cell, the other positions of
+    its wavefront are pads -- bitwise the one-pass result; the number of steps differs from (group, target) to
+    (group, target)"""
+    stats, tabs = _run(T=2, P=3, D=6, S=9, N=70, C=90, Ttab_is_one=ttab1, mode=mode, sort=True, nth=mode & 1, seed=31 + mode,
+                       below_grid=True, nvar=nvar, cap=12)
+    assert tabs["npass"].max() >= 3 and tabs["npass"].min() >= 2
+    assert int(tabs["nv"].max()) <= tabs["vmax"] and int(tabs["nv"].min()) == int(tabs["npass"].reshape(-1, 3).sum(1).min())
+    # every chain of every patch and variable got its four FMAs exactly once; the rest went to the scratch accumulator
+    wg = stats[0]
+    real = sum(w.fma_count - w.pad_fma_count for w in wg.waves)
+    assert real == 90 * 3 * nvar * 4
+
+
+def test_row_passes_two_groups_and_a_full_buffer():
+    """519 chains (a full group and a group of one chain) with buffers of 16 slots; a one-chain group needs one pass"""
+    stats, tabs = _run(T=1, P=2, D=4, S=7, N=64, C=519, Ttab_is_one=True, mode=1, sort=True, nth=1, seed=41, cap=16)
+    assert int(tabs["npass"][:2].min()) >= 2 and int(tabs["npass"][2:].max()) == 1
+    assert stats[0].dma_bytes == int(tabs["ucount"][:2].sum()) * 512
 
 
 def test_register_budget():
-    """the programs stay inside the registers the kernel may use: 128 VGPRs (16 wavefronts per
-    workgroup = 4 per SIMD) and user SGPRs below s96 (VCC, FLAT_SCRATCH, XNACK_MASK above); SGPR
-    pairs used as addresses are even-aligned"""
+    """the programs stay inside the registers the kernel may use: 128 VGPRs (16 wavefronts per workgroup = 4 per SIMD)
+    and user SGPRs below s96 (VCC, FLAT_SCRATCH, XNACK_MASK above); SGPR pairs used as addresses are even-aligned"""
     import re
-    assert gen.V_LAST < 128 and gen.NCONS + gen.NLOAD == 16 and gen.NQMIN >= 3
-    assert emu.genml.V_LAST < 128
-    for prog in (gen.consumer(), gen.loader(0), gen.loader(1), emu.genml.consumer(), emu.genruns.consumer()):
+    assert gen.V_LAST < 128 and gen.NCONS + gen.NLOAD == 16
+    for prog in (gen.consumer(), gen.loader(0), gen.loader(1)):
         for ln in prog:
             for m in re.finditer(r"\b[sv]\[(\d+):(\d+)\]", ln):
                 assert int(m.group(1)) % 2 == 0, ln   # (gfx950: SGPR address pairs and VGPR tuples are 64-bit aligned)
@@ -199,43 +172,18 @@ def test_register_budget():
                 assert hi <= 95, ln
             for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", ln):
                 hi = int(m.group(2) or m.group(3))
-                assert hi <= max(gen.V_LAST, emu.genml.V_LAST), ln
+                assert hi <= gen.V_LAST, ln
 
 
 def test_committed_include_is_the_generators_output(tmp_path, monkeypatch):
-    """beat_amd/csrc/gfcell_asm.inc is generated (tools/gen_gfcell_asm.py) and committed: the file the library is
-    built from must be what the generator -- i.e. the program the emulator tests above run -- writes today"""
+    """beat_amd/csrc/gfruns_asm.inc is generated (tools/gen_gfruns_asm.py) and committed: the file the library is
+    built from must be what the generator -- i.e. the programs the emulator tests above run -- writes today"""
     import importlib
-    import os
-    import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, os.path.join(root, "tools"))
-    gen = importlib.import_module("gen_gfcell_asm")
-    committed = open(os.path.join(root, "beat_amd", "csrc", "gfcell_asm.inc")).read()
-    monkeypatch.delenv("GC_ABLATIONS", raising=False)
-    real_join = os.path.join
-
-    def join(*a):
-        p = real_join(*a)
-        return str(tmp_path / "gfcell_asm.inc") if p.endswith("gfcell_asm.inc") else p
-    monkeypatch.setattr(gen.os.path, "join", join)
-    gen.main()
-    monkeypatch.undo()
-    assert open(str(tmp_path / "gfcell_asm.inc")).read() == committed
-    genml = importlib.import_module("gen_gfml_asm")
-    committed = open(os.path.join(root, "beat_amd", "csrc", "gfml_asm.inc")).read()
-    monkeypatch.delenv("GM_ABLATIONS", raising=False)
-
-    def join2(*a):
-        p = real_join(*a)
-        return str(tmp_path / "gfml_asm.inc") if p.endswith("gfml_asm.inc") else p
-    monkeypatch.setattr(genml.os.path, "join", join2)
-    genml.main()
-    monkeypatch.undo()
-    assert open(str(tmp_path / "gfml_asm.inc")).read() == committed
     genruns = importlib.import_module("gen_gfruns_asm")
     committed = open(os.path.join(root, "beat_amd", "csrc", "gfruns_asm.inc")).read()
     monkeypatch.delenv("GR_ABLATIONS", raising=False)
+    real_join = os.path.join
 
     def join3(*a):
         p = real_join(*a)

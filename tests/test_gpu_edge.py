@@ -140,12 +140,22 @@ def test_weights_update_and_reuse(ctx, orc):
         np.testing.assert_allclose(b[c], ref, rtol=1e-9)
 
 
-@pytest.mark.parametrize("D,S,C,interp", [(12, 20, 300, "multilinear"), (12, 20, 300, "nearest_neighbor"),
-                                          (40, 64, 130, "multilinear"), (3, 11, 600, "nearest_neighbor")])
-def test_kernel_selection_by_lds_capacity(ctx, orc, monkeypatch, D, S, C, interp):
-    """libraries with many (duration, start-time) rows: the chain-shared kernels are chosen by
-    what fits LDS (two row buffers -> k_gfstack_dma, one -> k_gfstack_shared, none -> the
-    streaming kernel); every choice gives the streaming kernel's bits and the oracle's values"""
+@pytest.mark.parametrize("D,S,C,interp,kernels,passes", [
+    (12, 20, 300, "multilinear", ("k_gfstack_runs<0,",), True),            # 252 dense slots per patch: row passes
+    (12, 20, 300, "nearest_neighbor", ("k_gfstack_ws<1,0,3,", "k_gfstack_dma<"), None),   # whichever group size measures fastest
+    (40, 64, 130, "multilinear", ("k_gfstack<1,",), False),                # below 192 chains, no two row buffers: streaming
+    (3, 11, 600, "nearest_neighbor", ("k_gfstack_ws<1,0,3,", "k_gfstack_dma<"), None),
+    (17, 41, 600, "nearest_neighbor", ("k_gfstack_ws<1,0,3,", "k_gfstack_dma<"), None),   # the tutorial grid
+    (17, 41, 600, "multilinear", ("k_gfstack_runs<0,",), True),
+    (40, 64, 600, "multilinear", ("k_gfstack_runs<0,",), True),            # ~1700 slots per patch: the tables overflow
+    (3, 25, 600, "multilinear", ("k_gfstack_runs<0,",), False),            # config 3: one pass per patch
+])
+def test_kernel_selection_by_lds_capacity(ctx, orc, monkeypatch, D, S, C, interp, kernels, passes):
+    """libraries with many (duration, start-time) rows: which kernel the selection takes (by NAME) -- the row-pass
+    kernels whatever the grid (k_gfstack_ws for one row per chain, k_gfstack_runs for multilinear from 192 chains on),
+    k_gfstack_dma where two row buffers of a small group's bound fit LDS, else the streaming kernel; a population that
+    needs more row passes than the runs kernel's tables hold is stacked by the streaming kernel standing in.  Every
+    choice gives the streaming kernel's bits and the oracle's values"""
     T, P, N = 2, 5, 64
     rng = np.random.default_rng(D * S + C)
     G = rng.standard_normal((T, P, D, S, N))
@@ -157,7 +167,14 @@ def test_kernel_selection_by_lds_capacity(ctx, orc, monkeypatch, D, S, C, interp
     a = gf.stack_all_batch(dur, st, sl, interpolation=interp)
     monkeypatch.delenv("BEATAMD_GF_KERNEL")
     b = gf.stack_all_batch(dur, st, sl, interpolation=interp)   # default selection
+    name, plan = ctx.last_kernel(), ctx.gf_plan()
+    assert name.startswith(kernels), (name, plan)
+    if passes is not None:
+        assert (plan["max_passes"] >= 2) == passes, plan
+    assert plan["plan"], plan
     assert np.array_equal(a, b)
+    if name.startswith("k_gfstack_ws") and D * S > 96:
+        assert plan["max_passes"] >= 2, plan
     for c in (0, C // 3, C - 1):
         ref = orc.stack_all(G, dur[c], st[c], sl[c], 0.5, 0.5, 0.0, 0.5, interp)
         np.testing.assert_allclose(b[c], ref, rtol=1e-11, atol=1e-12)

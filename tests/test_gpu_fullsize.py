@@ -204,22 +204,19 @@ def test_fullsize_shipped_dma_kernel_at_bench_shape(full, monkeypatch, C):
         assert ctx.last_kernel().startswith("k_gfstack<"), ctx.last_kernel()
         monkeypatch.delenv("BEATAMD_GF_KERNEL")
         assert torch.equal(out, ref), "k_gfstack_dma differs from the streaming kernel (%s)" % interp
-        if nrow == 4:   # the shipped multilinear kernel (rows read once per run of chains sharing a cell), the static
-            # kernel and the round-3 cell kernel
+        if nrow == 4:   # the shipped multilinear kernel (rows read once per run of chains sharing a cell)
             monkeypatch.delenv("BEATAMD_GS_CG")
             out2 = gf.stack_all_batch(dur_d, st_d, sl_d, interpolation=interp)
             assert ctx.last_kernel().startswith("k_gfstack_runs<0,"), ctx.last_kernel()
             assert torch.equal(out2, ref), "k_gfstack_runs differs from the streaming kernel"
-            monkeypatch.setenv("BEATAMD_GS_RUNS", "0")
+            # ... and with row buffers of 24 slots (the bench population touches 45 rows per patch): row passes
+            monkeypatch.setenv("BEATAMD_GR_CAP", "24")
+            monkeypatch.setenv("BEATAMD_GR_PASS_ALLOC", "8")
             out2 = gf.stack_all_batch(dur_d, st_d, sl_d, interpolation=interp)
-            assert ctx.last_kernel().startswith("k_gfstack_ml<0,"), ctx.last_kernel()
-            assert torch.equal(out2, ref), "k_gfstack_ml differs from the streaming kernel"
-            monkeypatch.delenv("BEATAMD_GS_RUNS")
-            monkeypatch.setenv("BEATAMD_GS_ML", "0")
-            out2 = gf.stack_all_batch(dur_d, st_d, sl_d, interpolation=interp)
-            assert ctx.last_kernel().startswith("k_gfstack_cell<0,"), ctx.last_kernel()
-            assert torch.equal(out2, ref), "k_gfstack_cell differs from the streaming kernel"
-            monkeypatch.delenv("BEATAMD_GS_ML")
+            assert ctx.last_kernel().startswith("k_gfstack_runs<0,") and ctx.gf_plan()["max_passes"] >= 2, ctx.gf_plan()
+            assert torch.equal(out2, ref), "k_gfstack_runs with row passes differs from the streaming kernel"
+            monkeypatch.delenv("BEATAMD_GR_CAP")
+            monkeypatch.delenv("BEATAMD_GR_PASS_ALLOC")
             del out2
             monkeypatch.setenv("BEATAMD_GS_CG", "512")
         del ref
@@ -289,7 +286,7 @@ def test_fullsize_fused_logp_through_dma_kernel(full, monkeypatch, C):
 def test_fullsize_fused_logp_multilinear(full, monkeypatch, cov):
     """the kernel the multilinear legs of bench.py time, asserted BY NAME at the bench shape
     in its fused epilogues -- k_gfstack_runs<1,..> (scalar-covariance misfit) and <2,..> (residual store feeding the
-    dense-W quadratic form) -- against the streaming kernel (1e-12), the static kernel k_gfstack_ml and the round-3 cell
+    dense-W quadratic form) -- against the streaming kernel (1e-12), itself with row passes (bitwise), the lane <-> chain
     kernel, and on sampled
     (chain, target) pairs against the oracle composition (oracle index maps + closed-form rows + oracle MVN) at
     1e-10.  No BEATAMD_GS_CG: that knob selects the lane <-> chain family instead."""
@@ -321,20 +318,22 @@ def test_fullsize_fused_logp_multilinear(full, monkeypatch, cov):
     f = pm.compile(ctx)
     Q = _population(full, C, seed_offset=31000)
     Qd = torch.from_numpy(Q).to("cuda:0")
-    for name in ("BEATAMD_GF_KERNEL", "BEATAMD_GS_CG", "BEATAMD_GS_ML", "BEATAMD_GS_CELL", "BEATAMD_GS_RUNS"):
+    for name in ("BEATAMD_GF_KERNEL", "BEATAMD_GS_CG", "BEATAMD_GS_ML"):
         monkeypatch.delenv(name, raising=False)
     mode = 1 if cov == "scalar" else 2
     LM = f.batch(Qd).cpu().numpy()
     assert ctx.last_kernel().startswith("k_gfstack_runs<%d," % mode), ctx.last_kernel()
-    monkeypatch.setenv("BEATAMD_GS_RUNS", "0")
+    monkeypatch.setenv("BEATAMD_GR_CAP", "24")       # row passes: the same kernel on other tables
+    monkeypatch.setenv("BEATAMD_GR_PASS_ALLOC", "8")
     LM2 = f.batch(Qd).cpu().numpy()
-    assert ctx.last_kernel().startswith("k_gfstack_ml<%d," % mode), ctx.last_kernel()
+    assert ctx.last_kernel().startswith("k_gfstack_runs<%d," % mode) and ctx.gf_plan()["max_passes"] >= 2, ctx.gf_plan()
     assert np.array_equal(LM, LM2)
-    monkeypatch.delenv("BEATAMD_GS_RUNS")
-    monkeypatch.setenv("BEATAMD_GS_ML", "0")
+    monkeypatch.delenv("BEATAMD_GR_CAP")
+    monkeypatch.delenv("BEATAMD_GR_PASS_ALLOC")
+    monkeypatch.setenv("BEATAMD_GS_CG", "256")       # the lane <-> chain kernel: same residuals, same epilogue
     LC = f.batch(Qd).cpu().numpy()
-    assert ctx.last_kernel().startswith("k_gfstack_cell<%d," % mode), ctx.last_kernel()
-    monkeypatch.delenv("BEATAMD_GS_ML")
+    assert ctx.last_kernel().startswith("k_gfstack_dma<4,4,%d," % mode), ctx.last_kernel()
+    monkeypatch.delenv("BEATAMD_GS_CG")
     monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
     LS = f.batch(Qd).cpu().numpy()
     assert ctx.last_kernel().startswith("k_gfstack<1,"), ctx.last_kernel()

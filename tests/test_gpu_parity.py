@@ -215,8 +215,8 @@ def test_stack_block_orders_identical(ctx, orc, monkeypatch, order, cgroup):
 @pytest.mark.parametrize("interp", ["nearest_neighbor", "multilinear"])
 def test_shared_row_kernel_equals_streaming_kernel(ctx, orc, monkeypatch, C, interp):
     """the chain-shared kernels (distinct rows staged once per chain group: k_gfstack_dma with
-    ds_read_b64 / ds_read_b128 layouts, single-buffer k_gfstack_shared) vs k_gfstack: bitwise
-    equal synthetics for one slip variable, and all equal to the oracle"""
+    ds_read_b64 / ds_read_b128 layouts, k_gfstack_ws, k_gfstack_runs with and without row passes) vs k_gfstack:
+    bitwise equal synthetics for one slip variable, and all equal to the oracle"""
     rng = np.random.default_rng(C)
     T, P, D, S, N = 3, 17, 3, 6, 200
     G = rng.standard_normal((T, P, D, S, N))
@@ -233,28 +233,33 @@ def test_shared_row_kernel_equals_streaming_kernel(ctx, orc, monkeypatch, C, int
         ref = orc.stack_all(G, dur[c], st[c], sl[c], 0.5, 0.25, 0.0, 0.5, interp)
         assert np.abs(b[c] - ref).max() <= 1e-11 * np.abs(ref).max()
     if interp == "multilinear":
-        # lane <-> sample kernels of gfcell.hip over dense LDS rows: k_gfstack_runs (cell order per patch, rows read
-        # once per run of chains sharing a cell, accumulators through the VGPR index: the default from 192 chains on),
-        # k_gfstack_ml (static order, four row reads per chain) and round 3's k_gfstack_cell; forced below; chain order
-        # and non-temporal requests are scheduling only
+        # k_gfstack_runs (gfcell.hip: lane <-> sample, cell order per patch, rows read once per run of chains sharing a
+        # cell, accumulators through the VGPR index: the default from 192 chains on), forced below; chain order and
+        # non-temporal requests are scheduling only; with row buffers of 8 slots (18 rows per patch here) every patch is
+        # staged in several ROW PASSES -- same bits; with tables sized for one pass per patch they overflow and the
+        # streaming kernel stands in
         if C >= 192:
             assert ctx.last_kernel().startswith("k_gfstack_runs<0,"), ctx.last_kernel()
-        for kern, srt, nth in (("runs", "1", "1"), ("runs", "0", "0"), ("ml", "0", "1"), ("ml", "0", "0"),
-                               ("cell", "1", "1"), ("cell", "0", "0")):
-            monkeypatch.setenv("BEATAMD_GS_ML", "0" if kern == "cell" else "1")
-            monkeypatch.setenv("BEATAMD_GS_RUNS", "1" if kern == "runs" else "0")
-            monkeypatch.setenv("BEATAMD_GS_CELL", "1")
+        monkeypatch.setenv("BEATAMD_GS_ML", "1")
+        for srt, nth, cap, alloc in (("1", "1", None, None), ("0", "0", None, None), ("1", "0", "8", "12"), ("0", "1", "10", "12"),
+                                     ("1", "1", "8", "1")):
             monkeypatch.setenv("BEATAMD_GC_SORT", srt)
             monkeypatch.setenv("BEATAMD_GS_NTHINT", nth)
-            assert np.array_equal(gf.stack_all_batch(dur, st, sl, interpolation=interp), a), (C, kern, srt, nth)
-            assert ctx.last_kernel() == "k_gfstack_%s<0,%s>" % (kern, nth), ctx.last_kernel()
-        for name in ("BEATAMD_GS_ML", "BEATAMD_GS_RUNS", "BEATAMD_GS_CELL", "BEATAMD_GC_SORT", "BEATAMD_GS_NTHINT"):
+            for name, val in (("BEATAMD_GR_CAP", cap), ("BEATAMD_GR_PASS_ALLOC", alloc)):
+                if val is None:
+                    monkeypatch.delenv(name, raising=False)
+                else:
+                    monkeypatch.setenv(name, val)
+            assert np.array_equal(gf.stack_all_batch(dur, st, sl, interpolation=interp), a), (C, srt, nth, cap, alloc)
+            assert ctx.last_kernel() == "k_gfstack_runs<0,%s>" % nth, ctx.last_kernel()
+            plan = ctx.gf_plan()
+            assert (plan["max_passes"] >= 2) == (cap is not None), plan
+        for name in ("BEATAMD_GS_ML", "BEATAMD_GC_SORT", "BEATAMD_GS_NTHINT", "BEATAMD_GR_CAP", "BEATAMD_GR_PASS_ALLOC"):
             monkeypatch.delenv(name)
     seen = set()
     for cg in ("64", "128", "256", "512", "1024"):
         monkeypatch.setenv("BEATAMD_GS_CG", cg)
-        for dma, nt, order in (("2", "64", "0"), ("2", "64", "1"), ("2", "32", "1"), ("1", "64", "0"),
-                               ("0", "64", "0")):
+        for dma, nt, order in (("2", "64", "0"), ("2", "64", "1"), ("2", "32", "1"), ("1", "64", "0")):
             if cg == "1024" and dma != "2":
                 continue   # 1024-chain groups exist for the LDS-DMA kernel only
             monkeypatch.setenv("BEATAMD_GS_DMA", dma)
@@ -278,15 +283,14 @@ def test_shared_row_kernel_equals_streaming_kernel(ctx, orc, monkeypatch, C, int
         if cg != "1024":
             assert "k_gfstack_dma<%d,%d,0,64,1>" % (w[cg], nrow) in seen, seen
             assert "k_gfstack_dma<%d,%d,0,64,0>" % (w[cg], nrow) in seen, seen
-            assert "k_gfstack_shared<%d,%d,0,64,0>" % (w[cg], nrow) in seen, seen
     if nrow == 1 and C > 0:
         assert "k_gfstack_ws<1,0,3,0>" in seen and "k_gfstack_ws<1,0,3,1>" in seen, seen
 
 
 @pytest.mark.parametrize("C", [200, 530])
 def test_ml_kernel_wrapped_floor_nodes(ctx, orc, monkeypatch, C):
-    """k_gfstack_runs / k_gfstack_ml keep a chain's four rows at two LDS addresses (dense rows; slot 0 of a duration line = a copy of
-    its LAST start-time node).  Times exactly on node 0 (floor node wraps with weight 0), times BELOW the first node
+    """k_gfstack_runs keeps a chain's four rows at two LDS addresses (rows in (duration line, node) order; the floor node of
+    start-time node 0 = a copy of the line's LAST node).  Times exactly on node 0 (floor node wraps with weight 0), times BELOW the first node
     (the reference's python index -1 wraps to the last node WITH weight, base.py:513-517) and one-node axes must come
     out as in the streaming kernel (bitwise) and the oracle"""
     rng = np.random.default_rng(40 + C)
@@ -307,13 +311,16 @@ def test_ml_kernel_wrapped_floor_nodes(ctx, orc, monkeypatch, C):
         a = gf.stack_all_batch(dur, st, sl, interpolation="multilinear")
         monkeypatch.delenv("BEATAMD_GF_KERNEL")
         monkeypatch.setenv("BEATAMD_GS_ML", "1")
-        for runs in ("1", "0"):
-            monkeypatch.setenv("BEATAMD_GS_RUNS", runs)
+        for cap in (None, "8"):     # one pass per patch / row passes (buffers of 8 slots)
+            if cap:
+                monkeypatch.setenv("BEATAMD_GR_CAP", cap)
+                monkeypatch.setenv("BEATAMD_GR_PASS_ALLOC", "40")
             b = gf.stack_all_batch(dur, st, sl, interpolation="multilinear")
-            assert ctx.last_kernel().startswith("k_gfstack_runs<0," if runs == "1" else "k_gfstack_ml<0,"), ctx.last_kernel()
-            assert np.array_equal(a, b), (T, P, D, S, N, runs)
+            assert ctx.last_kernel().startswith("k_gfstack_runs<0,"), ctx.last_kernel()
+            assert np.array_equal(a, b), (T, P, D, S, N, cap)
         monkeypatch.delenv("BEATAMD_GS_ML")
-        monkeypatch.delenv("BEATAMD_GS_RUNS")
+        monkeypatch.delenv("BEATAMD_GR_CAP")
+        monkeypatch.delenv("BEATAMD_GR_PASS_ALLOC")
         for c in (0, 1, 2, 3, 4, C - 1):
             ref = orc.stack_all(G, dur[c], st[c], sl[c], 0.5, 0.5, 0.0, 0.5, "multilinear")
             assert np.abs(b[c] - ref).max() <= 1e-11 * max(np.abs(ref).max(), 1.0)
@@ -469,7 +476,7 @@ def test_fused_model_512_chain_groups(ctx, monkeypatch, name):
 def test_multilinear_with_several_slip_variables_through_the_runs_kernel(ctx, monkeypatch, nvar, cov, shifts):
     """BEAT's usual FFI set-up samples uparr AND uperp (static_dist_vars, beat/config.py:83) with the default
     multilinear interpolation: 530 chains run through k_gfstack_runs (steps cycle through the variables' libraries
-    patch by patch) -- against the static kernel (bitwise: same order), the streaming kernel (another summation
+    patch by patch) -- against itself with row passes (bitwise), the streaming kernel (another summation
     order over the variables: 1e-12) and the oracle on sampled chains"""
     from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
     from oracle import problem_oracle
@@ -479,15 +486,18 @@ def test_multilinear_with_several_slip_variables_through_the_runs_kernel(ctx, mo
     f = prob.compile(ctx)
     Q = draw_population(spec, host["layout"], host["lower"], host["upper"], 530)
     mode = 1 if cov == "scalar" else 2
-    for name in ("BEATAMD_GF_KERNEL", "BEATAMD_GS_CG", "BEATAMD_GS_ML", "BEATAMD_GS_RUNS"):
+    for name in ("BEATAMD_GF_KERNEL", "BEATAMD_GS_CG", "BEATAMD_GS_ML"):
         monkeypatch.delenv(name, raising=False)
     B = f.batch(Q)
     assert ctx.last_kernel().startswith("k_gfstack_runs<%d," % mode), ctx.last_kernel()
-    monkeypatch.setenv("BEATAMD_GS_RUNS", "0")
+    # row passes (buffers of 12 slots; the library has 3 x 25 rows per patch): the same bits
+    monkeypatch.setenv("BEATAMD_GR_CAP", "12")
+    monkeypatch.setenv("BEATAMD_GR_PASS_ALLOC", "40")
     B2 = f.batch(Q)
-    assert ctx.last_kernel().startswith("k_gfstack_ml<%d," % mode), ctx.last_kernel()
+    assert ctx.last_kernel().startswith("k_gfstack_runs<%d," % mode) and ctx.gf_plan()["max_passes"] >= 2, ctx.gf_plan()
     assert np.array_equal(B, B2)
-    monkeypatch.delenv("BEATAMD_GS_RUNS")
+    monkeypatch.delenv("BEATAMD_GR_CAP")
+    monkeypatch.delenv("BEATAMD_GR_PASS_ALLOC")
     # the chain order is scheduling only: hypocentre keys of the model path (default), start-time index keys, input order
     for knob, val in (("BEATAMD_GC_KEYS", "0"), ("BEATAMD_GC_SORT", "0")):
         monkeypatch.setenv(knob, val)

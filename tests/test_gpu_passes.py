@@ -56,6 +56,7 @@ def test_nn_row_passes_equal_streaming_kernel(ctx, orc, monkeypatch, C):
     for order in ("1", "0"):
         monkeypatch.setenv("BEATAMD_GS_ORDER", order)
         monkeypatch.setenv("BEATAMD_GS_NTHINT", order)
+        monkeypatch.setenv("BEATAMD_WS_MAP", order)    # distinct rows by presence map (default) / by ranking the row ids
         b = gf.stack_all_batch(dur, st, sl)
         assert ctx.last_kernel() == "k_gfstack_ws<1,0,3,%s>" % order, ctx.last_kernel()
         st_ = ctx.gf_group_stats()
@@ -118,3 +119,75 @@ def test_float_storage_kernel_with_row_passes(ctx, monkeypatch):
     A0 = f.batch(Q)
     assert np.array_equal(A, B)
     np.testing.assert_allclose(A0, A, rtol=1e-11, atol=1e-9)
+
+
+@pytest.mark.parametrize("C", [518, 530, 1100])
+def test_ml_row_passes_equal_streaming_kernel(ctx, orc, monkeypatch, C):
+    """multilinear on the tutorial grid (17 x 42 = 714 dense slots per patch, a row buffer holds 104): chains over all
+    duration lines and (a) a band of start times -- 2-3 passes along the duration axis --, (b) the whole start-time axis
+    -- ~15 passes, more than the tables are sized for by default: the streaming kernel stands in --, (c) the same with
+    larger tables.  Bitwise the streaming kernel; times on / below the first grid node included"""
+    T, P, D, S, N = 2, 7, 17, 41, 130
+    rng = np.random.default_rng(100 + C)
+    G = rng.standard_normal((T, P, D, S, N))
+    gf = _lib(ctx, G)
+    sl = rng.uniform(-1, 5, (C, P))
+    for case in ("band", "all", "all_big_tables"):
+        dur = rng.uniform(0.0, 4.0, (C, P))
+        st = rng.uniform(5.0, 9.0, (C, T, P)) if case == "band" else rng.uniform(0.0, 19.9, (C, T, P))
+        st[0::11, :, 0] = 0.0          # on node 0: the floor node wraps (weight 0)
+        st[1::13, :, 1] = -0.2         # below node 0: the last node enters with weight
+        dur[2::7, 3] = 0.0
+        st[:, :, 5] = 7.3              # a patch whose chains all agree: one pass between patches of several
+        dur[:, 5] = 2.1
+        monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
+        a = gf.stack_all_batch(dur, st, sl, interpolation="multilinear")
+        assert ctx.last_kernel().startswith("k_gfstack<1,"), ctx.last_kernel()
+        monkeypatch.delenv("BEATAMD_GF_KERNEL")
+        if case == "all_big_tables":
+            monkeypatch.setenv("BEATAMD_GR_PASS_ALLOC", "40")
+        for order in ("1", "0"):
+            monkeypatch.setenv("BEATAMD_GS_ORDER", order)
+            monkeypatch.setenv("BEATAMD_GS_NTHINT", order)
+            monkeypatch.setenv("BEATAMD_GC_SORT", order)
+            b = gf.stack_all_batch(dur, st, sl, interpolation="multilinear")
+            assert ctx.last_kernel() == "k_gfstack_runs<0,%s>" % order, ctx.last_kernel()
+            plan = ctx.gf_plan()
+            assert plan["max_passes"] >= (2 if case == "band" else 8) and "passes" in plan["plan"], plan
+            assert np.array_equal(a, b), (C, case, order)
+        monkeypatch.delenv("BEATAMD_GR_PASS_ALLOC", raising=False)
+        for c in (0, 1, 2, 517, C - 1):
+            ref = orc.stack_all(G, dur[c], st[c], sl[c], 0.0, 0.25, 0.0, 0.5, "multilinear")
+            assert np.abs(a[c] - ref).max() <= 1e-11 * max(np.abs(ref).max(), 1.0)
+
+
+@pytest.mark.parametrize("nvar,cov,shifts", [(1, "scalar", False), (2, "toeplitz", True), (3, "scalar", True)])
+def test_fused_model_on_a_fine_grid_ml(ctx, monkeypatch, nvar, cov, shifts):
+    """the fused log-likelihood through k_gfstack_runs with row passes (scalar-weight epilogue / residual store), one to
+    three slip variables, station shifts (tables per target: another number of steps per target): 600 chains of a model
+    whose library has 17 durations x 41 start times; against the streaming kernel (1e-11), itself with other buffers
+    (bitwise) and a sub-batch (bitwise)"""
+    from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
+    spec = SyntheticSpec((5,), (6,), (1.0,), T=3, N=96, D=17, S=41, du_min=0.0, du_dt=0.25, covariance=cov,
+                         slip_varnames=("uparr", "uperp", "utens")[:nvar], station_shifts=shifts, time_bounds=(0.0, 3.0),
+                         interpolation="multilinear")
+    prob, host = build_problem(spec)
+    f = prob.compile(ctx)
+    C = 600
+    Q = draw_population(spec, host["layout"], host["lower"], host["upper"], C)
+    monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
+    A = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack<1,"), ctx.last_kernel()
+    monkeypatch.delenv("BEATAMD_GF_KERNEL")
+    mode = 1 if cov == "scalar" else 2
+    B = f.batch(Q)
+    plan = ctx.gf_plan()
+    assert ctx.last_kernel().startswith("k_gfstack_runs<%d," % mode) and 2 <= plan["max_passes"] <= 6, (ctx.last_kernel(), plan)
+    assert np.isfinite(B).all()
+    np.testing.assert_allclose(A, B, rtol=1e-11, atol=1e-9)
+    assert np.array_equal(f.batch(Q[:518]), B[:518])
+    monkeypatch.setenv("BEATAMD_GR_CAP", "40")
+    monkeypatch.setenv("BEATAMD_GR_PASS_ALLOC", "40")
+    B2 = f.batch(Q)
+    assert ctx.gf_plan()["max_passes"] > plan["max_passes"]
+    assert np.array_equal(B2, B)

@@ -1,15 +1,14 @@
 #!/usr/bin/env python
 """
-gfcell_emu.py -- functional model of the k_gfstack_cell wavefront program (gfcell_asm.inc) and a
-numpy twin of its command-stream builder (k_gc_order / k_gc_tables in beat_amd/csrc/gfcell.hip).
+gfcell_emu.py -- functional model of the k_gfstack_runs wavefront programs (gfruns_asm.inc) and a numpy twin of the
+table builders (k_gc_order / k_gm_tables in beat_amd/csrc/gfcell.hip), row passes included.
 
-The wavefront program is register-allocated by hand and runs from tables; its control flow
-(buffer-set alternation, ring of three row buffers, barrier count per wavefront, pointer
-arithmetic) is checked here on the CPU -- tests/test_gfcell_program.py interprets the very
-instruction list tools/gen_gfcell_asm.py emits, for all 16 wavefronts of a workgroup, against a
-direct evaluation of the multilinear stack (reference beat/ffi/base.py:663-704).  Timing, hazards
-and wait counts are NOT modelled (the GPU tests cover the real thing); fma is evaluated as a*b+c
-on both sides.
+The wavefront programs are register-allocated by hand and run from tables; their control flow (ring of three row
+buffers, barrier count per wavefront, pointer arithmetic, the VGPR index register, scalar descriptor loads) is
+checked here on the CPU -- tests/test_gfcell_program.py interprets the very instruction lists
+tools/gen_gfruns_asm.py emits, for all 16 wavefronts of a workgroup, against a direct evaluation of the multilinear
+stack (reference beat/ffi/base.py:663-704).  Timing, hazards and wait counts are NOT modelled (the GPU tests cover
+the real thing); fma is evaluated as a*b+c on both sides.
 
 Test infrastructure only: nothing in the product imports this module.
 """
@@ -20,18 +19,19 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-import gen_gfcell_asm as gen  # noqa: E402
-import gen_gfml_asm as genml  # noqa: E402
-import gen_gfruns_asm as genruns  # noqa: E402
+import gen_gfruns_asm as gen  # noqa: E402
 
+genruns = gen
 U32 = np.uint32
 MASK64 = (1 << 64) - 1
 DEAD = 0xFFFFFFFF
 NCH, NCONS, NLOAD = gen.NCHAIN, gen.NCONS, gen.NLOAD
 CG, WAVES = NCONS * NCH, NCONS + NLOAD
-QREC, QUAD, WSTRIDE, NQMIN, LTAB, BOUNCE = gen.QREC, gen.QUAD, gen.WSTRIDE, gen.NQMIN, gen.LTAB, gen.BOUNCE
+LTABDW, LREQ = gen.LTABDW, gen.LREQ
 TPITCH = 65 * 8
 PARAM_BYTES = WAVES * 128
+# row slots of an LDS buffer: three buffers behind the parameter blocks in 160 KB (an even number)
+CAP = ((160 * 1024 - PARAM_BYTES) // (3 * 512)) // 2 * 2
 
 
 # =============================================================================== memory
@@ -120,184 +120,150 @@ def gc_order(rowoff, C, T, P, S, sort=True, keys=None, global_members=True):
     return order
 
 
-def gc_tables(rowoff, fac, slips, order, C, T, P, DS, nvar=1):
-    """-> wtab bytes, ltab dwords, ucount; layouts as k_gc_tables writes them"""
+PASS_ALLOC = 6     # passes per patch the device tables are sized for (k_gfstack_runs falls back to k_gfstack beyond)
+
+
+def max_passes(D, S, cap=CAP):
+    """upper bound of the row passes of a patch: one when the patch's D * (S + 1) dense slots fit a buffer; else every
+    pass but the last is closed with more than cap - 4 slots or 2 * LREQ requests (>= 60 slots), and the passes hold at
+    most min(4 * CG, 4 * dense) slots together (a slot may be staged in up to four passes)"""
+    dense = D * (S + 1)
+    if dense <= cap:
+        return 1
+    fill = max(1, min(cap - 3, 60))
+    return (min(4 * CG, 4 * dense) + fill - 1) // fill + 1
+
+
+def gm_tables(rowoff, fac, slips, order, C, T, P, D, S, nvar=1, cap=None):
+    """numpy twin of k_gm_tables (gfcell.hip) -> dict(wtab, ltab, dtab, ucount [GT*P] rows the loaders move, npass [GT*P],
+    nv [GT] vsteps, vmax, smax): per (group, target, patch) the chains' cells are cut into ROW PASSES (greedy over the
+    cells in ascending (ceil-duration line, ceil start-time node) order, a pass holds at most `cap` row slots and
+    2 * LREQ row requests); per pass and slip variable one STEP: the loaders' request lines (rows compactly in
+    (line, node) order), the consumers' descriptor lines (chains of the pass in cell order at positions 0..n-1, pads
+    into the scratch accumulator behind them) and weight records"""
+    cap = CAP if cap is None else cap
     ngroups = order.size // CG
-    nsteps = P * nvar
-    GT = ngroups * T
-    wtab = np.zeros(GT * NCONS * (nsteps + 1) * WSTRIDE + 4096, dtype=np.uint8)
-    ltab = np.zeros(GT * (nsteps + 3) * NLOAD * 32, dtype=np.uint32)
-    ucount = np.zeros(GT * P, dtype=np.uint32)
-    for g in range(ngroups):
-        for t in range(T):
-            gt = g * T + t
-            for p in range(P):
-                row0 = (t * P + p) * DS
-                ids = order[g * CG:(g + 1) * CG]
-                live = ids != DEAD
-                rel = np.zeros((CG, 4), dtype=np.int64)
-                rel[live] = rowoff[ids[live], t, p].astype(np.int64) - row0
-                distinct = np.unique(rel[live])
-                slot = {int(r): i for i, r in enumerate(distinct)}
-                U = distinct.size
-                ucount[gt * P + p] = U
-                for iv in range(nvar):
-                    s = p * nvar + iv
-                    ring = (s % 3) * DS
-                    npair = (U + 1) // 2
-                    for ll in range(NLOAD):
-                        h = ltab[((gt * (nsteps + 3) + s) * NLOAD + ll) * 32:][:32]
-                        h[0] = (npair - ll + NLOAD - 1) // NLOAD if npair > ll else 0
-                        for d in range(1, 32):
-                            pr = ll + NLOAD * (d - 1)
-                            if pr < npair:
-                                ra = int(distinct[2 * pr])
-                                single = 2 * pr + 1 >= U
-                                rb = ra if single else int(distinct[2 * pr + 1])
-                                h[d] = ra | ((rb - ra) << 8) | ((2 * pr) << 16) | ((1 << 24) if single else 0)
-                            else:
-                                h[d] = 0
-                    for w in range(NCONS):
-                        wb = ((gt * NCONS + w) * (nsteps + 1) + s) * WSTRIDE
-
-                        def rec(bb):
-                            return wb + (bb // 4) * QUAD + (bb % 4) * QREC
-
-                        def aux(bb):
-                            return wtab[rec(bb) + 128:rec(bb) + 192].view(np.uint32)
-                        js = [j for j in range(NCH) if live[w * NCH + j]]
-                        js.sort(key=lambda j: (tuple(rel[w * NCH + j]), j))
-                        batches = []
-                        for j in js:
-                            k4 = tuple(rel[w * NCH + j])
-                            if batches and batches[-1][0] == k4 and len(batches[-1][1]) < 4:
-                                batches[-1][1].append(j)
-                            else:
-                                batches.append((k4, [j]))
-                        nb = len(batches)
-                        nbe = max(((nb + 3) // 4) * 4, 4 * NQMIN)
-                        nq = nbe // 4
-                        xe = ring * 512
-
-                        def cf(bb, cnt):
-                            return cnt | ((1 << gen.CF_LAST) if bb == nbe - 1 else 0) | \
-                                ((1 << gen.CF_CROSS) if (bb % 4 == 0 and bb // 4 + 2 == nq - 1) else 0)
-                        for e in range(nb, nbe):
-                            me = aux(e)
-                            me[gen.A_ACC01] = me[gen.A_ACC23] = 0x80008000
-                            me[gen.A_CF] = cf(e, 0)
-                            me[gen.A_XO:gen.A_XO + 4] = xe
-                            if e >= 1:
-                                aux(e - 1)[gen.A_XN:gen.A_XN + 4] = xe
-                        aux(nbe - 1)[gen.A_XN:gen.A_XN + 4] = xe
-                        for b, (k4, chains) in enumerate(batches):
-                            wq = wtab[rec(b):rec(b) + 128].view(np.float64)
-                            m = [0x8000] * 4
-                            for q, j in enumerate(chains):
-                                c = int(ids[w * NCH + j])
-                                wq[4 * q:4 * q + 4] = fac[c, t, p] * slips[iv][c, p]
-                                m[q] = 0x8000 | (2 * j)
-                            me = aux(b)
-                            me[gen.A_ACC01] = m[0] | (m[1] << 16)
-                            me[gen.A_ACC23] = m[2] | (m[3] << 16)
-                            me[gen.A_CF] = cf(b, len(chains))
-                            x = [(ring + slot[int(r)]) * 512 for r in k4]
-                            me[gen.A_XO:gen.A_XO + 4] = x
-                            if b >= 1:
-                                aux(b - 1)[gen.A_XN:gen.A_XN + 4] = x
-    return wtab, ltab, ucount
-
-
-def gm_tables(rowoff, fac, slips, order, C, T, P, D, S, runs=False, nvar=1):
-    """numpy twin of k_gm_tables<RUNS> (gfcell.hip): record table, request table and moved-row counts of k_gfstack_ml;
-    runs: the chains of a wavefront in cell order, weights-only records and the descriptor lines of k_gfstack_runs"""
-    ngroups = order.size // CG
-    nsteps, GT, DS, S1 = P * nvar, ngroups * T, D * S, S + 1
-    nslot = D * S1
+    GT, DS, S1 = ngroups * T, D * S, S + 1
+    dense_n = D * S1
     slips = [slips] if nvar == 1 and not isinstance(slips, (list, tuple)) else list(slips)
-    wtab = np.zeros(GT * NCONS * (nsteps + 1) * genml.WSTRIDE + 8192, dtype=np.uint8)
-    ltab = np.zeros(GT * (nsteps + 3) * NLOAD * 32, dtype=np.uint32)
+    maxpass = max_passes(D, S, cap)
+    vmax = P * maxpass
+    smax = vmax * nvar
+    wtab = np.zeros(GT * NCONS * (smax + 1) * gen.WSTRIDE + 8192, dtype=np.uint8)
+    ltab = np.zeros(GT * (smax + 3) * NLOAD * LTABDW, dtype=np.uint32)
+    dtab = np.zeros(GT * NCONS * (smax + 1) * gen.DLINE + 64, dtype=np.uint32)
     ucount = np.zeros(GT * P, dtype=np.uint32)
-    dtab = np.zeros(GT * NCONS * (nsteps + 1) * genruns.DLINE + 64, dtype=np.uint32)
+    npass_o = np.zeros(GT * P, dtype=np.uint32)
+    nv = np.zeros(GT, dtype=np.uint32)
 
     def row_of(sl):
         d, s1 = divmod(sl, S1)
         return d * S + (s1 - 1 if s1 else S - 1)
+
+    def slots_of(key):
+        sb_, sa_ = key >> 16, key & 0xFFFF
+        return sorted({sa_, sa_ + 1, sb_, sb_ + 1})
+
+    def req_bound(n, nlines):
+        return n if S > 255 else n // 2 + 2 * nlines + 1
     for g in range(ngroups):
         ids = order[g * CG:(g + 1) * CG]
         live = ids != DEAD
         for t in range(T):
             gt = g * T + t
+            v = 0
             for p in range(P):
                 row0 = (t * P + p) * DS
                 rel = np.zeros((CG, 4), dtype=np.int64)
                 rel[live] = rowoff[ids[live], t, p].astype(np.int64) - row0
                 dc, sc, df = rel[:, 0] // S, rel[:, 0] % S, rel[:, 2] // S
                 sb, sa = dc * S1 + sc, df * S1 + sc
-                sa[~live] = 0
-                sb[~live] = 0
-                present = np.zeros(nslot + 1, dtype=bool)
-                for arr in (sa[live], sa[live] + 1, sb[live], sb[live] + 1):
-                    present[arr] = True
-                reqs, sl, moved = [], 0, 0
-                while sl < nslot:
-                    if not present[sl]:
-                        sl += 1
-                        continue
-                    ra = row_of(sl)
-                    if sl + 1 < nslot and present[sl + 1]:
-                        rb = row_of(sl + 1)
-                        if rb > ra and rb - ra < 256:
-                            reqs.append(ra | ((rb - ra) << 8) | (sl << 16))
-                            sl += 2
-                            moved += 2
-                            continue
-                    reqs.append(ra | (sl << 16) | (1 << 24))
-                    sl += 1
-                    moved += 1
+                key = np.where(live, (sb << 16) | sa, 0xFFFFFFFF)
+                cells = sorted(set(int(x) for x in key[live]))
+                # ---- passes: greedy over the cells in ascending order
+                allslots = set()
+                for kc in cells:
+                    allslots.update(slots_of(kc))
+                lines_all = {sl // S1 for sl in allslots}
+                pass_of = {}
+                if len(allslots) <= cap and req_bound(len(allslots), len(lines_all)) <= NLOAD * LREQ:
+                    for kc in cells:
+                        pass_of[kc] = 0
+                    npass = 1
+                else:
+                    cur, have, lines = 0, set(), set()
+                    for kc in cells:
+                        sl4 = slots_of(kc)
+                        need = [x for x in sl4 if x not in have]
+                        nl = {x // S1 for x in sl4} - lines
+                        if have and (len(have) + len(need) > cap or
+                                     req_bound(len(have) + len(need), len(lines) + len(nl)) > NLOAD * LREQ):
+                            cur += 1
+                            have, lines = set(), set()
+                        have.update(sl4)
+                        lines.update(x // S1 for x in sl4)
+                        pass_of[kc] = cur
+                    npass = cur + 1
+                assert npass <= maxpass, (npass, maxpass)
+                npass_o[gt * P + p] = npass
+                cpass = np.array([pass_of.get(int(k_), -1) for k_ in key])
+                moved = 0
+                for k in range(npass):
+                    inpass = live & (cpass == k)
+                    dense = sorted({x for kc in cells if pass_of[kc] == k for x in slots_of(kc)})
+                    cidx = {sl: i for i, sl in enumerate(dense)}
+                    n = len(dense)
+                    assert n <= cap
+                    moved += n
+                    reqs, i = [], 0
+                    while i < n:
+                        ra = row_of(dense[i])
+                        if i + 1 < n:
+                            rb = row_of(dense[i + 1])
+                            if rb > ra and rb - ra < 256:
+                                reqs.append(ra | ((rb - ra) << 16) | (i << 24))
+                                i += 2
+                                continue
+                        reqs.append(ra | (i << 24))
+                        i += 1
+                    assert len(reqs) <= NLOAD * LREQ, (len(reqs), n)
+                    for iv in range(nvar):
+                        s = (v + k) * nvar + iv
+                        for ll in range(NLOAD):
+                            h = ltab[((gt * (smax + 3) + s) * NLOAD + ll) * LTABDW:][:LTABDW]
+                            mine = reqs[ll::NLOAD]
+                            h[0] = len(mine)
+                            h[1] = p * DS
+                            h[2:2 + len(mine)] = mine
+                        ring = (s % 3) * cap
+                        for w in range(NCONS):
+                            lo = w * NCH
+                            mem = [j for j in range(NCH) if inpass[lo + j]]
+                            perm = sorted(mem, key=lambda jj: (int(key[lo + jj]), jj))
+                            base_w = (gt * NCONS + w) * (smax + 1) + s
+                            for r in range(NCH):
+                                q = r % 4
+                                rec = base_w * gen.WSTRIDE + (r // 8) * gen.PAIR + ((r // 4) % 2) * 8
+                                dl = base_w * gen.DLINE + gen.ddword(r)
+                                if r < len(perm):
+                                    j = perm[r]
+                                    kk_ = lo + j
+                                    c = int(ids[kk_])
+                                    wv = [fac[c, t, p, kk] * slips[iv][c, p] for kk in range(4)]
+                                    nxt = 1 if (r + 1 < len(perm) and int(key[lo + perm[r + 1]]) != int(key[kk_])) else 0
+                                    dtab[dl] = gen.D_BASE | j | (nxt << 31)
+                                    dtab[dl + 1] = int(ring + cidx[int(sa[kk_])]) | (int(ring + cidx[int(sb[kk_])]) << 16)
+                                else:
+                                    wv = [0.0] * 4
+                                    dtab[dl] = gen.D_BASE | gen.SCRATCH
+                                    dtab[dl + 1] = int(ring) | (int(ring) << 16)
+                                for kk in range(4):
+                                    wtab[rec + (4 * q + kk) * 16:rec + (4 * q + kk) * 16 + 8].view(np.float64)[0] = wv[kk]
                 ucount[gt * P + p] = moved
-                for iv in range(nvar):
-                  s = p * nvar + iv
-                  for ll in range(NLOAD):
-                      h = ltab[((gt * (nsteps + 3) + s) * NLOAD + ll) * 32:][:32]
-                      mine = reqs[ll::NLOAD]
-                      assert len(mine) <= 31
-                      h[0] = len(mine)
-                      h[1:1 + len(mine)] = mine
-                  ring = (s % 3) * nslot
-                  for w in range(NCONS):
-                      if runs:
-                          key = np.where(live[w * NCH:(w + 1) * NCH], (sb[w * NCH:(w + 1) * NCH] << 16) | sa[w * NCH:(w + 1) * NCH],
-                                         0xFFFFFFFF)
-                          perm = sorted(range(NCH), key=lambda jj: (int(key[jj]), jj))
-                      else:
-                          perm = list(range(NCH))
-                      def opens_at(r):
-                          j = perm[r]
-                          return bool(live[w * NCH + j]) and (r == 0 or int(key[perm[r - 1]]) != int(key[j]))
-                      for r, j in enumerate(perm):
-                          k = w * NCH + j
-                          q = r % 4
-                          c = int(ids[k]) if live[k] else 0
-                          wv = [(fac[c, t, p, kk] * slips[iv][c, p]) if live[k] else 0.0 for kk in range(4)]
-                          if runs:
-                              rec = (((gt * NCONS + w) * (nsteps + 1) + s) * genruns.WSTRIDE + (r // 8) * genruns.PAIR +
-                                     ((r // 4) % 2) * 8)
-                              for kk in range(4):
-                                  wtab[rec + (4 * q + kk) * 16:rec + (4 * q + kk) * 16 + 8].view(np.float64)[0] = wv[kk]
-                              nxt = 1 if (r + 1 < NCH and opens_at(r + 1)) else 0
-                              dl = ((gt * NCONS + w) * (nsteps + 1) + s) * genruns.DLINE + genruns.ddword(r)
-                              dtab[dl] = genruns.D_BASE | j | (nxt << 31)
-                              dtab[dl + 1] = int(ring + sa[k]) | (int(ring + sb[k]) << 16)
-                              continue
-                          rec = ((gt * NCONS + w) * (nsteps + 1) + s) * genml.WSTRIDE + (r // 4) * genml.REC
-                          for kk in range(4):
-                              wtab[rec + (4 * q + kk) * 16:rec + (4 * q + kk) * 16 + 8].view(np.float64)[0] = wv[kk]
-                          wtab[rec + (2 * q) * 16 + 8:rec + (2 * q) * 16 + 12].view(np.uint32)[0] = (ring + sa[k]) * 512
-                          wtab[rec + (2 * q + 1) * 16 + 8:rec + (2 * q + 1) * 16 + 12].view(np.uint32)[0] = (ring + sb[k]) * 512
-    if runs:
-        return wtab, ltab, ucount, dtab
-    return wtab, ltab, ucount
+                v += npass
+            nv[gt] = v
+            # (the request lines behind the last step stay empty: the loaders read three steps ahead)
+    return dict(wtab=wtab, ltab=ltab, dtab=dtab, ucount=ucount, npass=npass_o, nv=nv, vmax=vmax, smax=smax, cap=cap)
 
 
 # =============================================================================== interpreter
@@ -306,8 +272,7 @@ class Barrier(Exception):
 
 
 def _parse_program(kind, nth):
-    lines = (gen.consumer() if kind == "consumer" else genml.consumer() if kind == "consumer_ml" else
-             genruns.consumer() if kind == "consumer_runs" else gen.loader(nth))
+    lines = gen.consumer() if kind == "consumer" else gen.loader(nth)
     labels, prog = {}, []
     for ln in lines:
         m = re.match(r"^(\w+)_%=:$", ln)
@@ -352,6 +317,7 @@ class Wave(object):
         self.nbarrier = 0
         self.ninstr = 0
         self.fma_count = 0
+        self.pad_fma_count = 0
 
     # ---- operand access
     def sreg(self, name):
@@ -599,18 +565,11 @@ class Wave(object):
                 # D = dpp(S0) * S1 + D ; row_newbcast:k: lane k of the lane's own 16-lane row
                 k = int(re.search(r"row_newbcast:(\d+)", ln).group(1))
                 ops = [o.split()[0] for o in ops]
-                if self.wg.static_acc == "runs":
-                    assert self.idx_en and ((self.m0 >> 12) & 0xF) == 0x8, ln
-                    d = self.vreg(ops[0]) + (self.m0 & 0xFF)
-                    assert genml.ACC <= d <= genml.V_LAST - 1 and (d - genml.ACC) % 2 == 0, (ln, d)
-                elif self.wg.static_acc:
-                    assert not self.idx_en, ln
-                    d = self.vreg(ops[0])
-                    assert genml.ACC <= d <= genml.V_LAST - 1 and (d - genml.ACC) % 2 == 0, (ln, d)
-                else:
-                    assert self.idx_en and ((self.m0 >> 12) & 0xF) == 0x8, ln
-                    d = self.vreg(ops[0]) + (self.m0 & 0xFF)
-                    assert gen.ACC <= d <= gen.V_LAST - 1 and (d - gen.ACC) % 2 == 0, (ln, d)
+                assert self.idx_en and ((self.m0 >> 12) & 0xF) == 0x8, ln
+                d = self.vreg(ops[0]) + (self.m0 & 0xFF)
+                assert gen.ACC <= d <= gen.V_LAST - 1 and (d - gen.ACC) % 2 == 0, (ln, d)
+                if d == gen.ACC + 2 * gen.SCRATCH:
+                    self.pad_fma_count += 1
                 a_ = self.src_f64(ops[1])[(np.arange(64) // 16) * 16 + k]
                 b_ = self.src_f64(ops[2])
                 c_ = (self.v[d].astype(np.uint64) | (self.v[d + 1].astype(np.uint64) << np.uint64(32))).view(np.float64)
@@ -725,17 +684,14 @@ class Wave(object):
 
 
 class Workgroup(object):
-    """one (group g, target t, tile) workgroup of k_gfstack_cell: 14 consumers + 2 loaders"""
+    """one (group g, target t, tile) workgroup of k_gfstack_runs: 14 consumers + 2 loaders"""
 
-    def __init__(self, mem, nth, lds_bytes, params, max_instr=5000000, static_acc=False):
+    def __init__(self, mem, nth, lds_bytes, params, max_instr=5000000):
         self.mem = mem
-        self.static_acc = static_acc   # k_gfstack_ml: the consumer program of tools/gen_gfml_asm.py
         self.lds = np.zeros(lds_bytes, dtype=np.uint8)
         self.max_instr = max_instr
         self.dma_bytes = 0
-        self.programs = {"consumer": _parse_program("consumer_runs" if static_acc == "runs" else
-                                                    "consumer_ml" if static_acc else "consumer", nth),
-                         "loader": _parse_program("loader", nth)}
+        self.programs = {"consumer": _parse_program("consumer", nth), "loader": _parse_program("loader", nth)}
         self.waves = []
         for w in range(WAVES):
             self.lds[w * 128:(w + 1) * 128].view(np.uint32)[:] = params[w]
@@ -761,7 +717,8 @@ class Workgroup(object):
 
 
 def wave_params(w, g, t, tile, a):
-    """the parameter block the C++ prologue of k_gfstack_cell writes (dict a: the kernel arguments)"""
+    """the parameter block the C++ prologue of k_gfstack_runs writes (dict a: the kernel arguments + the tables of
+    gm_tables)"""
     P = np.zeros(32, dtype=np.uint32)
 
     def put64(k, x):
@@ -769,13 +726,13 @@ def wave_params(w, g, t, tile, a):
     gt = g * a["Ttab"] + (0 if a["Ttab"] == 1 else t)
     n0 = tile * 64
     N, T = a["N"], a["T"]
+    smax = a["smax"]
+    nsteps = int(a["nv"][gt]) * a.get("nvar", 1)
     if w < NCONS:
-        put64(gen.P_WP, a["wtab"] + ((gt * NCONS + w) * (a["nsteps"] + 1)) * a.get("wstride", WSTRIDE))
+        put64(gen.P_WP, a["wtab"] + ((gt * NCONS + w) * (smax + 1)) * gen.WSTRIDE)
         P[gen.P_RB0] = PARAM_BYTES
-        P[gen.P_NSTEP] = a["nsteps"]
-        P[gen.P_BNC] = PARAM_BYTES + 3 * a["DS"] * 512 + w * BOUNCE
-        if "dtab" in a:
-            put64(gen.P_DP, a["dtab"] + ((gt * NCONS + w) * (a["nsteps"] + 1)) * genruns.DLINE * 4)
+        P[gen.P_NSTEP] = nsteps
+        put64(gen.P_DP, a["dtab"] + ((gt * NCONS + w) * (smax + 1)) * gen.DLINE * 4)
         put64(gen.P_OUT, a["out"] + (t * N + n0) * 8)
         P[gen.P_CTN] = T * N * 8
         P[gen.P_MODE] = a["mode"]
@@ -788,13 +745,12 @@ def wave_params(w, g, t, tile, a):
         P[gen.P_TRB] = PARAM_BYTES + w * 16 * TPITCH
     else:
         ll = w - NCONS
-        put64(gen.PL_LT, a["ltab"] + (((gt * (a["nsteps"] + 3)) * NLOAD + ll) * 32) * 4)
+        put64(gen.PL_LT, a["ltab"] + (((gt * (smax + 3)) * NLOAD + ll) * LTABDW) * 4)
         put64(gen.PL_GROW, a["G"] + ((t * a["rows_per_target"]) * N + n0) * 8)
-        P[gen.PL_DSRB] = a["DS"] * N * 8
         P[gen.PL_ROWB] = N * 8
         P[gen.PL_RB0] = PARAM_BYTES
-        P[gen.PL_BUFB] = a.get("ucap", a["DS"]) * 512
-        P[gen.PL_NSTEP] = a["nsteps"]
+        P[gen.PL_BUFB] = a["cap"] * 512
+        P[gen.PL_NSTEP] = nsteps
         P[gen.PL_NLANES] = min(32, (N - n0 + 1) // 2)
         P[gen.PL_NVAR] = a.get("nvar", 1)
         put64(gen.PL_G1, a.get("G1", a["G"]) + ((t * a["rows_per_target"]) * N + n0) * 8)
@@ -802,9 +758,5 @@ def wave_params(w, g, t, tile, a):
     return P
 
 
-def lds_bytes(DS):
-    return PARAM_BYTES + max(3 * DS * 512 + NCONS * BOUNCE, NCONS * 16 * TPITCH)
-
-
-def lds_bytes_ml(nslot):
-    return PARAM_BYTES + max(3 * nslot * 512, NCONS * 16 * TPITCH)
+def lds_bytes(cap):
+    return PARAM_BYTES + max(3 * cap * 512, NCONS * 16 * TPITCH)
