@@ -186,6 +186,10 @@ int beatamd_ctx::check_status()
             set_error("Matrix is not positive definite");   // numpy.linalg.LinAlgError's text
             return BEATAMD_ENOTPSD;
         }
+        if (st & ST_BAD_SCALE) {
+            set_error("PoissonProposal: a step width outside (0, 500] (or NaN): the draws of that parameter are NaN");
+            return BEATAMD_EINVAL;
+        }
     }
     return BEATAMD_OK;
 }

@@ -43,7 +43,7 @@ void set_error(const char *fmt, ...);
     } while (0)
 
 // device status bits set by kernels (checked at synchronisation points)
-enum : int { ST_INDEX_OOB = 1, ST_BAD_HYPO = 2, ST_NOT_PSD = 4, ST_BAD_COV = 8 };
+enum : int { ST_INDEX_OOB = 1, ST_BAD_HYPO = 2, ST_NOT_PSD = 4, ST_BAD_COV = 8, ST_BAD_SCALE = 16 };
 
 struct DevBuf {
     void *p = nullptr;

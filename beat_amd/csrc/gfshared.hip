@@ -1308,7 +1308,7 @@ k_gfstack_ws(GsArgs a)
                 "s_cselect_b32 %0, 0, %0\n\t"
                 "s_cselect_b32 %1, %4, 0\n\t"
                 "s_cselect_b64 %2, %5, %6"
-                : "+s"(iv_run), "=s"(ds), "=s"(dw) : "s"(nvar), "s"(slot_step), "s"(dw_wrap), "s"(dw_next) : "scc");
+                : "+s"(iv_run), "=&s"(ds), "=&s"(dw) : "s"(nvar), "s"(slot_step), "s"(dw_wrap), "s"(dw_next) : "scc");
             ps_run += ds;
             pw_run += dw;
         }

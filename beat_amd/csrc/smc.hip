@@ -366,25 +366,32 @@ __global__ void __launch_bounds__(256) k_philox_chain(int64_t C, uint64_t seed, 
 //   kind 2  LaplaceProposal  (standard_exponential() - standard_exponential()) * scale
 //   kind 3  PoissonProposal  poisson(lam = scale) - scale        (base.py:150-155; integer steps around zero mean)
 // Poisson variate from ONE uniform by inversion (sequential search from k = 0, pmf recurrence p_k = p_{k-1} lam / k).
-// Exact in law while exp(-lam) is a normal double; the callers accept step widths lam <= 500 (a wider integer
-// proposal is refused by the host side, beat_amd/sampler/metropolis.py) -- beyond that the draw is NaN.
-__device__ __forceinline__ double poisson_from_uniform(double u, double lam)
+// Exact in law while exp(-lam) is a normal double; step widths lam <= 500 only: a wider one (or NaN) raises
+// ST_BAD_SCALE -> BEATAMD_EINVAL at the next synchronisation (the host side refuses it beforehand,
+// beat_amd/sampler/metropolis.py) and the draw is NaN.  The search stops where the cumulative sum stops growing (a
+// uniform above the rounded sum, ~1e-13 of the draws at lam near 500, lands on that far-tail k instead of the search cap).
+__device__ __forceinline__ double poisson_from_uniform(double u, double lam, int *status)
 {
-    if (!(lam > 0.0)) return 0.0;
-    if (lam > 500.0) return __builtin_nan("");
+    if (lam == 0.0) return 0.0;
+    if (!(lam > 0.0 && lam <= 500.0)) {
+        atomicOr(status, ST_BAD_SCALE);
+        return __builtin_nan("");
+    }
     double p = exp(-lam), F = p;
     int k = 0;
     while (u > F && k < 4096) {
         k++;
         p *= lam / (double)k;
-        F += p;
+        const double Fn = F + p;
+        if (Fn == F && (double)k > lam) break;
+        F = Fn;
     }
     return (double)k;
 }
 
 __global__ void __launch_bounds__(256) k_philox_univariate(double *delta, int64_t C, int64_t np, int kind,
                                                           const double *scale, uint64_t seed, uint32_t step,
-                                                          uint64_t first_chain, const uint32_t *step_dev)
+                                                          uint64_t first_chain, const uint32_t *step_dev, int *status)
 {
     if (step_dev) step = *step_dev;
     const int64_t npair = (np + 1) / 2;
@@ -411,8 +418,8 @@ __global__ void __launch_bounds__(256) k_philox_univariate(double *delta, int64_
         b = log(u53(q[2], q[3])) - log(u2);
     } else {
         const double la = scale[2 * j], lb = (2 * j + 1 < np) ? scale[2 * j + 1] : 0.0;
-        delta[c * np + 2 * j] = poisson_from_uniform(u1, la) - la;
-        if (2 * j + 1 < np) delta[c * np + 2 * j + 1] = poisson_from_uniform(u2, lb) - lb;
+        delta[c * np + 2 * j] = poisson_from_uniform(u1, la, status) - la;
+        if (2 * j + 1 < np) delta[c * np + 2 * j + 1] = poisson_from_uniform(u2, lb, status) - lb;
         return;
     }
     delta[c * np + 2 * j] = a * scale[2 * j];
@@ -426,7 +433,7 @@ int launch_philox_univariate(beatamd_ctx *ctx, double *delta, int64_t C, int64_t
     if (n == 0) return BEATAMD_OK;
     ScopedTimer tm(ctx, "proposal");
     hipLaunchKernelGGL(k_philox_univariate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       delta, C, np, kind, scale, seed, step, first_chain, ctx->step_dev);
+                       delta, C, np, kind, scale, seed, step, first_chain, ctx->step_dev, ctx->d_status);
     BA_HIP(hipGetLastError());
     return BEATAMD_OK;
 }
@@ -467,6 +474,7 @@ struct DrawProposeArgs {
     uint64_t seed, first_chain;
     uint32_t step;
     const uint32_t *step_dev;
+    int *status;
     const double *Q0, *scaling, *lower, *upper;
     double *Qprop, *log_u;
     int32_t *inbounds;
@@ -519,8 +527,8 @@ __global__ void __launch_bounds__(256) k_draw_propose(DrawProposeArgs a)
             }
             if (a.kind == 3) {
                 const double la = a.factor[2 * j], lb = (2 * j + 1 < K) ? a.factor[2 * j + 1] : 0.0;
-                x = poisson_from_uniform(u53(r[0], r[1]), la) - la;
-                y = poisson_from_uniform(u53(r[2], r[3]), lb) - lb;
+                x = poisson_from_uniform(u53(r[0], r[1]), la, a.status) - la;
+                y = poisson_from_uniform(u53(r[2], r[3]), lb, a.status) - lb;
             } else {
                 x *= a.factor[2 * j];
                 if (2 * j + 1 < K) y *= a.factor[2 * j + 1];
@@ -587,6 +595,7 @@ int launch_draw_propose(beatamd_ctx *ctx, int64_t C, int64_t K, int64_t np, int 
     DrawProposeArgs a;
     a.C = C; a.K = K; a.np = np; a.kind = kind; a.factor = factor; a.df = df;
     a.seed = seed; a.first_chain = first_chain; a.step = step; a.step_dev = ctx->step_dev;
+    a.status = ctx->d_status;
     a.Q0 = Q0; a.scaling = scaling; a.lower = lower; a.upper = upper;
     a.Qprop = Qprop; a.log_u = log_u; a.inbounds = inbounds;
     ScopedTimer tm(ctx, "proposal");

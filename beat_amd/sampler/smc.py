@@ -171,6 +171,7 @@ def _dump_stage(step, homepath, layout, out_names, backend):
     same gathered arrays) + the sampler state needed to resume (smc.py:549-557)"""
     if homepath is None:
         return
+    step._stage_files_on = True
     # per-chain step state of all ranks (scaling, acceptance counters) for an exact resume
     st = step.stepper.state_dict()
     sc = parallel.allgather_rows(step.stepper.scaling[:, None])[:, 0].cpu().numpy()
@@ -200,7 +201,11 @@ def _dump_stage(step, homepath, layout, out_names, backend):
         if path is None:
             path = stage_path(homepath, stage)
             os.makedirs(path, exist_ok=True)
-        np.savez(os.path.join(path, "sampler_state.npz"), **state)
+        # (atomic: a reader -- an on_stage callback, a resume -- sees the complete archive or none; np.savez keeps the
+        # name it is given when it ends in .npz)
+        tmp = os.path.join(path, ".sampler_state.tmp.npz")
+        np.savez(tmp, **state)
+        os.replace(tmp, os.path.join(path, "sampler_state.npz"))
 
     if not getattr(step, "async_stage_files", True):
         return write()
@@ -218,15 +223,22 @@ def _dump_stage(step, homepath, layout, out_names, backend):
 
 
 def _join_stage_writer(step):
-    """wait for the stage files in flight (before the next ones are written, before a resume reads them, at the end
-    of smc_sample) and surface a failure of the writer"""
+    """wait for the stage files in flight (before the next ones are written, before an on_stage callback or a resume
+    reads them, at the end of smc_sample) and surface a failure of the writer ON EVERY RANK: only rank 0 writes, and a
+    rank that raised alone would leave the others waiting in the next collective.  Called by all ranks at
+    the same places; with several ranks that costs one broadcast of a flag per stage."""
     w = getattr(step, "_stage_writer", None)
-    if w is None:
-        return
-    step._stage_writer = None
-    w[0].join()
-    if "error" in w[1]:
-        raise w[1]["error"]
+    err = None
+    if w is not None:
+        step._stage_writer = None
+        w[0].join()
+        err = w[1].get("error")
+    if getattr(step, "world", 1) > 1 and getattr(step, "_stage_files_on", False):
+        failed = parallel.broadcast_array(np.array([1.0 if err is not None else 0.0]), src=0)
+        if failed[0] and err is None:
+            err = RuntimeError("rank 0 failed to write the stage files")
+    if err is not None:
+        raise err
 
 
 def load_stage(step, homepath, stage):
@@ -275,7 +287,8 @@ def update_last_samples(step, Q_local):
 
 
 def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, homepath=None,
-               layout=None, out_names=None, backend="bin", resume_stage=None, update=None, final_stage=True):
+               layout=None, out_names=None, backend="bin", resume_stage=None, update=None, final_stage=True,
+               async_stage_files=True):
     """smc.py:333-546 stage loop.  Returns the final population (n_chains, nparams), the
     likelihood vectors (host arrays) and the list of betas.  With ``homepath`` every stage leaves
     a ``stage_<k>`` / ``stage_final`` directory of NumpyChain/TextChain traces
@@ -287,11 +300,16 @@ def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, 
     the new weights before the next tempering step is chosen.  Every rank holds the same gathered
     population, so every rank updates its own model copy identically.
 
+    ``async_stage_files`` (default on): the stage directories are written by a thread beside the next stage's sampling;
+    the writer is joined before the next stage's files, before every ``on_stage`` callback (which may read the
+    directory) and at the end of the call; ``sampler_state.npz`` appears atomically.  Off: written in line.
+
     ``final_stage=False`` stops after ``max_stages`` tempering stages WITHOUT the stage at beta = 1 (the state of the
     last stage can be resumed from its directory); by default a run that exhausts ``max_stages`` still ends with the
     final stage like a converged one."""
     import time
     step.n_steps = int(n_steps)
+    step.async_stage_files = bool(async_stage_files)
     if n_steps < 1:
         raise TypeError("Argument `n_steps` should be above 0.")
     step.update_map_point = None
@@ -343,6 +361,8 @@ def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, 
         betas.append(step.beta)
         timed("io_s", _dump_stage, step, homepath, layout, out_names, backend)
         if on_stage is not None:
+            if homepath is not None:
+                timed("io_s", _join_stage_writer, step)     # (the callback may read the stage directory)
             on_stage(step)
     if not final_stage and step.beta < 1.0:
         step.stage_betas = betas

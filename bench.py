@@ -53,24 +53,29 @@ def algorithmic_bytes_per_chain_step(spec, nvar=1):
     return gathered + tables + data
 
 
-def cpu_baseline(spec, seconds=12.0):
-    """Reference-equivalent CPU path (oracle/beat_oracle.c bo_ffi_seismic_forward, the C
-    restatement pinned to the reference) on the host cores of this box, on a bounded
-    sample: T_sub of the T targets with the full P x N gather per target."""
-    from multiprocessing import get_context
+def _numa_nodes(cpus):
+    """-> [(node id, [cpus of this process on the node])] from sysfs; one pseudo node when sysfs has none"""
+    import glob
+    nodes = []
+    for d in sorted(glob.glob("/sys/devices/system/node/node[0-9]*"), key=lambda x: int(x.rsplit("node", 1)[1])):
+        try:
+            lst = open(os.path.join(d, "cpulist")).read().strip()
+        except OSError:
+            continue
+        mine = []
+        for part in lst.split(","):
+            if not part:
+                continue
+            a, _, b = part.partition("-")
+            mine += [c for c in range(int(a), int(b or a) + 1) if c in cpus]
+        if mine:
+            nodes.append((int(d.rsplit("node", 1)[1]), mine))
+    return nodes or [(0, sorted(cpus))]
 
+
+def _make_cpu_eval(G, spec, data, w, slog, ml):
     from oracle import oracle as orc  # noqa: F401  (cpu_baseline leg only)
-
-    T_sub = 4
-    ncores = len(os.sched_getaffinity(0))
-    rng = np.random.default_rng(spec.seed)
-    P, N, S = spec.P, spec.N, spec.S
-    ml = spec.interpolation == "multilinear"
-    D_cpu = 2 if ml else 1  # D reduced: same gathered volume per step, fits host RAM
-    G = rng.standard_normal((T_sub, P, D_cpu, S, N))
-    data = rng.standard_normal((T_sub, N))
-    w = np.full(T_sub, 2.0)
-    slog = np.zeros(T_sub)
+    P = spec.P
     lib_cfg = dict(dur_min=spec.du_min, dur_dt=spec.du_dt, st_min=spec.st_min, st_dt=spec.st_dt)
     fault = dict(ndip=spec.n_patch_dip, nstrike=spec.n_patch_strike, patch_size=spec.patch_size)
 
@@ -81,34 +86,128 @@ def cpu_baseline(spec, seconds=12.0):
                       nuc_strike=[r.uniform(0, 19.49)], nuc_dip=[r.uniform(0, 19.49)], time=[0.0])
         orc.ffi_seismic_forward([G], lib_cfg, fault, params, data, w, slog, 0.0,
                                 interpolation=spec.interpolation, return_synthetics=False)
+    return one
 
-    global _cpu_one
-    _cpu_one = one
+
+def _cpu_worker_main(i, cpu, node_slot, first_of_node, shape, bufs, G_parent, ctx_args, barrier, budget, out_q):
+    """one forked worker = one chain at a time on one core (iter_parallel_chains, beat/sampler/base.py:428-595),
+    pinned; it reads the library copy of ITS NUMA node, first-touched by the node's first worker"""
+    try:
+        os.sched_setaffinity(0, {cpu})
+    except OSError:
+        pass
+    G = np.frombuffer(bufs[node_slot], dtype=np.float64).reshape(shape)
+    if first_of_node:
+        step = max(1, shape[0] // 8)
+        for a in range(0, shape[0], step):      # first touch -> the pages land on this worker's node
+            G[a:a + step] = G_parent[a:a + step]
+    barrier.wait()
+    one = _make_cpu_eval(G, *ctx_args)
+    one(10 ** 6 + i)                            # warm (page tables)
+    barrier.wait()
+    t0 = time.perf_counter()
+    k = 0
+    while time.perf_counter() - t0 < budget:
+        one(1000 * i + k)
+        k += 1
+    out_q.put((i, k, time.perf_counter() - t0))
+
+
+def cpu_baseline(spec, seconds=14.0):
+    """Reference-equivalent CPU path on the host cores of this box, on a bounded sample: T_sub of the T targets with the
+    full P x N gather per target, scaled to a whole chain-step.
+      * the C restatement (oracle/beat_oracle.c bo_ffi_seismic_forward, pinned to the reference) on one core and on all
+        cores: one forked, PINNED worker per core, one chain at a time each (iter_parallel_chains,
+        beat/sampler/base.py:428-595), the library shared read-only -- ONE COPY PER NUMA NODE, first-touched by a worker
+        of that node (round 4 shared the parent's copy: every page on one node, 256 workers scaled x3.9);
+      * the reference's numpy stack_all arithmetic (fancy-index gather + product + einsum, beat/ffi/base.py:651-661),
+        which is what SURVEY 8(d) names, timed on one core beside it."""
+    import mmap
+    from multiprocessing import get_context
+
+    from oracle import oracle as orc  # noqa: F401  (cpu_baseline leg only)
+
+    cpus = set(os.sched_getaffinity(0))
+    ncores = len(cpus)
+    nodes = _numa_nodes(cpus)
+    P, N, S = spec.P, spec.N, spec.S
+    ml = spec.interpolation == "multilinear"
+    D_cpu = 2 if ml else 1  # D reduced: same gathered volume per step, fits host RAM
+    # targets per evaluation: 16 of 64 when the host has room for a copy per node (+ the parent's), else fewer
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+    except ImportError:
+        avail = 16e9
+    T_sub = 16
+    while T_sub > 2 and (len(nodes) + 1.5) * T_sub * P * D_cpu * S * N * 8 > 0.5 * avail:
+        T_sub //= 2
+    T_sub = min(T_sub, spec.T)
+    rng = np.random.default_rng(spec.seed)
+    shape = (T_sub, P, D_cpu, S, N)
+    G = np.empty(shape)
+    base = rng.standard_normal(shape[1:])       # (one target's rows drawn, the others scaled copies: the gather and the
+    for t in range(T_sub):                      #  FMAs cost the same, 5 GB of normals would take the leg's whole budget)
+        np.multiply(base, 1.0 + 1e-3 * t, out=G[t])
+    del base
+    data = rng.standard_normal((T_sub, N))
+    w = np.full(T_sub, 2.0)
+    slog = np.zeros(T_sub)
+    ctx_args = (spec, data, w, slog, ml)
+    one = _make_cpu_eval(G, *ctx_args)
     one(0)
     t0 = time.perf_counter()
     n1 = 0
-    while time.perf_counter() - t0 < seconds / 3:
+    while time.perf_counter() - t0 < seconds / 4:
         one(n1)
         n1 += 1
     t1 = (time.perf_counter() - t0) / n1
     rate1 = (T_sub / spec.T) / t1  # full chain-steps/s on one core
-    # all cores, one chain per forked worker (iter_parallel_chains, sampler/base.py:428-595)
-    rate_all, nsteps = rate1, n1
+    row_bytes_eval = float(T_sub) * P * N * 8 * (4 if ml else 1)
+    # ---- the reference's numpy path on one core (same rows, same volume): gather copy, product, sum over patches
+    didx = np.zeros(P, dtype=np.int16)
+    tidx = np.arange(T_sub)[:, None]
+    pidx = np.arange(P)
+    r_ = np.random.default_rng(1)
+    n_np, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds / 8 or n_np == 0:
+        sidx = r_.integers(0, S, (T_sub, P)).astype(np.int16)
+        slips = r_.uniform(0, 5, P)
+        cut = G[tidx, pidx, didx, sidx, :]                       # base.py:651-656 (nn; multilinear does this four times)
+        out_np = np.einsum("ijk->ik", cut * slips[None, :, None])   # base.py:658-661
+        n_np += 1
+    t_np = (time.perf_counter() - t0) / n_np * (4 if ml else 1)
+    rate_numpy = (T_sub / spec.T) / t_np
+    del cut, out_np
+    # ---- all cores
+    rate_all, nsteps, dt_all, per_node = rate1, n1, t1 * n1, {nodes[0][0]: 1}
     if ncores > 1:
-        budget = seconds * 2 / 3
-        ctx = get_context("fork")
-        with ctx.Pool(ncores) as pool:
-            pool.map(_cpu_worker, range(ncores))  # warm (page tables of the forked workers)
-            t0 = time.perf_counter()
-            counts = pool.map(_cpu_worker_for, [(i, budget) for i in range(ncores)])
-            dt = time.perf_counter() - t0
-        nsteps = int(sum(counts))
-        rate_all = nsteps * (T_sub / spec.T) / dt
+        budget = seconds / 2
+        mp = get_context("fork")
+        bufs = [mmap.mmap(-1, G.nbytes) for _ in nodes]          # anonymous shared mappings, untouched until a worker fills them
+        barrier = mp.Barrier(ncores)
+        out_q = mp.Queue()
+        procs, i = [], 0
+        for slot, (node, ncpus) in enumerate(nodes):
+            for k, cpu in enumerate(ncpus):
+                pr = mp.Process(target=_cpu_worker_main, args=(i, cpu, slot, k == 0, shape, bufs, G, ctx_args, barrier,
+                                                               budget, out_q))
+                pr.start()
+                procs.append(pr)
+                i += 1
+        res = [out_q.get(timeout=600) for _ in procs]
+        for pr in procs:
+            pr.join()
+        nsteps = int(sum(r[1] for r in res))
+        dt_all = max(r[2] for r in res)
+        rate_all = nsteps * (T_sub / spec.T) / dt_all
+        per_node = {str(node): len(ncpus) for node, ncpus in nodes}
+        for b in bufs:
+            b.close()
     phys = None
     try:   # physical cores (SURVEY 8(d)): distinct (package, core) pairs of the CPUs this process may use
-        cpus = sorted(os.sched_getaffinity(0))
         ids = set()
-        for c in cpus:
+        for c in sorted(cpus):
             base = "/sys/devices/system/cpu/cpu%d/topology/" % c
             ids.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
         phys = len(ids)
@@ -116,29 +215,17 @@ def cpu_baseline(spec, seconds=12.0):
         pass
     return dict(value=rate_all, unit="chain-steps/s", cores=ncores, cores_physical=phys, kind="port",
                 extrapolated_from="%d of %d targets per evaluation, scaled to a full chain-step" % (T_sub, spec.T),
-                value_1core=rate1,
+                value_1core=rate1, scaling_all_cores_vs_1core=rate_all / rate1,
+                value_1core_numpy_reference_path=rate_numpy,
+                numpy_note="the reference's numpy stack_all arithmetic (fancy-index gather, product, einsum; beat/ffi/base.py:651-661) "
+                           "on the same sample, one core: what SURVEY 8(d) names; the C port is %.1f x that per core" % (rate1 / rate_numpy),
+                host_gather_GBs_all_cores=nsteps * row_bytes_eval / dt_all / 1e9,
+                host_gather_GBs_1core=row_bytes_eval / t1 / 1e9,
+                numa_nodes=len(nodes), workers_per_numa_node=per_node,
+                library_copies="one per NUMA node, first-touched by a pinned worker of that node",
                 sample="%d of %d targets (full %dx%d gather per target), %d sample evaluations, "
                        "oracle/beat_oracle.c (C restatement of the reference numpy/C path), "
-                       "%d forked workers x 1 thread" % (T_sub, spec.T, P, N, nsteps, ncores))
-
-
-_cpu_one = None
-
-
-def _cpu_worker(i):
-    _cpu_one(i)
-    return 0
-
-
-def _cpu_worker_for(a):
-    """run sample evaluations until the time budget is spent; -> count"""
-    i, budget = a
-    t0 = time.perf_counter()
-    k = 0
-    while time.perf_counter() - t0 < budget:
-        _cpu_one(1000 * i + k)
-        k += 1
-    return k
+                       "%d forked pinned workers x 1 thread" % (T_sub, spec.T, P, N, nsteps, ncores))
 
 
 def make_spec(args):
@@ -631,11 +718,11 @@ def main():
             from beat_amd.sampler import smc_sample
             n_smc = 50
             smc_out = {}
-            runs_ = [(B, False, f, ""), (B, True, f, ""), (2048, False, f, "")]
+            runs_ = [(B, False, f, ""), (B, True, f, ""), (2048, False, f, ""), (4096, True, f, "")]
             if "multilinear" in legs:
                 runs_.append((B, False, f_ml, "_multilinear"))      # the reference's default interpolation, end to end
             for nch, with_files, f_smc, tag_ in runs_:
-                if nch == 2048 and B >= 2048:
+                if nch > B and B >= 2048:
                     continue
                 st = SMC(f_smc, lo, up, n_chains=nch, device=dev, random_seed=11, tune_interval=25)
                 home = tempfile.mkdtemp(prefix="beatamd_smc_") if with_files else None

@@ -96,7 +96,10 @@ def univariate(C, npar, kind, scale, seed, step, first_chain=0):
                 while u[i] > F and k < 4096:
                     k += 1
                     p *= lam[i] / k
-                    F += p
+                    Fn = F + p
+                    if Fn == F and k > lam[i]:      # the cumulative sum has stopped growing: the far tail
+                        break
+                    F = Fn
                 out[i] = k
             return out - lam
         la, lb = sc[np.minimum(2 * j, npar)], sc[np.minimum(2 * j + 1, npar)]

@@ -56,3 +56,41 @@ def test_write_population_roundtrip(tmp_path):
     np.testing.assert_array_equal(ch.get_values("durations")[0], pop[1, 4:8])
     np.testing.assert_array_equal(ch.get_values("seis_like")[0], lp[1, :2])
     assert ch.get_values("like")[0] == lp[1, 4] and ch.get_values("geo_like").shape == (1, 1)
+
+
+def test_packed_population_writer_is_bytewise_the_per_chain_writer(tmp_path):
+    """write_population packs all chains' records at once and writes every file with one open / one write from a thread
+    pool: the files are byte for byte what NumpyChain.setup + .write leave chain by chain (the writer the
+    reference fixture test above pins), for a population above the threading threshold, and at 4096 chains it takes a
+    fraction of a second"""
+    import time
+    from beat_amd.backend import population_shapes
+    from beat_amd.models import ParameterLayout
+    lay = ParameterLayout(OrderedDict([("uparr", 40), ("durations", 40), ("nucleation_strike", 1), ("h_any_P_0_Z", 1)]))
+    names = ["seis_like_any_P_0_%d" % i for i in range(6)] + ["geo_like_0", "geo_like_1", "laplacian_like", "like"]
+    rng = np.random.default_rng(1)
+    C = 300
+    pop, lp = rng.random((C, lay.size)), rng.random((C, len(names)))
+    path = write_population(str(tmp_path / "fast"), 3, lay, names, pop, lp)
+    shapes, groups = population_shapes(lay, names)
+    slow = str(tmp_path / "slow")
+    for c in (0, 1, 77, 299):
+        ch = NumpyChain(slow, shapes)
+        ch.setup(1, c, overwrite=True)
+        pt = lay.rmap(pop[c])
+        row = [pt[k] for k in lay.varsizes]
+        row += [lp[c, idx] if k in ("seis_like", "geo_like") else lp[c, idx[0]] for k, idx in groups.items()]
+        ch.write(row)
+        assert open(ch.filename, "rb").read() == open(os.path.join(path, "chain-%d.bin" % c), "rb").read()
+    assert len(os.listdir(path)) == C
+    lay2 = ParameterLayout(OrderedDict([("uparr", 400), ("durations", 400), ("velocities", 400), ("h_any_P_0_Z", 1)]))
+    names2 = ["seis_like_any_P_0_%d" % i for i in range(64)] + ["like"]
+    C = 4096
+    pop, lp = rng.random((C, lay2.size)), rng.random((C, len(names2)))
+    t0 = time.perf_counter()
+    path = write_population(str(tmp_path / "big"), 1, lay2, names2, pop, lp)
+    dt = time.perf_counter() - t0
+    assert len(os.listdir(path)) == C and dt < 5.0, dt
+    ch = NumpyChain.load(os.path.join(path, "chain-4095.bin"))
+    np.testing.assert_array_equal(ch.get_values("velocities")[0], pop[4095, 800:1200])
+    print("4096 chains x %d values: %.3f s" % (lay2.size + len(names2), dt))

@@ -10,7 +10,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_config4_joint_multifault_512_chains_n4096():
+@pytest.mark.parametrize("interp,kernel", [("multilinear", "k_gfstack_runs<2,"), ("nearest_neighbor", "k_gfstack_ws<1,2,3,")])
+def test_config4_joint_multifault_512_chains_n4096(interp, kernel):
+    """both interpolations (the reference's default for this composite is multilinear, beat/config.py:571-575); the
+    kernel that stacks the 512-chain batch is asserted by name: the runs kernel / the loader-consumer kernel, both
+    outside their round-4 envelopes on this (2 durations x 60 start times) library"""
     import torch
 
     import beat_amd
@@ -27,7 +31,7 @@ def test_config4_joint_multifault_512_chains_n4096():
     T, N, D, S = 35, 4096, 2, 60
     spec = SyntheticSpec((10, 10), (20, 20), (2.0, 2.0), T=T, N=N, D=D, S=S, st_dt=0.5,
                          slip_varnames=("uparr", "uperp"), covariance="toeplitz", station_shifts=True,
-                         geodetic_nobs=sizes, vel_bounds=(3.0, 4.0), time_bounds=(0.0, 2.0))
+                         geodetic_nobs=sizes, vel_bounds=(3.0, 4.0), time_bounds=(0.0, 2.0), interpolation=interp)
     prob, host = build_problem(spec, device_library=True, ctx=ctx)
     gd = prob.geodetic
     data = np.concatenate([g["d%d_displacement" % i] for i in range(len(sizes))])
@@ -43,6 +47,7 @@ def test_config4_joint_multifault_512_chains_n4096():
     Qd = torch.from_numpy(Q).cuda()
     LL = f.batch(Qd)
     ctx.synchronize()
+    assert ctx.last_kernel().startswith(kernel), (ctx.last_kernel(), ctx.gf_plan())
     kernel = ctx.last_kernel()
     LL = LL.cpu().numpy()
     assert LL.shape == (C, T + 2 + 1) and np.isfinite(LL).all()

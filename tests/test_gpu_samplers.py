@@ -558,6 +558,12 @@ def test_univariate_proposals_match_philox_reference_and_their_laws(ctx):
     np.testing.assert_allclose((k[:, 1] == 2).mean(), np.exp(-3.0) * 4.5, atol=4e-3)
     with pytest.raises(ValueError):
         ctx.proposal_draw_univariate(4, np.ones(4), 5, seed=1, step=0)
+    # a Poisson step width beyond 500 (or NaN) handed to the C entry point directly: flagged on the device, raised at the
+    # next synchronisation -- never silent NaN rows
+    with pytest.raises(ValueError):
+        ctx.proposal_draw_univariate(3, np.array([3.0, 600.0]), 8, seed=1, step=0)
+        ctx.synchronize()
+    ctx.synchronize()       # (the status word is cleared by the raise)
 
 
 def test_metropolis_with_per_parameter_proposal_on_device(ctx):
