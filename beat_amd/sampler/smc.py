@@ -37,7 +37,7 @@ class SMC(object):
 
     def __init__(self, target, lower, upper, n_chains=100, tune=True, tune_interval=100,
                  coef_variation=1.0, check_bound=True, proposal_name="MultivariateNormal",
-                 device=None, random_seed=42, scale=1.0, use_graph=False):
+                 device=None, random_seed=42, scale=1.0, use_graph=False, shard="chains"):
         import torch
         self.torch = torch
         proposal_df(proposal_name)  # validates the name
@@ -53,7 +53,13 @@ class SMC(object):
         self.stage = 0
         self.rng = np.random.RandomState(random_seed)  # identical on every rank
         self.rank, self.world, _ = parallel.ensure_group()
-        self.block = parallel.chain_block(self.n_chains, self.rank, self.world)
+        # shard = "chains" (default): every rank steps its contiguous block of chains on a replicated model, the end
+        # points are all-gathered per stage.  "targets": the MODEL is sharded (beat_amd.models.sharded: each rank holds
+        # the library rows of its targets) -- every rank steps ALL chains with identical decisions, nothing to gather
+        if shard not in ("chains", "targets"):
+            raise ValueError("shard must be 'chains' or 'targets'")
+        self.shard = shard
+        self.block = (0, self.n_chains) if shard == "targets" else parallel.chain_block(self.n_chains, self.rank, self.world)
         n_local = self.block[1] - self.block[0]
         self.stepper = BatchedMetropolis(target, lower, upper, n_local, device=device, tune=tune,
                                          tune_interval=tune_interval, scale=scale, seed=random_seed,
@@ -96,7 +102,10 @@ class SMC(object):
         """smc.py:188-240 -- instead of reading trace files: all-gather the ranks' blocks; the
         gathered arrays stay on the device."""
         self.ops.check()  # surfaces an out-of-library index of the finished stage (IndexError)
-        self.Q_all, self.L_all = parallel.allgather_population(Q_local, L_local, self.n_chains)
+        if self.shard == "targets":
+            self.Q_all, self.L_all = Q_local, L_local      # every rank stepped the whole population
+        else:
+            self.Q_all, self.L_all = parallel.allgather_population(Q_local, L_local, self.n_chains)
         if self.Q_all.shape[0] != self.n_chains:
             raise RuntimeError("gathered %d chains, expected %d (process group not initialised?)"
                                % (self.Q_all.shape[0], self.n_chains))
@@ -174,8 +183,11 @@ def _dump_stage(step, homepath, layout, out_names, backend):
     step._stage_files_on = True
     # per-chain step state of all ranks (scaling, acceptance counters) for an exact resume
     st = step.stepper.state_dict()
-    sc = parallel.allgather_rows(step.stepper.scaling[:, None])[:, 0].cpu().numpy()
-    ac = parallel.allgather_rows(step.stepper.accepted_since_tune[:, None])[:, 0].cpu().numpy()
+    if getattr(step, "shard", "chains") == "targets":     # every rank holds every chain's step state
+        sc, ac = step.stepper.scaling.cpu().numpy(), step.stepper.accepted_since_tune.cpu().numpy()
+    else:
+        sc = parallel.allgather_rows(step.stepper.scaling[:, None])[:, 0].cpu().numpy()
+        ac = parallel.allgather_rows(step.stepper.accepted_since_tune[:, None])[:, 0].cpu().numpy()
     _join_stage_writer(step)          # (at most one stage is being written at a time)
     if step.rank != 0:
         return
