@@ -42,7 +42,7 @@ def main():
     lo, up = lay.bounds(host["lower"], host["upper"])
     f = TargetShardedLogp(prob, ctx) if mode == "targets" else prob.compile(ctx)
     if mode == "targets":
-        assert f.world == world and f.nllk == 5 + 2 + 1 + 1 and sum(f.n_local) == (3 if rank == 0 else 2 if world == 2 else 5)
+        assert f.world == world and f.nllk == 5 + 2 + 1 + 1 and sum(f.n_local) == {1: [5], 2: [3, 2]}[world][rank]
     Q = torch.from_numpy(draw_population(spec, lay, host["lower"], host["upper"], 300)).to(dev)
     Q[7, lay.offset("durations")] = 99.0           # a chain outside the library grid: like = NaN on every rank
     LL = f.batch(Q)
@@ -53,7 +53,7 @@ def main():
         pass                   # ... and leaves NaN in that chain's `like`
     step = SMC(f, lo, up, n_chains=256, device=dev, random_seed=11, tune_interval=3,
                shard="targets" if mode == "targets" else "chains")
-    pop, lp, betas = smc_sample(4, step, max_stages=2)
+    pop, lp, betas = smc_sample(4, step, max_stages=3, final_stage=False)
     if mode == "targets" and world > 1:
         both = parallel.allgather_rows(torch.stack([step.Q_all.sum(), step.L_all.sum()])[None])
         assert torch.equal(both[0], both[1]), both
