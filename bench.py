@@ -233,8 +233,8 @@ def make_spec(args):
     prior = dict(nuc_margin=0.0, time_bounds=(0.0, 0.0)) if args.prior == "survey" \
         else dict(nuc_margin=6.0, time_bounds=(0.0, 0.5))
     return SyntheticSpec((20,), (20,), (1.0,), T=args.targets, N=args.samples, D=args.ndurations,
-                         S=args.nstarttimes, covariance=args.covariance, interpolation=args.interp,
-                         **prior)
+                         S=args.nstarttimes, du_min=args.duration_min, du_dt=args.duration_sampling,
+                         covariance=args.covariance, interpolation=args.interp, **prior)
 
 
 def main():
@@ -250,6 +250,10 @@ def main():
     ap.add_argument("--samples", type=int, default=4096)
     ap.add_argument("--nstarttimes", type=int, default=25)
     ap.add_argument("--ndurations", type=int, default=3)
+    ap.add_argument("--duration-min", type=float, default=0.5, help="first node of the library's duration axis [s]")
+    ap.add_argument("--duration-sampling", type=float, default=0.5, help="spacing of the duration axis [s]; "
+                    "`--samples 512 --ndurations 17 --nstarttimes 41 --duration-min 0 --duration-sampling 0.25` makes the "
+                    "tutorial-grid library of realistic_grid_leg the main workload (rocprof runs)")
     ap.add_argument("--prior", default="survey", choices=["survey", "narrow"],
                     help="survey: SURVEY 8(d) population (default); narrow: round 1's confined hypocentre")
     ap.add_argument("--step-scale", type=float, default=5e-4,

@@ -77,6 +77,42 @@ profile)
   find $O -name "*.db" -size +2M -delete; find $O -name "*.csv" -size +2M -delete
   du -sh $O
   ;;
+profile5)
+  # round 5: kernel stats + separate FETCH_SIZE / WRITE_SIZE passes of the headline run, the multilinear run and the two
+  # runs on the tutorial-grid library (row passes); kernel stats of the default command and of the configs[3] leg
+  tag=$1; O=$R/gpurun_out/prof_$tag
+  rm -rf $O; mkdir -p $O; cd /tmp
+  B="python $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-variant-legs --no-narrow-leg --no-batch-leg"
+  G="--samples 512 --ndurations 17 --nstarttimes 41 --duration-min 0 --duration-sampling 0.25 --no-streaming-leg"
+  prof() { t=$1; shift; mkdir -p $O/$t
+    timeout 600 rocprofv3 --kernel-trace --stats -d $O/$t/stats -o bench -- "$@" > $O/$t/stats_run.log 2>&1
+    timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/$t/fetch -o bench -- "$@" > $O/$t/fetch_run.log 2>&1
+    timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/$t/write -o bench -- "$@" > $O/$t/write_run.log 2>&1
+  }
+  prof c512_nn $B
+  prof c512_ml $B --interp multilinear --no-streaming-leg
+  prof grid_nn $B $G
+  prof grid_ml $B $G --interp multilinear
+  prof grid_nn_c2048 $B $G --chains 2048
+  prof grid_ml_c2048 $B $G --chains 2048 --interp multilinear
+  mkdir -p $O/default $O/config4
+  timeout 900 rocprofv3 --kernel-trace --stats -d $O/default/stats -o bench -- python $R/bench.py --no-cpu-baseline > $O/default/stats_run.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats -d $O/config4/stats -o bench -- python $R/bench.py --no-cpu-baseline --variant-legs config4 --no-streaming-leg --no-batch-leg --no-narrow-leg --steps 10 > $O/config4/stats_run.log 2>&1
+  S="python $R/tools/summarize_rocpd2.py"
+  $S $O/c512_nn $O/out ${tag}_bench_c512_nn k_gfstack_ws "k_gfstack<0" k_ws_tables k_fast_sweep > $O/sum_c512_nn.log 2>&1
+  $S $O/c512_ml $O/out ${tag}_bench_c512_ml k_gfstack_runs k_gm_tables > $O/sum_c512_ml.log 2>&1
+  $S $O/grid_nn $O/out ${tag}_grid_c512_nn k_gfstack_ws k_ws_tables > $O/sum_grid_nn.log 2>&1
+  $S $O/grid_ml $O/out ${tag}_grid_c512_ml k_gfstack_runs k_gm_tables > $O/sum_grid_ml.log 2>&1
+  $S $O/grid_nn_c2048 $O/out ${tag}_grid_c2048_nn k_gfstack_ws > $O/sum_grid_nn2048.log 2>&1
+  $S $O/grid_ml_c2048 $O/out ${tag}_grid_c2048_ml k_gfstack_runs > $O/sum_grid_ml2048.log 2>&1
+  $S $O/default $O/out ${tag}_bench_default "k_quadform<128>" k_gfstack_runs "k_gemm_f64<0>" k_gfstack_ws > $O/sum_default.log 2>&1
+  $S $O/config4 $O/out ${tag}_config4 k_gfstack_runs k_gfstack_ws k_gm_tables k_ws_tables "k_quadform<128>" > $O/sum_config4.log 2>&1
+  grep -h "^{\"metric" $O/*/stats_run.log > $O/out/${tag}_bench_lines_under_profiler.jsonl
+  tail -2 $O/default/stats_run.log | cut -c1-300
+  cat $O/sum_*.log | grep -E "kernel\"|avg_us|corrected|write_bytes|no dispatch" | cut -c1-160
+  find $O -name "*.db" -size +2M -delete; find $O -name "*.csv" -size +2M -delete
+  du -sh $O
+  ;;
 stats)
   tag=$1; shift; O=$R/gpurun_out/$tag; rm -rf $O; mkdir -p $O; cd /tmp
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/s -o run -- "$@" > $O/run.log 2>&1
