@@ -93,6 +93,7 @@ _PROTOS = {
     "beatamd_ctx_last_kernel": [_vp, C.c_char_p, _i64],
     "beatamd_ctx_gf_group_stats": [_vp, _pi64, C.POINTER(_f64), _pi64, _pi64],
     "beatamd_ctx_gf_plan": [_vp, C.c_char_p, _i64, C.POINTER(_f64), _pi64],
+    "beatamd_ctx_reload_knobs": [_vp],
     "beatamd_smc_calc_beta": [_vp, _i64, _vp, _i64, _f64, _f64, C.POINTER(_f64), _vp],
     "beatamd_smc_stage_weights": [_vp, _i64, _vp, _i64, _f64, _vp],
     "beatamd_smc_resample": [_vp, _i64, _vp, _f64, _vp],

@@ -460,7 +460,7 @@ int launch_triu_solve_vec(beatamd_ctx *ctx, int64_t nbatch, int64_t n, const dou
     BA_CHECK(lds <= 160 * 1024, BEATAMD_EINVAL, "triu_solve: n = %lld does not fit the LDS (max %d)", (long long)n,
              (int)(160 * 1024 / 8 - TS_B - TS_B * TS_B));
     ScopedTimer tm(ctx, "triu_solve");
-    (void)hipFuncSetAttribute((const void *)k_triu_solve_vec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    BA_HIP(hipFuncSetAttribute((const void *)k_triu_solve_vec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_triu_solve_vec, dim3((unsigned)nbatch), dim3(1024), lds, ctx->stream, W, n, X, ctx->d_status);
     BA_HIP(hipGetLastError());
     return BEATAMD_OK;

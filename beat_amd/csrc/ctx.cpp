@@ -1,6 +1,8 @@
 // ctx.cpp -- context lifetime, staging, timing, error reporting.
 #include "ctx.hpp"
 
+#include <cstdlib>
+
 namespace beatamd {
 
 static thread_local char g_err[1024] = "";
@@ -194,6 +196,27 @@ int beatamd_ctx::check_status()
     return BEATAMD_OK;
 }
 
+namespace beatamd {
+
+void GfKnobs::read_env()
+{
+    auto rd = [](const char *name) { const char *e = getenv(name); return e ? atoi(e) : KNOB_UNSET; };
+    gf_kernel = rd("BEATAMD_GF_KERNEL"); gs_cg = rd("BEATAMD_GS_CG"); gs_ws = rd("BEATAMD_GS_WS"); gs_dma = rd("BEATAMD_GS_DMA");
+    gs_nt = rd("BEATAMD_GS_NT"); ws_map = rd("BEATAMD_WS_MAP"); gs_pair = rd("BEATAMD_GS_PAIR"); gs_nthint = rd("BEATAMD_GS_NTHINT");
+    gs_order = rd("BEATAMD_GS_ORDER"); gs_fit = rd("BEATAMD_GS_FIT"); gs_win = rd("BEATAMD_GS_WIN"); gf_tinv = rd("BEATAMD_GF_TINV");
+    gs_tune = rd("BEATAMD_GS_TUNE"); gf_order = rd("BEATAMD_GF_ORDER"); gf_cgroup = rd("BEATAMD_GF_CGROUP"); gs_ml = rd("BEATAMD_GS_ML");
+    gc_global = rd("BEATAMD_GC_GLOBAL"); gc_sort = rd("BEATAMD_GC_SORT"); gc_keys = rd("BEATAMD_GC_KEYS"); gr_cap = rd("BEATAMD_GR_CAP");
+    gr_pass_alloc = rd("BEATAMD_GR_PASS_ALLOC"); gr_var = rd("BEATAMD_GR_VAR"); sweep_v1 = rd("BEATAMD_SWEEP_V1");
+}
+
+const GfKnobs &gf_knobs(beatamd_ctx *ctx)
+{
+    if (ctx->knobs_live) ctx->knobs.read_env();
+    return ctx->knobs;
+}
+
+}  // namespace beatamd
+
 extern "C" {
 
 const char *beatamd_last_error(void) { return g_err; }
@@ -223,7 +246,19 @@ int beatamd_ctx_create(int device, beatamd_ctx **out)
     BA_HIP(hipGetDeviceProperties(&prop, device));
     c->num_cu = prop.multiProcessorCount;
     c->scratch.resize(SL_COUNT);
+    c->knobs.read_env();
+    {
+        const char *live = getenv("BEATAMD_KNOBS_LIVE");
+        c->knobs_live = live && atoi(live) != 0;
+    }
     *out = c;
+    return BEATAMD_OK;
+}
+
+int beatamd_ctx_reload_knobs(beatamd_ctx *c)
+{
+    BA_CHECK(c != nullptr, BEATAMD_EINVAL, "ctx_reload_knobs: NULL context");
+    c->knobs.read_env();
     return BEATAMD_OK;
 }
 

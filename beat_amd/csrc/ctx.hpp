@@ -128,6 +128,23 @@ struct FfiModel {
     int64_t nllk() const;
 };
 
+// A/B and test knobs of the stacking path (BEATAMD_G* / BEATAMD_WS_* environment variables; DESIGN.md 3.1b lists them).
+// Read ONCE when the context is created (and again on beatamd_ctx_reload_knobs); a context created with
+// BEATAMD_KNOBS_LIVE=1 in the environment -- the test suite, the A/B tools -- re-reads them at every stacking call so
+// that one process can compare kernels.  KNOB_UNSET: the variable is not set, the default applies.
+constexpr int KNOB_UNSET = -2147483647;
+struct GfKnobs {
+    int gf_kernel = KNOB_UNSET, gs_cg = KNOB_UNSET, gs_ws = KNOB_UNSET, gs_dma = KNOB_UNSET, gs_nt = KNOB_UNSET,
+        ws_map = KNOB_UNSET, gs_pair = KNOB_UNSET, gs_nthint = KNOB_UNSET, gs_order = KNOB_UNSET, gs_fit = KNOB_UNSET,
+        gs_win = KNOB_UNSET, gf_tinv = KNOB_UNSET, gs_tune = KNOB_UNSET, gf_order = KNOB_UNSET, gf_cgroup = KNOB_UNSET,
+        gs_ml = KNOB_UNSET, gc_global = KNOB_UNSET, gc_sort = KNOB_UNSET, gc_keys = KNOB_UNSET, gr_cap = KNOB_UNSET,
+        gr_pass_alloc = KNOB_UNSET, gr_var = KNOB_UNSET, sweep_v1 = KNOB_UNSET;
+    void read_env();
+    static int get(int v, int dflt) { return v == KNOB_UNSET ? dflt : v; }
+    static bool is(int v, int x) { return v != KNOB_UNSET && v == x; }       // set and equal to x
+    static bool set(int v) { return v != KNOB_UNSET; }
+};
+
 struct KTimer {
     double total_ms = 0;
     int64_t n = 0;
@@ -167,6 +184,8 @@ struct beatamd_ctx {
     // measured chains-per-workgroup choice per problem shape: key -> (group size, row bound)
     std::map<std::vector<int64_t>, std::pair<int, int>> gs_tuned;
     int gs_cg = 0;
+    beatamd::GfKnobs knobs;
+    bool knobs_live = false;
     // device-resident Philox step counter (beatamd_ctx_set_step_counter): the proposal draws read it
     // instead of their `step` argument and advance it, so that a captured step replays correctly
     uint32_t *step_dev = nullptr;
@@ -182,6 +201,8 @@ struct beatamd_ctx {
 namespace beatamd {
 
 bool is_device_ptr(const void *p);
+// the knobs in force for a stacking call (re-read from the environment first in live mode)
+const GfKnobs &gf_knobs(beatamd_ctx *ctx);
 
 // RAII-ish staging of one array argument.  Host pointers are mirrored in a scratch slot.
 struct Arg {

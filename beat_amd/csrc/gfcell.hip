@@ -26,8 +26,6 @@
 // contiguous physical register range, so they are register-allocated by hand); tools/gfcell_emu.py interprets
 // them on the CPU (tests/test_gfcell_program.py).  Rounds 3 / 4 shipped two more consumer programs in this file
 // (k_gfstack_cell, k_gfstack_ml); both were retired in round 5 (DESIGN.md 3.1d-e keeps what they measured).
-#include <cstdlib>
-
 #include "kernels.hpp"
 #include "gfruns_asm.inc"
 
@@ -45,12 +43,6 @@ constexpr int GR_CAP = ((160 * 1024 - GC_PARAM_BYTES) / (3 * 512)) / 2 * 2;
 // (group, target) is stacked by k_gfstack instead (device-side flag, no host synchronisation)
 constexpr int GR_PASS_ALLOC = 6;
 constexpr int64_t GR_DENSE_MAX = 16384;         // D * (S + 1) the table kernel's LDS maps are sized for
-
-static int env_int(const char *name, int dflt)
-{
-    const char *e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
 
 // ---------------------------------------------------------------------------- chain order
 // Chains that rupture alike choose the same cells patch after patch; a wavefront that holds alike chains needs
@@ -152,11 +144,11 @@ __global__ void __launch_bounds__(GC_TB) k_gc_order(GcOrderArgs a)
 }
 
 // launches the chain order of a batch into oa.order (scratch for members / keys behind it)
-static int launch_gc_order(beatamd_ctx *ctx, GcOrderArgs &oa, int64_t ngroups)
+static int launch_gc_order(beatamd_ctx *ctx, GcOrderArgs &oa, int64_t ngroups, const GfKnobs &kn)
 {
     void *p = nullptr;
     const size_t norder = (size_t)(ngroups * GC_CG + 64);
-    const bool global = oa.sort && ngroups > 1 && oa.C <= GC_MEMBERS_MAX && env_int("BEATAMD_GC_GLOBAL", 1) != 0;
+    const bool global = oa.sort && ngroups > 1 && oa.C <= GC_MEMBERS_MAX && GfKnobs::get(kn.gc_global, 1) != 0;
     BA_TRY(ctx->get_scratch(SL_GC_ORDER, norder * sizeof(uint32_t) + (global ? (size_t)oa.C * 12 + 64 : 0), &p));
     oa.order = (uint32_t *)p;
     oa.members = nullptr;
@@ -611,11 +603,10 @@ __global__ void __launch_bounds__(1024) k_gfstack_runs(GcArgs a)
 // dense-slot / row ids beyond 16 bits or the table kernel's LDS maps, byte offsets beyond 32 bits.
 bool gfstack_ml_applicable(const GfStackCall &k)
 {
-    // A/B and test knobs, read per call so that one process can compare kernels (a few getenv calls next to a
-    // launch of milliseconds; the launch-bound geometry step reads its knobs once)
-    const int knob = env_int("BEATAMD_GS_ML", -1);   // 0: off, 1: forced also for small batches
-    const int gfk = env_int("BEATAMD_GF_KERNEL", -1);
-    const bool cg_fixed = getenv("BEATAMD_GS_CG") != nullptr;
+    const GfKnobs &kn = *k.knobs;
+    const int knob = GfKnobs::get(kn.gs_ml, -1);   // 0: off, 1: forced also for small batches
+    const int gfk = GfKnobs::get(kn.gf_kernel, -1);
+    const bool cg_fixed = GfKnobs::set(kn.gs_cg);
     const SeisLib &L = *k.libs[0];
     if (knob == 0 || gfk == 0) return false;
     if (k.interp != BEATAMD_MULTILINEAR || k.nvar < 1 || k.nvar > 3) return false;
@@ -640,17 +631,18 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
     *ovf_out = nullptr;
     // row passes: none when every dense slot of a patch (and the row requests they can take) fits a buffer; else the
     // passes are counted on the device and the tables sized for GR_PASS_ALLOC per patch (BEATAMD_GR_CAP: tests)
-    const int cap = std::min(GR_CAP, std::max(8, env_int("BEATAMD_GR_CAP", GR_CAP)));
+    const GfKnobs &kn = *k.knobs;
+    const int cap = std::min(GR_CAP, std::max(8, GfKnobs::get(kn.gr_cap, GR_CAP)));
     const bool passes = dense > cap || (L.S > 255 ? dense : dense / 2 + 2 * L.D + 1) > GC_NLOAD * GC_LREQ;
-    const int64_t vmax = L.P * (passes ? std::max(1, env_int("BEATAMD_GR_PASS_ALLOC", GR_PASS_ALLOC)) : 1);
+    const int64_t vmax = L.P * (passes ? std::max(1, GfKnobs::get(kn.gr_pass_alloc, GR_PASS_ALLOC)) : 1);
     const int64_t smax = vmax * k.nvar;
 
     GcOrderArgs oa;
     oa.C = k.C; oa.T = Ttab; oa.P = L.P; oa.S = L.S; oa.rowoff = rowoff;
     // chains that rupture alike share cells patch after patch -> put them into one wavefront (k_gc_order)
-    oa.sort = env_int("BEATAMD_GC_SORT", 1) != 0;
-    if (env_int("BEATAMD_GC_KEYS", 1)) { oa.key[0] = k.order_key[0]; oa.key[1] = k.order_key[1]; }
-    BA_TRY(launch_gc_order(ctx, oa, ngroups));   // (reads the row ids of k_gf_tables, launched before this call)
+    oa.sort = GfKnobs::get(kn.gc_sort, 1) != 0;
+    if (GfKnobs::get(kn.gc_keys, 1)) { oa.key[0] = k.order_key[0]; oa.key[1] = k.order_key[1]; }
+    BA_TRY(launch_gc_order(ctx, oa, ngroups, kn));   // (reads the row ids of k_gf_tables, launched before this call)
 
     GmTabArgs ta;
     memset(&ta, 0, sizeof(ta));
@@ -707,11 +699,11 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
         a.partial = (double *)p;
     }
     int64_t nblocks = ngroups * L.T * a.ntile;
-    const int order_knob = env_int("BEATAMD_GS_ORDER", 1);
+    const int order_knob = GfKnobs::get(kn.gs_order, 1);
     a.xcd_order = (ngroups > 1 && order_knob != 0) ? 1 : 0;
     if (a.xcd_order) nblocks = ((L.T * a.ntile + 7) / 8) * 8 * ngroups;
     BA_CHECK(nblocks < (int64_t)0x7fffffff, BEATAMD_EINVAL, "gfstack: batch too large");
-    const int nth_knob = env_int("BEATAMD_GS_NTHINT", -1);
+    const int nth_knob = GfKnobs::get(kn.gs_nthint, -1);
     const int nth = nth_knob >= 0 ? (nth_knob != 0) : (ngroups == 1);
     const size_t ring = std::max<size_t>((size_t)3 * cap * 512, (size_t)GC_NCONS * 16 * GC_TPITCH);
     const size_t lds = GC_PARAM_BYTES + ring;
@@ -733,7 +725,7 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
         void (*kern)(GcArgs) = nth ? k_gfstack_runs<1, 0> : k_gfstack_runs<0, 0>;
 #if GR_NVARIANT > 1
         {
-            const int var = env_int("BEATAMD_GR_VAR", 0);   // timing experiments (GR_ABLATIONS builds; wrong results)
+            const int var = GfKnobs::get(kn.gr_var, 0);   // timing experiments (GR_ABLATIONS builds; wrong results)
             void (*vk[])(GcArgs) = {kern, k_gfstack_runs<1, 1>, k_gfstack_runs<1, 2>, k_gfstack_runs<1, 3>, k_gfstack_runs<1, 4>,
                                     k_gfstack_runs<1, 5>, k_gfstack_runs<1, 6>};
             if (var >= 1 && var < GR_NVARIANT) kern = vk[var];

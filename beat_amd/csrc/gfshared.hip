@@ -28,8 +28,6 @@
 // kernels.  Per chain the patches and rows are accumulated in the same order with
 // the same fma() as in k_gfstack: for one slip variable all kernels produce bitwise identical
 // synthetics (tests/test_gpu_parity.py).
-#include <cstdlib>
-
 #include "kernels.hpp"
 
 namespace beatamd {
@@ -1732,7 +1730,7 @@ k_gfstack_wsp(GsArgs a)
 
 
 template <int WAVES, int NROW, int MODE>
-static void launch_shared_one(dim3 grid, size_t lds, hipStream_t s, const GsArgs &a)
+static int launch_shared_one(dim3 grid, size_t lds, hipStream_t s, const GsArgs &a)
 {
     void (*kern)(GsArgs) = nullptr;
     if constexpr (WAVES == 16) {
@@ -1745,25 +1743,25 @@ static void launch_shared_one(dim3 grid, size_t lds, hipStream_t s, const GsArgs
                             : k_gfstack_dma<WAVES, NROW, MODE, 64, 0>;
     }
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
+        BA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, s, a);
+    return BEATAMD_OK;
 }
 
 template <int WAVES, int NROW>
-static void launch_shared_mode(int mode, dim3 grid, size_t lds, hipStream_t s, const GsArgs &a)
+static int launch_shared_mode(int mode, dim3 grid, size_t lds, hipStream_t s, const GsArgs &a)
 {
-    if (mode == GF_STORE_SYN) launch_shared_one<WAVES, NROW, GF_STORE_SYN>(grid, lds, s, a);
-    else if (mode == GF_RESID_SCALAR) launch_shared_one<WAVES, NROW, GF_RESID_SCALAR>(grid, lds, s, a);
-    else launch_shared_one<WAVES, NROW, GF_RESID_STORE>(grid, lds, s, a);
+    if (mode == GF_STORE_SYN) return launch_shared_one<WAVES, NROW, GF_STORE_SYN>(grid, lds, s, a);
+    if (mode == GF_RESID_SCALAR) return launch_shared_one<WAVES, NROW, GF_RESID_SCALAR>(grid, lds, s, a);
+    return launch_shared_one<WAVES, NROW, GF_RESID_STORE>(grid, lds, s, a);
 }
 
 template <int WAVES>
-static void launch_shared_nrow(int nrow, int mode, dim3 grid, size_t lds, hipStream_t s,
-                               const GsArgs &a)
+static int launch_shared_nrow(int nrow, int mode, dim3 grid, size_t lds, hipStream_t s,
+                              const GsArgs &a)
 {
-    if (nrow == 1) launch_shared_mode<WAVES, 1>(mode, grid, lds, s, a);
-    else launch_shared_mode<WAVES, 4>(mode, grid, lds, s, a);
+    if (nrow == 1) return launch_shared_mode<WAVES, 1>(mode, grid, lds, s, a);
+    return launch_shared_mode<WAVES, 4>(mode, grid, lds, s, a);
 }
 
 // (single-row interpolation only: with four rows per chain the consumers run out of registers and
@@ -2081,14 +2079,13 @@ bool gfstack_shared_applicable(const GfStackCall &k, int *cg_out, int *ucap_out)
     const SeisLib &L = *k.libs[0];
     const int nrow = k.interp == BEATAMD_MULTILINEAR ? 4 : 1;
     if (L.N % 2 != 0) return false;
-    const char *e = getenv("BEATAMD_GF_KERNEL");  // 0 = streaming kernel, 1 = shared kernel
-    if (e && atoi(e) == 0) return false;
-    const bool forced = e && atoi(e) == 1;
+    const GfKnobs &kn = *k.knobs;
+    if (GfKnobs::is(kn.gf_kernel, 0)) return false;   // 0 = streaming kernel, 1 = shared kernel
+    const bool forced = GfKnobs::is(kn.gf_kernel, 1);
     if (!forced && k.C < 48) return false;  // too few chains to share rows
     int cg = pick_group(k.C);
-    const char *gq = getenv("BEATAMD_GS_CG");
-    if (gq && (atoi(gq) == 64 || atoi(gq) == 128 || atoi(gq) == 256 || atoi(gq) == 512 ||
-               atoi(gq) == 1024)) cg = atoi(gq);
+    const int gq = GfKnobs::get(kn.gs_cg, 0);
+    if (gq == 64 || gq == 128 || gq == 256 || gq == 512 || gq == 1024) cg = gq;
     const int64_t DS = L.D * L.S;
     int64_t ucap = std::min<int64_t>((int64_t)cg * nrow, DS);
     if (ws_wanted(k, cg)) {
@@ -2114,14 +2111,15 @@ bool gfstack_shared_applicable(const GfStackCall &k, int *cg_out, int *ucap_out)
 // (duration x start-time) grid (row passes, k_ws_tables)
 static bool ws_wanted(const GfStackCall &k, int CG)
 {
-    const char *e = getenv("BEATAMD_GS_WS"), *ed = getenv("BEATAMD_GS_DMA"), *en = getenv("BEATAMD_GS_NT");
-    const bool want = e ? atoi(e) != 0 : (GS_WS_DEFAULT != 0);
-    return want && CG == WS_CG && k.interp != BEATAMD_MULTILINEAR && k.libs[0]->N % 2 == 0 && !(ed && atoi(ed) != 2) &&
-           !(en && atoi(en) != 64);
+    const GfKnobs &kn = *k.knobs;
+    const bool want = GfKnobs::get(kn.gs_ws, GS_WS_DEFAULT) != 0;
+    return want && CG == WS_CG && k.interp != BEATAMD_MULTILINEAR && k.libs[0]->N % 2 == 0 &&
+           !(GfKnobs::set(kn.gs_dma) && kn.gs_dma != 2) && !(GfKnobs::set(kn.gs_nt) && kn.gs_nt != 64);
 }
 
 static int launch_gfstack_ws(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *rowoff, int64_t Ttab)
 {
+    const GfKnobs &kn = *k.knobs;
     const SeisLib &L = *k.libs[0];
     const int64_t ngroups = (k.C + WS_CG - 1) / WS_CG;
     const int64_t GT = ngroups * Ttab, GTP = GT * L.P;
@@ -2157,7 +2155,7 @@ static int launch_gfstack_ws(beatamd_ctx *ctx, const GfStackCall &k, const uint3
     ta.w = (double *)p;
     {
         ScopedTimer tm(ctx, "grouptables");
-        const bool map = ta.DS <= WS_MAP_MAX && !(getenv("BEATAMD_WS_MAP") && atoi(getenv("BEATAMD_WS_MAP")) == 0);   // (0: tests of the ranking path)
+        const bool map = ta.DS <= WS_MAP_MAX && !GfKnobs::is(kn.ws_map, 0);   // (BEATAMD_WS_MAP=0: tests of the ranking path)
         const size_t mlds = map ? (size_t)ta.DS * sizeof(uint16_t) : 0;
         if (maxpass > 1) {
             if (map) hipLaunchKernelGGL((k_ws_tables<0, 1>), dim3((unsigned)GTP), dim3(WS_CG), mlds, ctx->stream, ta);
@@ -2173,7 +2171,7 @@ static int launch_gfstack_ws(beatamd_ctx *ctx, const GfStackCall &k, const uint3
     GsArgs a;
     memset(&a, 0, sizeof(a));
     bool f32 = k.f32;   // float copies: the pair gather of k_gfstack_wsp<1>
-    const bool pair64 = getenv("BEATAMD_GS_PAIR") && atoi(getenv("BEATAMD_GS_PAIR")) == 1;   // A/B: ds_read_b128 pairs
+    const bool pair64 = GfKnobs::is(kn.gs_pair, 1);   // A/B: ds_read_b128 pairs
     for (int v = 0; v < k.nvar; v++) {
         a.G[v] = k.libs[v]->g;
         a.G32[v] = k.libs[v]->g32;
@@ -2195,16 +2193,12 @@ static int launch_gfstack_ws(beatamd_ctx *ctx, const GfStackCall &k, const uint3
         BA_TRY(ctx->get_scratch(SL_PARTIAL, (size_t)k.C * L.T * a.ntile * sizeof(double), &p));
         a.partial = (double *)p;
     }
-    {
-        const char *e = getenv("BEATAMD_GS_NTHINT");
-        a.nthint = e ? (atoi(e) != 0) : (GS_NTHINT_DEFAULT && ngroups == 1);
-    }
+    a.nthint = GfKnobs::set(kn.gs_nthint) ? (kn.gs_nthint != 0) : (GS_NTHINT_DEFAULT && ngroups == 1);
     int64_t nblocks = ngroups * L.T * a.ntile;
     {
         // chain groups of one (target, tile) on one XCD (several groups only)
-        const char *e = getenv("BEATAMD_GS_ORDER");
-        a.xcd_order = (ngroups > 1 && !(e && atoi(e) == 0)) ? 1 : 0;
-        if (e && atoi(e) == 1) a.xcd_order = 1;
+        a.xcd_order = (ngroups > 1 && !GfKnobs::is(kn.gs_order, 0)) ? 1 : 0;
+        if (GfKnobs::is(kn.gs_order, 1)) a.xcd_order = 1;
         if (a.xcd_order) nblocks = ((L.T * a.ntile + 7) / 8) * 8 * ngroups;
     }
     BA_CHECK(nblocks < (int64_t)0x7fffffff, BEATAMD_EINVAL, "gfstack: batch too large");
@@ -2241,6 +2235,7 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
                           const double *fac, int CG, int ucap, int64_t Ttab)
 {
     if (ws_wanted(k, CG)) return launch_gfstack_ws(ctx, k, rowoff, Ttab);
+    const GfKnobs &kn = *k.knobs;
     const SeisLib &L = *k.libs[0];
     const int nrow = k.interp == BEATAMD_MULTILINEAR ? 4 : 1;
     const int64_t ngroups = (k.C + CG - 1) / CG;
@@ -2267,7 +2262,7 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     ga.w_var_stride = (nrow == 1) ? ngroups * L.P * CG : GTP * 4 * CG;
     BA_TRY(ctx->get_scratch(SL_GS_W, ((size_t)ga.w_var_stride * k.nvar + (size_t)3 * 4 * CG) * sizeof(double), &p));
     ga.w = (double *)p;
-    const bool fit_lds = CG <= 128 && !(getenv("BEATAMD_GS_FIT") && atoi(getenv("BEATAMD_GS_FIT")) == 0);
+    const bool fit_lds = CG <= 128 && !GfKnobs::is(kn.gs_fit, 0);
     ga.umax = nullptr;
     if (fit_lds) {
         BA_TRY(ctx->get_scratch(SL_GS_UMAX, sizeof(uint32_t), &p));
@@ -2279,14 +2274,13 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     // small groups size their LDS by the measured row count and keep dense slots): the row
     // buffers then hold 32 * depth slots
     {
-        const char *ew = getenv("BEATAMD_GS_WIN"), *ed = getenv("BEATAMD_GS_DMA");
         const int depth = (ucap + 31) / 32;
-        const bool dma2 = !(ed && (atoi(ed) == 0 || atoi(ed) == 1)) && L.N % 2 == 0;
+        const bool dma2 = !(GfKnobs::is(kn.gs_dma, 0) || GfKnobs::is(kn.gs_dma, 1)) && L.N % 2 == 0;
         // (8- and 16-wavefront workgroups are alone on their CU anyway; smaller groups would lose
         // a resident workgroup to the larger row buffers -- measured: 256 chains 6.6 -> 11.2 ms)
         // (multilinear: every chain reads four rows per patch, the lane-group masks are dense and
         // the windows bring nothing: measured 21.1 vs 20.2 ms)
-        ga.windowed = (CG >= 512 && nrow == 1 && dma2 && ucap > 32 && ucap <= 128 && !(ew && atoi(ew) == 0) &&
+        ga.windowed = (CG >= 512 && nrow == 1 && dma2 && ucap > 32 && ucap <= 128 && !GfKnobs::is(kn.gs_win, 0) &&
                        (size_t)2 * 32 * depth * (GS_NT_MAX + 2) * 8 <= 158 * 1024) ? 1 : 0;
         ga.depth = depth;
         if (ga.windowed) ucap = 32 * depth;
@@ -2312,8 +2306,7 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     a.CG = CG; a.ucap = ucap; a.ustride = ga.ustride;
     a.nt = 64;
     {
-        const char *e = getenv("BEATAMD_GS_NT");
-        if (e && (atoi(e) == 48 || atoi(e) == 32)) a.nt = atoi(e);
+        if (GfKnobs::is(kn.gs_nt, 32)) a.nt = 32;
         if (CG == 1024) a.nt = 32;
     }
     a.ngroups = ngroups;
@@ -2375,18 +2368,14 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     size_t lds = (size_t)ucap * (a.nt + 2) * sizeof(double);
     {
         // two row buffers (the candidates were chosen so that they fit); BEATAMD_GS_DMA=1: the ds_read_b128 layout (A/B)
-        const char *e = getenv("BEATAMD_GS_DMA");
         BA_CHECK(2 * lds <= 158 * 1024, BEATAMD_EINVAL, "internal: k_gfstack_dma row buffers exceed LDS");
-        a.dma = (e && atoi(e) == 1) ? 1 : 2;   // 2: ds_read_b64 / pitch NT+1 (default); 1: b128 / pitch NT+2
+        a.dma = GfKnobs::is(kn.gs_dma, 1) ? 1 : 2;   // 2: ds_read_b64 / pitch NT+1 (default); 1: b128 / pitch NT+2
         if (a.nt == 32 && a.dma != 2) { a.nt = 64; a.ntile = (int)((L.N + 63) / 64); nblocks = ngroups * L.T * a.ntile;
                                         lds = (size_t)ucap * (a.nt + 2) * sizeof(double); }
         BA_CHECK(CG != 1024 || a.dma == 2, BEATAMD_EINVAL, "gfstack: 1024-chain groups need the LDS-DMA kernel");
         BA_CHECK(!ga.windowed || a.dma == 2, BEATAMD_EINVAL, "internal: window slots need the ds_read_b64 kernel");
         a.ws = 0;
-        {
-            const char *e = getenv("BEATAMD_GS_NTHINT");
-            a.nthint = e ? (atoi(e) != 0) : (GS_NTHINT_DEFAULT && ngroups == 1);
-        }
+        a.nthint = GfKnobs::set(kn.gs_nthint) ? (kn.gs_nthint != 0) : (GS_NTHINT_DEFAULT && ngroups == 1);
         a.f32pair = 0;
         if (a.dma == 2 && a.nt == 64 && CG <= 512 && f32) {
             a.f32pair = 1;
@@ -2397,9 +2386,8 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     }
     {
         // chain groups of one (target, tile) on one XCD (several groups only)
-        const char *e = getenv("BEATAMD_GS_ORDER");
-        a.xcd_order = (ngroups > 1 && !(e && atoi(e) == 0)) ? 1 : 0;
-        if (e && atoi(e) == 1) a.xcd_order = 1;
+        a.xcd_order = (ngroups > 1 && !GfKnobs::is(kn.gs_order, 0)) ? 1 : 0;
+        if (GfKnobs::is(kn.gs_order, 1)) a.xcd_order = 1;
         if (a.xcd_order) nblocks = ((L.T * a.ntile + 7) / 8) * 8 * ngroups;
     }
     if (a.f32pair)
@@ -2419,11 +2407,11 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
              ucap, twin ? " sized by the previous launch's distinct-row count" : "");
     {
         dim3 grid((unsigned)nblocks);
-        if (CG == 1024) launch_shared_nrow<16>(nrow, k.mode, grid, lds, ctx->stream, a);
-        else if (CG == 512) launch_shared_nrow<8>(nrow, k.mode, grid, lds, ctx->stream, a);
-        else if (CG == 256) launch_shared_nrow<4>(nrow, k.mode, grid, lds, ctx->stream, a);
-        else if (CG == 128) launch_shared_nrow<2>(nrow, k.mode, grid, lds, ctx->stream, a);
-        else launch_shared_nrow<1>(nrow, k.mode, grid, lds, ctx->stream, a);
+        if (CG == 1024) BA_TRY(launch_shared_nrow<16>(nrow, k.mode, grid, lds, ctx->stream, a));
+        else if (CG == 512) BA_TRY(launch_shared_nrow<8>(nrow, k.mode, grid, lds, ctx->stream, a));
+        else if (CG == 256) BA_TRY(launch_shared_nrow<4>(nrow, k.mode, grid, lds, ctx->stream, a));
+        else if (CG == 128) BA_TRY(launch_shared_nrow<2>(nrow, k.mode, grid, lds, ctx->stream, a));
+        else BA_TRY(launch_shared_nrow<1>(nrow, k.mode, grid, lds, ctx->stream, a));
     }
     BA_HIP(hipGetLastError());
     }

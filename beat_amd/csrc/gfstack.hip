@@ -342,8 +342,11 @@ static void launch_nvar(int nvar, int mode, dim3 grid, hipStream_t s, const GfAr
     else launch_mode<INTERP, 3, VEC, W>(mode, grid, s, a);
 }
 
-int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &k)
+int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &call)
 {
+    GfStackCall k = call;
+    const GfKnobs &kn = gf_knobs(ctx);
+    k.knobs = &kn;
     const SeisLib &L = *k.libs[0];
     BA_CHECK(k.nvar >= 1 && k.nvar <= 3, BEATAMD_EINVAL, "gfstack: 1..3 slip variables supported");
     for (int v = 1; v < k.nvar; v++) {
@@ -359,8 +362,7 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &k)
     // Without explicit start times and without station shifts the start-time and duration
     // indices of a chain are the same for every target (seismic.py:1283-1296 tiles starttimes0
     // over the targets): the tables are then built once per (chain, patch) instead of T times.
-    const bool tinv = !k.st.explicit_st && !k.st.shift_off &&
-                      !(getenv("BEATAMD_GF_TINV") && atoi(getenv("BEATAMD_GF_TINV")) == 0);
+    const bool tinv = !k.st.explicit_st && !k.st.shift_off && !GfKnobs::is(kn.gf_tinv, 0);
     const int64_t Ttab = tinv ? 1 : L.T;
     const int64_t CTP = k.C * Ttab * L.P;
     const int nrow = k.interp == BEATAMD_MULTILINEAR ? 4 : 1;
@@ -407,8 +409,7 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &k)
             // bitwise equal for every group size, the outputs are simply rewritten) and the
             // fastest is kept.  BEATAMD_GS_CG fixes the size, BEATAMD_GS_TUNE=0 uses the static
             // table of pick_group (measured on config 3).
-            const bool tune = !getenv("BEATAMD_GS_CG") &&
-                              !(getenv("BEATAMD_GS_TUNE") && atoi(getenv("BEATAMD_GS_TUNE")) == 0);
+            const bool tune = !GfKnobs::set(kn.gs_cg) && !GfKnobs::is(kn.gs_tune, 0);
             if (tune) {
                 const std::vector<int64_t> key = {k.C, nrow, k.nvar, k.mode, L.T, L.P, L.D, L.S, L.N, Ttab, f32_all ? 1 : 0};
                 auto it = ctx->gs_tuned.find(key);
@@ -454,10 +455,8 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &k)
     a.Ttab = Ttab; a.rows_per_target = L.P * L.D * L.S;
     a.C = k.C;
     {
-        const char *e = getenv("BEATAMD_GF_ORDER");
-        a.order = e ? atoi(e) : 1;
-        const char *g = getenv("BEATAMD_GF_CGROUP");
-        a.cgroup = g ? atoi(g) : 128;
+        a.order = GfKnobs::get(kn.gf_order, 1);
+        a.cgroup = GfKnobs::get(kn.gf_cgroup, 128);
         if (a.cgroup < 1) a.cgroup = 1;
     }
     a.rowoff = ta.rowoff;

@@ -56,6 +56,7 @@ struct GfStackCall {
     // optional scheduling hint: two per-chain sort keys that put chains which rupture alike next to each other
     // (the fused model path: hypocentre strike / dip of the first subfault).  Never changes a result.
     ChainVec order_key[2];
+    const GfKnobs *knobs = nullptr;   // set by launch_gfstack (gf_knobs(ctx)): the selection functions read them here
 };
 int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &call);
 int launch_sum_tiles(beatamd_ctx *ctx, const double *partial, int64_t n, int ntile, double *quad,

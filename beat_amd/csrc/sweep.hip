@@ -274,10 +274,7 @@ static int launch_sweep(beatamd_ctx *ctx, SweepParams &p, int nmax_cells)
              nmax_cells);
     p.nmax = (nmax_cells + 1) & ~1;
     p.status = ctx->d_status;
-    {
-        const char *e = getenv("BEATAMD_SWEEP_V1");
-        p.first_version = (e && atoi(e) != 0) ? 1 : 0;
-    }
+    p.first_version = GfKnobs::get(gf_knobs(ctx).sweep_v1, 0) != 0 ? 1 : 0;     // (A/B: the round-3 kernel)
     ScopedTimer tm(ctx, "sweep");
     if (p.nmax <= 1600) {
         const int W = 4;

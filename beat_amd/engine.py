@@ -415,6 +415,11 @@ class Context(object):
         return dict(chains_per_group=cg.value, mean_rows=mean.value, max_rows=mx.value,
                     row_bytes=rb.value)
 
+    def reload_knobs(self):
+        """read the BEATAMD_G* / BEATAMD_WS_MAP / BEATAMD_SWEEP_V1 knobs from the environment again (they are read once,
+        when the context is created, unless it was created under BEATAMD_KNOBS_LIVE=1)"""
+        check(self._lib.beatamd_ctx_reload_knobs(self._h))
+
     def gf_plan(self, passes=True):
         """-> dict(plan=<what the kernel selection chose for the last stacking launch and why>, mean_passes, max_passes:
         row passes per (chain group, target, patch); 1 unless a patch touched more rows than an LDS buffer holds)"""

@@ -608,6 +608,7 @@ def main():
     if world == 1 and not args.no_streaming_leg and spec.covariance == "scalar":
         saved = {k: os.environ.get(k) for k in ("BEATAMD_GF_KERNEL", "BEATAMD_GF_ORDER")}
         os.environ["BEATAMD_GF_KERNEL"], os.environ["BEATAMD_GF_ORDER"] = "0", "0"
+        ctx.reload_knobs()      # (the context reads its knobs once)
         Bs = min(B, 128)
         leg = run_leg(spec, f, Bs, 4, 1, seed_offset=1000)
         for k, v in saved.items():
@@ -615,6 +616,7 @@ def main():
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        ctx.reload_knobs()
         ms, n = leg["times"]["gfstack"]
         alg_s = algorithmic_bytes_per_chain_step(spec) * Bs
         ach = alg_s / (ms / max(n, 1) * 1e-3) / 1e9

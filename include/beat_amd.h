@@ -65,6 +65,11 @@ int beatamd_ctx_destroy(beatamd_ctx *ctx);
 int beatamd_ctx_set_stream(beatamd_ctx *ctx, void *hip_stream);
 int beatamd_ctx_use_own_stream(beatamd_ctx *ctx);
 int beatamd_ctx_synchronize(beatamd_ctx *ctx);
+/* The A/B and test knobs of the stacking path (environment variables BEATAMD_GF_*, BEATAMD_GS_*, BEATAMD_GC_*,
+ * BEATAMD_GR_*, BEATAMD_WS_MAP, BEATAMD_SWEEP_V1; defaults = the shipped path) are read ONCE, when the context is
+ * created.  This call reads them again.  A context created while BEATAMD_KNOBS_LIVE=1 is in the environment re-reads
+ * them at every stacking call (test suites and A/B tools that compare kernels inside one process). */
+int beatamd_ctx_reload_knobs(beatamd_ctx *ctx);
 /* Device-resident step counter of the proposal generator.  With a counter set (uint32 in device
  * memory, NULL to unset) beatamd_proposal_draw / _univariate take the Philox step from it instead
  * of their `step` argument and add one to it afterwards: a Metropolis step captured in a HIP graph

@@ -9,6 +9,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the tests compare kernels inside one process by flipping the BEATAMD_G* knobs: contexts created by the suite re-read
+# them at every stacking call (a production context reads them once, beatamd_ctx_reload_knobs)
+os.environ.setdefault("BEATAMD_KNOBS_LIVE", "1")
 
 
 def pytest_configure(config):

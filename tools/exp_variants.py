@@ -8,6 +8,8 @@ variant = {"name":..., "env": {"BEATAMD_GS_NT": "32"}, "chains": 512, "prior": "
            "interp": "nearest_neighbor", "steps": 6}"""
 import json
 import os
+
+os.environ.setdefault("BEATAMD_KNOBS_LIVE", "1")   # this tool flips the BEATAMD_G* knobs between launches
 import sys
 import time
 

@@ -4,6 +4,8 @@ aid): python tools/time_ml.py [--interp multilinear] [--chains 512] [--reps 6]; 
 average launch time of the 'gfstack' timer and the kernel that ran."""
 import argparse
 import os
+
+os.environ.setdefault("BEATAMD_KNOBS_LIVE", "1")   # this tool flips the BEATAMD_G* knobs between launches
 import sys
 
 import numpy as np

@@ -1,6 +1,7 @@
 """time the multilinear stacking at the bench shape with float-stored libraries (k_gfstack_dmaf) against the
 float64 cell kernel: python tools/time_ml32.py [chains=512]"""
 import os, sys
+os.environ.setdefault("BEATAMD_KNOBS_LIVE", "1")   # this tool flips the BEATAMD_G* knobs between launches
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import beat_amd

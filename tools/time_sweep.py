@@ -1,4 +1,5 @@
 import os, sys, time
+os.environ.setdefault("BEATAMD_KNOBS_LIVE", "1")   # this tool flips BEATAMD_SWEEP_V1 between launches
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch, beat_amd
 ctx = beat_amd.get_context(0)
