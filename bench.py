@@ -272,7 +272,7 @@ def main():
                          "tempering, geometry mode")
     ap.add_argument("--variant-legs", default="multilinear,toeplitz,default_config,stage_update,smc,pt,prewhitened,geometry,fp32,config4,realistic_grid",
                     help="which of the labelled configuration legs to run (comma separated)")
-    ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "r4_bench_c512_nn_gfstack_ws_summary.json"),
+    ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "r5_bench_c512_nn_gfstack_ws_summary.json"),
                     help="rocprofv3 PMC summary (tools/run_profile.sh + tools/summarize_rocpd.py) of THIS "
                          "command; supplies roofline.traffic when its configuration matches")
     ap.add_argument("--gf-order", type=int, default=None,
@@ -436,32 +436,30 @@ def main():
         largest named `bound` (none is ever above 1); SURVEY 8(d)'s independent-chain byte count is
         kept as a figure (`algorithmic_equiv_GBs`), not a fraction, for the chain-shared kernels"""
         gf_ms, gf_n = leg["times"]["gfstack"]
-        alg = algorithmic_bytes_per_chain_step(spec_leg) * n_chains  # per launch
+        nvar = len(spec_leg.slip_varnames)
+        alg = algorithmic_bytes_per_chain_step(spec_leg, nvar) * n_chains  # per launch
         rows_per_patch = 4 if spec_leg.interpolation == "multilinear" else 1
         avg_ms = gf_ms / max(gf_n, 1)
         st = leg["stats"]
         shared = st["row_bytes"] > 0
-        cell = leg["kernel"].startswith("k_gfstack_cell")
-        ml_static = leg["kernel"].startswith("k_gfstack_ml")
         ml_runs = leg["kernel"].startswith("k_gfstack_runs")
-        # bytes the kernel has to move from HBM: every distinct row of every (group, target,
-        # patch) once (chain-shared kernels) or every chain's rows (streaming kernel), + tables
+        # bytes the kernel has to move from HBM: every distinct row of every (group, target, patch) and slip variable once
+        # (chain-shared kernels; with row passes a row that two passes need is counted twice) or every chain's rows
+        # (streaming kernel), + tables
         tables = n_chains * spec_leg.T * spec_leg.P * 4 * rows_per_patch * 2 + spec_leg.T * spec_leg.N * 8
         need_bytes = (st["row_bytes"] if shared else
-                      float(n_chains) * spec_leg.T * spec_leg.P * spec_leg.N * 8 * rows_per_patch) + tables
-        # LDS operands: one 8-byte operand per FMA and lane for the lane <-> chain kernels; the
-        # cell kernel keeps the rows of a cell in registers (its LDS reads are per cell, not per chain)
-        # (k_gfstack_runs reads a cell's rows once per run of chains sharing it: its LDS operand bytes depend on the
-        # population; 4.2 chains per row quartet on this one -> not modelled here)
-        lds_bytes = 0.0 if (cell or ml_runs) else float(n_chains) * spec_leg.T * spec_leg.P * spec_leg.N * 8 * rows_per_patch
+                      float(n_chains) * spec_leg.T * spec_leg.P * spec_leg.N * 8 * rows_per_patch * nvar) + tables
+        # LDS operands: one 8-byte operand per FMA and lane for the lane <-> chain kernels (k_gfstack_runs reads a cell's
+        # rows once per run of chains sharing it: its LDS operand bytes depend on the population -> not modelled here)
+        lds_bytes = 0.0 if ml_runs else float(n_chains) * spec_leg.T * spec_leg.P * spec_leg.N * 8 * rows_per_patch * nvar
         lds_floor_ms = lds_bytes / (LDS_PEAK_GBS * 1e9) * 1e3
-        flops = 2.0 * n_chains * spec_leg.T * spec_leg.P * spec_leg.N * rows_per_patch
+        flops = 2.0 * n_chains * spec_leg.T * spec_leg.P * spec_leg.N * rows_per_patch * nvar
         t = avg_ms * 1e-3
         hbm_frac = need_bytes / t / 1e9 / HBM_PEAK_GBS if gf_n else 0.0
         lds_frac = lds_floor_ms / avg_ms if (gf_n and shared) else 0.0
         valu_frac = flops / t / 1e12 / FP64_VALU_PEAK_TFLOPS if gf_n else 0.0
         bound = "lds" if (shared and lds_frac > hbm_frac) else "hbm"
-        if (cell or ml_runs) and valu_frac > max(hbm_frac, lds_frac):
+        if ml_runs and valu_frac > max(hbm_frac, lds_frac):
             bound = "fp64_valu"   # the largest of its fractions; see `note` for what actually limits it
         roof = {
             "bound": bound,
@@ -475,6 +473,9 @@ def main():
             "traffic": None,
             "hbm_frac_required_bytes": hbm_frac,
             "hbm_required_bytes_per_launch": need_bytes,
+            "hbm_required_bytes_note": "distinct row segments every chain group stages (+ tables); with several groups per launch the "
+                                       "groups of a (target, tile) share an XCD and rows they have in common come from its L2, so the "
+                                       "HBM counters can read LESS than this (the fraction is then an upper bound of the HBM share)",
             "lds_frac": lds_frac,
             "lds_gather_bytes_per_launch": lds_bytes,
             "lds_floor_ms": lds_floor_ms,
@@ -484,30 +485,19 @@ def main():
             "avg_launch_ms": avg_ms,
             "launches": gf_n,
             "chains_per_group": st["chains_per_group"],
+            "slip_variables": nvar,
             "distinct_rows_per_patch": {"mean": st["mean_rows"], "max": st["max_rows"],
                                         "of": spec_leg.D * spec_leg.S},
         }
         if ml_runs:
-            roof["note"] = ("rows of a cell read from LDS once per run of chains sharing it (4.2 chains per cell on this population with "
-                            "the hypocentre chain order), accumulators through the VGPR index register with ONE scalar instruction per "
+            roof["note"] = ("rows of a cell read from LDS once per run of chains sharing it (4.2 chains per cell on the config-3 population "
+                            "with the hypocentre chain order), accumulators through the VGPR index register with ONE scalar instruction per "
                             "chain (s_add_u32 m0, d, d: accumulator and new-cell bit), descriptors by scalar loads, weights-only record "
-                            "ring a step ahead.  Timing-only builds on one box (profiles/r4_variants.md): 13.7 ms as shipped, 11.1 without "
-                            "new-cell blocks, 10.0 also without record loads, 6.3 also without the FMAs (= the 38 GB of row traffic at "
-                            "6.1 TB/s); the FMAs alone are 7.8 ms at the 2 GHz the part sustains -- what is left is per-wavefront "
-                            "instruction latency at four wavefronts per SIMD (128-VGPR budget)")
-        if ml_static:
-            roof["note"] = ("static accumulators, lane <-> sample: every FMA takes its 8-byte row operand from LDS by contiguous "
-                            "512-byte ds_read_b64 (no bank conflicts); SQ_LDS_IDX_ACTIVE = 0.77 of the CU cycles from the row reads "
-                            "alone, ~0.87 with the LDS-DMA writes of the row ring, at the 2.0 GHz the part sustains under this "
-                            "kernel (GRBM_GUI_ACTIVE; `lds_frac` is quoted against 2.4 GHz) -- LDS-bound; only sharing rows "
-                            "between chains lowers the floor, and that needs dynamic accumulator addressing (k_gfstack_cell: "
-                            "control-bound at 18.2 ms; profiles/r4_variants.md)")
-        if cell:
-            roof["note"] = ("rows of a cell in registers, accumulators through the VGPR index register: the FP64 pipe is "
-                            "0.30 busy with FMAs (all VALU instructions: 0.55, LDS 0.49 by the SQ counters of "
-                            "profiles/r3_cell_v4_sq_counters.json), HBM 0.28 -- none of them is the limit: two thirds "
-                            "of the time is the per-record / per-chain control skeleton (an M0 write in index mode "
-                            "stalls the wave ~27 cycles; profiles/r3_variants.md)")
+                            "ring a step ahead; a patch that touches more rows than a 104-slot LDS buffer holds is staged in row passes "
+                            "along the duration axis.  Timing-only builds on one box, config 3 (profiles/r4_variants.md): 13.7 ms as "
+                            "shipped, 11.1 without new-cell blocks, 10.0 also without record loads, 6.3 also without the FMAs (= the 38 GB "
+                            "of row traffic at 6.1 TB/s); the FMAs alone are 7.8 ms at the 2 GHz the part sustains -- what is left is "
+                            "per-wavefront instruction latency at four wavefronts per SIMD (128-VGPR budget)")
         return roof
 
     def attach_traffic(roof_d, summary_path):
@@ -520,12 +510,8 @@ def main():
         pmc = json.load(open(summary_path))
         kern = pmc.get("kernel", "").replace("beatamd::", "").split("(")[0].replace(" ", "")
         mine = roof_d["kernel"].replace(" ", "")
-        # (the cell kernel reports <epilogue, loader threads>, its symbol is <loader threads, variant>)
-        # (the cell / static / runs kernels report <epilogue, loader hint>; the symbols are k_gfstack_cell<hint, variant> and
-        # k_gfstack_mlr<hint, variant, program>: program 1 = k_gfstack_runs)
-        same = kern == mine or (kern.startswith("k_gfstack_cell<") and mine.startswith("k_gfstack_cell<")) or \
-            (kern.startswith("k_gfstack_mlr<") and kern.endswith(",1>") and mine.startswith("k_gfstack_runs<")) or \
-            (kern.startswith("k_gfstack_mlr<") and kern.endswith(",0>") and mine.startswith("k_gfstack_ml<"))
+        # (the runs kernel reports <epilogue, loader hint>; its symbol is k_gfstack_runs<hint, variant>)
+        same = kern == mine or (kern.startswith("k_gfstack_runs<") and mine.startswith("k_gfstack_runs<"))
         if "hbm_read_bytes_per_launch_corrected" not in pmc or not same:
             return
         tr = pmc["hbm_read_bytes_per_launch_corrected"] + pmc.get("hbm_write_bytes_per_launch", 0.0)
@@ -629,7 +615,7 @@ def main():
             "note": "no cross-chain row reuse: algorithmic bytes = HBM bytes (block order chain-major)"}
         if Bs == 128 and spec.T == 64 and spec.N == 4096:
             attach_traffic(out["roofline_streaming"], os.path.join(ROOT, "profiles",
-                                                                   "r4_bench_c512_nn_gfstack0_summary.json"))
+                                                                   "r5_bench_c512_nn_gfstack0_summary.json"))
     # ---- the same population in larger batches: chain groups of one (target, tile) share an XCD,
     # rows common to several groups come from its L2 (labelled leg; `value` stays the 512-chain batch)
     if world == 1 and not args.no_batch_leg and spec.covariance == "scalar" and B < 2048:
@@ -701,7 +687,7 @@ def main():
             leg = run_leg(spec_ml, f_ml, B, Kl, 2, seed_offset=1000)
             roof_ml = stack_roofline(spec_ml, leg, B)
             if B == 512 and T == 64 and N == 4096 and args.prior == "survey" and not env_knobs:
-                attach_traffic(roof_ml, os.path.join(ROOT, "profiles", "r4_bench_c512_ml_gfstack_mlr_summary.json"))
+                attach_traffic(roof_ml, os.path.join(ROOT, "profiles", "r5_bench_c512_ml_gfstack_runs_summary.json"))
             out["multilinear_leg"] = {
                 "interpolation": "multilinear (4 rows per patch and chain; beat/ffi/base.py:663-704)",
                 "chains": B, "steps": Kl, "chain_steps_per_s": B * Kl / leg["dt"],
@@ -979,7 +965,7 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
 
-        def own_library_leg(spec_l, chains_list, interps, n_steps, fix_problem=None):
+        def own_library_leg(spec_l, chains_list, interps, n_steps, fix_problem=None, traffic_tag=None):
             """build a problem with its own device library, time `chains_list` x `interps` on it, free it"""
             res = {}
             t0 = time.perf_counter()
@@ -1002,6 +988,10 @@ def main():
                 for nch in chains_list:
                     leg = run_leg(sp_i, f_i, nch, n_steps, 2, seed_offset=1000)
                     roof_l = stack_roofline(sp_i, leg, nch)
+                    if traffic_tag and not env_knobs:
+                        attach_traffic(roof_l, os.path.join(ROOT, "profiles", "r5_%s_c%d_%s_gfstack_%s_summary.json" % (
+                            traffic_tag, nch, "nn" if interp == "nearest_neighbor" else "ml",
+                            "ws" if interp == "nearest_neighbor" else "runs")))
                     plan = ctx.gf_plan() if hasattr(ctx, "gf_plan") else None
                     res["%s_%d_chains" % ("nn" if interp == "nearest_neighbor" else "multilinear", nch)] = {
                         "chains": nch, "steps": n_steps, "chain_steps_per_s": nch * n_steps / leg["dt"],
@@ -1063,7 +1053,7 @@ def main():
             from beat_amd.synthetic import SyntheticSpec
             spr = SyntheticSpec((20,), (20,), (1.0,), T=64, N=512, D=17, S=41, st_min=0.0, st_dt=0.5, du_min=0.0, du_dt=0.25,
                                 nuc_margin=0.0, time_bounds=(0.0, 0.0))
-            rr = own_library_leg(spr, (512, 2048), ("nearest_neighbor", "multilinear"), max(Kl // 2, 3))
+            rr = own_library_leg(spr, (512, 2048), ("nearest_neighbor", "multilinear"), max(Kl // 2, 3), traffic_tag="grid")
             rr["workload"] = ("one 20 x 20 subfault, 64 targets x 512 samples, durations 0-4 s @ 0.25 s (D=17) x start times 0-20 s "
                               "@ 0.5 s (S=41): library (64,400,17,41,512) f64 = %.1f GB; SURVEY 8(d) population with the duration "
                               "prior spanning the library axis (U(0,4) s)" % (spr.lib_bytes / 1e9))
