@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
         __syncthreads();
         const int nreq = sh_n;
         // ---- walk positions of the wavefronts: the chains of the pass in cell order, the others (pads) behind them
-        int r = 0;
+        int r = 0, nmem_w = 0;
         if (slot) {
             int nmem = 0, rk = 0, rp = 0;
             for (int q = 0; q < GC_NCHAIN; q++) {
@@ -465,6 +465,7 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
             }
             r = mine ? rk : nmem + rp;
             poskey[w * GC_NCHAIN + r] = mine ? key : 0xffffffffu;
+            nmem_w = nmem;
         }
         __syncthreads();
         const bool next_opens = mine && r + 1 < GC_NCHAIN && poskey[w * GC_NCHAIN + r + 1] != 0xffffffffu &&
@@ -493,6 +494,8 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
             // a pad (a chain of another pass, an empty chain slot): zero weights into the scratch accumulator, no row reads
             dl[0] = (uint32_t)GR_D_BASE | (uint32_t)(mine ? j : GC_SCRATCH) | ((next_opens ? 1u : 0u) << 31);
             dl[1] = (ring + ca) | ((ring + cb) << 16);
+            // chains of the wavefront in this step: the walk leaves the step at the first checkpoint behind them
+            if (j == 0) a.dtab[((gt * GC_NCONS + w) * (a.smax + 1) + s) * GR_DLINE + GR_D_NCH] = (uint32_t)nmem_w;
         }
         __syncthreads();
     }

@@ -408,6 +408,26 @@ class LogpForwFunc(object):
         T, N = wm.data.shape
         return self.ctx.ffi_synthetics_batch(self.model_id, wavemap_index, Q, T, N, residuals=residuals)
 
+    def release(self):
+        """free what this compiled model holds on the device BESIDES the libraries: the model record and the weight sets
+        (a dense set is T x N x N doubles: 8.6 GB at config 3).  The function cannot be called afterwards.  Explicit, not
+        a finaliser: wavemap objects may be shared between models."""
+        if self.model_id is None:
+            return
+        self.ctx.ffi_model_destroy(self.model_id)
+        self.model_id = None
+        for wm in self.problem.wavemaps:
+            if wm._wset is not None:
+                self.ctx.weights_destroy(wm._wset)
+                wm._wset = None
+            if getattr(wm, "_whitened_with", None) is not None:
+                wm._whitened_with = None
+        g = self.problem.geodetic
+        if g is not None:
+            for ws in getattr(g, "_wsets", []):
+                self.ctx.weights_destroy(ws)
+            g._wsets = []
+
     def batch(self, Q, out=None):
         """Q (C, nparams) numpy or torch-cuda -> LL (C, nllk)"""
         if Q.shape[-1] != self.nparams:

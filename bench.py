@@ -651,6 +651,8 @@ def main():
         wm0 = prob.wavemaps[0]
         Kl = max(K // 2, 3)
         N, T = spec.N, spec.T
+        f_ml = f_tp = f_pw = f_pm = f_mt = upd = leg = leg2 = leg64 = Lq = L_unrounded = L_rounded = None
+        Wd = slog_d = wm_pw = wm_ml = gstep = gQ = gL = gf_ = s_pt = ls_pt = man = st = pop_s = lp_s = None
 
         def variant(interp="nearest_neighbor", weights=None, slog=None, prewhiten=False):
             """another compiled model over the SAME device library (no second copy unless pre-whitened)"""
@@ -741,6 +743,8 @@ def main():
                                "handed in (beatamd_ffi_astep_batch) on the prior population -- later stages concentrate the "
                                "population (fewer distinct rows per patch), which is why sampling-only can exceed `value`")
             out["smc_leg"] = smc_out
+        if f_ml is not None:
+            f_ml.release()
         f_ml = None
         f_tp = None
         if legs & {"toeplitz", "pt", "prewhitened"}:
@@ -787,7 +791,8 @@ def main():
                     "chains": B, "steps": Kl, "chain_steps_per_s": B * Kl / leg["dt"], "ms_per_step": leg["dt"] / Kl * 1e3,
                     "kernel": leg["kernel"],
                     "kernel_ms_per_step": {k: (v[0] / Kl) for k, v in leg["times"].items() if v[1]}}}
-                del f_mt
+                f_mt.release()
+                f_mt = None
         if "pt" in legs:
             # parallel tempering: 4 temperatures x 256 replicas = the per-GPU share of BASELINE configs[4];
             # the sampler times its own rounds (set-up of the replicas excluded)
@@ -833,7 +838,10 @@ def main():
                         "points evaluated again" % B,
                 "stage_update_s": upd.last_ms * 1e-3 + t_re, "update_weights_s": upd.last_ms * 1e-3,
                 "reevaluation_s": t_re, "repaired_on_host": upd.n_repaired}}
-        del f_tp
+        upd = Lq = None
+        if f_tp is not None:
+            f_tp.release()
+        f_tp = None
         torch.cuda.empty_cache()
         if "prewhitened" in legs:
             # W.G and W.d computed once, no dense W.r per step (needs a second copy of the library)
@@ -859,7 +867,8 @@ def main():
                         "configuration": "multilinear interpolation on the pre-whitened library (Toeplitz covariance folded in)",
                         "chains": B, "steps": Kl, "chain_steps_per_s": B * Kl / leg["dt"],
                         "ms_per_step": leg["dt"] / Kl * 1e3, "kernel": leg["kernel"]}
-                    del f_pm
+                    f_pm.release()
+                    f_pm = None
                 if "stage_update" in legs:
                     # on the pre-whitened path an update re-whitens all 62.9 GB of rows in place (M = W_new inv(W_old))
                     from beat_amd.covariance import NoiseCovarianceUpdate
@@ -885,7 +894,9 @@ def main():
                         "stage_update_s": upd.last_ms * 1e-3 + t_re, "update_weights_s": upd.last_ms * 1e-3,
                         "rewhitening_s": w_ms * 1e-3, "rewhitening_TFLOPs": wflops / (w_ms * 1e-3) / 1e12 if w_ms else None,
                         "reevaluation_s": t_re}
-                del f_pw
+                upd = Lq = None
+                f_pw.release()
+                f_pw = None
             except (RuntimeError, MemoryError) as exc:   # not enough HBM for the copy beside other allocations
                 out["prewhitened_leg"] = {"skipped": str(exc)[:200]}
             torch.cuda.empty_cache()
@@ -960,8 +971,14 @@ def main():
                 "us_per_step_eager": gleg["eager"], "us_per_step_hip_graph": gleg["graph"],
                 "chain_steps_per_s": 1024 / (min(gleg.values()) * 1e-6)}
         if legs & {"config4", "realistic_grid"}:
-            # legs with libraries of their own: the main problem's weights and models are not needed any more
+            # legs with libraries of their own: the variant models of the main library (dense weight sets of 8.6 GB each,
+            # the whitened library copy, update buffers) are not needed any more
             import gc
+            for f_old in (f_ml, f_tp, f_pw):
+                if f_old is not None:
+                    f_old.release()
+            f_ml = f_tp = f_pw = f_pm = f_mt = upd = leg = leg2 = leg64 = Lq = L_unrounded = L_rounded = None   # noqa: F841
+            Wd = slog_d = wm_pw = wm_ml = gstep = gQ = gL = gf_ = s_pt = ls_pt = man = st = pop_s = lp_s = None     # noqa: F841
             gc.collect()
             torch.cuda.empty_cache()
 
@@ -974,7 +991,6 @@ def main():
                 fix_problem(prob_l, host_l)
             host_of[spec_l] = host_l
             nvar_l = len(spec_l.slip_varnames)
-            f_first = None
             for interp in interps:
                 import copy as _copy
                 sp_i = _copy.copy(spec_l)
@@ -983,7 +999,6 @@ def main():
                 for wm in prob_l.wavemaps:
                     wm.interpolation = interp
                 f_i = prob_l.compile(ctx)      # (the libraries are uploaded / adopted once: init_optimization keeps lib_id)
-                f_first = f_first or f_i
                 torch.cuda.synchronize()
                 for nch in chains_list:
                     leg = run_leg(sp_i, f_i, nch, n_steps, 2, seed_offset=1000)
@@ -1001,11 +1016,12 @@ def main():
                         "kernel_ms_per_step": {k: (v[0] / n_steps) for k, v in leg["times"].items() if v[1]},
                         "roofline": roof_l}
                     del leg
+                f_i.release()
                 del f_i
             res["setup_s"] = time.perf_counter() - t0
             res["library"] = "%d slip variable(s) x (%d,%d,%d,%d,%d) f64 = %.1f GB each" % (
                 nvar_l, spec_l.T, spec_l.P, spec_l.D, spec_l.S, spec_l.N, spec_l.lib_bytes / 1e9)
-            del prob_l, host_l, f_first
+            del prob_l, host_l
             gc.collect()
             torch.cuda.empty_cache()
             return res

@@ -116,9 +116,12 @@ def test_runs_program_one_group(mode):
 
 def test_runs_program_shares_row_reads():
     stats, tabs = _run(T=2, P=3, D=2, S=5, N=64, C=80, Ttab_is_one=True, mode=0, sort=True, nth=0, seed=11)
-    # four FMAs per POSITION and step (pads and empty chain slots go to the scratch accumulator): nothing depends on the data
-    assert sum(w.fma_count for w in stats[0].waves) == emu.CG * 3 * 4
-    assert sum(w.pad_fma_count for w in stats[0].waves) == (emu.CG - 80) * 3 * 4
+    # four FMAs per chain and step into its accumulator; the pads (empty chain slots here) go to the scratch accumulator,
+    # and only up to the first checkpoint behind a wavefront's last chain (early exit): 80 chains = two full wavefronts,
+    # one with 6 chains (walks to checkpoint 8: 2 pads) and eleven with none (walk to checkpoint 4: 4 pads)
+    wg = stats[0]
+    assert sum(w.fma_count - w.pad_fma_count for w in wg.waves) == 80 * 3 * 4
+    assert sum(w.pad_fma_count for w in wg.waves) == (2 + 11 * 4) * 3 * 4
     stats, tabs = _run(T=1, P=2, D=2, S=4, N=64, C=519, Ttab_is_one=True, mode=1, sort=True, nth=1, seed=3)
     # LDS-DMA moved every distinct row segment of the group once
     assert stats[0].dma_bytes == int(tabs["ucount"][:2].sum()) * 512

@@ -93,6 +93,13 @@ DHALF = 40            # DHALF + 2(r - NHALF), +1
 DSTRIDE = DLINE * 4
 D_BASE = 0x4000       # d = D_BASE | slot | new << 31;  d + d = 0x8000 (DST_REL) | 2 * slot, carry = new
 FORCE_WAIT = 12       # position whose block waits for everything in flight (the second half of the descriptors)
+# EARLY EXIT (round 5): with row passes a wavefront has only some of its chains in a step (12 of 37 on the tutorial grid);
+# the table kernel puts them at positions 0..n-1 and n into dword D_NCH of the descriptor line.  At the checkpoints below
+# the walk leaves the step when every chain of the pass is done (the pads up to the checkpoint still run: zero weights
+# into the scratch accumulator); the exit stub issues the loads the skipped blocks would have issued.
+CHECKPOINTS = (4, 8, 12, 16, 24)
+D_NCH = 38            # dword of the descriptor line that holds n (the two dwords behind the first half are free)
+S_NCH, S_NCH_NEXT = 8, 9   # n of the step in hand / of the next step (loaded with the next step's first half)
 assert D_A + 2 * NHALF <= D_B and D_B + 2 * (NPOS - NHALF) - 1 <= S_LAST
 
 # parameter block of a consumer wavefront (dwords)
@@ -338,13 +345,33 @@ def fma4(r, xset):
           % (vp(ACC), vp(rec_w(i)), vp(x + 2 * k), 4 * q + k))
 
 
+def load_next_first_half():
+    """chains 0..NHALF-1 of the NEXT step (their registers are free) and its chain count"""
+    load_descriptors(0, NHALF, DSTRIDE)
+    e("s_load_dword s%d, %s, 0x%x" % (S_NCH_NEXT, sp(S_DP), DSTRIDE + 4 * D_NCH))
+
+
+def step_advance(last_label):
+    """bookkeeping at the end of a step (in front of the last chain's FMAs / of an early exit)"""
+    e("s_sub_u32 s%d, s%d, 1" % (S_NSTEP, S_NSTEP))
+    e("s_cmp_eq_u32 s%d, 0" % S_NSTEP)
+    br("s_cbranch_scc1", last_label)
+    e("s_waitcnt vmcnt(%d)" % (AHEAD - 1))           # record 0 of the next step
+    e("s_add_u32 s%d, s%d, %d" % (S_WP, S_WP, WSTRIDE))
+    e("s_addc_u32 s%d, s%d, 0" % (S_WP + 1, S_WP + 1))
+    e("s_add_u32 s%d, s%d, %d" % (S_DP, S_DP, DSTRIDE))
+    e("s_addc_u32 s%d, s%d, 0" % (S_DP + 1, S_DP + 1))
+
+
 def block_one(r):
-    """chain at sorted position r; ONE copy of the chain loop and one row set: a chain whose successor opens a cell
+    """chain at walk position r; ONE copy of the chain loop and one row set: a chain whose successor opens a cell
     reads the new rows into the same registers right behind its own FMAs and waits for them (no cover for the LDS round
-    trip, but no out-of-line block, no taken far branches, half the code: 1-2.5 % faster than the two-copy version,
-    ablation 'two')"""
+    trip, but no out-of-line block, no taken far branches, half the code: 1-2.5 % faster than a two-copy version)"""
     i, q = r // 4, r % 4
     lab("B%d_0" % r)
+    if r in CHECKPOINTS and 'noexit' not in ABL:
+        e("s_cmp_le_u32 s%d, %d" % (S_NCH, r))      # every chain of the pass is done: leave the step
+        br("s_cbranch_scc1", "X%d" % r)
     if r % 8 == 0:
         # (the VGPR index applies to vector ALU destinations only: a build with s_set_gpr_idx_idx 0 in front of this
         # load gives the same bits and is 0.8 % slower)
@@ -352,7 +379,7 @@ def block_one(r):
     if r == FORCE_WAIT:
         e("s_waitcnt lgkmcnt(0)")               # descriptors of chains NHALF.. (requested at the step's start)
     if r == NHALF:
-        load_descriptors(0, NHALF, DSTRIDE)     # chains 0..NHALF-1 of the NEXT step: their registers are free
+        load_next_first_half()
     if r < NCHAIN - 1:
         rn = r + 1
         if rn % 8 == 0:
@@ -365,17 +392,12 @@ def block_one(r):
         reads(0)
         lgkm0()
     else:
-        e("s_sub_u32 s%d, s%d, 1" % (S_NSTEP, S_NSTEP))
-        e("s_cmp_eq_u32 s%d, 0" % S_NSTEP)
-        br("s_cbranch_scc1", "LAST_0")
-        e("s_waitcnt vmcnt(%d)" % (AHEAD - 1))
-        e("s_add_u32 s%d, s%d, %d" % (S_WP, S_WP, WSTRIDE))
-        e("s_addc_u32 s%d, s%d, 0" % (S_WP + 1, S_WP + 1))
-        e("s_add_u32 s%d, s%d, %d" % (S_DP, S_DP, DSTRIDE))
-        e("s_addc_u32 s%d, s%d, 0" % (S_DP + 1, S_DP + 1))
+        step_advance("LAST_0")
         select(r)
         fma4(r, 0)
-        e("s_waitcnt lgkmcnt(0)")
+        lab("STEPEND")
+        e("s_waitcnt lgkmcnt(0)")                    # the next step's first half and its chain count
+        e("s_mov_b32 s%d, s%d" % (S_NCH, S_NCH_NEXT))
         idx0()
         addresses(0, 0)
         e("s_barrier")
@@ -383,6 +405,26 @@ def block_one(r):
         lgkm0()
         load_descriptors(NHALF, NPOS - NHALF, 0)
         br("s_branch", "B0_0")
+
+
+def exit_stubs():
+    """early exits of the chain walk: issue what the skipped blocks would have issued -- the record pairs still to be
+    requested (the ring and the vmcnt waits count them), the next step's first half when the walk has not reached
+    position NHALF -- then the step's bookkeeping, and join the end of the step behind the last chain's FMAs"""
+    for r in CHECKPOINTS:
+        if 'noexit' in ABL:
+            break
+        lab("X%d" % r)
+        for m in range(r, NPOS):
+            if m % 8 == 0:
+                request_pair(m // 8 + AHEAD)
+        if r <= NHALF:
+            load_next_first_half()
+        step_advance("LASTX")
+        br("s_branch", "STEPEND")
+    lab("LASTX")                                     # the last step ended early: nothing left to add
+    e("s_waitcnt lgkmcnt(0)")
+    br("s_branch", "EPI")
 
 
 def consumer():
@@ -398,6 +440,7 @@ def consumer():
     e("v_add_u32 v%d, s%d, v%d" % (V_RING, S_RB0, V_RING))
     e("v_mov_b32 v%d, 0x200" % V_C512)
     load_descriptors(0, NHALF, 0)
+    e("s_load_dword s%d, %s, 0x%x" % (S_NCH, sp(S_DP), 4 * D_NCH))
     load_descriptors(NHALF, NPOS - NHALF, 0)
     for r in range(AHEAD):
         request_pair(r)
@@ -421,6 +464,9 @@ def consumer():
     fma4(NPOS - 1, 0)
     e("s_waitcnt lgkmcnt(0)")                          # the descriptor load ahead must not land in the epilogue's registers
     br("s_branch", "EPI")
+    _in_loop[0] = True
+    exit_stubs()
+    _in_loop[0] = False
     epilogue(XA, XB, ACC, NCHAIN, True)
     return list(L)
 
@@ -565,7 +611,7 @@ def clobbers(vlast):
     return c
 
 
-VARIANTS = [set(), {"nofma"}, {"nox"}, {"nonew"}, {"norec"}, {"nonew", "norec"}, {"nonew", "norec", "nofma"}]
+VARIANTS = [set(), {"nofma"}, {"nox"}, {"nonew"}, {"norec"}, {"nonew", "norec"}, {"noexit"}]
 
 
 def main():
@@ -585,7 +631,7 @@ def main():
                           ("G1", PL_G1), ("G2", PL_G2)):
             f.write("#define GC_PL_%s %d\n" % (name, val))
         for name, val in (("PAIR", PAIR), ("WSTRIDE", WSTRIDE), ("NHALF", NHALF), ("DLINE", DLINE), ("DHALF", DHALF),
-                          ("D_BASE", D_BASE)):
+                          ("D_BASE", D_BASE), ("D_NCH", D_NCH)):
             f.write("#define GR_%s %d\n" % (name, val))
         variants = VARIANTS if os.environ.get("GR_ABLATIONS") else VARIANTS[:1]
         f.write("#define GR_NVARIANT %d\n" % len(variants))

@@ -241,6 +241,7 @@ def gm_tables(rowoff, fac, slips, order, C, T, P, D, S, nvar=1, cap=None):
                             mem = [j for j in range(NCH) if inpass[lo + j]]
                             perm = sorted(mem, key=lambda jj: (int(key[lo + jj]), jj))
                             base_w = (gt * NCONS + w) * (smax + 1) + s
+                            dtab[base_w * gen.DLINE + gen.D_NCH] = len(perm)     # chains of the wavefront in this step (early exit)
                             for r in range(NCH):
                                 q = r % 4
                                 rec = base_w * gen.WSTRIDE + (r // 8) * gen.PAIR + ((r // 4) % 2) * 8
