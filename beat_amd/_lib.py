@@ -18,7 +18,7 @@ W_SCALAR, W_DENSE = 0, 1
 INTERPOLATIONS = {"nearest_neighbor": NEAREST_NEIGHBOR, "multilinear": MULTILINEAR}
 
 OK, EINVAL, EHIP, EINDEX, ENOMEM, ENAN, ENOTPSD, EBADCOV = 0, -1, -2, -3, -4, -5, -6, -7
-ABI_VERSION = 115   # include/beat_amd.h BEATAMD_VERSION this module was written against
+ABI_VERSION = 116   # include/beat_amd.h BEATAMD_VERSION this module was written against
 
 
 class BeatAmdError(RuntimeError):

@@ -42,7 +42,7 @@ extern "C" {
 /* ABI revision: bumped whenever an entry point changes its signature or an error code is added
  * (1.1: beatamd_weights_update gained kind/count in round 2; BEATAMD_EBADCOV).  beat_amd/_lib.py
  * refuses a library whose revision differs from the header it was written against. */
-#define BEATAMD_VERSION 115
+#define BEATAMD_VERSION 116
 
 #define BEATAMD_NEAREST_NEIGHBOR 0 /* interpolation="nearest_neighbor" */
 #define BEATAMD_MULTILINEAR 1      /* interpolation="multilinear"      */
