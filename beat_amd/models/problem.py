@@ -439,7 +439,12 @@ class LogpForwFunc(object):
     def update_weights(self, wavemap_index, weights, slog_pdet):
         """seismic.py:1509-1534 update_weights: new chol_inverse + slog_pdet per dataset.  Kind
         and size must match the uploaded set (checked by the library).  numpy arrays or torch-cuda
-        tensors (the per-stage covariance update keeps them on the device)."""
+        tensors (the per-stage covariance update keeps them on the device).
+
+        Pre-whitened wavemaps are re-whitened IN PLACE through the chain of ratios M = W_new . inv(W_old); a RESUMED run
+        (smc_sample(resume_stage=...)) installs the saved stage's weights by whitening from the operator it was compiled
+        with instead of replaying that chain, so the restored likelihoods agree with the saved ones to rounding
+        (~1e-12 relative), not bit for bit."""
         import torch
         wm = self.problem.wavemaps[wavemap_index]
         T, N = wm.data.shape
@@ -477,6 +482,10 @@ class LogpForwFunc(object):
             self.ctx.ffi_model_update_data(self.model_id, wavemap_index, d)
             self.ctx.weights_update(wm._wset, np.ones(T), sl)
             self.ctx.synchronize()
+            #  M (T x N x N, 8.6 GB at config 3) and the old operator go before the new one is kept: the peak
+            # next to the libraries is then two operators (new + M), not three.  The operator stays on the device because
+            # the next update needs it at once; release() / a dead wavemap frees it.
+            del M, old
             wm.data, wm.slog_pdet, wm._whitened_with = d.cpu().numpy(), _host(sl), wd
             self._dirty = None
             return

@@ -258,7 +258,9 @@ int beatamd_ffi_model_destroy(beatamd_ctx *ctx, int32_t model_id);
  *           update_weights / analyse_noise call it at the MAP point of a stage (:1509-1534,
  *           beat/covariance.py:333-395)
  *   Q [C,nparams] -> out [C,T,N] of wavemap `wavemap_index`: synthetics, or (residuals != 0)
- *   data - synthetics (seismic.py:1332).  An index outside the library is BEATAMD_EINDEX. */
+ *   data - synthetics (seismic.py:1332).  An index outside the library is BEATAMD_EINDEX; the rows of
+ *   such a chain are then UNSPECIFIED (they differ between the stacking kernels; the reference raises
+ *   IndexError before producing any). */
 int beatamd_ffi_synthetics_batch(beatamd_ctx *ctx, int32_t model_id, int32_t wavemap_index, int64_t C,
                                  const double *Q, int32_t residuals, double *out);
 
