@@ -235,7 +235,7 @@ enum Slot : int {
     SL_QPROP, SL_LPROP, SL_MISC, SL_GS_UROWS, SL_GS_UCOUNT, SL_GS_SLOT, SL_GS_W, SL_GS_UMAX, SL_GS_USLOT,
     SL_CHAINBAD, SL_Z, SL_ROWSCALE, SL_CUM, SL_STAGE2, SL_WHITEN,
     SL_CHOL_A, SL_CHOL_X, SL_CHOL_D, SL_CHOL_T, SL_CHOL_L,
-    SL_GC_ORDER, SL_GC_STREAM, SL_GC_HDR, SL_GC_META, SL_DELTA, SL_LOGU, SL_COUNT
+    SL_GC_ORDER, SL_GS_ORDER, SL_GC_STREAM, SL_GC_HDR, SL_GC_META, SL_DELTA, SL_LOGU, SL_COUNT
 };
 
 }  // namespace beatamd

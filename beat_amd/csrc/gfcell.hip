@@ -143,6 +143,34 @@ __global__ void __launch_bounds__(GC_TB) k_gc_order(GcOrderArgs a)
     a.order[(int64_t)blockIdx.x * GC_CG + r1] = live ? (uint32_t)c : GC_DEAD;
 }
 
+__global__ void __launch_bounds__(256) k_members_pad(uint32_t *members, int64_t C, int64_t padded)
+{
+    const int64_t i = C + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < padded) members[i] = GC_DEAD;
+}
+
+int launch_chain_members(beatamd_ctx *ctx, int64_t C, ChainVec key, int64_t padded, const uint32_t **members)
+{
+    *members = nullptr;
+    if (C > GC_MEMBERS_MAX || !key.base) return BEATAMD_OK;
+    void *p = nullptr;
+    BA_TRY(ctx->get_scratch(SL_GS_ORDER, (size_t)padded * sizeof(uint32_t) + (size_t)C * sizeof(double) + 64, &p));
+    GcOrderArgs oa;
+    memset(&oa, 0, sizeof(oa));
+    oa.C = C; oa.T = 1; oa.P = 1; oa.S = 1;
+    oa.key[0] = key; oa.key[1] = key;
+    oa.members = (uint32_t *)p;
+    oa.key0 = reinterpret_cast<double *>(((uintptr_t)(oa.members + padded) + 7) & ~(uintptr_t)7);
+    const unsigned nb = (unsigned)((C + 255) / 256);
+    hipLaunchKernelGGL(k_gc_key0, dim3(nb), dim3(256), 0, ctx->stream, oa);
+    hipLaunchKernelGGL(k_gc_members, dim3(nb), dim3(256), 0, ctx->stream, oa);
+    if (padded > C)
+        hipLaunchKernelGGL(k_members_pad, dim3((unsigned)((padded - C + 255) / 256)), dim3(256), 0, ctx->stream, oa.members, C, padded);
+    BA_HIP(hipGetLastError());
+    *members = oa.members;
+    return BEATAMD_OK;
+}
+
 // launches the chain order of a batch into oa.order (scratch for members / keys behind it)
 static int launch_gc_order(beatamd_ctx *ctx, GcOrderArgs &oa, int64_t ngroups, const GfKnobs &kn)
 {

@@ -242,6 +242,9 @@ struct GsArgs {
     // (nullptr: P, one per patch), vmax apart
     const uint32_t *nv;
     int64_t vmax;
+    // k_gfstack_ws / _wsp: chain of lane `tid` of group g = order[g*512 + tid] (nullptr: g*512 + tid) -- batches of several
+    // groups are cut into groups along the hypocentre (launch_chain_members): a slice of the fault per group
+    const uint32_t *order;
     const uint32_t *urows, *uent, *ucount;
     const uint16_t *slot;
     const double *w;
@@ -1147,7 +1150,7 @@ k_gfstack_ws(GsArgs a)
 
     // ==================================== consumer ====================================
     static_assert(NROW == 1, "the loader / consumer kernel exists for single-row interpolation");
-    const int64_t c = g * CG + tid;
+    const int64_t c = a.order ? (int64_t)a.order[g * CG + tid] : g * CG + tid;     // (beyond the batch: >= C)
     // the zero row of every buffer (slot index ucap; the loaders never write it): what a lane reads, with weight 0, in
     // the row passes of a patch that do not hold its chain's row
     for (int i = tid; i < NB * GS_PITCH; i += CG) xbuf[(i / GS_PITCH) * bufsz + a.ucap * GS_PITCH + (i % GS_PITCH)] = 0.0;
@@ -1565,7 +1568,7 @@ k_gfstack_wsp(GsArgs a)
     }
 
     // ==================================== consumer ====================================
-    const int64_t c = g * CG + tid;
+    const int64_t c = a.order ? (int64_t)a.order[g * CG + tid] : g * CG + tid;
     // the zero row of every buffer (slot index ucap): see k_gfstack_ws
     for (int i = tid; i < NB * GS_PITCH; i += CG)
         reinterpret_cast<elem_t *>(xbuf)[(i / GS_PITCH) * bufsz + a.ucap * GS_PITCH + (i % GS_PITCH)] = (elem_t)0;
@@ -1813,6 +1816,7 @@ struct WsTabArgs {
     int64_t vmax;             // vsteps per (group, target) the tables are strided by
     const uint32_t *rowoff;   // [C,T,P] global row ids (k_gf_tables)
     ChainVec slips[4];
+    const uint32_t *order;    // [ngroups*512] chain at position i of the batch, ~0 behind the last (nullptr: i)
     uint32_t *npass;          // [gtp] passes of the patch (phase 0 out)
     const uint32_t *voff;     // [gtp] first vstep of the patch; nullptr: one pass per patch, vstep = patch
     uint32_t *utotal;         // [gtp] distinct rows (statistics)
@@ -1868,8 +1872,9 @@ __global__ void __launch_bounds__(WS_CG) k_ws_tables(WsTabArgs a)
     const int64_t gt = gtp / a.P;
     const int64_t t = gt % a.T;
     const int64_t g = gt / a.T;
-    const int64_t c = g * WS_CG + tid;
-    const bool live = c < a.C;
+    const int64_t pos_in_batch = g * WS_CG + tid;
+    const bool live = pos_in_batch < a.C;
+    const int64_t c = live ? (a.order ? (int64_t)a.order[pos_in_batch] : pos_in_batch) : 0;
     const uint32_t v = live ? a.rowoff[(c * a.T + t) * a.P + p] : 0xffffffffu;
     gm[tid] = 0;
     uint32_t pos = 0, U = 0;
@@ -2137,6 +2142,10 @@ static int launch_gfstack_ws(beatamd_ctx *ctx, const GfStackCall &k, const uint3
     ta.C = k.C; ta.T = Ttab; ta.P = L.P; ta.DS = L.D * L.S; ta.vmax = vmax;
     ta.rowoff = rowoff;
     for (int v = 0; v < k.nvar; v++) ta.slips[v] = k.slips[v];
+    // several groups: cut the batch into its groups along the first order key (the fused model path hands the
+    // hypocentre): a slice of the fault per group = fewer distinct rows to stage per group and patch.  Scheduling only.
+    if (ngroups > 1 && k.order_key[0].base && GfKnobs::get(kn.gc_global, 1) != 0)
+        BA_TRY(launch_chain_members(ctx, k.C, k.order_key[0], ngroups * WS_CG, &ta.order));
     // [utotal GTP][npass GTP][voff GTP][nv GT]
     BA_TRY(ctx->get_scratch(SL_GS_UCOUNT, (size_t)(3 * GTP + GT) * sizeof(uint32_t), &p));
     ta.utotal = (uint32_t *)p;
@@ -2186,6 +2195,7 @@ static int launch_gfstack_ws(beatamd_ctx *ctx, const GfStackCall &k, const uint3
     a.ntile = (int)((L.N + 63) / 64);
     a.nv = maxpass > 1 ? nv : nullptr;
     a.vmax = vmax;
+    a.order = ta.order;
     a.uent = ta.uent; a.ucount = ta.ucount; a.slot = ta.slot; a.w = ta.w;
     a.w_var_stride = ta.w_var_stride;
     a.data = k.data; a.wscalar = k.wscalar; a.out = k.out;

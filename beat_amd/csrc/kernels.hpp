@@ -72,6 +72,9 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &call, const uint3
 // gfcell.hip: multilinear stacking with the rows of a cell in registers (518-chain groups, row passes): k_gfstack_runs.
 // *ovf (device, nullable on return): nonzero after the launch = the tables overflowed and nothing was stacked -- the
 // caller enqueues k_gfstack behind it as a stand-in guarded by the same flag
+// the chains of a batch in ascending order of a per-chain key (ties: chain id): members[i] = chain at position i,
+// padded with ~0 up to `padded` entries (C <= 4096: C * C comparisons); members = nullptr when the batch is larger
+int launch_chain_members(beatamd_ctx *ctx, int64_t C, ChainVec key, int64_t padded, const uint32_t **members);
 bool gfstack_ml_applicable(const GfStackCall &call);
 int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &call, const uint32_t *rowoff,
                       const double *fac, int64_t Ttab, const int **ovf);

@@ -93,6 +93,10 @@ def test_fused_model_on_a_fine_grid_nn(ctx, monkeypatch, nvar, cov, shifts):
     # (the streaming kernel sums the misfit over 512-sample tiles, the chain-shared kernels over 64-sample tiles)
     np.testing.assert_allclose(A, B, rtol=1e-11, atol=1e-9)
     assert np.array_equal(f.batch(Q[:512]), B[:512])
+    # several groups are cut along the hypocentre (a slice of the fault per group): scheduling only
+    monkeypatch.setenv("BEATAMD_GC_GLOBAL", "0")
+    assert np.array_equal(f.batch(Q), B)
+    monkeypatch.delenv("BEATAMD_GC_GLOBAL")
     # the lane <-> chain kernel with 128-chain groups (its row buffers hold a group's whole bound) has the same epilogue
     monkeypatch.setenv("BEATAMD_GS_CG", "128")
     B2 = f.batch(Q)
