@@ -399,7 +399,9 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
             if (live) cp = linesplit[dc] ? mark[dc * S1 + sc] : linepass[dc];
             a.cpass[gtp * GC_CG + tid] = cp;
         }
-        if (tid == 0) a.npass[gtp] = (uint32_t)sh_npass;
+        // (pass ids are bytes: a patch cut into more than 250 passes -- buffers of a few slots in tests -- counts as an
+        // overflow of the tables: the streaming kernel stands in)
+        if (tid == 0) a.npass[gtp] = sh_npass > 250 ? 0x100000u : (uint32_t)sh_npass;
         return;
     }
     if constexpr (!FILL) return;
