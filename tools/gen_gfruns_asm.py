@@ -320,6 +320,8 @@ def reads(xset):
     # (one ds_read2_b64 per row pair -- offset0:64 offset1:0 -- halves the LDS instructions of a new cell and is 2 %
     # SLOWER: 13.6 against 13.3 ms in one session)
     e("ds_read_b64 %s, v%d offset:512" % (vp(x + 0), b))
+    if 'one' in ABL:     # timing only: one row and one FMA per chain (what a nearest-neighbour form of this program would do)
+        return
     e("ds_read_b64 %s, v%d" % (vp(x + 2), b))
     e("ds_read_b64 %s, v%d offset:512" % (vp(x + 4), a))
     e("ds_read_b64 %s, v%d" % (vp(x + 6), a))
@@ -340,7 +342,7 @@ def fma4(r, xset):
         return
     i, q = r // 4, r % 4
     x = XA if xset == 0 else XB
-    for k in range(4):
+    for k in range(1 if 'one' in ABL else 4):
         e("v_fmac_f64_dpp %s, %s, %s row_newbcast:%d row_mask:0xf bank_mask:0xf"
           % (vp(ACC), vp(rec_w(i)), vp(x + 2 * k), 4 * q + k))
 
@@ -611,7 +613,7 @@ def clobbers(vlast):
     return c
 
 
-VARIANTS = [set(), {"nofma"}, {"nox"}, {"nonew"}, {"norec"}, {"nonew", "norec"}, {"noexit"}]
+VARIANTS = [set(), {"nofma"}, {"nox"}, {"nonew"}, {"norec"}, {"one"}, {"one", "norec"}]
 
 
 def main():
