@@ -123,6 +123,8 @@ int ffi_logp_device(beatamd_ctx *ctx, FfiModel &m, int64_t C, const double *Q, d
             k.order_key[0] = ChainVec{Q, np, m.layout.nuc_strike_off};   // (scheduling hint of k_gfstack_runs)
             k.order_key[1] = ChainVec{Q, np, m.layout.nuc_dip_off};
             k.st.shift_off = wm.shift_off;
+    k.st.nslot = wm.nslot; k.st.tslot = wm.tslot; k.st.slot_shift_off = wm.slot_shift_off;
+            k.st.nslot = wm.nslot; k.st.tslot = wm.tslot; k.st.slot_shift_off = wm.slot_shift_off;
             k.st.chain_bad = chain_bad;
             k.interp = wm.interp;
             k.f32 = wm.f32;
@@ -693,7 +695,23 @@ int beatamd_ffi_model_add_wavemap(beatamd_ctx *ctx, int32_t model_id, const int3
     }
     BA_TRY(dev_alloc_copy(ctx, data, (size_t)w.T * w.N * 8, (void **)&w.data));
     BA_TRY(dev_alloc_copy(ctx, hp_off, (size_t)w.T * 8, (void **)&w.hp_off));
-    if (shift_off) BA_TRY(dev_alloc_copy(ctx, shift_off, (size_t)w.T * 8, (void **)&w.shift_off));
+    if (shift_off) {
+        BA_TRY(dev_alloc_copy(ctx, shift_off, (size_t)w.T * 8, (void **)&w.shift_off));
+        // slots in the order of first appearance
+        std::vector<int32_t> tslot((size_t)w.T);
+        std::vector<int64_t> slot_off;
+        for (int64_t t = 0; t < w.T; t++) {
+            size_t k = 0;
+            while (k < slot_off.size() && slot_off[k] != shift_off[t]) k++;
+            if (k == slot_off.size()) slot_off.push_back(shift_off[t]);
+            tslot[(size_t)t] = (int32_t)k;
+        }
+        if ((int64_t)slot_off.size() < w.T) {
+            w.nslot = (int32_t)slot_off.size();
+            BA_TRY(dev_alloc_copy(ctx, tslot.data(), tslot.size() * sizeof(int32_t), (void **)&w.tslot));
+            BA_TRY(dev_alloc_copy(ctx, slot_off.data(), slot_off.size() * sizeof(int64_t), (void **)&w.slot_shift_off));
+        }
+    }
     m->wavemaps.push_back(std::move(w));
     return BEATAMD_OK;
 }
@@ -832,6 +850,8 @@ int beatamd_ffi_model_destroy(beatamd_ctx *ctx, int32_t model_id)
         if (w.data) (void)hipFree(w.data);
         if (w.hp_off) (void)hipFree(w.hp_off);
         if (w.shift_off) (void)hipFree(w.shift_off);
+        if (w.tslot) (void)hipFree(w.tslot);
+        if (w.slot_shift_off) (void)hipFree(w.slot_shift_off);
     }
     if (m->geo.data) (void)hipFree(m->geo.data);
     if (m->geo.odws) (void)hipFree(m->geo.odws);
@@ -1140,7 +1160,7 @@ int beatamd_ctx_gf_group_stats(beatamd_ctx *ctx, int64_t *chains_per_group, doub
     *mean_rows = (double)tot / (double)uc.size();
     *max_rows = mx;
     // every distinct row is staged once per (group, target) and slip variable
-    *row_bytes = tot * ctx->gs_trep * ctx->gs_N * 8 * ctx->gs_nvar;
+    *row_bytes = (int64_t)((double)tot * ctx->gs_trep) * ctx->gs_N * 8 * ctx->gs_nvar;
     return BEATAMD_OK;
 }
 

@@ -286,6 +286,8 @@ int beatamd_ctx_destroy(beatamd_ctx *c)
                 if (w.data) (void)hipFree(w.data);
                 if (w.hp_off) (void)hipFree(w.hp_off);
                 if (w.shift_off) (void)hipFree(w.shift_off);
+                if (w.tslot) (void)hipFree(w.tslot);
+                if (w.slot_shift_off) (void)hipFree(w.slot_shift_off);
             }
             if (m->geo.data) (void)hipFree(m->geo.data);
             if (m->geo.odws) (void)hipFree(m->geo.odws);

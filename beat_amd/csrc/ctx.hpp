@@ -86,6 +86,11 @@ struct Wavemap {
     int32_t wset = -1;
     int64_t *hp_off = nullptr;     // device [T]
     int64_t *shift_off = nullptr;  // device [T] or nullptr
+    // targets that share a station correction (the channels of a station: heart.py:2941-2950 repeats the station
+    // indices per channel) have the same start times -> the index tables are built per SLOT = distinct shift variable
+    int32_t nslot = 0;             // 0: no shifts, or every target has its own (tables per target)
+    int32_t *tslot = nullptr;      // device [T]: slot of target t
+    int64_t *slot_shift_off = nullptr;   // device [nslot]: the shift variable of the slot
     int interp = 0;
     int64_t T = 0, N = 0;
     bool f32 = false;   // read the libraries' float copies where a kernel supports it
@@ -170,7 +175,8 @@ struct beatamd_ctx {
     // name of the stacking kernel of the most recent launch (tests assert which kernel ran)
     char last_gf_kernel[96] = "";
     // distinct-row statistics of the most recent chain-shared launch (bench.py roofline leg)
-    int64_t gs_ngtp = 0, gs_N = 0, gs_trep = 1;   // trep: targets served by one table cell
+    int64_t gs_ngtp = 0, gs_N = 0;
+    double gs_trep = 1;             // targets served by one table cell (T / table slots)
     int gs_nvar = 1;                // slip variables: every distinct row is staged once per variable
     bool gs_has_passes = false;     // the statistics slot holds [rows per patch][passes per patch]
     // what the selection chose for the most recent stacking launch and why (beatamd_ctx_gf_plan)

@@ -544,6 +544,7 @@ struct GcArgs {
     const double *G[4];
     int nvar, ucap, ntile, mode, xcd_order;
     int64_t C, T, P, N, DS, Ttab, rows_per_target, ngroups;
+    const int32_t *tslot;         // [T] table slot of a target (nullptr: Ttab == 1 ? 0 : t)
     int64_t smax;                 // steps per (group, target) the tables are strided by
     const uint32_t *nv;           // [group, target] vsteps (nullptr: P)
     const int *ovf;               // nonzero: the tables overflowed, k_gfstack does the work
@@ -579,7 +580,7 @@ __global__ void __launch_bounds__(1024) k_gfstack_runs(GcArgs a)
         t = gt0 % a.T;
         g = gt0 / a.T;
     }
-    const int64_t gt = g * a.Ttab + (a.Ttab == 1 ? 0 : t);
+    const int64_t gt = g * a.Ttab + (a.tslot ? (int64_t)a.tslot[t] : (a.Ttab == 1 ? 0 : t));
     const int64_t n0 = (int64_t)tile * 64;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)gsm;
     const uint32_t rb0 = lds0 + GC_PARAM_BYTES;
@@ -722,6 +723,7 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
     a.mode = k.mode;
     a.C = k.C; a.T = L.T; a.P = L.P; a.N = L.N; a.DS = DS;
     a.Ttab = Ttab; a.rows_per_target = L.P * DS;
+    a.tslot = k.tslot;
     a.ngroups = ngroups; a.smax = smax;
     a.nv = passes ? nv : nullptr;
     a.ovf = passes ? ovf : nullptr;
@@ -748,7 +750,7 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
              passes ? "patches that touch more are staged in passes along the duration axis (tables sized for 6 passes per patch; "
                       "beyond that the streaming kernel takes the batch)" : "one pass per patch");
     ctx->gs_ngtp = GTP;
-    ctx->gs_trep = L.T / Ttab;
+    ctx->gs_trep = (double)L.T / (double)Ttab;
     ctx->gs_N = L.N;
     ctx->gs_cg = GC_CG;
     ctx->gs_nvar = k.nvar;

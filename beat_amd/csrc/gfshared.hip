@@ -233,6 +233,7 @@ struct GsArgs {
     // tables per (group, target, patch), or per (group, patch) when the start times do not depend
     // on the target (no station shifts): Ttab = T or 1; the row ids are then those of target 0 and
     // target t reads rows_per_target * t further on
+    const int32_t *tslot;    // [T] table slot of a target (nullptr: Ttab == 1 ? 0 : t)
     int64_t Ttab, rows_per_target;
     // twin launches of small groups (launcher): run only if the batch's largest distinct-row count
     // *guard_umax is <= guard_fit (mode 1) / > guard_fit (mode 2); mode 0: always
@@ -411,8 +412,9 @@ k_gfstack_dma(GsArgs a)
         t = gt0 % a.T;
         g = gt0 / a.T;
     }
-    const int64_t gt = g * a.Ttab + (a.Ttab == 1 ? 0 : t);                       // table cell
-    const int64_t tbase = (a.Ttab == 1) ? t * a.rows_per_target * a.N : 0;      // doubles
+    const int64_t slot = a.tslot ? (int64_t)a.tslot[t] : (a.Ttab == 1 ? 0 : t);
+    const int64_t gt = g * a.Ttab + slot;                                        // table cell
+    const int64_t tbase = (t - slot) * a.rows_per_target * a.N;                  // doubles
     const int64_t c = g * CG + tid;
     const int64_t N = a.N;
     const int64_t n0 = (int64_t)tile * GS_NT;
@@ -710,8 +712,9 @@ k_gfstack_dmaf(GsArgs a)
         t = gt0 % a.T;
         g = gt0 / a.T;
     }
-    const int64_t gt = g * a.Ttab + (a.Ttab == 1 ? 0 : t);                       // table cell
-    const int64_t tbase = (a.Ttab == 1) ? t * a.rows_per_target * a.N : 0;      // doubles
+    const int64_t slot = a.tslot ? (int64_t)a.tslot[t] : (a.Ttab == 1 ? 0 : t);
+    const int64_t gt = g * a.Ttab + slot;                                        // table cell
+    const int64_t tbase = (t - slot) * a.rows_per_target * a.N;                  // doubles
     const int64_t c = g * CG + tid;
     const int64_t N = a.N;
     const int64_t n0 = (int64_t)tile * GS_NT;
@@ -994,8 +997,9 @@ k_gfstack_ws(GsArgs a)
         t = gt0 % a.T;
         g = gt0 / a.T;
     }
-    const int64_t gt = g * a.Ttab + (a.Ttab == 1 ? 0 : t);                       // table cell
-    const int64_t tbase = (a.Ttab == 1) ? t * a.rows_per_target * a.N : 0;      // doubles
+    const int64_t slot = a.tslot ? (int64_t)a.tslot[t] : (a.Ttab == 1 ? 0 : t);
+    const int64_t gt = g * a.Ttab + slot;                                        // table cell
+    const int64_t tbase = (t - slot) * a.rows_per_target * a.N;                  // doubles
     const int64_t N = a.N;
     const int64_t n0 = (int64_t)tile * GS_NT;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)xbuf;
@@ -1403,8 +1407,9 @@ k_gfstack_wsp(GsArgs a)
         t = gt0 % a.T;
         g = gt0 / a.T;
     }
-    const int64_t gt = g * a.Ttab + (a.Ttab == 1 ? 0 : t);                       // table cell
-    const int64_t tbase = (a.Ttab == 1) ? t * a.rows_per_target * a.N : 0;      // doubles
+    const int64_t slot = a.tslot ? (int64_t)a.tslot[t] : (a.Ttab == 1 ? 0 : t);
+    const int64_t gt = g * a.Ttab + slot;                                        // table cell
+    const int64_t tbase = (t - slot) * a.rows_per_target * a.N;                  // doubles
     const int64_t N = a.N;
     const int64_t n0 = (int64_t)tile * GS_NT;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)xbuf;
@@ -2189,6 +2194,7 @@ static int launch_gfstack_ws(beatamd_ctx *ctx, const GfStackCall &k, const uint3
     a.nvar = k.nvar; a.nrow = 1;
     a.C = k.C; a.T = L.T; a.P = L.P; a.N = L.N;
     a.Ttab = Ttab; a.rows_per_target = L.P * L.D * L.S;
+    a.tslot = k.tslot;
     a.CG = WS_CG; a.ucap = cap; a.ustride = WS_USTRIDE;
     a.nt = 64; a.dma = 2; a.ws = 3;
     a.ngroups = ngroups;
@@ -2227,7 +2233,7 @@ static int launch_gfstack_ws(beatamd_ctx *ctx, const GfStackCall &k, const uint3
              "D*S = %lld) rows), %s", cap, (long long)(L.D * L.S),
              maxpass > 1 ? "patches that touch more are staged in passes of equal size" : "one pass per patch");
     ctx->gs_ngtp = GTP;
-    ctx->gs_trep = L.T / Ttab;
+    ctx->gs_trep = (double)L.T / (double)Ttab;
     ctx->gs_N = L.N;
     ctx->gs_cg = WS_CG;
     ctx->gs_nvar = k.nvar;
@@ -2313,6 +2319,7 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
     a.nvar = k.nvar; a.nrow = nrow;
     a.C = k.C; a.T = L.T; a.P = L.P; a.N = L.N;
     a.Ttab = Ttab; a.rows_per_target = L.P * L.D * L.S;
+    a.tslot = k.tslot;
     a.CG = CG; a.ucap = ucap; a.ustride = ga.ustride;
     a.nt = 64;
     {
@@ -2406,7 +2413,7 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t
         snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "%s<%d,%d,%d,%d,%d>",
                  "k_gfstack_dma", CG / 64, nrow, k.mode, a.nt, a.dma == 2 ? 1 : 0);
     ctx->gs_ngtp = GTP;
-    ctx->gs_trep = L.T / Ttab;
+    ctx->gs_trep = (double)L.T / (double)Ttab;
     ctx->gs_N = L.N;
     ctx->gs_cg = CG;
     ctx->gs_nvar = k.nvar;

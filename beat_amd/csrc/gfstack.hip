@@ -48,8 +48,9 @@ __device__ __forceinline__ bool wrap_index(int &i, int n)
 __global__ void __launch_bounds__(256) k_gf_tables(TabArgs a)
 {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    // a.T = number of targets the tables are built for: all of them, or 1 when the start times do
-    // not depend on the target (row ids of target 0; the stacking kernels add the target's base)
+    // a.T = number of table slots: all targets, the distinct station shifts (a.st.shift_off then holds the shift
+    // variable of the SLOT), or 1 when the start times do not depend on the target.  Row ids are those of "target" =
+    // slot index; the stacking kernels add (target - slot) x rows per target
     const int64_t total = a.C * a.T * a.P;
     if (idx >= total) return;
     const int64_t p = idx % a.P;
@@ -121,7 +122,8 @@ struct GfArgs {
     int order;        // 0: blocks ordered (chain, target, tile); 1: (group, target, chain, tile)
     int64_t C;
     int cgroup;       // order 1: chains per group
-    int64_t Ttab, rows_per_target;   // tables per (chain, target, patch) or, Ttab = 1, per (chain, patch)
+    int64_t Ttab, rows_per_target;   // tables per (chain, table slot, patch): Ttab slots (T, the station shifts, or 1)
+    const int32_t *tslot;            // [T] slot of a target (nullptr: Ttab == 1 ? 0 : t)
     // stand-in launch behind k_gfstack_runs: works only when *guard != 0 (the runs kernel's tables overflowed)
     const int *guard;
 };
@@ -174,8 +176,9 @@ __global__ void __launch_bounds__(256) k_gfstack(GfArgs a)
         c = c0 + (r - t * gsz);
     }
     const int64_t ct = c * a.T + t;
-    const int64_t ctt = c * a.Ttab + (a.Ttab == 1 ? 0 : t);                   // table cell
-    const int64_t tbase = (a.Ttab == 1) ? t * a.rows_per_target : 0;         // rows
+    const int64_t slot = a.tslot ? (int64_t)a.tslot[t] : (a.Ttab == 1 ? 0 : t);
+    const int64_t ctt = c * a.Ttab + slot;                                    // table cell
+    const int64_t tbase = (t - slot) * a.rows_per_target;                     // rows
     const int64_t N = a.N;
     const int P = (int)a.P;
 
@@ -363,7 +366,11 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &call)
     // indices of a chain are the same for every target (seismic.py:1283-1296 tiles starttimes0
     // over the targets): the tables are then built once per (chain, patch) instead of T times.
     const bool tinv = !k.st.explicit_st && !k.st.shift_off && !GfKnobs::is(kn.gf_tinv, 0);
-    const int64_t Ttab = tinv ? 1 : L.T;
+    // ... and with station corrections only on the station: one table slot per distinct shift variable (the channels of
+    // a station share it)
+    const bool slots = !k.st.explicit_st && k.st.shift_off && k.st.nslot > 0 && !GfKnobs::is(kn.gf_tinv, 0);
+    const int64_t Ttab = tinv ? 1 : slots ? (int64_t)k.st.nslot : L.T;
+    k.tslot = slots ? k.st.tslot : nullptr;
     const int64_t CTP = k.C * Ttab * L.P;
     const int nrow = k.interp == BEATAMD_MULTILINEAR ? 4 : 1;
 
@@ -373,6 +380,7 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &call)
     ta.st_min = L.st_min; ta.st_dt = L.st_dt; ta.du_min = L.du_min; ta.du_dt = L.du_dt;
     ta.durations = k.durations;
     ta.st = k.st;
+    if (slots) ta.st.shift_off = k.st.slot_shift_off;
     ta.status = ctx->d_status;
     void *p = nullptr;
     BA_TRY(ctx->get_scratch(SL_ROWOFF, (size_t)CTP * nrow * sizeof(uint32_t), &p));
@@ -453,6 +461,7 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &call)
     }
     a.T = L.T; a.P = L.P; a.N = L.N;
     a.Ttab = Ttab; a.rows_per_target = L.P * L.D * L.S;
+    a.tslot = k.tslot;
     a.C = k.C;
     {
         a.order = GfKnobs::get(kn.gf_order, 1);

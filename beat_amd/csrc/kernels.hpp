@@ -22,6 +22,11 @@ struct StartTimeSrc {
     const double *Q = nullptr;
     int64_t nparams = 0;
     const int64_t *shift_off = nullptr;  // device [T] or nullptr (no station corrections)
+    // table slots: targets with the same shift variable share their index tables (nslot > 0: tslot [T] -> slot,
+    // slot_shift_off [nslot]; device pointers)
+    int32_t nslot = 0;
+    const int32_t *tslot = nullptr;
+    const int64_t *slot_shift_off = nullptr;
     // model mode: chains whose times fall outside the library grid are marked here (their
     // `like` becomes NaN, which the Metropolis step rejects); nullptr in the explicit API
     int32_t *chain_bad = nullptr;
@@ -57,6 +62,7 @@ struct GfStackCall {
     // (the fused model path: hypocentre strike / dip of the first subfault).  Never changes a result.
     ChainVec order_key[2];
     const GfKnobs *knobs = nullptr;   // set by launch_gfstack (gf_knobs(ctx)): the selection functions read them here
+    const int32_t *tslot = nullptr;   // set by launch_gfstack: table slot of a target when targets share tables (device [T])
 };
 int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &call);
 int launch_sum_tiles(beatamd_ctx *ctx, const double *partial, int64_t n, int ntile, double *quad,
