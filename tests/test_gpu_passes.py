@@ -195,3 +195,32 @@ def test_fused_model_on_a_fine_grid_ml(ctx, monkeypatch, nvar, cov, shifts):
     B2 = f.batch(Q)
     assert ctx.gf_plan()["max_passes"] > plan["max_passes"]
     assert np.array_equal(B2, B)
+
+
+@pytest.mark.parametrize("interp,C", [("nearest_neighbor", 600), ("multilinear", 300), ("nearest_neighbor", 40)])
+def test_targets_of_a_station_share_their_index_tables(ctx, monkeypatch, interp, C):
+    """station corrections are per STATION, a station has several channels = targets (heart.py:2941-2950 repeats the
+    station indices per channel): the index tables (row ids, LDS slots, passes) are built per distinct shift variable,
+    not per target -- 7 targets on 3 stations here.  Bitwise the per-target tables (BEATAMD_GF_TINV=0) in every kernel
+    family, and the oracle on sampled chains"""
+    from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
+    from oracle import problem_oracle
+    spec = SyntheticSpec((5,), (6,), (1.0,), T=7, N=96, D=3, S=25, station_shifts=True, interpolation=interp,
+                         slip_varnames=("uparr", "uperp"), covariance="toeplitz")
+    prob, host = build_problem(spec)
+    assert len(set(np.asarray(host["time_shifts"][1]).tolist())) == 3
+    f = prob.compile(ctx)
+    Q = draw_population(spec, host["layout"], host["lower"], host["upper"], C)
+    B = f.batch(Q)
+    name = ctx.last_kernel()
+    monkeypatch.setenv("BEATAMD_GF_TINV", "0")
+    A = f.batch(Q)
+    assert ctx.last_kernel() == name
+    monkeypatch.delenv("BEATAMD_GF_TINV")
+    assert np.array_equal(A, B), name
+    monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
+    S_ = f.batch(Q)
+    np.testing.assert_allclose(S_, B, rtol=1e-11, atol=1e-9)
+    for c in (0, C - 1):
+        ref, _ = problem_oracle.forward(host, Q[c])
+        np.testing.assert_allclose(B[c], ref, rtol=1e-9, atol=1e-9)
