@@ -195,6 +195,15 @@ def test_fused_model_on_a_fine_grid_ml(ctx, monkeypatch, nvar, cov, shifts):
     B2 = f.batch(Q)
     assert ctx.gf_plan()["max_passes"] > plan["max_passes"]
     assert np.array_equal(B2, B)
+    # tables sized for ONE pass per patch overflow: the runs kernel returns at once, the streaming kernel stands in (its own
+    # tile sums / residuals, the guarded sum of tiles) -- the streaming kernel's bits, no host synchronisation in between
+    monkeypatch.setenv("BEATAMD_GR_PASS_ALLOC", "1")
+    B3 = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack_runs<%d," % mode)
+    assert np.array_equal(B3, A)
+    monkeypatch.delenv("BEATAMD_GR_PASS_ALLOC")
+    monkeypatch.delenv("BEATAMD_GR_CAP")
+    assert np.array_equal(f.batch(Q), B)      # ... and the flag is cleared for the next call
 
 
 @pytest.mark.parametrize("interp,C", [("nearest_neighbor", 600), ("multilinear", 300), ("nearest_neighbor", 40)])
