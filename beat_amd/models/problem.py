@@ -430,6 +430,8 @@ class LogpForwFunc(object):
 
     def batch(self, Q, out=None):
         """Q (C, nparams) numpy or torch-cuda -> LL (C, nllk)"""
+        if self.model_id is None:
+            raise RuntimeError("this compiled model was released")
         if Q.shape[-1] != self.nparams:
             raise ValueError("expected %d parameters, got %d" % (self.nparams, Q.shape[-1]))
         if self._dirty:

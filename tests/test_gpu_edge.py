@@ -178,3 +178,24 @@ def test_kernel_selection_by_lds_capacity(ctx, orc, monkeypatch, D, S, C, interp
     for c in (0, C // 3, C - 1):
         ref = orc.stack_all(G, dur[c], st[c], sl[c], 0.5, 0.5, 0.0, 0.5, interp)
         np.testing.assert_allclose(b[c], ref, rtol=1e-11, atol=1e-12)
+
+
+def test_release_frees_the_models_device_state(ctx):
+    """LogpForwFunc.release(): the model record and its weight sets (T x N x N doubles each when dense) are destroyed, the
+    libraries stay; the function refuses further calls, a second compile of the same problem works"""
+    import torch
+    from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
+    spec = SyntheticSpec((4,), (4,), (1.0,), T=3, N=512, D=3, S=25, covariance="toeplitz", geodetic_nobs=(9,))
+    prob, host = build_problem(spec)
+    Q = draw_population(spec, host["layout"], host["lower"], host["upper"], 6)
+    f = prob.compile(ctx)
+    a = f.batch(Q)
+    free0, _ = torch.cuda.mem_get_info(0)
+    f.release()
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert free1 - free0 >= 3 * 512 * 512 * 8 * 0.9          # the dense weight set went back
+    with pytest.raises((ValueError, TypeError, RuntimeError)):
+        f.batch(Q)
+    f.release()                                              # idempotent
+    g = prob.compile(ctx)
+    assert np.array_equal(g.batch(Q), a)
