@@ -239,3 +239,45 @@ def test_chain_order_twin_is_a_permutation_whatever_the_keys():
                 assert f0[band == b].max() <= f0[band == b + 1].min()
             for b in range(4):
                 assert np.all(np.diff(f1[band == b]) >= 0)
+
+
+def test_pass_partition_invariants():
+    """the row passes of a (group, target, patch) -- numpy twin of k_gm_tables' count phase, the statement-for-statement
+    mirror of the device code -- for random populations on small and large (duration x start-time) grids and buffer
+    sizes: every cell has exactly one pass, the passes follow the cell order, a pass's distinct row slots fit the buffer
+    and its row requests the two loaders' request lines"""
+    rng = np.random.default_rng(8)
+    for trial in range(300):
+        D, S = int(rng.integers(1, 20)), int(rng.integers(1, 70))
+        cap = int(rng.choice([8, 12, 24, 40, 104]))
+        S1 = S + 1
+        n = int(rng.integers(1, emu.CG + 1))
+        spread_d = int(rng.integers(1, D + 1))
+        dc = rng.integers(0, spread_d, n) + int(rng.integers(0, D - spread_d + 1))
+        sc = rng.integers(0, min(S, int(rng.integers(1, S + 1))), n)
+        df = (dc + D - 1) % D
+        keys = sorted(set(int(((d * S1 + s_) << 16) | (f * S1 + s_)) for d, s_, f in zip(dc, sc, df)))
+        pass_of = emu.passes_along_the_duration_axis(keys, D, S, cap)
+        assert set(pass_of) == set(keys)
+        order = [pass_of[k] for k in keys]
+        assert order == sorted(order) and order[0] == 0 and set(order) == set(range(max(order) + 1))
+        for k in range(max(order) + 1):
+            slots = set()
+            for key in keys:
+                if pass_of[key] == k:
+                    sb, sa = key >> 16, key & 0xFFFF
+                    slots.update((sa, sa + 1, sb, sb + 1))
+            assert len(slots) <= max(cap, 4), (D, S, cap, k, len(slots))
+            dense = sorted(slots)
+
+            def row_of(sl):
+                d, s1 = divmod(sl, S1)
+                return d * S + (s1 - 1 if s1 else S - 1)
+            nreq, i = 0, 0
+            while i < len(dense):
+                if i + 1 < len(dense) and 0 < row_of(dense[i + 1]) - row_of(dense[i]) < 256:
+                    i += 2
+                else:
+                    i += 1
+                nreq += 1
+            assert nreq <= emu.NLOAD * emu.LREQ, (D, S, cap, nreq)

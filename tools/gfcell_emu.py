@@ -124,14 +124,78 @@ PASS_ALLOC = 6     # passes per patch the device tables are sized for (k_gfstack
 
 
 def max_passes(D, S, cap=CAP):
-    """upper bound of the row passes of a patch: one when the patch's D * (S + 1) dense slots fit a buffer; else every
-    pass but the last is closed with more than cap - 4 slots or 2 * LREQ requests (>= 60 slots), and the passes hold at
-    most min(4 * CG, 4 * dense) slots together (a slot may be staged in up to four passes)"""
+    """upper bound of the row passes of a patch (sizes the twin's tables; the device sizes its tables for PASS_ALLOC passes
+    and lets k_gfstack stand in beyond): one when the patch's D * (S + 1) dense slots fit a buffer; else at most one pass
+    per ceil line plus the cuts of the lines that do not fit alone (a cut pass holds more than cap - 4 slots)"""
     dense = D * (S + 1)
     if dense <= cap:
         return 1
-    fill = max(1, min(cap - 3, 60))
-    return (min(4 * CG, 4 * dense) + fill - 1) // fill + 1
+    return 2 * D + (4 * CG + max(1, cap - 4) - 1) // max(1, cap - 4) + 1
+
+
+def req_bound(n, nlines, S):
+    """gm_req_bound (gfcell.hip): the row requests n slots over nlines duration lines can take at most"""
+    return n if S > 255 else n // 2 + 2 * nlines + 1
+
+
+def passes_along_the_duration_axis(cells, D, S, cap):
+    """the count phase of k_gm_tables (gfcell.hip), statement for statement: cells = ascending (B << 16 | A) keys of a
+    (group, target, patch) -> {key: pass}.  Per duration line three bitsets over the start-time slots s' -- C: used as a
+    ceil line, F: used as a floor line, X: ceil nodes of the line's cells --; a greedy over the ceil lines closes a pass
+    when the next line's slots (or requests) do not fit; a line that does not fit alone is cut along the start-time axis."""
+    S1, lim = S + 1, NLOAD * LREQ
+    bC, bF, bX = [set() for _ in range(D)], [set() for _ in range(D)], [set() for _ in range(D)]
+    for key in cells:
+        sb, sa = key >> 16, key & 0xFFFF
+        dc, sc, df = sb // S1, sb % S1, sa // S1
+        bC[dc].update((sc, sc + 1))
+        bF[df].update((sc, sc + 1))
+        bX[dc].add(sc)
+
+    def fl(d):
+        return D - 1 if d == 0 else d - 1
+    linepass, cellpass = {}, {}
+    cur, n, nlines, first, opened = -1, 0, 0, -1, False
+    for d in range(D):
+        if not bX[d]:
+            continue
+        f = fl(d)
+        wrap_c = opened and d == D - 1 and first == 0 and D > 1
+        floor_in = opened and f != d and first <= f < d
+        if f == d:
+            add, lines_add = len(bC[d] | bF[d]), 1
+        else:
+            add = len(bC[d] | (bF[d] if wrap_c else set())) - (len(bF[d]) if wrap_c else 0)
+            add += (len(bF[f] | bC[f]) - len(bC[f])) if floor_in else len(bF[f])
+            lines_add = (0 if wrap_c else 1) + (0 if (floor_in and bC[f]) else 1)
+        alone = add if f == d else len(bC[d]) + len(bF[f])
+        if opened and (n + add > cap or req_bound(n + add, nlines + lines_add, S) > lim):
+            opened = False
+        if not opened:
+            if alone > cap or req_bound(alone, 1 if f == d else 2, S) > lim:
+                m, prev = 0, -2
+                cur += 1
+                for s_ in sorted(bX[d]):
+                    addc = (1 if s_ == prev + 1 else 2) * (1 if f == d else 2)
+                    if m and (m + addc > cap or req_bound(m + addc, 2, S) > lim):
+                        cur += 1
+                        m, prev = 0, -2
+                    m += (1 if s_ == prev + 1 else 2) * (1 if f == d else 2)
+                    prev = s_
+                    cellpass[(d, s_)] = cur
+                continue
+            cur += 1
+            opened, first, n, nlines = True, d, alone, (1 if f == d else 2)
+        else:
+            n += add
+            nlines += lines_add
+        linepass[d] = cur
+    out = {}
+    for key in cells:
+        sb = key >> 16
+        dc, sc = sb // S1, sb % S1
+        out[key] = cellpass[(dc, sc)] if (dc, sc) in cellpass else linepass[dc]
+    return out
 
 
 def gm_tables(rowoff, fac, slips, order, C, T, P, D, S, nvar=1, cap=None):
@@ -164,8 +228,6 @@ def gm_tables(rowoff, fac, slips, order, C, T, P, D, S, nvar=1, cap=None):
         sb_, sa_ = key >> 16, key & 0xFFFF
         return sorted({sa_, sa_ + 1, sb_, sb_ + 1})
 
-    def req_bound(n, nlines):
-        return n if S > 255 else n // 2 + 2 * nlines + 1
     for g in range(ngroups):
         ids = order[g * CG:(g + 1) * CG]
         live = ids != DEAD
@@ -181,29 +243,14 @@ def gm_tables(rowoff, fac, slips, order, C, T, P, D, S, nvar=1, cap=None):
                 key = np.where(live, (sb << 16) | sa, 0xFFFFFFFF)
                 cells = sorted(set(int(x) for x in key[live]))
                 # ---- passes: greedy over the cells in ascending order
-                allslots = set()
-                for kc in cells:
-                    allslots.update(slots_of(kc))
-                lines_all = {sl // S1 for sl in allslots}
-                pass_of = {}
-                if len(allslots) <= cap and req_bound(len(allslots), len(lines_all)) <= NLOAD * LREQ:
-                    for kc in cells:
-                        pass_of[kc] = 0
-                    npass = 1
+                # one pass when every dense slot of a patch (and the requests they can take) fits a buffer -- what the
+                # launcher decides from D and S alone --, else the count phase of k_gm_tables
+                dense_n_ = D * S1
+                if dense_n_ <= cap and (dense_n_ if S > 255 else dense_n_ // 2 + 2 * D + 1) <= NLOAD * LREQ:
+                    pass_of = {kc: 0 for kc in cells}
                 else:
-                    cur, have, lines = 0, set(), set()
-                    for kc in cells:
-                        sl4 = slots_of(kc)
-                        need = [x for x in sl4 if x not in have]
-                        nl = {x // S1 for x in sl4} - lines
-                        if have and (len(have) + len(need) > cap or
-                                     req_bound(len(have) + len(need), len(lines) + len(nl)) > NLOAD * LREQ):
-                            cur += 1
-                            have, lines = set(), set()
-                        have.update(sl4)
-                        lines.update(x // S1 for x in sl4)
-                        pass_of[kc] = cur
-                    npass = cur + 1
+                    pass_of = passes_along_the_duration_axis(cells, D, S, cap)
+                npass = max(pass_of.values()) + 1 if pass_of else 1
                 assert npass <= maxpass, (npass, maxpass)
                 npass_o[gt * P + p] = npass
                 cpass = np.array([pass_of.get(int(k_), -1) for k_ in key])
