@@ -1186,6 +1186,21 @@ int beatamd_ctx_gf_plan(beatamd_ctx *ctx, char *buf, int64_t buflen, double *mea
     return BEATAMD_OK;
 }
 
+int beatamd_ctx_gf_chain_groups(beatamd_ctx *ctx, int64_t C, const double *key0, const double *key1,
+                                int64_t chains_per_group, uint32_t *members)
+{
+    ENTER(ctx);
+    BA_CHECK(C > 0 && key0 && key1 && members && chains_per_group > 0, BEATAMD_EINVAL, "gf_chain_groups: bad argument");
+    const int64_t ngroups = (C + chains_per_group - 1) / chains_per_group;
+    const ChainVec key[2] = {ChainVec{key0, 1, 0}, ChainVec{key1, 1, 0}};
+    const uint32_t *m = nullptr;
+    BA_TRY(launch_chain_members(ctx, C, key, chains_per_group, ngroups, &m));
+    BA_CHECK(m != nullptr, BEATAMD_EINVAL, "gf_chain_groups: batches of more than 8192 chains or 64 groups are not cut");
+    BA_HIP(hipStreamSynchronize(ctx->stream));
+    BA_HIP(hipMemcpy(members, m, (size_t)(ngroups * chains_per_group) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return BEATAMD_OK;
+}
+
 // ------------------------------------------------------------------ SMC stage transition
 int beatamd_smc_calc_beta(beatamd_ctx *ctx, int64_t C, const double *likelihoods, int64_t stride,
                           double beta, double coef_variation, double *beta_new, double *weights)

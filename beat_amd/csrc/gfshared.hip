@@ -244,7 +244,7 @@ struct GsArgs {
     const uint32_t *nv;
     int64_t vmax;
     // k_gfstack_ws / _wsp: chain of lane `tid` of group g = order[g*512 + tid] (nullptr: g*512 + tid) -- batches of several
-    // groups are cut into groups along the hypocentre (launch_chain_members): a slice of the fault per group
+    // groups are cut into groups by bisection along the hypocentre keys (launch_chain_members): a piece of the fault per group
     const uint32_t *order;
     const uint32_t *urows, *uent, *ucount;
     const uint16_t *slot;
@@ -2147,10 +2147,10 @@ static int launch_gfstack_ws(beatamd_ctx *ctx, const GfStackCall &k, const uint3
     ta.C = k.C; ta.T = Ttab; ta.P = L.P; ta.DS = L.D * L.S; ta.vmax = vmax;
     ta.rowoff = rowoff;
     for (int v = 0; v < k.nvar; v++) ta.slips[v] = k.slips[v];
-    // several groups: cut the batch into its groups along the first order key (the fused model path hands the
-    // hypocentre): a slice of the fault per group = fewer distinct rows to stage per group and patch.  Scheduling only.
-    if (ngroups > 1 && k.order_key[0].base && GfKnobs::get(kn.gc_global, 1) != 0)
-        BA_TRY(launch_chain_members(ctx, k.C, k.order_key[0], ngroups * WS_CG, &ta.order));
+    // several groups: cut the batch into its groups by bisection along the order keys (the fused model path hands the
+    // hypocentre): a compact piece of the fault per group = fewer distinct rows to stage per group and patch.  Scheduling only.
+    if (ngroups > 1 && k.order_key[0].base && k.order_key[1].base && GfKnobs::get(kn.gc_global, 1) != 0)
+        BA_TRY(launch_chain_members(ctx, k.C, k.order_key, WS_CG, ngroups, &ta.order, GfKnobs::get(kn.gc_global, 1) == 2));
     // [utotal GTP][npass GTP][voff GTP][nv GT]
     BA_TRY(ctx->get_scratch(SL_GS_UCOUNT, (size_t)(3 * GTP + GT) * sizeof(uint32_t), &p));
     ta.utotal = (uint32_t *)p;

@@ -78,9 +78,11 @@ int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &call, const uint3
 // gfcell.hip: multilinear stacking with the rows of a cell in registers (518-chain groups, row passes): k_gfstack_runs.
 // *ovf (device, nullable on return): nonzero after the launch = the tables overflowed and nothing was stacked -- the
 // caller enqueues k_gfstack behind it as a stand-in guarded by the same flag
-// the chains of a batch in ascending order of a per-chain key (ties: chain id): members[i] = chain at position i,
-// padded with ~0 up to `padded` entries (C <= 4096: C * C comparisons); members = nullptr when the batch is larger
-int launch_chain_members(beatamd_ctx *ctx, int64_t C, ChainVec key, int64_t padded, const uint32_t **members);
+// the chains of a batch cut into ngroups groups of cg chain slots by recursive bisection along the key in which a part's
+// chains spread wider (k_gc_cut): members[g * cg + i] = i-th chain of group g, ~0 behind the last chain (one workgroup
+// sorting in LDS: C <= 8192, <= 64 groups); members = nullptr when the batch is larger or a key is missing
+int launch_chain_members(beatamd_ctx *ctx, int64_t C, const ChainVec key[2], int64_t cg, int64_t ngroups, const uint32_t **members,
+                         int strips = 0);
 bool gfstack_ml_applicable(const GfStackCall &call);
 int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &call, const uint32_t *rowoff,
                       const double *fac, int64_t Ttab, const int **ovf);

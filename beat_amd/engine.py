@@ -432,6 +432,22 @@ class Context(object):
             out.update(mean_passes=mean.value, max_passes=mx.value)
         return out
 
+    def gf_chain_groups(self, key0, key1, chains_per_group=512):
+        """how a batch is cut into its chain groups (scheduling only): key0 / key1 (C,) per-chain keys -- the hypocentre
+        (strike, dip) in the fused model path -> uint32 array [ngroups, chains_per_group] of chain ids, 0xffffffff behind
+        the last chain (recursive bisection along the key of the wider extent, k_gc_cut)"""
+        import torch
+        dev = "cuda:%d" % self.device
+        k0, k1 = [k if _is_dev(k) else torch.as_tensor(np.ascontiguousarray(k, dtype=np.float64)).to(dev) for k in (key0, key1)]
+        self._adopt_stream(k0, k1)
+        k0, k1 = f64(k0), f64(k1)
+        Cn = int(k0.numel())
+        ng = (Cn + chains_per_group - 1) // chains_per_group
+        out = np.empty(ng * chains_per_group, dtype=np.uint32)
+        check(self._lib.beatamd_ctx_gf_chain_groups(self._h, Cn, ptr(k0), ptr(k1), int(chains_per_group),
+                                                    out.ctypes.data_as(C.c_void_p)))
+        return out.reshape(ng, chains_per_group)
+
     # -- sampler steps on the device (SMC stage transition, proposals, exchange)
     def smc_calc_beta(self, likelihoods, beta, coef_variation, stride=1, n=None):
         """smc.py:133-165 -> (beta_new, weights); likelihoods: (C,) array or a strided view

@@ -42,7 +42,7 @@ extern "C" {
 /* ABI revision: bumped whenever an entry point changes its signature or an error code is added
  * (1.1: beatamd_weights_update gained kind/count in round 2; BEATAMD_EBADCOV).  beat_amd/_lib.py
  * refuses a library whose revision differs from the header it was written against. */
-#define BEATAMD_VERSION 116
+#define BEATAMD_VERSION 117
 
 #define BEATAMD_NEAREST_NEIGHBOR 0 /* interpolation="nearest_neighbor" */
 #define BEATAMD_MULTILINEAR 1      /* interpolation="multilinear"      */
@@ -97,6 +97,15 @@ int beatamd_ctx_gf_group_stats(beatamd_ctx *ctx, int64_t *chains_per_group, doub
  * rows than an LDS row buffer holds.  No reference counterpart: the reference gathers one chain's rows by fancy
  * indexing (beat/ffi/base.py:651-704); this reports how the batch shares them. */
 int beatamd_ctx_gf_plan(beatamd_ctx *ctx, char *buf, int64_t buflen, double *mean_passes, int64_t *max_passes);
+
+/* how a batch of C chains is cut into its chain groups (scheduling only; results never depend on it): recursive
+ * bisection of the batch along the key in which a part's chains spread wider -- the fused model path hands the hypocentre
+ * (strike, dip) of every chain, so that a group covers a compact piece of the fault and stages fewer distinct library rows.
+ *   key0 / key1 [C] (device)   members [ceil(C / chains_per_group) * chains_per_group] (host): members[g * cpg + i] =
+ *   i-th chain of group g, 0xffffffff behind the last chain.  C <= 8192 and at most 64 groups (larger batches are not cut: BEATAMD_EINVAL).
+ * No reference counterpart (the reference evaluates one chain per process, beat/sampler/base.py:428-595). */
+int beatamd_ctx_gf_chain_groups(beatamd_ctx *ctx, int64_t C, const double *key0, const double *key1,
+                                int64_t chains_per_group, uint32_t *members);
 
 /* ---------------------------------------------------------------- fast sweep -------
  * replaces: fast_sweep_ext.fast_sweep(slowness, patch_size, h_strk, h_dip, num_strk,

@@ -198,16 +198,33 @@ def test_committed_include_is_the_generators_output(tmp_path, monkeypatch):
 
 
 def test_chain_order_twin_is_a_permutation_whatever_the_keys():
-    """gc_order (numpy twin of k_gc_order): every chain exactly once per group, with caller keys (hypocentre), with
-    start-index keys, with NaN / inf keys (proposals outside everything), for full, partial and single-chain groups; with
-    keys the first key ascends from band to band and the second inside a band"""
+    """gc_order (numpy twin of k_gc_cut / k_gc_members / k_gc_order): every chain exactly once per group, with caller keys
+    (hypocentre), with start-index keys, with NaN / inf keys (proposals outside everything), for full, partial and
+    single-chain groups; batches of several groups are bisected along the key of the wider extent; with keys the first key
+    ascends from band to band and the second inside a band, and the number of bands follows the group's extents"""
     rng = np.random.default_rng(3)
     T, P, D, S = 1, 6, 3, 9
-    for C in (1, 36, 37, 518, 519, 1100):
+
+    def finite(k):
+        return np.where(np.abs(k) <= 1.79e308, k, 0.0)
+
+    def check_cut(groups, f0, f1, lo, hi):
+        """groups [lo, hi): the first half of the groups lies below the rest in the key of the wider extent"""
+        if hi - lo <= 1:
+            return
+        ids = np.concatenate(groups[lo:hi])
+        half = (hi - lo) // 2
+        f = f1 if np.ptp(f1[ids]) > np.ptp(f0[ids]) else f0
+        left, right = np.concatenate(groups[lo:lo + half]), np.concatenate(groups[lo + half:hi])
+        assert f[left].max() <= f[right].min()
+        check_cut(groups, f0, f1, lo, lo + half)
+        check_cut(groups, f0, f1, lo + half, hi)
+
+    for C in (1, 36, 37, 518, 519, 1100, 2100, 2600):
         st = rng.uniform(0.0, 0.5 * (S - 1) - 0.01, (C, T, P))
         du = rng.uniform(0.5, 0.5 + 0.5 * (D - 1), (C, P))
         ro, _ = emu.gf_tables_ml(st, du, 0.0, 0.5, 0.5, 0.5, D, S, T, P)
-        k0, k1 = rng.uniform(0, 20, C), rng.uniform(0, 20, C)
+        k0, k1 = rng.uniform(0, 20, C), rng.uniform(0, 10, C)
         for keys in (None, (k0, k1)):
             if keys is not None and C > 5:
                 keys[0][3], keys[1][4] = np.nan, np.inf
@@ -215,30 +232,48 @@ def test_chain_order_twin_is_a_permutation_whatever_the_keys():
             assert order.size == ((C + emu.CG - 1) // emu.CG) * emu.CG
             assert sorted(order[order != emu.DEAD].tolist()) == list(range(C))
             ngr = order.size // emu.CG
+            groups = []
             for g in range(ngr):
                 ids = order[g * emu.CG:(g + 1) * emu.CG]
                 live = ids[ids != emu.DEAD]
                 assert live.size == min(emu.CG, C - g * emu.CG)         # full groups first
                 assert np.all(ids[:live.size] != emu.DEAD)              # dead slots behind the live ones
+                groups.append(live.astype(np.int64))
             if ngr > 1:
-                # several groups: the batch is cut in the order of the first key (a slice of the fault per group)
-                f0 = (ro[:, 0, 0, 3] % S).astype(float) if keys is None else np.where(np.abs(keys[0]) <= 1.79e308, keys[0], 0.0)
-                for g in range(ngr - 1):
-                    a_, b_ = order[g * emu.CG:(g + 1) * emu.CG], order[(g + 1) * emu.CG:(g + 2) * emu.CG]
-                    assert f0[a_[a_ != emu.DEAD]].max() <= f0[b_[b_ != emu.DEAD]].min()
+                if keys is None:
+                    f0, f1 = (ro[:, 0, 0, 3] % S).astype(float), (ro[:, 0, P // 2, 3] % S).astype(float)
+                else:
+                    f0, f1 = finite(keys[0]), finite(keys[1])
+                check_cut(groups, f0, f1, 0, ngr)
                 plain = emu.gc_order(ro, C, T, P, S, True, keys=keys, global_members=False)
                 assert all(np.all(plain[g * emu.CG:(g + 1) * emu.CG][:min(emu.CG, C - g * emu.CG)] // emu.CG == g) for g in range(ngr))
         if C >= 518:
             order = emu.gc_order(ro, C, T, P, S, True, keys=(k0, k1))
-            ids = order[:emu.CG]
-            nw = emu.CG // emu.NCH
-            band = (np.arange(emu.CG) // emu.NCH) * 4 // nw
-            f0 = np.where(np.abs(k0[ids]) <= 1.79e308, k0[ids], 0.0)
-            f1 = np.where(np.abs(k1[ids]) <= 1.79e308, k1[ids], 0.0)
-            for b in range(3):
-                assert f0[band == b].max() <= f0[band == b + 1].min()
-            for b in range(4):
-                assert np.all(np.diff(f1[band == b]) >= 0)
+            nbs = set()
+            for g in range(C // emu.CG):
+                ids = order[g * emu.CG:(g + 1) * emu.CG]
+                nw = emu.CG // emu.NCH
+                f0, f1 = finite(k0[ids]), finite(k1[ids])
+                nb = max(1, min(nw, int(np.rint(np.sqrt(nw * np.ptp(f0) / np.ptp(f1))))))
+                nbs.add(nb)
+                band = (np.arange(emu.CG) // emu.NCH) * nb // nw
+                for b in range(nb - 1):
+                    assert f0[band == b].max() <= f0[band == b + 1].min()
+                for b in range(nb):
+                    assert np.all(np.diff(f1[band == b]) >= 0)
+            if C == 518:
+                assert nbs == {5}      # one group over 20 x 10: sqrt(14 * 2) = 5.3
+            if C == 2100:
+                assert len(nbs) > 1 or nbs != {5}, nbs     # (pieces of the fault have other aspect ratios)
+    # the members of a cut (device layout: group g at g * cg)
+    F0, F1 = rng.uniform(0, 20, 1300), rng.uniform(0, 20, 1300)
+    m = emu.gc_cut(F0, F1, 1300, 512, 3)
+    assert sorted(m.tolist()) == list(range(1300))
+    g0, g1, g2 = m[:512], m[512:1024], m[1024:]
+    rest = np.concatenate([g1, g2])
+    wide = F1 if np.ptp(F1) > np.ptp(F0) else F0
+    assert wide[g0].max() <= wide[rest].min() and g2.size == 276
+    assert np.all(np.diff(g0) > 0) and np.all(np.diff(g1) > 0)          # inside a group: by chain id
 
 
 def test_pass_partition_invariants():

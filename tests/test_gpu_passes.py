@@ -233,3 +233,54 @@ def test_targets_of_a_station_share_their_index_tables(ctx, monkeypatch, interp,
     for c in (0, C - 1):
         ref, _ = problem_oracle.forward(host, Q[c])
         np.testing.assert_allclose(B[c], ref, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("C,cpg", [(600, 512), (1300, 512), (2100, 518), (2600, 512), (4096, 518), (4096, 512), (5000, 518), (8192, 512), (3, 2), (130, 128)])
+def test_chain_groups_of_a_batch_equal_the_numpy_twin(ctx, C, cpg):
+    """k_gc_cut / k_gc_members (batches of several chain groups are bisected along the hypocentre key of the wider extent:
+    a compact piece of the fault per group) against tools/gfcell_emu.gc_cut, index for index; odd group counts, partial
+    last group, ties, NaN / inf keys.  Scheduling only -- the stacking tests pin that results do not depend on it"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gfcell_emu as emu
+    rng = np.random.default_rng(C + cpg)
+    k0, k1 = rng.uniform(0, 20, C), rng.uniform(0, 20 if C % 2 else 9, C)
+    k0[rng.integers(0, C, 40)] = k0[C // 2]      # ties
+    k1[rng.integers(0, C, 40)] = k1[C // 3]
+    if C > 12:
+        k0[5], k1[11], k1[12] = np.nan, np.inf, -np.inf
+    got = ctx.gf_chain_groups(k0, k1, cpg)
+    ng = (C + cpg - 1) // cpg
+    fin = [np.where(np.abs(k) <= 1.79e308, k, 0.0) for k in (k0, k1)]
+    want = np.full(ng * cpg, 0xffffffff, dtype=np.uint32)
+    want[:C] = emu.gc_cut(fin[0], fin[1], C, cpg, ng)
+    assert np.array_equal(got.ravel(), want)
+    live = got.ravel()[:C]
+    assert sorted(live.tolist()) == list(range(C))
+
+
+@pytest.mark.parametrize("interp", ["nearest_neighbor", "multilinear"])
+def test_batches_of_many_groups_cut_into_pieces_of_the_fault(ctx, monkeypatch, interp):
+    """2600 chains = 6 chain groups (three levels of the cut, a 3 + 3 and 1 + 2 split, partial last group) of the fused
+    model: bitwise the batch taken group by group as the chains come (BEATAMD_GC_GLOBAL=0) and the streaming kernel's
+    likelihoods to rounding"""
+    from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
+    spec = SyntheticSpec((6,), (7,), (1.0,), T=2, N=64, D=3, S=25, interpolation=interp, time_bounds=(0.0, 2.0))
+    prob, host = build_problem(spec)
+    f = prob.compile(ctx)
+    C = 2600
+    Q = draw_population(spec, host["layout"], host["lower"], host["upper"], C)
+    if interp == "nearest_neighbor":
+        monkeypatch.setenv("BEATAMD_GS_CG", "512")   # (a library this small would be stacked in 128-chain groups)
+    B = f.batch(Q)
+    name = ctx.last_kernel()
+    assert name.startswith("k_gfstack_ws<" if interp == "nearest_neighbor" else "k_gfstack_runs<"), name
+    monkeypatch.setenv("BEATAMD_GC_GLOBAL", "0")
+    assert np.array_equal(f.batch(Q), B)
+    monkeypatch.delenv("BEATAMD_GC_GLOBAL")
+    assert np.array_equal(f.batch(Q[:1100]), B[:1100])
+    monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
+    A = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack<"), ctx.last_kernel()
+    np.testing.assert_allclose(A, B, rtol=1e-11, atol=1e-9)

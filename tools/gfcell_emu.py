@@ -87,24 +87,53 @@ def gf_tables_ml(st, du, st_min, st_dt, du_min, du_dt, D, S, T, P):
     return ro.astype(np.uint32), fa
 
 
+def gc_cut(F0, F1, C, cg, ngroups):
+    """numpy twin of k_gc_key0 / k_gc_cut / k_gc_members (gfcell.hip): the batch cut into ngroups groups of cg chain slots
+    by recursive bisection -- a range of groups [lo, hi) with more than one group is split into its first (hi - lo) // 2
+    groups and the rest along the key in which ITS chains spread wider (key 0 on a tie), the first part takes the
+    (hi - lo) // 2 * cg chains that come first by (key, chain id) -> members [C] (group g = members[g*cg : (g+1)*cg])"""
+    lo = np.zeros(C, dtype=np.int64)
+    hi = np.full(C, ngroups, dtype=np.int64)
+    allc = np.arange(C)
+    widest = ngroups
+    while widest > 1:
+        nlo, nhi = lo.copy(), hi.copy()
+        for a_, b_ in sorted(set(zip(lo.tolist(), hi.tolist()))):
+            if b_ - a_ <= 1:
+                continue
+            ids = allc[(lo == a_) & (hi == b_)]
+            f0, f1 = F0[ids], F1[ids]
+            f = f1 if (f1.max() - f1.min() > f0.max() - f0.min()) else f0
+            rank = np.argsort(np.lexsort((ids, f)))
+            half = (b_ - a_) // 2
+            left = rank < half * cg
+            nlo[ids] = np.where(left, a_, a_ + half)
+            nhi[ids] = np.where(left, a_ + half, b_)
+        lo, hi = nlo, nhi
+        widest -= widest // 2
+    members = np.empty(C, dtype=np.int64)
+    for g in range(ngroups):
+        ids = allc[lo == g]
+        members[g * cg:g * cg + ids.size] = ids
+    return members
+
+
 def gc_order(rowoff, C, T, P, S, sort=True, keys=None, global_members=True):
-    """numpy twin of k_gc_key0 / k_gc_members / k_gc_order (gfcell.hip): batches of several groups are cut into groups in
-    the order of the first key (C <= 4096), then inside a group: bands of whole wavefronts by the first key, inside a
-    band by the second; keys: optional (k0[C], k1[C]) of the caller (hypocentre strike / dip), else start-time indices
-    at patches 0, P/2"""
+    """numpy twin of the chain order (gfcell.hip): batches of several groups are cut into groups by gc_cut (C <= 8192, <= 64 groups),
+    then inside a group (k_gc_order): bands of whole wavefronts by the first key -- as many as make a wavefront's chains a
+    square piece of the group's extent in the two keys --, inside a band by the second; keys: optional (k0[C], k1[C]) of the
+    caller (hypocentre strike / dip), else start-time indices at patches 0, P/2 (five bands)"""
     ngroups = (C + CG - 1) // CG
     order = np.full(ngroups * CG, DEAD, dtype=np.uint32)
     allc = np.arange(C)
     if keys is not None:
         F0, F1 = [np.where(np.abs(k) <= 1.79e308, k, 0.0) for k in keys]
-        nb = 4
     else:
         F0 = (rowoff[allc, 0, 0, 3] % S).astype(np.float64)
         F1 = (rowoff[allc, 0, P // 2, 3] % S).astype(np.float64)
-        nb = 5
     members = allc
-    if sort and global_members and ngroups > 1 and C <= 4096:
-        members = np.lexsort((allc, F0))
+    if sort and global_members and 1 < ngroups <= 64 and C <= 8192:
+        members = gc_cut(F0, F1, C, CG, ngroups)
     for g in range(ngroups):
         cs = members[g * CG:min(C, (g + 1) * CG)]
         if not sort:
@@ -114,6 +143,11 @@ def gc_order(rowoff, C, T, P, S, sort=True, keys=None, global_members=True):
         f0, f1 = F0[cs], F1[cs]
         r0 = np.argsort(np.lexsort((tid, f0)))
         nw = (cs.size + NCH - 1) // NCH
+        nb = 5
+        if keys is not None:
+            e0, e1 = f0.max() - f0.min(), f1.max() - f1.min()
+            r = float(nw) * e0 / e1 if e1 > 0.0 else float(nw) * float(nw)
+            nb = max(1, min(nw, int(np.rint(np.sqrt(r)))))
         band = (r0 // NCH) * nb // nw
         r1 = np.argsort(np.lexsort((tid, f1, band)))
         order[g * CG + r1] = cs
