@@ -753,6 +753,16 @@ __global__ void __launch_bounds__(1024) k_gfstack_runs(GcArgs a)
 #if GR_NVARIANT > 1
 #define GR_VARIANT(V) if constexpr (VAR == V) { if (wave < GC_NCONS) { GR_CONSUMER_##V(paddr); } else { GC_LOADER_1(paddr); } }
     GR_VARIANT(1) GR_VARIANT(2) GR_VARIANT(3) GR_VARIANT(4) GR_VARIANT(5) GR_VARIANT(6)
+#if GR_NVARIANT > 7
+    GR_VARIANT(7) GR_VARIANT(8)
+#endif
+#if GR_NVARIANT > 9
+#define GR_VARIANT_NL(V) if constexpr (VAR == V) { if (wave < GC_NCONS) { GR_CONSUMER_##V(paddr); } }
+    GR_VARIANT_NL(9) GR_VARIANT_NL(10) GR_VARIANT_NL(11) GR_VARIANT_NL(12)
+#if GR_NVARIANT > 13
+    GR_VARIANT_NL(13) GR_VARIANT_NL(14) GR_VARIANT_NL(15) GR_VARIANT_NL(16)
+#endif
+#endif
 #endif
 }
 
@@ -886,7 +896,17 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
         {
             const int var = GfKnobs::get(kn.gr_var, 0);   // timing experiments (GR_ABLATIONS builds; wrong results)
             void (*vk[])(GcArgs) = {kern, k_gfstack_runs<1, 1>, k_gfstack_runs<1, 2>, k_gfstack_runs<1, 3>, k_gfstack_runs<1, 4>,
-                                    k_gfstack_runs<1, 5>, k_gfstack_runs<1, 6>};
+                                    k_gfstack_runs<1, 5>, k_gfstack_runs<1, 6>,
+#if GR_NVARIANT > 7
+                                    k_gfstack_runs<1, 7>, k_gfstack_runs<1, 8>,
+#endif
+#if GR_NVARIANT > 9
+                                    k_gfstack_runs<1, 9>, k_gfstack_runs<1, 10>, k_gfstack_runs<1, 11>, k_gfstack_runs<1, 12>,
+#endif
+#if GR_NVARIANT > 13
+                                    k_gfstack_runs<1, 13>, k_gfstack_runs<1, 14>, k_gfstack_runs<1, 15>, k_gfstack_runs<1, 16>,
+#endif
+                                    };
             if (var >= 1 && var < GR_NVARIANT) kern = vk[var];
         }
 #endif

@@ -50,6 +50,9 @@ import os
 
 NCHAIN = 37            # chains per consumer wavefront
 NCONS, NLOAD = 14, 2   # consumer / loader wavefronts
+if os.environ.get("GR_NCONS"):       # experiments (tools/build_ablations.sh): other splits of the sixteen wavefronts
+    NCONS = int(os.environ["GR_NCONS"])
+    NLOAD = 16 - NCONS
 NPOS = NCHAIN          # positions a consumer walks per step
 SCRATCH = NCHAIN       # accumulator slot of the pads
 LREQ = 46              # row requests per loader and step
@@ -295,6 +298,8 @@ def request_pair(p):
 def load_descriptors(first, count, byte_off):
     """scalar loads of the descriptor dwords of `count` chains from chain `first` on"""
     reg, dw, n_left = dreg(first), ddword(first), 2 * count
+    if 'nosm' in ABL and _in_loop[0]:    # (timing only: the descriptors of step 0 stay)
+        return
     while n_left:
         n = 16
         while n > n_left or reg % min(n, 4):
@@ -350,6 +355,9 @@ def fma4(r, xset):
 def load_next_first_half():
     """chains 0..NHALF-1 of the NEXT step (their registers are free) and its chain count"""
     load_descriptors(0, NHALF, DSTRIDE)
+    if 'nosm' in ABL and _in_loop[0]:
+        e("s_mov_b32 s%d, s%d" % (S_NCH_NEXT, S_NCH))
+        return
     e("s_load_dword s%d, %s, 0x%x" % (S_NCH_NEXT, sp(S_DP), DSTRIDE + 4 * D_NCH))
 
 
@@ -361,8 +369,9 @@ def step_advance(last_label):
     e("s_waitcnt vmcnt(%d)" % (AHEAD - 1))           # record 0 of the next step
     e("s_add_u32 s%d, s%d, %d" % (S_WP, S_WP, WSTRIDE))
     e("s_addc_u32 s%d, s%d, 0" % (S_WP + 1, S_WP + 1))
-    e("s_add_u32 s%d, s%d, %d" % (S_DP, S_DP, DSTRIDE))
-    e("s_addc_u32 s%d, s%d, 0" % (S_DP + 1, S_DP + 1))
+    if 'dfix' not in ABL:     # (timing only: every step reads the descriptor lines of steps 0 / 1 -- scalar-cache hits)
+        e("s_add_u32 s%d, s%d, %d" % (S_DP, S_DP, DSTRIDE))
+        e("s_addc_u32 s%d, s%d, 0" % (S_DP + 1, S_DP + 1))
 
 
 def block_one(r):
@@ -613,7 +622,11 @@ def clobbers(vlast):
     return c
 
 
-VARIANTS = [set(), {"nofma"}, {"nox"}, {"nonew"}, {"norec"}, {"one"}, {"one", "norec"}]
+# (variants 9-12 run WITHOUT loader wavefronts -- gfcell.hip lets them return --: the consumers alone, with and without
+# their s_barrier per step = what the barrier's skew between the fourteen consumers costs)
+VARIANTS = [set(), {"nofma"}, {"nox"}, {"nonew"}, {"norec"}, {"one"}, {"one", "norec"}, {"dfix"}, {"dfix", "norec"},
+            {"nobar"}, {"noload"}, {"nobar", "norec"}, {"noload", "norec"},
+            {"nobar", "nox"}, {"nobar", "nosm"}, {"nobar", "nox", "nosm", "norec"}, {"nobar", "nofma"}]
 
 
 def main():
