@@ -161,6 +161,18 @@ def test_row_passes_two_groups_and_a_full_buffer():
     assert stats[0].dma_bytes == int(tabs["ucount"][:2].sum()) * 512
 
 
+def test_emulator_catches_a_missing_wait():
+    """the emulator's loads are asynchronous (poison in the destination until the s_waitcnt that covers them; LDS-DMA rows
+    reach LDS at the loader's wait): a consumer program WITHOUT the waits of its new-cell blocks cannot pass"""
+    gen.ABL.add("nolgkm")
+    try:
+        with pytest.raises((AssertionError, IndexError, RuntimeError)):
+            _run(T=1, P=3, D=2, S=5, N=64, C=80, Ttab_is_one=True, mode=0, sort=True, nth=0, seed=11)
+    finally:
+        gen.ABL.discard("nolgkm")
+    _run(T=1, P=3, D=2, S=5, N=64, C=80, Ttab_is_one=True, mode=0, sort=True, nth=0, seed=11)
+
+
 def test_register_budget():
     """the programs stay inside the registers the kernel may use: 128 VGPRs (16 wavefronts per workgroup = 4 per SIMD)
     and user SGPRs below s96 (VCC, FLAT_SCRATCH, XNACK_MASK above); SGPR pairs used as addresses are even-aligned"""

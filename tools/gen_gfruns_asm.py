@@ -333,7 +333,7 @@ def reads(xset):
 
 
 def lgkm0():
-    if 'nox' not in ABL:
+    if 'nox' not in ABL and 'nolgkm' not in ABL:      # ('nolgkm': the emulator's test that a missing wait is caught)
         e("s_waitcnt lgkmcnt(0)")
 
 

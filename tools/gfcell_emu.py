@@ -400,6 +400,50 @@ class Wave(object):
         self.ninstr = 0
         self.fma_count = 0
         self.pad_fma_count = 0
+        # Loads are ASYNCHRONOUS: a destination register holds POISON from issue until the s_waitcnt that covers the load
+        # (LDS and vector-memory operations return in order, scalar loads do not: with a scalar load in flight only
+        # lgkmcnt(0) proves anything).  A program that uses a register before its wait computes NaN / indexes out of
+        # range / selects a wild accumulator, and the tests that compare results fail; LDS-DMA rows reach LDS at the
+        # loader's wait, not at issue.
+        self.pend_lds = []      # [(commit function)] in issue order
+        self.pend_sm = []
+        self.pend_vm = []
+
+    POISON_LO, POISON_HI, POISON_S = 0xDEADBEEF, 0x7FF8DEAD, 0xDEADBEEF
+
+    def _wait(self, ln):
+        mv = re.search(r"vmcnt\((\d+)\)", ln)
+        ml = re.search(r"lgkmcnt\((\d+)\)", ln)
+        if mv:
+            n = int(mv.group(1))
+            while len(self.pend_vm) > n:
+                self.pend_vm.pop(0)()
+        if ml:
+            n = int(ml.group(1))
+            if n == 0:
+                for f in self.pend_lds + self.pend_sm:
+                    f()
+                del self.pend_lds[:], self.pend_sm[:]
+            elif not self.pend_sm:
+                while len(self.pend_lds) > n:
+                    self.pend_lds.pop(0)()
+            # (a counted wait with scalar loads in flight guarantees nothing)
+
+    def _drain(self):
+        for f in self.pend_vm + self.pend_lds + self.pend_sm:
+            f()
+        del self.pend_vm[:], self.pend_lds[:], self.pend_sm[:]
+
+    def _load_v(self, queue, d, lanes, words):
+        """vector destination registers d.. <- words [nreg][64] for `lanes`, at the wait; poison until then"""
+        words = [np.array(w_, dtype=np.uint32) for w_ in words]
+        for kk in range(len(words)):
+            self.v[d + kk][lanes] = self.POISON_HI if (kk % 2 == 1) else self.POISON_LO
+
+        def commit():
+            for kk, w_ in enumerate(words):
+                self.v[d + kk][lanes] = w_[lanes]
+        queue.append(commit)
 
     # ---- operand access
     def sreg(self, name):
@@ -519,7 +563,10 @@ class Wave(object):
                                                       or op.startswith("ds_")):
                 raise RuntimeError("%s executed with a non-zero VGPR index" % op)
             # ------------------------------------------------ scalar
-            if op in ("s_nop", "s_waitcnt"):
+            if op == "s_nop":
+                continue
+            if op == "s_waitcnt":
+                self._wait(ln)
                 continue
             if op == "s_barrier":
                 self.nbarrier += 1
@@ -598,7 +645,12 @@ class Wave(object):
                 base = self.sreg(ops[1])
                 assert base[1] % 2 == 0, ln
                 addr = self.get_s64(ops[1]) + int(ops[2], 0)
-                self.s[r[1]:r[1] + n] = mem.read(addr, 4 * n).view(np.uint32)
+                vals = np.array(mem.read(addr, 4 * n).view(np.uint32), dtype=np.uint64)
+                self.s[r[1]:r[1] + n] = self.POISON_S
+
+                def commit_s(r0=r[1], n=n, vals=vals):
+                    self.s[r0:r0 + n] = vals
+                self.pend_sm.append(commit_s)
             # ------------------------------------------------ vector
             elif op == "v_mbcnt_lo_u32_b32":
                 self.wr32(self.vreg(ops[0]), np.minimum(np.arange(64), 32) + self.src32(ops[2]))
@@ -704,13 +756,15 @@ class Wave(object):
                 d = int(re.match(r"v\[(\d+):(\d+)\]", ops[0]).group(1))
                 areg = re.sub(r"\s+offset[01]:\d+", "", ops[1]).strip()
                 base_a = self.v[self.vreg(areg)].astype(np.int64)
+                words = [np.zeros(64, dtype=np.uint32) for _ in range(4)]
                 for half, o in enumerate((o0, o1)):
                     addr = base_a + 8 * o
                     for i in np.nonzero(self.lanes())[0]:
                         if not (0 <= addr[i] and addr[i] + 8 <= lds.size):
                             raise IndexError("LDS read out of range: %s lane %d addr %d" % (ln, i, addr[i]))
                         w = lds[addr[i]:addr[i] + 8].view(np.uint32)
-                        self.v[d + 2 * half][i], self.v[d + 2 * half + 1][i] = w[0], w[1]
+                        words[2 * half][i], words[2 * half + 1][i] = w[0], w[1]
+                self._load_v(self.pend_lds, d, self.lanes(), words)
             elif op in ("ds_read_b32", "ds_read_b64", "ds_write_b64"):
                 off = imm_off
                 m = self.lanes()
@@ -724,21 +778,30 @@ class Wave(object):
                     n = 4 if op == "ds_read_b32" else 8
                     addr = self.v[self.vreg(ops[1])].astype(np.int64) + off
                     d = self.vreg(ops[0])
+                    words = [np.zeros(64, dtype=np.uint32) for _ in range(n // 4)]
                     for i in np.nonzero(m)[0]:
                         if not (0 <= addr[i] and addr[i] + n <= lds.size):
                             raise IndexError("LDS read out of range: %s lane %d addr %d" % (ln, i, addr[i]))
                         w = lds[addr[i]:addr[i] + n].view(np.uint32)
-                        self.v[d][i] = w[0]
+                        words[0][i] = w[0]
                         if n == 8:
-                            self.v[d + 1][i] = w[1]
+                            words[1][i] = w[1]
+                    self._load_v(self.pend_lds, d, m, words)
             # ------------------------------------------------ global
             elif op == "global_load_lds_dwordx4":
                 base = self.get_s64(ops[1].replace(" nt", ""))
                 voff = self.v[self.vreg(ops[0])].astype(np.int64)
+                moves = []
                 for i in np.nonzero(self.lanes())[0]:
                     dst = self.m0 + 16 * i
                     assert PARAM_BYTES <= dst and dst + 16 <= lds.size, ("LDS-DMA destination", ln, dst)
-                    lds[dst:dst + 16] = mem.read(base + int(voff[i]), 16)
+                    moves.append((dst, np.array(mem.read(base + int(voff[i]), 16))))
+                    lds[dst:dst + 16] = 0xA5         # (not there yet)
+
+                def commit_dma(moves=moves):
+                    for dst, data in moves:
+                        lds[dst:dst + 16] = data
+                self.pend_vm.append(commit_dma)
                 self.wg.dma_bytes += 16 * int(self.lanes().sum())
             elif op in ("global_load_dwordx2", "global_load_dword", "global_load_dwordx3", "global_load_dwordx4"):
                 n = 16 if op.endswith("x4") else 12 if op.endswith("x3") else 8 if op.endswith("x2") else 4
@@ -747,10 +810,12 @@ class Wave(object):
                 base = self.get_s64(last)
                 voff = self.v[self.vreg(ops[1])].astype(np.int64)
                 d = self.vreg(ops[0])
+                words = [np.zeros(64, dtype=np.uint32) for _ in range(n // 4)]
                 for i in np.nonzero(self.lanes())[0]:
                     w = mem.read(base + int(voff[i]) + off, n).view(np.uint32)
                     for kk in range(n // 4):
-                        self.v[d + kk][i] = w[kk]
+                        words[kk][i] = w[kk]
+                self._load_v(self.pend_vm, d, self.lanes(), words)
             elif op == "global_store_dwordx2":
                 d = self.vreg(ops[1])
                 if ops[2] == "off":
@@ -762,6 +827,7 @@ class Wave(object):
                     mem.write(int(addr[i]), np.array([self.v[d][i], self.v[d + 1][i]], dtype=np.uint32).view(np.uint8))
             else:
                 raise NotImplementedError(ln)
+        self._drain()
         self.done = True
 
 
