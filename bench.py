@@ -511,10 +511,13 @@ def main():
                             "with the hypocentre chain order), accumulators through the VGPR index register with ONE scalar instruction per "
                             "chain (s_add_u32 m0, d, d: accumulator and new-cell bit), descriptors by scalar loads, weights-only record "
                             "ring a step ahead; a patch that touches more rows than a 104-slot LDS buffer holds is staged in row passes "
-                            "along the duration axis.  Timing-only builds on one box, config 3 (profiles/r4_variants.md): 13.7 ms as "
-                            "shipped, 11.1 without new-cell blocks, 10.0 also without record loads, 6.3 also without the FMAs (= the 38 GB "
-                            "of row traffic at 6.1 TB/s); the FMAs alone are 7.8 ms at the 2 GHz the part sustains -- what is left is "
-                            "per-wavefront instruction latency at four wavefronts per SIMD (128-VGPR budget)")
+                            "along the duration axis.  Timing-only builds on one box, config 3 (profiles/r5_variants.md, r4_variants.md): 13.4 ms as "
+                            "shipped; the consumer wavefronts ALONE (no loaders) 11.7, without their step barrier 10.8, also without row "
+                            "reads / scalar loads / records 9.4, without the FMAs 7.8 (the FMAs alone: 7.8 ms at 2 GHz); the loaders' 38 GB "
+                            "alone 6.3 (6.1 TB/s).  VALU 54 % busy, scalar unit 45 %, SQ_WAIT_ANY 58 % of the wavefront cycles "
+                            "(profiles/r5_runs_sq_counters.json): a wavefront walks a serial path per step and four wavefronts per SIMD "
+                            "(74 accumulator registers each) do not fill each other's waits; rows requested a cell ahead were built and "
+                            "measured (1.7 % slower, profiles/r5_rows_a_cell_ahead.patch)")
         return roof
 
     def attach_traffic(roof_d, summary_path):
