@@ -234,7 +234,8 @@ __global__ void __launch_bounds__(GC_TB) k_gc_order(GcOrderArgs a)
     int nb = 5;
     if (a.key[0].base && a.key[1].base) {
         const double e0 = mx0 - mn0, e1 = mx1 - mn1;
-        const double r = e1 > 0.0 ? (double)nw * e0 / e1 : (double)nw * (double)nw;
+        double r = e1 > 0.0 ? (double)nw * e0 / e1 : (double)nw * (double)nw;
+        if (!(r <= (double)nw * (double)nw)) r = (double)nw * (double)nw;      // (extents that overflow, inf / inf)
         nb = max(1, min(nw, (int)rint(sqrt(r))));
         if (a.nbands > 0) nb = min(nw, a.nbands);
     }

@@ -146,7 +146,10 @@ def gc_order(rowoff, C, T, P, S, sort=True, keys=None, global_members=True):
         nb = 5
         if keys is not None:
             e0, e1 = f0.max() - f0.min(), f1.max() - f1.min()
-            r = float(nw) * e0 / e1 if e1 > 0.0 else float(nw) * float(nw)
+            with np.errstate(all="ignore"):
+                r = float(nw) * e0 / e1 if e1 > 0.0 else float(nw) * float(nw)
+            if not (r <= float(nw) * float(nw)):       # (extents that overflow, inf / inf)
+                r = float(nw) * float(nw)
             nb = max(1, min(nw, int(np.rint(np.sqrt(r)))))
         band = (r0 // NCH) * nb // nw
         r1 = np.argsort(np.lexsort((tid, f1, band)))
