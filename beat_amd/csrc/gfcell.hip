@@ -763,6 +763,12 @@ __global__ void __launch_bounds__(1024) k_gfstack_runs(GcArgs a)
 #if GR_NVARIANT > 13
     GR_VARIANT_NL(13) GR_VARIANT_NL(14) GR_VARIANT_NL(15) GR_VARIANT_NL(16)
 #endif
+#if GR_NVARIANT > 17
+    GR_VARIANT(17)
+#endif
+#if GR_NVARIANT > 18
+    GR_VARIANT(18) GR_VARIANT(19) GR_VARIANT_NL(20) GR_VARIANT_NL(21) GR_VARIANT_NL(22)
+#endif
 #endif
 #endif
 }
@@ -906,6 +912,12 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
 #endif
 #if GR_NVARIANT > 13
                                     k_gfstack_runs<1, 13>, k_gfstack_runs<1, 14>, k_gfstack_runs<1, 15>, k_gfstack_runs<1, 16>,
+#endif
+#if GR_NVARIANT > 17
+                                    k_gfstack_runs<1, 17>,
+#endif
+#if GR_NVARIANT > 18
+                                    k_gfstack_runs<1, 18>, k_gfstack_runs<1, 19>, k_gfstack_runs<1, 20>, k_gfstack_runs<1, 21>, k_gfstack_runs<1, 22>,
 #endif
                                     };
             if (var >= 1 && var < GR_NVARIANT) kern = vk[var];

@@ -348,8 +348,10 @@ def fma4(r, xset):
     i, q = r // 4, r % 4
     x = XA if xset == 0 else XB
     for k in range(1 if 'one' in ABL else 4):
+        # ('indep', timing only: the four FMAs of a chain into four different registers -- no dependent chain)
+        dst = ACC - 2 * k if 'indep' in ABL else ACC
         e("v_fmac_f64_dpp %s, %s, %s row_newbcast:%d row_mask:0xf bank_mask:0xf"
-          % (vp(ACC), vp(rec_w(i)), vp(x + 2 * k), 4 * q + k))
+          % (vp(dst), vp(rec_w(i)), vp(x + 2 * k), 4 * q + k))
 
 
 def load_next_first_half():
@@ -397,11 +399,17 @@ def block_one(r):
             e("s_waitcnt vmcnt(%d)" % (AHEAD - 1))     # record pair of chain rn
         select(r)
         fma4(r, 0)
-        br("s_cbranch_scc0", "B%d_0" % rn)          # the next chain stays in the cell
-        idx0()
-        addresses(rn, 0)
-        reads(0)
-        lgkm0()
+        if 'nobr' in ABL:     # timing only: no new-cell test at all
+            pass
+        elif 'ool' in ABL:    # experiment: the new-cell block out of line, the common path falls through
+            br("s_cbranch_scc1", "NC%d" % r)
+            _ool.append(r)
+        else:
+            br("s_cbranch_scc0", "B%d_0" % rn)          # the next chain stays in the cell
+            idx0()
+            addresses(rn, 0)
+            reads(0)
+            lgkm0()
     else:
         step_advance("LAST_0")
         select(r)
@@ -416,6 +424,20 @@ def block_one(r):
         lgkm0()
         load_descriptors(NHALF, NPOS - NHALF, 0)
         br("s_branch", "B0_0")
+
+
+_ool = []
+
+
+def new_cell_blocks():
+    for r in _ool:
+        lab("NC%d" % r)
+        idx0()
+        addresses(r + 1, 0)
+        reads(0)
+        lgkm0()
+        br("s_branch", "B%d_0" % (r + 1))
+    del _ool[:]
 
 
 def exit_stubs():
@@ -476,6 +498,7 @@ def consumer():
     e("s_waitcnt lgkmcnt(0)")                          # the descriptor load ahead must not land in the epilogue's registers
     br("s_branch", "EPI")
     _in_loop[0] = True
+    new_cell_blocks()
     exit_stubs()
     _in_loop[0] = False
     epilogue(XA, XB, ACC, NCHAIN, True)
@@ -626,7 +649,8 @@ def clobbers(vlast):
 # their s_barrier per step = what the barrier's skew between the fourteen consumers costs)
 VARIANTS = [set(), {"nofma"}, {"nox"}, {"nonew"}, {"norec"}, {"one"}, {"one", "norec"}, {"dfix"}, {"dfix", "norec"},
             {"nobar"}, {"noload"}, {"nobar", "norec"}, {"noload", "norec"},
-            {"nobar", "nox"}, {"nobar", "nosm"}, {"nobar", "nox", "nosm", "norec"}, {"nobar", "nofma"}]
+            {"nobar", "nox"}, {"nobar", "nosm"}, {"nobar", "nox", "nosm", "norec"}, {"nobar", "nofma"},
+            {"ool"}, {"nobr"}, {"indep"}, {"nobar", "nobr"}, {"nobar", "indep"}, {"nobar", "nobr", "indep"}]
 
 
 def main():
