@@ -18,7 +18,7 @@ W_SCALAR, W_DENSE = 0, 1
 INTERPOLATIONS = {"nearest_neighbor": NEAREST_NEIGHBOR, "multilinear": MULTILINEAR}
 
 OK, EINVAL, EHIP, EINDEX, ENOMEM, ENAN, ENOTPSD, EBADCOV = 0, -1, -2, -3, -4, -5, -6, -7
-ABI_VERSION = 117   # include/beat_amd.h BEATAMD_VERSION this module was written against
+ABI_VERSION = 118   # include/beat_amd.h BEATAMD_VERSION this module was written against
 
 
 class BeatAmdError(RuntimeError):
@@ -70,6 +70,7 @@ _PROTOS = {
     "beatamd_weights_create": [_vp, _i32, _i64, _i64, _vp, _vp, _pi32],
     "beatamd_weights_update": [_vp, _i32, _i32, _i64, _vp, _vp],
     "beatamd_weights_destroy": [_vp, _i32],
+    "beatamd_weights_band": [_vp, _i32, _pi64],
     "beatamd_mvn_chol_logp_batch": [_vp, _i32, _i64, _vp, _vp, _vp],
     "beatamd_laplacian_create": [_vp, _i64, _vp, _f64, _pi32],
     "beatamd_laplacian_destroy": [_vp, _i32],

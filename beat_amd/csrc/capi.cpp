@@ -56,6 +56,10 @@ int wset_quad(beatamd_ctx *ctx, const WeightSet &w, int64_t C, const double *X, 
 {
     if (w.kind == BEATAMD_W_SCALAR)
         return launch_scalar_quad(ctx, C, w.nd, w.M, X, xs_c, xs_d, w.w, quad);
+    // banded whitening operators (the reference's "exponential" noise structure gives bidiagonal ones): two products per
+    // sample instead of a row of the dense matrix
+    if (w.band >= 0 && w.wb && GfKnobs::get(gf_knobs(ctx).qf_band, 1) != 0)
+        return launch_quadform_banded(ctx, w.wb, w.band, w.M, w.nd, C, X, xs_c, xs_d, quad, w.nd);
     QuadformCall q;
     q.A = w.w;
     q.a_stride = w.M * w.M;
@@ -497,6 +501,19 @@ static int wset_fill(beatamd_ctx *ctx, WeightSet *w, const double *weights, cons
         BA_HIP(hipMemcpyAsync(&flag, p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         BA_HIP(hipStreamSynchronize(ctx->stream));
         w->upper_tri = flag;
+        // banded?  (upper-triangular with nothing beyond a few columns right of the diagonal)
+        w->band = -1;
+        if (w->wb) { BA_HIP(hipFree(w->wb)); w->wb = nullptr; }
+        if (flag && w->M > 2 * QF_BAND_LIMIT) {
+            BA_TRY(ctx->get_scratch(SL_MISC, (size_t)w->nd * 8 + 64, &p));
+            int64_t band = -1;
+            BA_TRY(launch_band_detect(ctx, w->w, w->nd, w->M, p, &band));
+            if (band >= 0 && band <= QF_BAND_LIMIT) {
+                BA_TRY(dev_alloc_copy(ctx, nullptr, (size_t)(w->nd * w->M * (band + 1)) * sizeof(double), (void **)&w->wb));
+                BA_TRY(launch_band_pack(ctx, w->w, w->nd, w->M, band, w->wb));
+                w->band = band;
+            }
+        }
     }
     return BEATAMD_OK;
 }
@@ -538,6 +555,15 @@ int beatamd_weights_update(beatamd_ctx *ctx, int32_t wset_id, int32_t kind, int6
     return wset_fill(ctx, w, weights, slog_pdet);
 }
 
+int beatamd_weights_band(beatamd_ctx *ctx, int32_t wset_id, int64_t *band)
+{
+    ENTER(ctx);
+    WeightSet *w = get_obj(ctx->wsets, wset_id);
+    BA_CHECK(w && band, BEATAMD_EINVAL, "weights_band: unknown weight set %d", wset_id);
+    *band = (w->kind == BEATAMD_W_DENSE && w->wb && GfKnobs::get(gf_knobs(ctx).qf_band, 1) != 0) ? w->band : -1;
+    return BEATAMD_OK;
+}
+
 int beatamd_weights_destroy(beatamd_ctx *ctx, int32_t wset_id)
 {
     ENTER(ctx);
@@ -545,6 +571,7 @@ int beatamd_weights_destroy(beatamd_ctx *ctx, int32_t wset_id)
     BA_CHECK(w, BEATAMD_EINVAL, "unknown weight set %d", wset_id);
     BA_HIP(hipStreamSynchronize(ctx->stream));
     if (w->w) BA_HIP(hipFree(w->w));
+    if (w->wb) BA_HIP(hipFree(w->wb));
     if (w->slog) BA_HIP(hipFree(w->slog));
     ctx->wsets[wset_id].reset();
     return BEATAMD_OK;

@@ -72,6 +72,12 @@ struct WeightSet {
     double *w = nullptr;     // [nd] or [nd,M,M]
     double *slog = nullptr;  // [nd]
     int upper_tri = 0;       // dense only: exact zeros below the diagonal in every W
+    // dense only: every W is upper-triangular AND banded -- no entry further than `band` columns right of the diagonal
+    // exceeds 2^-40 of the largest entry of its matrix (-1: not banded / band > QF_BAND_MAX).  The whitening operator of
+    // the reference's "exponential" noise structure (covariance.py:24-51: C_ij = exp(-|i-j| dt / t0), a Markov kernel) is
+    // bidiagonal: band = 1.  wb [nd, M, band + 1]: row i = W[i, i .. i+band] (k_quadform_banded)
+    int64_t band = -1;
+    double *wb = nullptr;
 };
 
 struct Laplacian {
@@ -143,7 +149,7 @@ struct GfKnobs {
         ws_map = KNOB_UNSET, gs_pair = KNOB_UNSET, gs_nthint = KNOB_UNSET, gs_order = KNOB_UNSET, gs_fit = KNOB_UNSET,
         gs_win = KNOB_UNSET, gf_tinv = KNOB_UNSET, gs_tune = KNOB_UNSET, gf_order = KNOB_UNSET, gf_cgroup = KNOB_UNSET,
         gs_ml = KNOB_UNSET, gc_global = KNOB_UNSET, gc_sort = KNOB_UNSET, gc_keys = KNOB_UNSET, gc_bands = KNOB_UNSET, gr_cap = KNOB_UNSET,
-        gr_pass_alloc = KNOB_UNSET, gr_var = KNOB_UNSET, sweep_v1 = KNOB_UNSET;
+        gr_pass_alloc = KNOB_UNSET, gr_var = KNOB_UNSET, sweep_v1 = KNOB_UNSET, qf_band = KNOB_UNSET;
     void read_env();
     static int get(int v, int dflt) { return v == KNOB_UNSET ? dflt : v; }
     static bool is(int v, int x) { return v != KNOB_UNSET && v == x; }       // set and equal to x

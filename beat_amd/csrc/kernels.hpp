@@ -100,6 +100,13 @@ struct QuadformCall {
     int64_t q_stride = 0;
 };
 int launch_quadform(beatamd_ctx *ctx, const QuadformCall &call);
+// banded upper-triangular operators (quadform.hip): the half bandwidth of a stack of matrices (entries beyond it are at most
+// 2^-40 of their matrix's largest; scratch: nd * 8 + 8 bytes), the compact band [nd, M, band + 1], and the quadratic form on it
+constexpr int QF_BAND_LIMIT = 16;
+int launch_band_detect(beatamd_ctx *ctx, const double *A, int64_t nd, int64_t M, void *scratch, int64_t *band_host);
+int launch_band_pack(beatamd_ctx *ctx, const double *A, int64_t nd, int64_t M, int64_t band, double *wb);
+int launch_quadform_banded(beatamd_ctx *ctx, const double *wb, int64_t band, int64_t M, int64_t nd, int64_t C, const double *X,
+                           int64_t xs_c, int64_t xs_d, double *quad, int64_t q_stride);
 // several small dense datasets (M <= 512 each) of one residual matrix in one launch, MVN epilogue
 // included: LL[c*ld + d] = -0.5 (slog_d + M_d (2 h + log 2pi) + exp(-2h) |W_d x_{c,d}|^2), h = Q[c, hp_off_d]
 struct QuadformSmallCall {

@@ -355,4 +355,148 @@ int launch_check_upper_tri(beatamd_ctx *ctx, const double *A, int64_t nd, int64_
     return BEATAMD_OK;
 }
 
+// ---- banded upper-triangular operators -----------------------------------------------------------
+// The whitening operator W = chol(inv(C)).T of a Markov covariance -- the reference's "exponential" noise structure,
+// covariance.py:24-51: C_ij = exp(-|i-j| dt / t0) -- is BIDIAGONAL (inv(C) is tridiagonal); what numpy's inv + cholesky
+// leave outside the band is rounding residue, ~2e-15 of the largest entry.  multivariate_normal_chol
+// (distributions.py:119-138) then needs two products per sample, not a row of 4096: an HBM-bound pass over the
+// residuals instead of an FP64-MFMA GEMM.  A weight set qualifies when every matrix is upper-triangular (exact zeros
+// below) and no entry further than `band` <= QF_BAND_LIMIT (16) columns right of the diagonal exceeds 2^-40 of its matrix's
+// largest entry; the dropped terms change a whitened sample by at most M * 2^-40 of its largest term (3.7e-9 at M = 4096
+// if they all had one sign; ~6e-11 as rounding residue) -- far inside the path's tolerance (1e-6), and stated in the
+// header.  BEATAMD_QF_BAND=0 keeps the dense kernel (A/B and the dense-W bench legs).
+constexpr double QF_BAND_EPS = 9.094947017729282e-13;   // 2^-40
+
+__global__ void __launch_bounds__(256) k_band_maxabs(const double *A, int64_t nd, int64_t M, unsigned long long *mx)
+{
+    // mx[d] = bits of max |A_d| (non-negative doubles order like their bit patterns)
+    const int64_t per = M * M;
+    const int d = blockIdx.y;
+    unsigned long long m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
+        const double v = fabs(A[(int64_t)d * per + i]);
+        const unsigned long long u = (v == v) ? (unsigned long long)__double_as_longlong(v) : 0x7ff8000000000000ull;
+        m = u > m ? u : m;
+    }
+    for (int off = 32; off; off >>= 1) {
+        const unsigned long long o = __shfl_down(m, off);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(&mx[d], m);
+}
+
+__global__ void __launch_bounds__(256) k_band_width(const double *A, int64_t nd, int64_t M, const unsigned long long *mx,
+                                                    int *band)
+{
+    // band[0] = max over all matrices of (column - row) of an entry above eps * max|A_d|  (NaN / inf anywhere: M)
+    const int64_t per = M * M;
+    const int d = blockIdx.y;
+    const double big = __longlong_as_double((long long)mx[d]);
+    int b = 0;
+    if (!(big <= 1.79e308)) b = (int)min(M, (int64_t)0x7fffffff);
+    const double thr = big * QF_BAND_EPS;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / M, c = i % M;
+        if (c > r && fabs(A[(int64_t)d * per + i]) > thr) b = max(b, (int)(c - r));
+    }
+    for (int off = 32; off; off >>= 1) b = max(b, __shfl_down(b, off));
+    if ((threadIdx.x & 63) == 0 && b) atomicMax(band, b);
+}
+
+__global__ void __launch_bounds__(256) k_band_pack(const double *A, int64_t nd, int64_t M, int64_t band, double *wb)
+{
+    const int64_t n = nd * M * (band + 1);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t k = i % (band + 1), r = (i / (band + 1)) % M, d = i / ((band + 1) * M);
+    wb[i] = (r + k < M) ? A[(d * M + r) * M + r + k] : 0.0;
+}
+
+int launch_band_detect(beatamd_ctx *ctx, const double *A, int64_t nd, int64_t M, void *scratch, int64_t *band_host)
+{
+    // scratch: [nd] uint64 + one int
+    unsigned long long *mx = (unsigned long long *)scratch;
+    int *band = reinterpret_cast<int *>(mx + nd);
+    BA_HIP(hipMemsetAsync(scratch, 0, (size_t)nd * 8 + 8, ctx->stream));
+    const unsigned gx = (unsigned)std::min<int64_t>((M * M + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_band_maxabs, dim3(gx, (unsigned)nd), dim3(256), 0, ctx->stream, A, nd, M, mx);
+    hipLaunchKernelGGL(k_band_width, dim3(gx, (unsigned)nd), dim3(256), 0, ctx->stream, A, nd, M, mx, band);
+    BA_HIP(hipGetLastError());
+    int b = 0;
+    BA_HIP(hipMemcpyAsync(&b, band, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    BA_HIP(hipStreamSynchronize(ctx->stream));
+    *band_host = b;
+    return BEATAMD_OK;
+}
+
+int launch_band_pack(beatamd_ctx *ctx, const double *A, int64_t nd, int64_t M, int64_t band, double *wb)
+{
+    const int64_t n = nd * M * (band + 1);
+    hipLaunchKernelGGL(k_band_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, A, nd, M, band, wb);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
+// quad[c, d] = sum_i ( sum_{k <= band} wb[d, i, k] x[c, d, i + k] )^2.  Workgroup = (dataset, QB_NC chains); thread <->
+// samples i = tid, tid + 256, ...: its band rows stay in L1 / L2 over the chains, the residual row is read once, coalesced
+// (the band's neighbours hit the line just read).  Per chain: every thread sums its samples in ascending order, then a fixed
+// tree over the wavefront and over the four wavefronts -- the same bits on every launch and every rank.
+constexpr int QB_NC = 8;
+struct QbArgs {
+    const double *wb;
+    int64_t M, nd, C, band;
+    const double *X;
+    int64_t xs_c, xs_d;
+    double *quad;
+    int64_t q_stride;
+};
+
+__global__ void __launch_bounds__(256) k_quadform_banded(QbArgs a)
+{
+    __shared__ double red[QB_NC][4];
+    const int tid = threadIdx.x;
+    const int64_t d = blockIdx.y, c0 = (int64_t)blockIdx.x * QB_NC;
+    const int nc = (int)min((int64_t)QB_NC, a.C - c0);
+    const double *wb = a.wb + d * a.M * (a.band + 1);
+    double q[QB_NC];
+#pragma unroll
+    for (int j = 0; j < QB_NC; j++) q[j] = 0.0;
+    for (int64_t i = tid; i < a.M; i += 256) {
+        const double *wr = wb + i * (a.band + 1);
+        const int kmax = (int)min(a.band, a.M - 1 - i);
+#pragma unroll
+        for (int j = 0; j < QB_NC; j++) {
+            if (j >= nc) break;
+            const double *x = a.X + (c0 + j) * a.xs_c + d * a.xs_d + i;
+            double y = 0.0;
+            for (int k = 0; k <= kmax; k++) y = fma(wr[k], x[k], y);
+            q[j] = fma(y, y, q[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < QB_NC; j++) {
+        double v = q[j];
+        for (int off = 32; off; off >>= 1) v += __shfl_down(v, off);
+        if ((tid & 63) == 0) red[j][tid >> 6] = v;
+    }
+    __syncthreads();
+    if (tid < nc) a.quad[(c0 + tid) * a.q_stride + d] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
+}
+
+int launch_quadform_banded(beatamd_ctx *ctx, const double *wb, int64_t band, int64_t M, int64_t nd, int64_t C, const double *X,
+                           int64_t xs_c, int64_t xs_d, double *quad, int64_t q_stride)
+{
+    if (C == 0 || nd == 0) return BEATAMD_OK;
+    QbArgs a;
+    a.wb = wb; a.M = M; a.nd = nd; a.C = C; a.band = band;
+    a.X = X; a.xs_c = xs_c; a.xs_d = xs_d; a.quad = quad; a.q_stride = q_stride;
+    BA_CHECK(nd <= 65535, BEATAMD_EINVAL, "quadform_banded: too many datasets");
+    {
+        ScopedTimer tm(ctx, "quadform");
+        hipLaunchKernelGGL(k_quadform_banded, dim3((unsigned)((C + QB_NC - 1) / QB_NC), (unsigned)nd), dim3(256), 0, ctx->stream, a);
+    }
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
 }  // namespace beatamd

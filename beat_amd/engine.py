@@ -228,6 +228,13 @@ class Context(object):
         count = int(W.numel()) if _is_dev(W) else int(W.size)
         check(self._lib.beatamd_weights_update(self._h, wset_id, kind, count, ptr(W), ptr(sl)))
 
+    def weights_band(self, wset_id):
+        """half bandwidth a dense weight set is evaluated on (banded upper-triangular whitening operators, e.g. the
+        bidiagonal ones of the reference's "exponential" noise structure), -1: the dense kernel"""
+        b = C.c_int64()
+        check(self._lib.beatamd_weights_band(self._h, wset_id, C.byref(b)))
+        return b.value
+
     def weights_destroy(self, wset_id):
         check(self._lib.beatamd_weights_destroy(self._h, wset_id))
 

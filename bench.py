@@ -767,9 +767,19 @@ def main():
             f_ml.release()
         f_ml = None
         f_tp = None
+        def set_band(on):
+            """banded evaluation of upper-triangular whitening operators (beatamd_weights_band) on / off: the dense-W legs
+            below time the FP64-MFMA kernel, i.e. with the band OFF; `banded` entries say what the same model does by default"""
+            if on:
+                os.environ.pop("BEATAMD_QF_BAND", None)
+            else:
+                os.environ["BEATAMD_QF_BAND"] = "0"
+            ctx.reload_knobs()
+
         if legs & {"toeplitz", "pt", "prewhitened"}:
             Wd, slog_d = dense_weights()
             spec_tp = spec_with(covariance="toeplitz")
+            set_band(False)
         if "toeplitz" in legs:
             # chain-batched W.R on the FP64 matrix cores
             f_tp = variant(weights=Wd, slog=slog_d)
@@ -778,7 +788,7 @@ def main():
             qflops = 2.0 * T * N * N / 2.0 * B
             qa = qflops / (q_ms / max(q_n, 1) * 1e-3) / 1e12
             out["toeplitz_leg"] = {
-                "covariance": "Toeplitz sigma^2 exp(-|i-j| dt/T0), dt 0.5, T0 2: dense upper-triangular W (8.6 GB)",
+                "covariance": "Toeplitz sigma^2 exp(-|i-j| dt/T0), dt 0.5, T0 2: dense upper-triangular W (8.6 GB) through the dense FP64-MFMA kernel (BEATAMD_QF_BAND=0; the library's default for this operator is the banded evaluation: `banded`)",
                 "chains": B, "steps": Kl, "chain_steps_per_s": B * Kl / leg["dt"],
                 "ms_per_step": leg["dt"] / Kl * 1e3,
                 "kernel_ms_per_step": {k: (v[0] / Kl) for k, v in leg["times"].items() if v[1]},
@@ -791,6 +801,26 @@ def main():
                     "algorithmic_bytes_per_launch": T * N * N * 4.0 + 2.0 * B * T * N * 8.0,   # W's upper half + R in, once
                     "note": "v_mfma_f64_16x16x4_f64; a register-resident MFMA loop reaches 49.4 TF on this part "
                             "(tools/micro/mfma64.hip), nominal 78.6"}}
+            # the same model as the library evaluates it BY DEFAULT: this covariance is the reference's "exponential" noise
+            # structure (covariance.py:24-51), a Markov kernel whose whitening operator is bidiagonal up to rounding residue
+            set_band(True)
+            band = ctx.weights_band(f_tp.problem.wavemaps[0]._wset)
+            legb = run_leg(spec_tp, f_tp, B, Kl, 2, seed_offset=1000)
+            like_b = f_tp.batch(leg["Q"])[:, -1].clone()
+            set_band(False)
+            like_d = f_tp.batch(leg["Q"])[:, -1]
+            band_dev = float(((like_b - like_d).abs() / like_d.abs()).max().item())
+            qb_ms, qb_n = legb["times"]["quadform"]
+            out["toeplitz_leg"]["banded"] = {
+                "what": "the same weight set evaluated on its band (default: beatamd_weights_band; the dense figures of this leg "
+                        "are measured with BEATAMD_QF_BAND=0): W = chol(inv(C)).T of C_ij = exp(-|i-j| dt/T0) is bidiagonal, "
+                        "entries beyond the band are <= 2^-40 of the largest (rounding residue of inv + cholesky)",
+                "half_bandwidth": band, "chains": B, "steps": Kl, "chain_steps_per_s": B * Kl / legb["dt"],
+                "ms_per_step": legb["dt"] / Kl * 1e3,
+                "kernel_ms_per_step": {k: (v[0] / Kl) for k, v in legb["times"].items() if v[1]},
+                "quadform_kernel": "k_quadform_banded", "quadform_avg_launch_ms": qb_ms / max(qb_n, 1),
+                "quadform_bytes_per_launch": 8.0 * B * T * N + 8.0 * T * N * ((band or 1) + 1) * ((B + 7) // 8),
+                "max_rel_dev_of_like_vs_dense": band_dev}
             if B == 512 and T == 64 and N == 4096 and not env_knobs:
                 qsum = os.path.join(ROOT, "profiles", "r4_bench_c512_toeplitz_quadform128_summary.json")
                 if os.path.exists(qsum):
@@ -811,6 +841,14 @@ def main():
                     "chains": B, "steps": Kl, "chain_steps_per_s": B * Kl / leg["dt"], "ms_per_step": leg["dt"] / Kl * 1e3,
                     "kernel": leg["kernel"],
                     "kernel_ms_per_step": {k: (v[0] / Kl) for k, v in leg["times"].items() if v[1]}}}
+                set_band(True)
+                legb = run_leg(spec_mt, f_mt, B, Kl, 2, seed_offset=1000)
+                set_band(False)
+                out["default_config_leg"]["multilinear_banded_W"] = {
+                    "configuration": "the same model with the weight set evaluated on its band (the library's default)",
+                    "chains": B, "steps": Kl, "chain_steps_per_s": B * Kl / legb["dt"], "ms_per_step": legb["dt"] / Kl * 1e3,
+                    "kernel": legb["kernel"],
+                    "kernel_ms_per_step": {k: (v[0] / Kl) for k, v in legb["times"].items() if v[1]}}
                 f_mt.release()
                 f_mt = None
         if "pt" in legs:
@@ -920,6 +958,7 @@ def main():
             except (RuntimeError, MemoryError) as exc:   # not enough HBM for the copy beside other allocations
                 out["prewhitened_leg"] = {"skipped": str(exc)[:200]}
             torch.cuda.empty_cache()
+        set_band(True)       # (the dense-W legs above ran with the band off)
         if "fp32" in legs:
             # float-storage library (SURVEY 8(f) row 2 "optional fp32 layout"): float copy of the library, the
             # float64 storage rounded to the same values (LAST leg on the shared library for that reason); rows
@@ -1030,9 +1069,11 @@ def main():
                             traffic_tag, nch, "nn" if interp == "nearest_neighbor" else "ml",
                             "ws" if interp == "nearest_neighbor" else "runs")))
                     plan = ctx.gf_plan() if hasattr(ctx, "gf_plan") else None
+                    wband = [ctx.weights_band(wm._wset) for wm in prob_l.wavemaps if getattr(wm, "_wset", None) is not None]
                     res["%s_%d_chains" % ("nn" if interp == "nearest_neighbor" else "multilinear", nch)] = {
                         "chains": nch, "steps": n_steps, "chain_steps_per_s": nch * n_steps / leg["dt"],
                         "ms_per_step": leg["dt"] / n_steps * 1e3, "kernel": leg["kernel"], "plan": plan,
+                        "whitening_operator_half_bandwidth": wband,     # (-1: dense kernel / scalar weights)
                         "gfstack_avg_launch_ms": roof_l["avg_launch_ms"],
                         "gfstack_ms_per_512_chains": roof_l["avg_launch_ms"] * 512.0 / nch,
                         "kernel_ms_per_step": {k: (v[0] / n_steps) for k, v in leg["times"].items() if v[1]},

@@ -42,7 +42,7 @@ extern "C" {
 /* ABI revision: bumped whenever an entry point changes its signature or an error code is added
  * (1.1: beatamd_weights_update gained kind/count in round 2; BEATAMD_EBADCOV).  beat_amd/_lib.py
  * refuses a library whose revision differs from the header it was written against. */
-#define BEATAMD_VERSION 117
+#define BEATAMD_VERSION 118
 
 #define BEATAMD_NEAREST_NEIGHBOR 0 /* interpolation="nearest_neighbor" */
 #define BEATAMD_MULTILINEAR 1      /* interpolation="multilinear"      */
@@ -183,6 +183,15 @@ int beatamd_weights_create(beatamd_ctx *ctx, int32_t kind, int64_t ndatasets, in
 int beatamd_weights_update(beatamd_ctx *ctx, int32_t wset_id, int32_t kind, int64_t count,
                            const double *weights, const double *slog_pdet);
 int beatamd_weights_destroy(beatamd_ctx *ctx, int32_t wset_id);
+/* BANDED whitening operators.  The reference's "exponential" noise structure (beat/covariance.py:24-51:
+ * C_ij = exp(-|i-j| dt / t0), a Markov kernel) has a BIDIAGONAL W = chol(inv(C)).T -- what numpy's inv + cholesky leave
+ * outside the band is rounding residue (~2e-15 of the largest entry).  A DENSE weight set whose matrices are all
+ * upper-triangular with no entry further than 16 columns right of the diagonal above 2^-40 of its matrix's largest entry is
+ * therefore evaluated on its band (two products per sample for the bidiagonal case instead of a matrix row; the dropped
+ * entries change a whitened sample by < M * 2^-40 of its largest term, far inside the 1e-6 tolerance of the path).
+ * *band = the half bandwidth in use, -1 when the dense kernel is used.  BEATAMD_QF_BAND=0 (environment) keeps the dense
+ * kernel for every set. */
+int beatamd_weights_band(beatamd_ctx *ctx, int32_t wset_id, int64_t *band);
 /*   residuals [C, nd, M]   hp [C, nd] (hyperparameter already resolved per dataset,
  *   distributions.py:117-126)   ->   logpts [C, nd]                                  */
 int beatamd_mvn_chol_logp_batch(beatamd_ctx *ctx, int32_t wset_id, int64_t C,

@@ -1084,3 +1084,71 @@ def test_float_storage_lds_dma_kernel(ctx, monkeypatch, interp, covariance, C):
     for c in (0, C // 2, C - 1):
         ref, _ = problem_oracle.forward(host32, Q[c])
         np.testing.assert_allclose(L32[c], ref, rtol=1e-9)
+
+
+@pytest.mark.parametrize("M", [40, 300, 1030])
+def test_banded_whitening_operators(ctx, orc, monkeypatch, M):
+    """the reference's "exponential" noise structure (covariance.py:24-51) is a Markov kernel: W = chol(inv(C)).T is
+    bidiagonal up to rounding residue -> the weight set is evaluated on its band (k_quadform_banded).  Against the dense
+    kernel (BEATAMD_QF_BAND=0), the oracle's dense product, and: wider bands, a band too wide, a non-triangular matrix,
+    small matrices, update from banded to dense and back"""
+    rng = np.random.default_rng(M)
+    nd, C = 3, 37
+    Ws, slogs = [], []
+    for d in range(nd):
+        Cd = (0.3 + d) * orc.exponential_data_covariance(M, 0.5, 2.0)
+        Ws.append(orc.cov_chol_inverse(Cd))
+        slogs.append(orc.cov_log_pdet(Cd))
+    W = np.stack(Ws)
+    assert np.abs(np.triu(W, 2)).max() < 1e-13 * np.abs(W).max() and np.abs(np.triu(W, 1)).max() > 0.1 * np.abs(W).max()
+    wid = ctx.weights_create_dense(W, slogs)
+    assert ctx.weights_band(wid) == 1
+    res = rng.standard_normal((C, nd, M))
+    hp = rng.uniform(-1, 1, (C, nd))
+    out = ctx.mvn_chol_logp_batch(wid, res, hp)
+    monkeypatch.setenv("BEATAMD_QF_BAND", "0")
+    assert ctx.weights_band(wid) == -1
+    dense = ctx.mvn_chol_logp_batch(wid, res, hp)
+    monkeypatch.delenv("BEATAMD_QF_BAND")
+    np.testing.assert_allclose(out, dense, rtol=1e-10)
+    assert np.array_equal(out, ctx.mvn_chol_logp_batch(wid, res, hp))          # (fixed summation order)
+    for c in range(0, C, 9):
+        np.testing.assert_allclose(out[c], orc.multivariate_normal_chol(Ws, slogs, hp[c], res[c]), rtol=1e-10)
+    # a band of five (an upper-triangular operator built directly), one dataset with a narrower band
+    Wb = np.zeros((nd, M, M))
+    for d in range(nd):
+        for k in range(6 if d else 3):
+            Wb[d] += np.diag(rng.uniform(0.5, 1.5, M - k) * (0.5 ** k), k)
+    ctx.weights_update(wid, Wb, slogs)
+    assert ctx.weights_band(wid) == 5
+    out5 = ctx.mvn_chol_logp_batch(wid, res, hp)
+    for c in range(0, C, 9):
+        np.testing.assert_allclose(out5[c], orc.multivariate_normal_chol(list(Wb), slogs, hp[c], res[c]), rtol=1e-10)
+    # an entry far from the diagonal, just above / below the threshold (2^-40 of the largest entry)
+    far = Wb.copy()
+    far[1, 0, M - 1] = 2.0 ** -39 * np.abs(Wb[1]).max()
+    ctx.weights_update(wid, far, slogs)
+    assert ctx.weights_band(wid) == (-1 if M > 33 else 5)
+    far[1, 0, M - 1] = 2.0 ** -41 * np.abs(Wb[1]).max()
+    ctx.weights_update(wid, far, slogs)
+    assert ctx.weights_band(wid) == 5
+    # below the diagonal: not triangular -> dense
+    low = Wb.copy()
+    low[2, 5, 4] = 1e-300
+    ctx.weights_update(wid, low, slogs)
+    assert ctx.weights_band(wid) == -1
+    np.testing.assert_allclose(ctx.mvn_chol_logp_batch(wid, res, hp)[::9],
+                               [orc.multivariate_normal_chol(list(low), slogs, hp[c], res[c]) for c in range(0, C, 9)], rtol=1e-10)
+    # NaN in an operator: dense (and NaN out, as the reference)
+    bad = Wb.copy()
+    bad[0, 3, 3] = np.nan
+    ctx.weights_update(wid, bad, slogs)
+    assert ctx.weights_band(wid) == -1
+    ctx.weights_update(wid, W, slogs)
+    assert ctx.weights_band(wid) == 1
+    assert np.array_equal(ctx.mvn_chol_logp_batch(wid, res, hp), out)
+    ctx.weights_destroy(wid)
+    # small matrices stay with the dense kernel
+    wid = ctx.weights_create_dense(W[:, :20, :20].copy(), slogs)
+    assert ctx.weights_band(wid) == -1
+    ctx.weights_destroy(wid)
