@@ -451,6 +451,8 @@ struct QbArgs {
     int64_t q_stride;
 };
 
+// BAND1: the bidiagonal case with the loop over the band unrolled (the same two fused multiply-adds per sample)
+template <int BAND1>
 __global__ void __launch_bounds__(256) k_quadform_banded(QbArgs a)
 {
     __shared__ double red[QB_NC][4];
@@ -464,6 +466,23 @@ __global__ void __launch_bounds__(256) k_quadform_banded(QbArgs a)
     for (int64_t i = tid; i < a.M; i += 256) {
         const double *wr = wb + i * (a.band + 1);
         const int kmax = (int)min(a.band, a.M - 1 - i);
+        if (BAND1) {
+            const double w0 = wr[0], w1 = wr[1];          // (w1 = 0 in the last row)
+            double x0[QB_NC], x1[QB_NC];
+#pragma unroll
+            for (int j = 0; j < QB_NC; j++) {
+                const double *x = a.X + (c0 + min(j, nc - 1)) * a.xs_c + d * a.xs_d + i;
+                x0[j] = x[0];
+                x1[j] = kmax ? x[1] : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < QB_NC; j++) {
+                double y = fma(w0, x0[j], 0.0);
+                if (kmax) y = fma(w1, x1[j], y);
+                if (j < nc) q[j] = fma(y, y, q[j]);
+            }
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < QB_NC; j++) {
             if (j >= nc) break;
@@ -493,7 +512,9 @@ int launch_quadform_banded(beatamd_ctx *ctx, const double *wb, int64_t band, int
     BA_CHECK(nd <= 65535, BEATAMD_EINVAL, "quadform_banded: too many datasets");
     {
         ScopedTimer tm(ctx, "quadform");
-        hipLaunchKernelGGL(k_quadform_banded, dim3((unsigned)((C + QB_NC - 1) / QB_NC), (unsigned)nd), dim3(256), 0, ctx->stream, a);
+        const dim3 grid((unsigned)((C + QB_NC - 1) / QB_NC), (unsigned)nd);
+        if (band == 1) hipLaunchKernelGGL(k_quadform_banded<1>, grid, dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(k_quadform_banded<0>, grid, dim3(256), 0, ctx->stream, a);
     }
     BA_HIP(hipGetLastError());
     return BEATAMD_OK;
