@@ -110,3 +110,28 @@ def test_metrop_and_pt_decisions():
     assert not orc.metrop_accept(1.0, np.nan, -12.0, -100.0)       # non-finite never accepted
     assert orc.pt_swap_accept(1.0, 0.5, -20.0, -10.0, np.log(0.9))  # alpha = +5
     assert not orc.pt_swap_accept(1.0, 0.5, -10.0, -20.0, np.log(0.9))
+
+
+def test_whitening_operator_of_the_exponential_structure_is_bidiagonal():
+    """the premise of the banded evaluation (beatamd_weights_band): the reference's "exponential" noise
+    structure (beat/covariance.py:24-51: C_ij = exp(-|i-j| dt / t0)) is a Markov kernel -- inv(C) is tridiagonal, so
+    W = cholesky(inv(C)).T (heart.py:211-237) is BIDIAGONAL; what numpy's inv + cholesky leave outside the band is rounding
+    residue far below the library's threshold 2^-40 of the largest entry.  Its closed form (AR(1) innovations):
+    W[i,i] = 1/sqrt(1-a^2), W[i,i+1] = -a/sqrt(1-a^2) for i < n-1, W[n-1,n-1] = 1, a = exp(-dt/t0)"""
+    from oracle import oracle as orc
+    n, dt, t0 = 700, 0.5, 2.0
+    C = orc.exponential_data_covariance(n, dt, t0)
+    W = orc.cov_chol_inverse(3.7 * C)
+    big = np.abs(W).max()
+    assert np.abs(np.tril(W, -1)).max() == 0.0
+    assert np.abs(np.triu(W, 2)).max() < 2.0 ** -40 * big and np.abs(np.triu(W, 2)).max() < 1e-13 * big
+    a = np.exp(-dt / t0)
+    d = np.full(n, 1.0 / np.sqrt(1.0 - a * a))
+    d[-1] = 1.0
+    np.testing.assert_allclose(np.diag(W) * np.sqrt(3.7), d, rtol=1e-11)
+    np.testing.assert_allclose(np.diag(W, 1) * np.sqrt(3.7), np.full(n - 1, -a / np.sqrt(1.0 - a * a)), rtol=1e-11)
+    # a covariance with a dense term added (a model-prediction covariance) has no band: the dense kernel's case
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((n, 40))
+    Wd = orc.cov_chol_inverse(C + 0.05 * A @ A.T / 40.0)
+    assert np.abs(np.triu(Wd, 17)).max() > 1e-6 * np.abs(Wd).max()
