@@ -127,7 +127,6 @@ int ffi_logp_device(beatamd_ctx *ctx, FfiModel &m, int64_t C, const double *Q, d
             k.order_key[0] = ChainVec{Q, np, m.layout.nuc_strike_off};   // (scheduling hint of k_gfstack_runs)
             k.order_key[1] = ChainVec{Q, np, m.layout.nuc_dip_off};
             k.st.shift_off = wm.shift_off;
-    k.st.nslot = wm.nslot; k.st.tslot = wm.tslot; k.st.slot_shift_off = wm.slot_shift_off;
             k.st.nslot = wm.nslot; k.st.tslot = wm.tslot; k.st.slot_shift_off = wm.slot_shift_off;
             k.st.chain_bad = chain_bad;
             k.interp = wm.interp;
