@@ -1343,13 +1343,29 @@ k_gfstack_ws(GsArgs a)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (MODE == GF_RESID_STORE) {
-        double *o = a.out + (c * a.T + t) * N + n0;
+        // A lane holds 64 consecutive samples of ITS chain: stored directly, every store instruction scatters 64 x 8 bytes
+        // over 64 rows of the residual matrix (T*N*8 bytes apart) -- 1 GB that way costs 0.8 ms of a 7 ms launch.  Through a
+        // per-wavefront LDS tile [64 chains][16 samples] (pitch 17) the same values leave as 128-byte runs: lane = (chain
+        // 4k + lane / 16, sample lane % 16), four full lines per instruction.  The row ring is free (barrier above).
+        constexpr int TP = 17;
+        double *tw = xbuf + GS_NT + wave * (64 * TP);
+        const uint32_t cu = (uint32_t)min(c, (int64_t)0xffffffff);
+        const int sl = lane & 15;
 #pragma unroll
-        for (int i0 = 0; i0 < GS_NT; i0 += 8) {
+        for (int i0 = 0; i0 < GS_NT; i0 += 16) {
 #pragma unroll
-            for (int i = i0; i < i0 + 8; i++)
-                if (live && i < nvalid) o[i] = xbuf[i] - acc[i];  // seismic.py:1332
-            __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < 16; i++) tw[lane * TP + i] = xbuf[i0 + i] - acc[i0 + i];  // seismic.py:1332
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const double v = tw[(k * 4 + (lane >> 4)) * TP + sl];
+                const int64_t cc = (int64_t)(uint32_t)__shfl((int)cu, k * 4 + (lane >> 4));   // chain of the row this lane stores
+                if (cc < a.C && i0 + sl < nvalid) a.out[(cc * a.T + t) * N + n0 + i0 + sl] = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     } else {
         const double w = a.wscalar[t];
@@ -2221,7 +2237,7 @@ static int launch_gfstack_ws(beatamd_ctx *ctx, const GfStackCall &k, const uint3
     // three row buffers of cap slots + the zero row each
     size_t lds = f32 ? (size_t)(cap + 1) * (64 + 2) * sizeof(float) * 3
                      : (size_t)(cap + 1) * (64 + (pair64 ? 2 : 1)) * sizeof(double) * 3;
-    lds = std::max<size_t>(lds, 64 * sizeof(double));   // the epilogue's data tile
+    lds = std::max<size_t>(lds, (64 + 8 * 64 * 17) * sizeof(double));   // the epilogue's data tile + the residual-store tiles of the 8 consumers
     BA_CHECK(lds <= 160 * 1024, BEATAMD_EINVAL, "internal: k_gfstack_ws row buffers exceed LDS");
     if (f32 || pair64)
         snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack_ws%s<%d,%d,%d>", f32 ? "32" : "p64", k.mode, a.ws,
