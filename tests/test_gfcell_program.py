@@ -328,3 +328,19 @@ def test_pass_partition_invariants():
                     i += 1
                 nreq += 1
             assert nreq <= emu.NLOAD * emu.LREQ, (D, S, cap, nreq)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_runs_program_random_shapes(seed):
+    """seeded random shapes through the emulator (asynchronous loads) against the reference arithmetic: grids from one node
+    to 6 x 10, one to 120 chains (partial wavefronts, two groups never -- those have their own tests), one or two slip
+    variables, every epilogue, small row buffers (row passes), sorted and unsorted chain order, times below the grid"""
+    rng = np.random.default_rng(1000 + seed)
+    D, S = int(rng.integers(1, 7)), int(rng.integers(1, 11))
+    cap = [None, 12, 16][int(rng.integers(0, 3))]
+    if cap is not None and (D * (S + 1) <= cap or S + 1 > cap // 2):
+        cap = None       # (a buffer holds at least two start-time nodes of a duration line pair)
+    _run(T=int(rng.integers(1, 3)), P=int(rng.integers(1, 5)), D=D, S=S, N=[64, 70][int(rng.integers(0, 2))],
+         C=int(rng.integers(1, 121)), Ttab_is_one=bool(rng.integers(0, 2)), mode=int(rng.integers(0, 3)),
+         sort=bool(rng.integers(0, 2)), nth=int(rng.integers(0, 2)), seed=seed, below_grid=bool(rng.integers(0, 2)) and D > 1 and S > 1,
+         nvar=int(rng.integers(1, 3)), cap=cap)
