@@ -41,6 +41,95 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable
 LDS_PEAK_GBS = 256 * 256 * 2.4   # 256 CUs x 256 B/clk (ds_read_b64, MI355X_MICROARCH.md LDS table) x 2.4 GHz
 FP64_VALU_PEAK_TFLOPS = 78.6
 
+LINE_CAP = 8192      # the driver keeps an 8 KB tail of stdout: the LAST line must fit in it with room to spare
+
+
+def _r(x, sig=5):
+    """float -> `sig` significant digits (ints, None, strings pass)"""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float("%.*g" % (sig, x))
+
+
+def _leg_summaries(out):
+    """one {cps, ms, k, frac} entry per timed leg of the full result object, keyed by its path"""
+    legs = {}
+
+    def visit(path, d):
+        cps = d.get("chain_steps_per_s", d.get("chain_steps_per_s_sampling_only"))
+        if cps is not None and path:
+            e = {"cps": _r(float(cps), 4)}
+            ms = d.get("ms_per_step", d.get("ms_per_step_incl_exchange", d.get("gfstack_avg_launch_ms", d.get("avg_launch_ms"))))
+            if ms is not None:
+                e["ms"] = _r(float(ms), 4)
+            roof = d.get("roofline") if isinstance(d.get("roofline"), dict) else (d if "frac" in d else None)
+            k = d.get("kernel") or (roof or {}).get("kernel")
+            if k:
+                e["k"] = k.replace(" ", "")
+            if roof is not None and roof.get("frac") is not None:
+                e["frac"] = _r(float(roof["frac"]), 3)
+                if roof.get("traffic") is not None:
+                    e["pmc"] = 1          # (frac from counter bytes of a committed summary of the same command)
+            legs[path] = e
+        for k_, v in d.items():
+            if isinstance(v, dict) and k_ not in ("roofline", "config", "cpu_baseline", "stage_transition",
+                                                  "roofline_quadform", "plan", "split_s"):
+                visit((path + "." if path else "") + k_.replace("_leg", ""), v)
+
+    visit("", {k: v for k, v in out.items() if isinstance(v, dict)})
+    return legs
+
+
+def compact_line(out, full_path=None):
+    """The ONE stdout line of a run: the contract fields, `roofline` (counter-based fraction where a PMC summary of the same
+    command is committed), `roofline_streaming` (SURVEY 8(d)'s algorithmic bytes, no cross-chain reuse), `cpu_baseline` and a
+    one-entry-per-leg summary.  Everything else (notes, plans, per-kernel splits) goes to the full object on disk.
+    Guaranteed < LINE_CAP bytes: legs are dropped from the end, then strings cut, before the cap is ever exceeded."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "repeats")
+    line = {k: _r(out[k], 6) for k in keep if k in out}
+    cfg = out.get("config", {})
+    line["config"] = {k: cfg[k] for k in ("workload", "chains_per_gpu", "global_chains", "parallelism") if k in cfg}
+    if cfg.get("env_knobs"):
+        line["config"]["env_knobs"] = cfg["env_knobs"]
+    rk = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms",
+          "hbm_counter_frac", "hbm_required_bytes_per_launch", "hbm_frac_required_bytes", "fp64_valu_frac", "lds_frac",
+          "frac_basis", "traffic_source", "launches", "chains")
+    for name in ("roofline", "roofline_streaming"):
+        if isinstance(out.get(name), dict):
+            line[name] = {k: _r(out[name][k], 5) for k in rk if k in out[name]}
+    if isinstance(out.get("cpu_baseline"), dict):
+        ck = ("value", "unit", "cores", "kind", "sample", "value_1core", "value_1core_numpy_reference_path",
+              "cgroup_cpu_quota_cores", "cpus_visible")
+        line["cpu_baseline"] = {k: _r(out["cpu_baseline"][k], 5) for k in ck if k in out["cpu_baseline"]}
+    for k in ("speedup_vs_cpu_baseline", "stage_transition_ms", "in_box_fraction", "setup_s"):
+        if k in out:
+            line[k] = _r(out[k], 5)
+    if isinstance(out.get("stage_transition"), dict):
+        line["stage_transition"] = out["stage_transition"]       # (ranks in the all-gather, population checksum: ~200 bytes)
+    if "kernel_ms_per_step" in out:
+        line["kernel_ms_per_step"] = {k: _r(v, 4) for k, v in out["kernel_ms_per_step"].items()}
+    legs = _leg_summaries(out)
+    legs.pop("roofline_streaming", None)
+    line["legs"] = legs
+    if full_path:
+        line["full"] = os.path.basename(full_path)
+    txt = json.dumps(line, separators=(",", ":"), allow_nan=False)
+    names = list(legs)
+    while len(txt) >= LINE_CAP - 512 and names:       # never reached by the shipped set of legs (tests/test_bench_contract.py)
+        legs.pop(names.pop())
+        line["legs_truncated"] = True
+        txt = json.dumps(line, separators=(",", ":"), allow_nan=False)
+    if len(txt) >= LINE_CAP - 512:
+        line["config"]["workload"] = line["config"].get("workload", "")[:200]
+        if "cpu_baseline" in line:
+            line["cpu_baseline"]["sample"] = str(line["cpu_baseline"].get("sample", ""))[:120]
+        txt = json.dumps(line, separators=(",", ":"), allow_nan=False)
+    assert len(txt) < LINE_CAP, len(txt)
+    return txt
+
 
 def algorithmic_bytes_per_chain_step(spec, nvar=1):
     """gathered rows + index/slip tables + the data read of the fused
@@ -259,6 +348,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="timed regions of --steps steps each; `value` is their median")
+    ap.add_argument("--full-json", default=os.path.join(ROOT, "bench_full.json"),
+                    help="where the complete result object (all legs, notes) is written; stdout gets the compact line")
     ap.add_argument("--chains", type=int, default=512, help="chains per GPU per step")
     ap.add_argument("--interp", default="nearest_neighbor",
                     choices=["nearest_neighbor", "multilinear"])
@@ -369,9 +462,10 @@ def main():
             parts.append(draw((min(PBLK, n_chains - j * PBLK),) + tail, gen))
         return torch.cat(parts, 0)
 
-    def run_leg(spec_leg, f_leg, n_chains, n_steps, n_warm, seed_offset, beta=2e-6):
-        """n_steps timed astep batches of n_chains chains; everything resident in HBM beforehand.
-        -> dict(dt, kernel times, in-box fraction, acceptance)"""
+    def run_leg(spec_leg, f_leg, n_chains, n_steps, n_warm, seed_offset, beta=2e-6, repeats=1):
+        """`repeats` timed regions of n_steps astep batches of n_chains chains each (every region bracketed by a barrier
+        and a device synchronisation on both sides); everything resident in HBM beforehand.
+        -> dict(dt = median region, dts, kernel times over all regions, in-box fraction, acceptance)"""
         box = host_of[spec_leg]
         lay_l = box.get("layout", lay)   # the legs of the main library share its parameter layout; only the prior box differs
         Q0 = torch.from_numpy(draw_population(spec_leg, lay_l, box["lower"], box["upper"], n_chains,
@@ -381,7 +475,7 @@ def main():
         L0 = f_leg.batch(Q0)
         # proposal rows: proposal_samples_array[stage_sample] of every chain (metropolis.py:289-313)
         first = seed_offset - 1000      # (the global index of this leg's first chain)
-        nsw = n_steps + n_warm
+        nsw = n_steps * repeats + n_warm
         delta = seeded_blocks(lambda shp, g: torch.randn(shp, generator=g, device=dev, dtype=torch.float64),
                               n_chains, first, (nsw, lay_l.size)).permute(1, 0, 2).contiguous()
         delta = delta * (args.step_scale * (up_s - lo_s))
@@ -405,31 +499,37 @@ def main():
         ctx.enable_timing(True)
         ctx.reset_timing()
         n_acc = 0
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(n_warm, n_warm + n_steps):
-            step(i)
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        dt = time.perf_counter() - t0
+        dts = []
+        for rep in range(repeats):
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n_warm + rep * n_steps, n_warm + (rep + 1) * n_steps):
+                step(i)
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            dts.append(time.perf_counter() - t0)
         ctx.synchronize()
         n_acc = int(accepted.sum().item())
+        # (device-event sums over all regions, divided by the launches they cover: per-launch averages)
         times = {k: ctx.kernel_time(k) for k in ("sweep", "tables", "grouptables", "gfstack", "quadform",
                                                  "finish", "astep")}
         ctx.enable_timing(False)
-        return dict(dt=dt, times=times, in_box=in_box, accept_last=n_acc / float(n_chains),
+        return dict(dt=sorted(dts)[len(dts) // 2], dts=dts, times=times, in_box=in_box,
+                    accept_last=n_acc / float(n_chains), steps_timed=n_steps * repeats,
                     kernel=ctx.last_kernel(), stats=ctx.gf_group_stats(), Q=Q0, L=L0)
 
     host_of = {spec: host}
-    main_leg = run_leg(spec, f, B, K, W, seed_offset=1000 + rank * B)
-    dt = main_leg["dt"]
-    tmax = torch.tensor([dt], device="cpu" if backend == "gloo" else dev, dtype=torch.float64)
+    # `value`: the MEDIAN of `--repeats` timed regions of exactly K steps each (max over ranks per region)
+    R = max(1, args.repeats)
+    main_leg = run_leg(spec, f, B, K, W, seed_offset=1000 + rank * B, repeats=R)
+    tmax = torch.tensor(main_leg["dts"], device="cpu" if backend == "gloo" else dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt_max = float(tmax.item())
+    region_s = [float(x) for x in tmax.tolist()]
+    dt_max = sorted(region_s)[len(region_s) // 2]
 
     # ---- SMC stage transition on the end points of the timed steps (select_end_points ->
     # calc_beta -> proposal factor -> resample -> restart points, smc.py:133-324): all-gather over
@@ -475,17 +575,17 @@ def main():
         hbm_frac = need_bytes / t / 1e9 / HBM_PEAK_GBS if gf_n else 0.0
         lds_frac = lds_floor_ms / avg_ms if (gf_n and shared) else 0.0
         valu_frac = flops / t / 1e12 / FP64_VALU_PEAK_TFLOPS if gf_n else 0.0
-        bound = "lds" if (shared and lds_frac > hbm_frac) else "hbm"
-        if ml_runs and valu_frac > max(hbm_frac, lds_frac):
-            bound = "fp64_valu"   # the largest of its fractions; see `note` for what actually limits it
+        # `bound`/`frac`: HBM bytes the kernel has to move (distinct rows, = what the PMC counters read: attach_traffic
+        # replaces the figure by the counter bytes when a summary of the same command is committed) over the peak; the LDS-gather
+        # and FP64 fractions and SURVEY 8(d)'s independent-chain byte count ride along as figures
         roof = {
-            "bound": bound,
+            "bound": "hbm",
             "kernel": leg["kernel"],
-            "achieved": (flops / t / 1e12 if bound == "fp64_valu" else
-                         (lds_bytes if bound == "lds" else need_bytes) / t / 1e9) if gf_n else 0.0,
-            "peak": FP64_VALU_PEAK_TFLOPS if bound == "fp64_valu" else (LDS_PEAK_GBS if bound == "lds" else HBM_PEAK_GBS),
-            "unit": "TFLOP/s" if bound == "fp64_valu" else "GB/s",
-            "frac": valu_frac if bound == "fp64_valu" else (lds_frac if bound == "lds" else hbm_frac),
+            "achieved": need_bytes / t / 1e9 if gf_n else 0.0,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": hbm_frac,
+            "frac_basis": "required bytes (distinct rows + tables) / HIP-event launch time",
             # HBM bytes per launch from the PMC counters of the same command (profiles/), else null
             "traffic": None,
             "hbm_frac_required_bytes": hbm_frac,
@@ -497,6 +597,7 @@ def main():
             "lds_gather_bytes_per_launch": lds_bytes,
             "lds_floor_ms": lds_floor_ms,
             "fp64_valu_frac": valu_frac,
+            "fp64_flops_per_launch": flops,
             "algorithmic_bytes_per_launch": alg,
             "algorithmic_equiv_GBs": alg / t / 1e9 if gf_n else 0.0,
             "avg_launch_ms": avg_ms,
@@ -539,6 +640,9 @@ def main():
         roof_d["traffic_source"] = os.path.relpath(summary_path, ROOT)
         roof_d["traffic_measured_in"] = "builder rocprofv3 --pmc passes of the same command (not this run)"
         roof_d["hbm_counter_frac"] = tr / (roof_d["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        roof_d["achieved"] = tr / (roof_d["avg_launch_ms"] * 1e-3) / 1e9
+        roof_d["frac"] = roof_d["hbm_counter_frac"]
+        roof_d["frac_basis"] = "PMC counter bytes (FETCH_SIZE x 2 + WRITE_SIZE) / HIP-event launch time"
 
     out = None
     if rank == 0:
@@ -575,7 +679,8 @@ def main():
                 "env_knobs": {k: os.environ[k] for k in env_knobs},
             },
             "roofline": roof,
-            "kernel_ms_per_step": {k: (v[0] / K) for k, v in main_leg["times"].items() if v[1]},
+            "kernel_ms_per_step": {k: (v[0] / main_leg["steps_timed"]) for k, v in main_leg["times"].items() if v[1]},
+            "repeats": R, "region_s": region_s,
             "in_box_fraction": main_leg["in_box"],
             "accept_rate_last_step": main_leg["accept_last"],
             "stage_transition_ms": stage_ms,
@@ -1145,7 +1250,20 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        # the complete object (every leg with its notes, plans, splits) goes to disk; stdout ends with ONE compact line
+        full_path = None
+        try:
+            with open(args.full_json, "w") as fh:
+                json.dump(out, fh, indent=1)
+            full_path = args.full_json
+            gdir = os.path.join(ROOT, "gpurun_out")
+            if os.path.isdir(gdir) and os.path.dirname(os.path.abspath(args.full_json)) != gdir:
+                with open(os.path.join(gdir, os.path.basename(args.full_json)), "w") as fh:
+                    json.dump(out, fh, indent=1)
+        except OSError as exc:
+            print("bench.py: full result not written (%s)" % exc, file=sys.stderr)
+        sys.stderr.flush()
+        print(compact_line(out, full_path), flush=True)
     if use_dist:
         dist.destroy_process_group()
 

@@ -30,3 +30,54 @@ def test_cpu_baseline_leg_small():
     assert set(out) >= {"value", "unit", "cores", "kind", "sample", "value_1core"}
     assert out["kind"] == "port" and out["unit"] == "chain-steps/s" and out["value"] > 0
     assert out["cores"] == len(os.sched_getaffinity(0))
+
+
+def _stub_result(n_extra_legs=0):
+    """a full result object of the shape bench.py builds (last round's committed one), with its verbose notes"""
+    import json
+    out = json.load(open(os.path.join(ROOT, "profiles", "r5_bench_default.json")))
+    for i in range(n_extra_legs):
+        out["extra_%d_leg" % i] = {"chain_steps_per_s": 1234.5 + i, "ms_per_step": 3.21, "kernel": "k_gfstack_ws<1,1,3,1>",
+                                   "note": "x" * 700, "roofline": {"frac": 0.5, "kernel": "k_gfstack_ws<1,1,3,1>"}}
+    return out
+
+
+def test_bench_line_is_compact_strict_json():
+    """the driver keeps an 8 KB tail of stdout and could not take the 40 KB line of round 5 apart; the line
+    bench.py prints last must be strict JSON, well below 8 KB, and carry the contract fields + roofline + cpu_baseline"""
+    import json
+
+    import bench
+    out = _stub_result()
+    assert len(json.dumps(out)) > 30000          # (the stub really is the object that broke the driver)
+    line = bench.compact_line(out, "/somewhere/bench_full.json")
+    assert "\n" not in line and len(line.encode()) < 6144, len(line)
+    d = json.loads(line, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))    # no NaN / Infinity
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "legs"):
+        assert k in d, k
+    assert set(d["roofline"]) >= {"bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                  "algorithmic_bytes_per_launch", "avg_launch_ms"}
+    assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample", "value_1core",
+                                      "value_1core_numpy_reference_path"}
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["roofline_streaming"]["bound"] == "hbm" and 0 < d["roofline_streaming"]["frac"] < 1
+    assert d["full"] == "bench_full.json"
+    legs = d["legs"]
+    assert {"multilinear", "batch_2048", "toeplitz.banded", "config4.N120.multilinear_512_chains",
+            "realistic_grid.nn_512_chains", "smc.2048_chains"} <= set(legs)
+    assert all(set(e) <= {"cps", "ms", "k", "frac", "pmc"} for e in legs.values())
+
+
+def test_bench_line_stays_below_the_cap_whatever_the_legs():
+    import json
+
+    import bench
+    line = bench.compact_line(_stub_result(n_extra_legs=200), None)
+    assert len(line.encode()) < bench.LINE_CAP
+    d = json.loads(line)
+    assert d.get("legs_truncated") is True and d["roofline"]["kernel"] and d["cpu_baseline"]["value"] > 0
+    # NaN in a leg never reaches the line
+    out = _stub_result()
+    out["multilinear_leg"]["chain_steps_per_s"] = float("nan")
+    json.loads(bench.compact_line(out), parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
