@@ -89,7 +89,7 @@ def compact_line(out, full_path=None):
     Guaranteed < LINE_CAP bytes: legs are dropped from the end, then strings cut, before the cap is ever exceeded."""
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data", "repeats")
-    line = {k: _r(out[k], 6) for k in keep if k in out}
+    line = {k: out[k] for k in keep if k in out}      # (full precision: value = chains x steps / time is checked)
     cfg = out.get("config", {})
     line["config"] = {k: cfg[k] for k in ("workload", "chains_per_gpu", "global_chains", "parallelism") if k in cfg}
     if cfg.get("env_knobs"):
