@@ -1212,6 +1212,14 @@ int beatamd_ctx_gf_plan(beatamd_ctx *ctx, char *buf, int64_t buflen, double *mea
     return BEATAMD_OK;
 }
 
+int beatamd_ctx_gf_tune_log(beatamd_ctx *ctx, char *buf, int64_t buflen)
+{
+    ENTER(ctx);
+    BA_CHECK(buf && buflen > 0, BEATAMD_EINVAL, "gf_tune_log: bad argument");
+    snprintf(buf, (size_t)buflen, "%s", ctx->gf_tune_log);
+    return BEATAMD_OK;
+}
+
 int beatamd_ctx_gf_chain_groups(beatamd_ctx *ctx, int64_t C, const double *key0, const double *key1,
                                 int64_t chains_per_group, uint32_t *members)
 {
@@ -1221,7 +1229,7 @@ int beatamd_ctx_gf_chain_groups(beatamd_ctx *ctx, int64_t C, const double *key0,
     const ChainVec key[2] = {ChainVec{key0, 1, 0}, ChainVec{key1, 1, 0}};
     const uint32_t *m = nullptr;
     BA_TRY(launch_chain_members(ctx, C, key, chains_per_group, ngroups, &m));
-    BA_CHECK(m != nullptr, BEATAMD_EINVAL, "gf_chain_groups: batches of more than 8192 chains or 64 groups are not cut");
+    BA_CHECK(m != nullptr, BEATAMD_EINVAL, "gf_chain_groups: groups of more than 8192 chains are not cut");
     BA_HIP(hipStreamSynchronize(ctx->stream));
     BA_HIP(hipMemcpy(members, m, (size_t)(ngroups * chains_per_group) * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return BEATAMD_OK;

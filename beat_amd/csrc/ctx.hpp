@@ -187,6 +187,7 @@ struct beatamd_ctx {
     bool gs_has_passes = false;     // the statistics slot holds [rows per patch][passes per patch]
     // what the selection chose for the most recent stacking launch and why (beatamd_ctx_gf_plan)
     char gf_plan[384] = "";
+    char gf_tune_log[512] = "";   // the most recent group-size measurement (launch_gfstack), in words
     // largest distinct-row count of the previous small-group launch, read back asynchronously
     // (pinned mailbox + event; never waited for): sizes the next launch's row buffers
     uint32_t *h_umax = nullptr;

@@ -137,7 +137,7 @@ __device__ __forceinline__ void gc_bitonic(double *skey, uint32_t *stag, int n, 
         }
 }
 
-__global__ void __launch_bounds__(GC_CUT_TB) k_gc_cut(GcOrderArgs a, int n)
+__global__ void __launch_bounds__(GC_CUT_TB) k_gc_cut(GcOrderArgs a, int n, int64_t chunk)
 {
     extern __shared__ __attribute__((aligned(16))) double skey[];          // [n]   n = C rounded up to a power of two
     uint32_t *stag = reinterpret_cast<uint32_t *>(skey + n);               // [n]
@@ -145,7 +145,12 @@ __global__ void __launch_bounds__(GC_CUT_TB) k_gc_cut(GcOrderArgs a, int n)
     __shared__ unsigned long long ext[4][GC_GROUPS_MAX];                   // of the range that starts at group lo
     __shared__ int axis[GC_GROUPS_MAX];
     const int tid = threadIdx.x;
-    const int C = (int)a.C, ng = (int)a.ngroups, cg = (int)a.cg;
+    // batches beyond GC_MEMBERS_MAX chains / GC_GROUPS_MAX groups: one workgroup per CHUNK of whole groups as the chains
+    // come (round 6: BEAT's recommended n_chains reaches 10 000); chain ids below are relative to the chunk
+    const int64_t base = (int64_t)blockIdx.x * chunk;
+    const int C = (int)min(chunk, a.C - base), cg = (int)a.cg;
+    const int ng = (C + cg - 1) / cg;
+    a.keyv[0] += base; a.keyv[1] += base; a.members += base;
     for (int i = tid; i < n; i += GC_CUT_TB) {
         stag[i] = i < C ? (uint32_t)i : 0xffffffffu;                        // (pads: behind every range)
         slo[i] = i < C ? 0 : 0xffff;
@@ -198,7 +203,7 @@ __global__ void __launch_bounds__(GC_CUT_TB) k_gc_cut(GcOrderArgs a, int n)
     }
     __syncthreads();
     gc_bitonic(skey, stag, n, tid);
-    for (int i = tid; i < C; i += GC_CUT_TB) a.members[i] = stag[i] & 0xffffu;
+    for (int i = tid; i < C; i += GC_CUT_TB) a.members[i] = (uint32_t)base + (stag[i] & 0xffffu);
 }
 
 __global__ void __launch_bounds__(GC_TB) k_gc_order(GcOrderArgs a)
@@ -260,7 +265,10 @@ __global__ void __launch_bounds__(256) k_members_pad(uint32_t *members, int64_t 
 
 // the cut of a batch into ngroups groups of cg chain slots -> oa.members (scratch at `p`: members [padded], two key vectors)
 static size_t gc_cut_bytes(int64_t C, int64_t padded) { return (size_t)padded * 4 + (size_t)C * 16 + 64; }
-static bool gc_cut_applicable(int64_t C, int64_t ngroups) { return C <= GC_MEMBERS_MAX && ngroups <= GC_GROUPS_MAX; }
+// chains per chunk of the cut: whole groups, at most GC_GROUPS_MAX of them and GC_MEMBERS_MAX chains (8192 for 512-chain
+// groups, 7770 = 15 x 518 for the runs kernel's)
+static int64_t gc_cut_chunk(int64_t cg) { return std::max<int64_t>(1, std::min<int64_t>(GC_MEMBERS_MAX / cg, GC_GROUPS_MAX)) * cg; }
+static bool gc_cut_applicable(int64_t C, int64_t ngroups) { return ngroups > 0 && C > 0 && C / ngroups <= GC_MEMBERS_MAX; }
 
 static int launch_gc_cut(beatamd_ctx *ctx, GcOrderArgs &oa, void *p, int64_t cg, int64_t ngroups, int64_t padded)
 {
@@ -269,11 +277,12 @@ static int launch_gc_cut(beatamd_ctx *ctx, GcOrderArgs &oa, void *p, int64_t cg,
     oa.keyv[1] = oa.keyv[0] + oa.C;
     oa.cg = cg; oa.ngroups = ngroups;
     hipLaunchKernelGGL(k_gc_key0, dim3((unsigned)((oa.C + 255) / 256)), dim3(256), 0, ctx->stream, oa);
+    const int64_t chunk = gc_cut_chunk(cg);
     int n = 2;
-    while (n < oa.C) n <<= 1;
+    while (n < std::min<int64_t>(oa.C, chunk)) n <<= 1;
     const size_t lds = (size_t)n * (8 + 4 + 2 + 2);
     BA_HIP(hipFuncSetAttribute((const void *)k_gc_cut, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_gc_cut, dim3(1), dim3(GC_CUT_TB), lds, ctx->stream, oa, n);
+    hipLaunchKernelGGL(k_gc_cut, dim3((unsigned)((oa.C + chunk - 1) / chunk)), dim3(GC_CUT_TB), lds, ctx->stream, oa, n, chunk);
     if (padded > oa.C)
         hipLaunchKernelGGL(k_members_pad, dim3((unsigned)((padded - oa.C + 255) / 256)), dim3(256), 0, ctx->stream, oa.members, oa.C, padded);
     return BEATAMD_OK;

@@ -2094,6 +2094,11 @@ int gfstack_shared_candidates(const GfStackCall &k, int *cgs, int *ucaps)
     for (int i = 0; i < 4; i++) {
         // a group size that would leave more than half of its lanes without a chain only pads
         if (cand[i] > 64 && (int64_t)cand[i] / 2 >= k.C) continue;
+        // large batches: small groups stage every distinct row many times over and have never been the fastest
+        // (config 3, 512 chains: 512 6.2, 256 2 x 3.6, 128 4 x 2.9, 64 8 x 2.4 ms); timing them on the first call of a
+        // shape cost 12 full launches (1 s at 4096 chains) -- from 1024 chains on 512 / 256 only
+        if (k.C >= 1024 && cand[i] < 256) continue;
+        if (k.C >= 384 && cand[i] < 128) continue;
         int u = 0;
         if (shared_fit(k, cand[i], &u)) { cgs[n] = cand[i]; ucaps[n] = u; n++; }
     }

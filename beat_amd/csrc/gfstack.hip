@@ -419,33 +419,53 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &call)
             // table of pick_group (measured on config 3).
             const bool tune = !GfKnobs::set(kn.gs_cg) && !GfKnobs::is(kn.gs_tune, 0);
             if (tune) {
-                const std::vector<int64_t> key = {k.C, nrow, k.nvar, k.mode, L.T, L.P, L.D, L.S, L.N, Ttab, f32_all ? 1 : 0};
+                // (key: the batch in whole 512-chain groups, capped -- 4096 and 4100 chains choose alike --; the epilogue
+                // mode costs every group size the same and is not part of it)
+                const int64_t cbucket = k.C < 512 ? k.C : 512 * std::min<int64_t>((k.C + 511) / 512, 16);
+                const std::vector<int64_t> key = {cbucket, nrow, k.nvar, L.T, L.P, L.D, L.S, L.N, Ttab, f32_all ? 1 : 0};
                 auto it = ctx->gs_tuned.find(key);
                 if (it == ctx->gs_tuned.end()) {
                     int cgs[4], ucaps[4];
                     const int nc = gfstack_shared_candidates(k, cgs, ucaps);
                     int best = -1;
-                    float best_ms = 0.f;
+                    float best_ms = 0.f, ms_of[4] = {0.f, 0.f, 0.f, 0.f};
                     hipEvent_t e0, e1;
                     BA_HIP(hipEventCreate(&e0));
                     BA_HIP(hipEventCreate(&e1));
                     for (int i = 0; i < nc && nc > 1; i++) {
                         float ms_min = 0.f;
-                        for (int rep = 0; rep < 3; rep++) {   // first launch of a size: warm-up
+                        for (int rep = 0; rep < 2; rep++) {   // first launch of a size: warm-up (code, tables' scratch)
                             BA_HIP(hipEventRecord(e0, ctx->stream));
                             BA_TRY(launch_gfstack_shared(ctx, k, ta.rowoff, ta.fac, cgs[i], ucaps[i], Ttab));
                             BA_HIP(hipEventRecord(e1, ctx->stream));
                             BA_HIP(hipEventSynchronize(e1));
                             float ms = 0.f;
                             BA_HIP(hipEventElapsedTime(&ms, e0, e1));
-                            if (rep == 1 || (rep == 2 && ms < ms_min)) ms_min = ms;
+                            if (rep == 1) ms_min = ms;
                         }
+                        ms_of[i] = ms_min;
                         if (best < 0 || ms_min < best_ms) { best = i; best_ms = ms_min; }
+                        // a candidate twice as slow as the best so far: the smaller sizes behind it only stage more rows
+                        if (ms_min > 2.f * best_ms) break;
                     }
                     (void)hipEventDestroy(e0);
                     (void)hipEventDestroy(e1);
                     if (nc == 1) best = 0;
                     if (best >= 0) it = ctx->gs_tuned.emplace(key, std::make_pair(cgs[best], ucaps[best])).first;
+                    // what was measured, once per problem shape: beatamd_ctx_gf_tune_log (and stderr under BEATAMD_VERBOSE)
+                    {
+                        char *w = ctx->gf_tune_log;
+                        size_t left = sizeof(ctx->gf_tune_log);
+                        int n = snprintf(w, left, "group size for %lld chains (T %lld, P %lld, D*S %lld, N %lld, %d row(s) per chain): ",
+                                         (long long)k.C, (long long)L.T, (long long)L.P, (long long)(L.D * L.S), (long long)L.N, nrow);
+                        for (int i = 0; i < nc && n > 0 && (size_t)n < left; i++) {
+                            w += n; left -= (size_t)n;
+                            n = ms_of[i] > 0.f ? snprintf(w, left, "%d: %.3f ms%s", cgs[i], ms_of[i], i + 1 < nc ? ", " : "")
+                                               : snprintf(w, left, "%d: %s%s", cgs[i], nc == 1 ? "only candidate" : "not timed", i + 1 < nc ? ", " : "");
+                        }
+                        if (best >= 0 && n > 0 && (size_t)n < left) { w += n; left -= (size_t)n; snprintf(w, left, " -> %d", cgs[best]); }
+                        if (getenv("BEATAMD_VERBOSE")) fprintf(stderr, "beat_amd: %s\n", ctx->gf_tune_log);
+                    }
                 }
                 if (it != ctx->gs_tuned.end()) { cg = it->second.first; ucap = it->second.second; }
             }

@@ -439,6 +439,13 @@ class Context(object):
             out.update(mean_passes=mean.value, max_passes=mx.value)
         return out
 
+    def gf_tune_log(self):
+        """the most recent group-size measurement of the lane <-> chain stacking kernels, in words (empty before the
+        first one): the first call of a problem shape launches every candidate group size twice and keeps the fastest"""
+        buf = C.create_string_buffer(512)
+        check(self._lib.beatamd_ctx_gf_tune_log(self._h, buf, 512))
+        return buf.value.decode()
+
     def gf_chain_groups(self, key0, key1, chains_per_group=512):
         """how a batch is cut into its chain groups (scheduling only): key0 / key1 (C,) per-chain keys -- the hypocentre
         (strike, dip) in the fused model path -> uint32 array [ngroups, chains_per_group] of chain ids, 0xffffffff behind

@@ -837,7 +837,7 @@ def main():
             from beat_amd.sampler import smc_sample
             n_smc = 50
             smc_out = {}
-            runs_ = [(B, False, f, ""), (B, True, f, ""), (2048, False, f, ""), (4096, True, f, "")]
+            runs_ = [(B, False, f, ""), (B, True, f, ""), (2048, False, f, ""), (4096, False, f, ""), (4096, True, f, "")]
             if "multilinear" in legs:
                 runs_.append((B, False, f_ml, "_multilinear"))      # the reference's default interpolation, end to end
             for nch, with_files, f_smc, tag_ in runs_:
@@ -845,6 +845,8 @@ def main():
                     continue
                 st = SMC(f_smc, lo, up, n_chains=nch, device=dev, random_seed=11, tune_interval=25)
                 home = tempfile.mkdtemp(prefix="beatamd_smc_") if with_files else None
+                ctx.enable_timing(True)
+                ctx.reset_timing()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 pop_s, lp_s, betas_s = smc_sample(n_smc, st, max_stages=3, homepath=home, final_stage=False,
@@ -856,11 +858,18 @@ def main():
                     shutil.rmtree(home, ignore_errors=True)
                 tmg = dict(st.timings)
                 nsteps_s = tmg.pop("steps")
+                # HIP-event sums of the context's timers over the whole call, per Metropolis step (the first call of a
+                # chain count measures the stacking kernel's group size: `group_size_measurement`, part of `gfstack`)
+                ksplit = {k: ctx.kernel_time(k)[0] / nsteps_s for k in ("sweep", "tables", "grouptables", "gfstack", "quadform",
+                                                                        "finish", "astep", "proposal", "stage") if ctx.kernel_time(k)[1]}
+                ctx.enable_timing(False)
                 smc_out["%d_chains%s%s" % (nch, "_with_stage_files" if with_files else "", tag_)] = {
                     "chains": nch, "stages": len(betas_s) - 1, "steps_per_stage": n_smc, "metropolis_steps": nsteps_s,
                     "wall_s": dt_s, "chain_steps_per_s_whole_call": nch * nsteps_s / dt_s,
                     "chain_steps_per_s_sampling_only": nch * nsteps_s / tmg["sample_s"],
-                    "split_s": tmg, "betas": [float(b_) for b_ in betas_s],
+                    "split_s": tmg, "kernel_ms_per_step": ksplit, "sampling_ms_per_step": tmg["sample_s"] / nsteps_s * 1e3,
+                    "group_size_measurement": ctx.gf_tune_log() if hasattr(ctx, "gf_tune_log") else None,
+                    "betas": [float(b_) for b_ in betas_s],
                     "acceptance_per_stage": [float(a_) for a_ in st.stage_acceptance], "finite": bool(np.isfinite(lp_s).all())}
                 del st
             smc_out["note"] = ("whole call incl. the initial evaluation of the prior population, transitions, all-gathers and "

@@ -42,7 +42,7 @@ extern "C" {
 /* ABI revision: bumped whenever an entry point changes its signature or an error code is added
  * (1.1: beatamd_weights_update gained kind/count in round 2; BEATAMD_EBADCOV).  beat_amd/_lib.py
  * refuses a library whose revision differs from the header it was written against. */
-#define BEATAMD_VERSION 118
+#define BEATAMD_VERSION 119
 
 #define BEATAMD_NEAREST_NEIGHBOR 0 /* interpolation="nearest_neighbor" */
 #define BEATAMD_MULTILINEAR 1      /* interpolation="multilinear"      */
@@ -97,12 +97,18 @@ int beatamd_ctx_gf_group_stats(beatamd_ctx *ctx, int64_t *chains_per_group, doub
  * rows than an LDS row buffer holds.  No reference counterpart: the reference gathers one chain's rows by fancy
  * indexing (beat/ffi/base.py:651-704); this reports how the batch shares them. */
 int beatamd_ctx_gf_plan(beatamd_ctx *ctx, char *buf, int64_t buflen, double *mean_passes, int64_t *max_passes);
+/* the chain-group size of the lane <-> chain stacking kernels is MEASURED on the first call of a problem shape (every
+ * candidate launched twice on the real inputs, the fastest kept; from 1024 chains on only 512 / 256 are candidates):
+ * this returns the most recent measurement in words ("group size for 4096 chains (...): 512: 35.8 ms, 256: 61.2 ms ->
+ * 512"), empty before the first one.  BEATAMD_VERBOSE=1 prints the same line to stderr when it happens.  No reference
+ * counterpart (the reference has no batch; beat/ffi/base.py:607-709 stacks one chain). */
+int beatamd_ctx_gf_tune_log(beatamd_ctx *ctx, char *buf, int64_t buflen);
 
 /* how a batch of C chains is cut into its chain groups (scheduling only; results never depend on it): recursive
  * bisection of the batch along the key in which a part's chains spread wider -- the fused model path hands the hypocentre
  * (strike, dip) of every chain, so that a group covers a compact piece of the fault and stages fewer distinct library rows.
  *   key0 / key1 [C] (device)   members [ceil(C / chains_per_group) * chains_per_group] (host): members[g * cpg + i] =
- *   i-th chain of group g, 0xffffffff behind the last chain.  C <= 8192 and at most 64 groups (larger batches are not cut: BEATAMD_EINVAL).
+ *   i-th chain of group g, 0xffffffff behind the last chain.  Batches beyond 8192 chains (or 64 groups) are cut chunk by chunk: chunks of min(8192 / chains_per_group, 64) whole groups as the chains come, each bisected on its own (chains_per_group <= 8192).
  * No reference counterpart (the reference evaluates one chain per process, beat/sampler/base.py:428-595). */
 int beatamd_ctx_gf_chain_groups(beatamd_ctx *ctx, int64_t C, const double *key0, const double *key1,
                                 int64_t chains_per_group, uint32_t *members);

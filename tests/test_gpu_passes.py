@@ -235,7 +235,8 @@ def test_targets_of_a_station_share_their_index_tables(ctx, monkeypatch, interp,
         np.testing.assert_allclose(B[c], ref, rtol=1e-9, atol=1e-9)
 
 
-@pytest.mark.parametrize("C,cpg", [(600, 512), (1300, 512), (2100, 518), (2600, 512), (4096, 518), (4096, 512), (5000, 518), (8192, 512), (3, 2), (130, 128)])
+@pytest.mark.parametrize("C,cpg", [(600, 512), (1300, 512), (2100, 518), (2600, 512), (4096, 518), (4096, 512), (5000, 518), (8192, 512), (3, 2), (130, 128),
+                                   (10000, 512), (10000, 518), (8193, 512), (20000, 518), (300, 2)])
 def test_chain_groups_of_a_batch_equal_the_numpy_twin(ctx, C, cpg):
     """k_gc_cut / k_gc_members (batches of several chain groups are bisected along the hypocentre key of the wider extent:
     a compact piece of the fault per group) against tools/gfcell_emu.gc_cut, index for index; odd group counts, partial
@@ -254,7 +255,7 @@ def test_chain_groups_of_a_batch_equal_the_numpy_twin(ctx, C, cpg):
     ng = (C + cpg - 1) // cpg
     fin = [np.where(np.abs(k) <= 1.79e308, k, 0.0) for k in (k0, k1)]
     want = np.full(ng * cpg, 0xffffffff, dtype=np.uint32)
-    want[:C] = emu.gc_cut(fin[0], fin[1], C, cpg, ng)
+    want[:C] = emu.gc_cut_chunked(fin[0], fin[1], C, cpg)      # (one chunk up to 8192 chains / 64 groups: = gc_cut)
     assert np.array_equal(got.ravel(), want)
     live = got.ravel()[:C]
     assert sorted(live.tolist()) == list(range(C))

@@ -118,6 +118,17 @@ def gc_cut(F0, F1, C, cg, ngroups):
     return members
 
 
+def gc_cut_chunked(F0, F1, C, cg):
+    """the cut of a batch of any size (gfcell.hip launch_gc_cut): chunks of min(8192 // cg, 64) whole groups as the chains
+    come, each cut by gc_cut on its own -> members [C]"""
+    chunk = max(1, min(8192 // cg, 64)) * cg
+    members = np.empty(C, dtype=np.int64)
+    for base in range(0, C, chunk):
+        n = min(chunk, C - base)
+        members[base:base + n] = base + gc_cut(F0[base:base + n], F1[base:base + n], n, cg, (n + cg - 1) // cg)
+    return members
+
+
 def gc_order(rowoff, C, T, P, S, sort=True, keys=None, global_members=True):
     """numpy twin of the chain order (gfcell.hip): batches of several groups are cut into groups by gc_cut (C <= 8192, <= 64 groups),
     then inside a group (k_gc_order): bands of whole wavefronts by the first key -- as many as make a wavefront's chains a
@@ -132,8 +143,8 @@ def gc_order(rowoff, C, T, P, S, sort=True, keys=None, global_members=True):
         F0 = (rowoff[allc, 0, 0, 3] % S).astype(np.float64)
         F1 = (rowoff[allc, 0, P // 2, 3] % S).astype(np.float64)
     members = allc
-    if sort and global_members and 1 < ngroups <= 64 and C <= 8192:
-        members = gc_cut(F0, F1, C, CG, ngroups)
+    if sort and global_members and 1 < ngroups:
+        members = gc_cut_chunked(F0, F1, C, CG)
     for g in range(ngroups):
         cs = members[g * CG:min(C, (g + 1) * CG)]
         if not sort:
