@@ -71,6 +71,7 @@ _PROTOS = {
     "beatamd_weights_update": [_vp, _i32, _i32, _i64, _vp, _vp],
     "beatamd_weights_destroy": [_vp, _i32],
     "beatamd_weights_band": [_vp, _i32, _pi64],
+    "beatamd_weights_band_info": [_vp, _i32, _pi64, C.POINTER(_f64)],
     "beatamd_mvn_chol_logp_batch": [_vp, _i32, _i64, _vp, _vp, _vp],
     "beatamd_laplacian_create": [_vp, _i64, _vp, _f64, _pi32],
     "beatamd_laplacian_destroy": [_vp, _i32],

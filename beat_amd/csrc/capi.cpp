@@ -140,6 +140,16 @@ int ffi_logp_device(beatamd_ctx *ctx, FfiModel &m, int64_t C, const double *Q, d
                 k.wscalar = ws->w;
                 k.quad = quad;
                 BA_TRY(launch_gfstack(ctx, k));
+            } else if (ws->band == 1 && ws->wb && ws->M == wm.N && ws->nd == wm.T &&
+                       GfKnobs::get(gf_knobs(ctx).qf_band, 1) != 0) {
+                // bidiagonal whitening operators (the "exponential" noise structure): the misfit rides in the stacking
+                // kernel where it has the epilogue, else residual store + k_quadform_banded (launch_gfstack decides)
+                k.mode = GF_RESID_BAND1;
+                k.band_w = ws->wb;
+                k.quad = quad;
+                BA_TRY(ctx->get_scratch(SL_RESID, (size_t)C * wm.T * wm.N * sizeof(double), &p));
+                k.out = (double *)p;
+                BA_TRY(launch_gfstack(ctx, k));
             } else {
                 k.mode = GF_RESID_STORE;
                 BA_TRY(ctx->get_scratch(SL_RESID, (size_t)C * wm.T * wm.N * sizeof(double), &p));
@@ -504,9 +514,15 @@ static int wset_fill(beatamd_ctx *ctx, WeightSet *w, const double *weights, cons
         w->band = -1;
         if (w->wb) { BA_HIP(hipFree(w->wb)); w->wb = nullptr; }
         if (flag && w->M > 2 * QF_BAND_LIMIT) {
-            BA_TRY(ctx->get_scratch(SL_MISC, (size_t)w->nd * 8 + 64, &p));
+            BA_TRY(ctx->get_scratch(SL_MISC, (size_t)w->nd * w->M * 8 + 64, &p));
             int64_t band = -1;
-            BA_TRY(launch_band_detect(ctx, w->w, w->nd, w->M, p, &band));
+            w->dropped_rel = 0.0;
+            BA_TRY(launch_band_detect(ctx, w->w, w->nd, w->M, p, &band, &w->dropped_rel));
+            // the choice is visible: beatamd_weights_band_info, and one line under BEATAMD_VERBOSE
+            if (getenv("BEATAMD_VERBOSE"))
+                fprintf(stderr, "beat_amd: weight set of %lld operators of %lld^2: %s (half bandwidth %lld, largest entry beyond it "
+                                "%.3g of its row's largest)\n", (long long)w->nd, (long long)w->M,
+                        band <= QF_BAND_LIMIT ? "evaluated on its band" : "dense", (long long)band, w->dropped_rel);
             if (band >= 0 && band <= QF_BAND_LIMIT) {
                 BA_TRY(dev_alloc_copy(ctx, nullptr, (size_t)(w->nd * w->M * (band + 1)) * sizeof(double), (void **)&w->wb));
                 BA_TRY(launch_band_pack(ctx, w->w, w->nd, w->M, band, w->wb));
@@ -552,6 +568,17 @@ int beatamd_weights_update(beatamd_ctx *ctx, int32_t wset_id, int32_t kind, int6
              (long long)count, (long long)want);
     BA_HIP(hipStreamSynchronize(ctx->stream));
     return wset_fill(ctx, w, weights, slog_pdet);
+}
+
+int beatamd_weights_band_info(beatamd_ctx *ctx, int32_t wset_id, int64_t *band, double *max_dropped_rel)
+{
+    ENTER(ctx);
+    WeightSet *w = get_obj(ctx->wsets, wset_id);
+    BA_CHECK(w && band && max_dropped_rel, BEATAMD_EINVAL, "weights_band_info: bad argument");
+    const bool on = w->kind == BEATAMD_W_DENSE && w->wb && GfKnobs::get(gf_knobs(ctx).qf_band, 1) != 0;
+    *band = on ? w->band : -1;
+    *max_dropped_rel = on ? w->dropped_rel : 0.0;
+    return BEATAMD_OK;
 }
 
 int beatamd_weights_band(beatamd_ctx *ctx, int32_t wset_id, int64_t *band)

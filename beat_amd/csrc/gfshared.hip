@@ -252,6 +252,8 @@ struct GsArgs {
     int64_t w_var_stride;
     const double *data, *wscalar;
     double *out, *partial;
+    const double *band_w;   // mode 3: [T,N,2] rows of the bidiagonal whitening operator
+    double *edges;          // mode 3: [C*T, ntile, 2] first / last residual of every tile
 };
 
 typedef double v2d __attribute__((ext_vector_type(2)));
@@ -1339,10 +1341,44 @@ k_gfstack_ws(GsArgs a)
     }
     __builtin_amdgcn_s_barrier();
     if (tid < GS_NT) xbuf[tid] = (tid < nvalid) ? a.data[t * N + n0 + tid] : 0.0;
+    if (MODE == GF_RESID_BAND1 && tid >= GS_NT && tid < 3 * GS_NT)     // (w0_i, w1_i) of the tile's samples behind the data
+        xbuf[tid] = ((tid - GS_NT) >> 1) < nvalid ? a.band_w[(t * N + n0) * 2 + (tid - GS_NT)] : 0.0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (MODE == GF_RESID_STORE) {
+    if (MODE == GF_RESID_BAND1) {
+        // distributions.py:119-138 with a bidiagonal W: y_i = W[i,i] r_i + W[i,i+1] r_{i+1} -- the two products of
+        // k_quadform_banded<1> in its order -- for the samples whose neighbour this lane holds; the tile's LAST sample needs
+        // the next tile's first residual: both go to `edges`, k_sum_tiles_band1 adds that term (the trace's very last
+        // sample has no neighbour and is finished here)
+        const double *wbt = xbuf + GS_NT;
+        const bool trace_end = n0 + nvalid == N;
+        double q = 0.0, ri = xbuf[0] - acc[0];
+        const double rfirst = ri;
+#pragma unroll
+        for (int i0 = 0; i0 < GS_NT; i0 += 8) {
+#pragma unroll
+            for (int i = i0; i < i0 + 8; i++) {
+                if (i + 1 < nvalid) {
+                    const double rn = xbuf[i + 1] - acc[i + 1];     // seismic.py:1332
+                    double y = fma(wbt[2 * i], ri, 0.0);
+                    y = fma(wbt[2 * i + 1], rn, y);
+                    q = fma(y, y, q);
+                    ri = rn;
+                } else if (i + 1 == nvalid && trace_end) {
+                    const double y = fma(wbt[2 * i], ri, 0.0);
+                    q = fma(y, y, q);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (live) {
+            const int64_t e = (c * a.T + t) * a.ntile + tile;
+            a.partial[e] = q;
+            a.edges[2 * e] = rfirst;
+            a.edges[2 * e + 1] = ri;        // residual of the tile's last valid sample
+        }
+    } else if (MODE == GF_RESID_STORE) {
         // A lane holds 64 consecutive samples of ITS chain: stored directly, every store instruction scatters 64 x 8 bytes
         // over 64 rows of the residual matrix (T*N*8 bytes apart) -- 1 GB that way costs 0.8 ms of a 7 ms launch.  Through a
         // per-wavefront LDS tile [64 chains][16 samples] (pitch 17) the same values leave as 128-byte runs: lane = (chain
@@ -1802,6 +1838,7 @@ static int launch_ws(int mode, dim3 grid, size_t lds, hipStream_t s, const GsArg
      : mode == GF_RESID_SCALAR ? NAME<__VA_ARGS__ GF_RESID_SCALAR, 3, 0> : NAME<__VA_ARGS__ GF_RESID_STORE, 3, 0>)
     if (pair == 1) kern = a.nthint ? BA_WS_PICK(k_gfstack_wsp, 1,) : BA_WS_PICK0(k_gfstack_wsp, 1,);
     else if (pair == 2) kern = a.nthint ? BA_WS_PICK(k_gfstack_wsp, 0,) : BA_WS_PICK0(k_gfstack_wsp, 0,);
+    else if (mode == GF_RESID_BAND1) kern = a.nthint ? k_gfstack_ws<1, GF_RESID_BAND1, 3, 1> : k_gfstack_ws<1, GF_RESID_BAND1, 3, 0>;
     else kern = a.nthint ? BA_WS_PICK(k_gfstack_ws, 1,) : BA_WS_PICK0(k_gfstack_ws, 1,);
 #undef BA_WS_PICK0
 #undef BA_WS_PICK
@@ -2226,9 +2263,14 @@ static int launch_gfstack_ws(beatamd_ctx *ctx, const GfStackCall &k, const uint3
     a.uent = ta.uent; a.ucount = ta.ucount; a.slot = ta.slot; a.w = ta.w;
     a.w_var_stride = ta.w_var_stride;
     a.data = k.data; a.wscalar = k.wscalar; a.out = k.out;
-    if (k.mode == GF_RESID_SCALAR) {
+    if (k.mode == GF_RESID_SCALAR || k.mode == GF_RESID_BAND1) {
         BA_TRY(ctx->get_scratch(SL_PARTIAL, (size_t)k.C * L.T * a.ntile * sizeof(double), &p));
         a.partial = (double *)p;
+    }
+    if (k.mode == GF_RESID_BAND1) {
+        BA_TRY(ctx->get_scratch(SL_EDGES, (size_t)k.C * L.T * a.ntile * 2 * sizeof(double), &p));
+        a.edges = (double *)p;
+        a.band_w = k.band_w;
     }
     a.nthint = GfKnobs::set(kn.gs_nthint) ? (kn.gs_nthint != 0) : (GS_NTHINT_DEFAULT && ngroups == 1);
     int64_t nblocks = ngroups * L.T * a.ntile;
@@ -2265,12 +2307,25 @@ static int launch_gfstack_ws(beatamd_ctx *ctx, const GfStackCall &k, const uint3
     }
     BA_HIP(hipGetLastError());
     if (k.mode == GF_RESID_SCALAR) BA_TRY(launch_sum_tiles(ctx, a.partial, k.C * L.T, a.ntile, k.quad));
+    if (k.mode == GF_RESID_BAND1)
+        BA_TRY(launch_sum_tiles_band1(ctx, a.partial, a.edges, k.band_w, k.C, L.T, L.N, a.ntile, 64, k.quad));
     return BEATAMD_OK;
 }
 
-int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *rowoff,
+int launch_gfstack_shared(beatamd_ctx *ctx, const GfStackCall &k_in, const uint32_t *rowoff,
                           const double *fac, int CG, int ucap, int64_t Ttab)
 {
+    GfStackCall k = k_in;
+    if (k.mode == GF_RESID_BAND1) {
+        // the bidiagonal epilogue exists in k_gfstack_ws (float64 rows); every other kernel stores the residuals and
+        // launch_gfstack runs k_quadform_banded behind it (BEATAMD_QF_FUSE=0: always -- A/B, tests)
+        const GfKnobs &kn0 = *k.knobs;
+        bool f32 = k.f32;
+        for (int v = 0; v < k.nvar; v++) f32 = f32 && k.libs[v]->g32 != nullptr;
+        const bool fuse = ws_wanted(k, CG) && !f32 && !GfKnobs::is(kn0.gs_pair, 1) && !GfKnobs::is(kn0.qf_fuse, 0);
+        if (!fuse) k.mode = GF_RESID_STORE;
+        ctx->gf_band_fused = fuse;
+    }
     if (ws_wanted(k, CG)) return launch_gfstack_ws(ctx, k, rowoff, Ttab);
     const GfKnobs &kn = *k.knobs;
     const SeisLib &L = *k.libs[0];

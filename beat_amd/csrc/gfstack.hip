@@ -326,6 +326,39 @@ int launch_sum_tiles(beatamd_ctx *ctx, const double *partial, int64_t n, int nti
     return BEATAMD_OK;
 }
 
+// mode 3 (bidiagonal whitening operator): the tiles of a (chain, target) in ascending order, behind each tile's inner
+// samples its last one -- y = W[i,i] r_last(tile) + W[i,i+1] r_first(tile + 1), the two products of k_quadform_banded<1> --
+// fixed order: deterministic, the same on every rank
+__global__ void __launch_bounds__(256) k_sum_tiles_band1(const double *partial, const double *edges, const double *band_w,
+                                                        int64_t n, int64_t T, int64_t N, int ntile, int NT, double *quad)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t t = i % T;
+    double s = 0.0;
+    for (int k = 0; k < ntile; k++) {
+        s += partial[i * ntile + k];
+        if (k + 1 < ntile) {
+            const int64_t smp = (int64_t)k * NT + NT - 1;
+            const double *w = band_w + (t * N + smp) * 2;
+            double y = fma(w[0], edges[(i * ntile + k) * 2 + 1], 0.0);
+            y = fma(w[1], edges[(i * ntile + k + 1) * 2], y);
+            s = fma(y, y, s);
+        }
+    }
+    quad[i] = s;
+}
+
+int launch_sum_tiles_band1(beatamd_ctx *ctx, const double *partial, const double *edges, const double *band_w, int64_t C,
+                           int64_t T, int64_t N, int ntile, int NT, double *quad)
+{
+    const int64_t n = C * T;
+    hipLaunchKernelGGL(k_sum_tiles_band1, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, partial, edges, band_w,
+                       n, T, N, ntile, NT, quad);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
 template <int INTERP, int NVAR, int VEC, int W>
 static void launch_mode(int mode, dim3 grid, hipStream_t s, const GfArgs &a)
 {
@@ -345,7 +378,24 @@ static void launch_nvar(int nvar, int mode, dim3 grid, hipStream_t s, const GfAr
     else launch_mode<INTERP, 3, VEC, W>(mode, grid, s, a);
 }
 
+static int launch_gfstack_impl(beatamd_ctx *ctx, const GfStackCall &call);
+
 int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &call)
+{
+    if (call.mode != GF_RESID_BAND1) return launch_gfstack_impl(ctx, call);
+    // bidiagonal whitening operator: fused into the stacking kernel where that kernel has the epilogue (k_gfstack_ws),
+    // else residual store + k_quadform_banded -- the caller gets quad [C,T] either way
+    BA_CHECK(call.band_w && call.quad && call.out && call.data, BEATAMD_EINVAL, "gfstack: mode 3 needs band_w, quad, out, data");
+    ctx->gf_band_fused = false;
+    BA_TRY(launch_gfstack_impl(ctx, call));
+    if (!ctx->gf_band_fused) {
+        const SeisLib &L = *call.libs[0];
+        BA_TRY(launch_quadform_banded(ctx, call.band_w, 1, L.N, L.T, call.C, call.out, L.T * L.N, L.N, call.quad, L.T));
+    }
+    return BEATAMD_OK;
+}
+
+static int launch_gfstack_impl(beatamd_ctx *ctx, const GfStackCall &call)
 {
     GfStackCall k = call;
     const GfKnobs &kn = gf_knobs(ctx);
@@ -404,6 +454,9 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &call)
     // multilinear from 192 chains on: the runs kernel (gfcell.hip).  When its tables can overflow (more row passes than they
     // are sized for) the streaming kernel below is enqueued behind it as a stand-in that works only if they did.
     const int *standin = nullptr;
+    // (mode 3: only launch_gfstack_shared may keep it -- the runs kernel and the streaming kernel store the residuals)
+    const int mode_in = k.mode;
+    if (mode_in == GF_RESID_BAND1) k.mode = GF_RESID_STORE;
     if (!f32_all && gfstack_ml_applicable(k)) {
         BA_TRY(launch_gfstack_ml(ctx, k, ta.rowoff, ta.fac, Ttab, &standin));
         if (!standin) return BEATAMD_OK;
@@ -411,6 +464,7 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &call)
     if (!standin) {
         int cg = 0, ucap = 0;
         if (gfstack_shared_applicable(k, &cg, &ucap)) {
+            k.mode = mode_in;
             // Chains per workgroup: which size is fastest depends on the library (distinct rows a
             // group can share, D*S), the batch and the population, so it is MEASURED once per
             // problem shape -- every candidate is launched on the real inputs (the kernels are

@@ -41,7 +41,14 @@ struct ChainVec {
 enum GfMode : int {
     GF_STORE_SYN = 0,     // out[c,t,n] = synthetics                      (stack_all)
     GF_RESID_SCALAR = 1,  // partial[c,t,tile] = sum (w_t (d - syn))^2     (fused logp, W = w I)
-    GF_RESID_STORE = 2    // out[c,t,n] = d[t,n] - synthetics              (feeds the dense W quadform)
+    GF_RESID_STORE = 2,   // out[c,t,n] = d[t,n] - synthetics              (feeds the dense W quadform)
+    // bidiagonal whitening operator (the reference's "exponential" noise structure, covariance.py:24-51; band detected at
+    // weights_create, quadform.hip): quad[c,t] = sum_i (w0_i r_i + w1_i r_{i+1})^2 (distributions.py:119-138 with a
+    // bidiagonal W) without storing the residuals.  Kernels WITH this epilogue (k_gfstack_ws): the inner samples of a tile
+    // in the kernel, the last sample of every tile -- its neighbour is the next tile's first residual -- by the tile-sum
+    // kernel from two edge residuals per (chain, target, tile).  Kernels without it store the residuals (mode 2) and
+    // launch_gfstack runs k_quadform_banded behind them: either way the caller gets `quad`.
+    GF_RESID_BAND1 = 3
 };
 
 struct GfStackCall {
@@ -56,7 +63,8 @@ struct GfStackCall {
     const double *data = nullptr;     // [T,N]   (modes 1,2)
     const double *wscalar = nullptr;  // [T]     (mode 1)
     double *out = nullptr;            // [C,T,N] (modes 0,2)
-    double *quad = nullptr;           // [C,T]   (mode 1) sum over tiles, fixed order
+    double *quad = nullptr;           // [C,T]   (modes 1, 3) sum over tiles, fixed order
+    const double *band_w = nullptr;   // [T,N,2] (mode 3) row i of the bidiagonal operator: (W[i,i], W[i,i+1]), 0 behind the end
     bool f32 = false;                 // rows from the libraries' float copies where the kernel supports it
     // optional scheduling hint: two per-chain sort keys that put chains which rupture alike next to each other
     // (the fused model path: hypocentre strike / dip of the first subfault).  Never changes a result.
@@ -67,6 +75,10 @@ struct GfStackCall {
 int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &call);
 int launch_sum_tiles(beatamd_ctx *ctx, const double *partial, int64_t n, int ntile, double *quad,
                      const int *guard = nullptr, int want = 0);
+// mode 3: quad[c,t] = sum over tiles of (partial + the tile's last sample: (w0 r_last + w1 r_first(next tile))^2), fixed order;
+// edges [C*T, ntile, 2] = (first, last residual of the tile), NT samples per tile
+int launch_sum_tiles_band1(beatamd_ctx *ctx, const double *partial, const double *edges, const double *band_w, int64_t C,
+                           int64_t T, int64_t N, int ntile, int NT, double *quad);
 // g[i] = (double)(float)g[i]; g32[i] = (float)g[i]  (float-storage copy of a GF library)
 int launch_round_to_f32(beatamd_ctx *ctx, double *g, float *g32, int64_t n);
 // gfshared.hip: chain-shared variant (distinct rows staged once per chain group)
@@ -103,7 +115,8 @@ int launch_quadform(beatamd_ctx *ctx, const QuadformCall &call);
 // banded upper-triangular operators (quadform.hip): the half bandwidth of a stack of matrices (entries beyond it are at most
 // 2^-40 of their matrix's largest; scratch: nd * 8 + 8 bytes), the compact band [nd, M, band + 1], and the quadratic form on it
 constexpr int QF_BAND_LIMIT = 16;
-int launch_band_detect(beatamd_ctx *ctx, const double *A, int64_t nd, int64_t M, void *scratch, int64_t *band_host);
+int launch_band_detect(beatamd_ctx *ctx, const double *A, int64_t nd, int64_t M, void *scratch, int64_t *band_host,
+                       double *dropped_rel_host);
 int launch_band_pack(beatamd_ctx *ctx, const double *A, int64_t nd, int64_t M, int64_t band, double *wb);
 int launch_quadform_banded(beatamd_ctx *ctx, const double *wb, int64_t band, int64_t M, int64_t nd, int64_t C, const double *X,
                            int64_t xs_c, int64_t xs_d, double *quad, int64_t q_stride);

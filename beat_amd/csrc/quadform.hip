@@ -361,20 +361,21 @@ int launch_check_upper_tri(beatamd_ctx *ctx, const double *A, int64_t nd, int64_
 // leave outside the band is rounding residue, ~2e-15 of the largest entry.  multivariate_normal_chol
 // (distributions.py:119-138) then needs two products per sample, not a row of 4096: an HBM-bound pass over the
 // residuals instead of an FP64-MFMA GEMM.  A weight set qualifies when every matrix is upper-triangular (exact zeros
-// below) and no entry further than `band` <= QF_BAND_LIMIT (16) columns right of the diagonal exceeds 2^-40 of its matrix's
-// largest entry; the dropped terms change a whitened sample by at most M * 2^-40 of its largest term (3.7e-9 at M = 4096
+// below) and no entry further than `band` <= QF_BAND_LIMIT (16) columns right of the diagonal exceeds 2^-40 of the largest
+// entry of ITS ROW (round 6; a matrix-wide maximum before); the dropped terms change a whitened sample by at most M * 2^-40 of its largest term (3.7e-9 at M = 4096
 // if they all had one sign; ~6e-11 as rounding residue) -- far inside the path's tolerance (1e-6), and stated in the
 // header.  BEATAMD_QF_BAND=0 keeps the dense kernel (A/B and the dense-W bench legs).
 constexpr double QF_BAND_EPS = 9.094947017729282e-13;   // 2^-40
 
-__global__ void __launch_bounds__(256) k_band_maxabs(const double *A, int64_t nd, int64_t M, unsigned long long *mx)
+// rmax[d*M + r] = bits of max |A_d[r, :]| (non-negative doubles order like their bit patterns; NaN -> a quiet-NaN pattern
+// that orders above every number).  One wavefront per row.
+__global__ void __launch_bounds__(256) k_band_rowmax(const double *A, int64_t nrows, int64_t M, unsigned long long *rmax)
 {
-    // mx[d] = bits of max |A_d| (non-negative doubles order like their bit patterns)
-    const int64_t per = M * M;
-    const int d = blockIdx.y;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
     unsigned long long m = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
-        const double v = fabs(A[(int64_t)d * per + i]);
+    for (int64_t c = threadIdx.x & 63; c < M; c += 64) {
+        const double v = fabs(A[row * M + c]);
         const unsigned long long u = (v == v) ? (unsigned long long)__double_as_longlong(v) : 0x7ff8000000000000ull;
         m = u > m ? u : m;
     }
@@ -382,25 +383,45 @@ __global__ void __launch_bounds__(256) k_band_maxabs(const double *A, int64_t nd
         const unsigned long long o = __shfl_down(m, off);
         m = o > m ? o : m;
     }
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(&mx[d], m);
+    if ((threadIdx.x & 63) == 0) rmax[row] = m;
 }
 
-__global__ void __launch_bounds__(256) k_band_width(const double *A, int64_t nd, int64_t M, const unsigned long long *mx,
-                                                    int *band)
+// PASS 0: band[0] = max over all rows of (column - row) of an entry above eps * max|its ROW|  (NaN / inf anywhere: M).
+// The threshold is relative to the entry's own row (operators with strongly heterogeneous row scales --
+// diag(1 / sigma_i) R -- would lose entries that matter in their row against a matrix-wide maximum).
+// PASS 1: dropped[0] = bits of the largest |entry| / max|its row| beyond `band0` columns right of the diagonal (what the banded
+// evaluation leaves out; reported by beatamd_weights_band_info).
+template <int PASS>
+__global__ void __launch_bounds__(256) k_band_width(const double *A, int64_t nrows, int64_t M, const unsigned long long *rmax,
+                                                    int *band, int64_t band0, unsigned long long *dropped)
 {
-    // band[0] = max over all matrices of (column - row) of an entry above eps * max|A_d|  (NaN / inf anywhere: M)
-    const int64_t per = M * M;
-    const int d = blockIdx.y;
-    const double big = __longlong_as_double((long long)mx[d]);
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int64_t r = row % M;
+    const double big = __longlong_as_double((long long)rmax[row]);
     int b = 0;
-    if (!(big <= 1.79e308)) b = (int)min(M, (int64_t)0x7fffffff);
+    unsigned long long dr = 0;
+    if (PASS == 0 && !(big <= 1.79e308)) b = (int)min(M, (int64_t)0x7fffffff);
     const double thr = big * QF_BAND_EPS;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = i / M, c = i % M;
-        if (c > r && fabs(A[(int64_t)d * per + i]) > thr) b = max(b, (int)(c - r));
+    for (int64_t c = r + 1 + (threadIdx.x & 63); c < M; c += 64) {
+        const double v = fabs(A[row * M + c]);
+        if (PASS == 0) {
+            if (v > thr) b = max(b, (int)(c - r));
+        } else if (c - r > band0 && big > 0.0) {
+            const unsigned long long u = (unsigned long long)__double_as_longlong(v / big);
+            dr = u > dr ? u : dr;
+        }
     }
-    for (int off = 32; off; off >>= 1) b = max(b, __shfl_down(b, off));
-    if ((threadIdx.x & 63) == 0 && b) atomicMax(band, b);
+    if (PASS == 0) {
+        for (int off = 32; off; off >>= 1) b = max(b, __shfl_down(b, off));
+        if ((threadIdx.x & 63) == 0 && b) atomicMax(band, b);
+    } else {
+        for (int off = 32; off; off >>= 1) {
+            const unsigned long long o = __shfl_down(dr, off);
+            dr = o > dr ? o : dr;
+        }
+        if ((threadIdx.x & 63) == 0 && dr) atomicMax(dropped, dr);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_band_pack(const double *A, int64_t nd, int64_t M, int64_t band, double *wb)
@@ -412,20 +433,32 @@ __global__ void __launch_bounds__(256) k_band_pack(const double *A, int64_t nd, 
     wb[i] = (r + k < M) ? A[(d * M + r) * M + r + k] : 0.0;
 }
 
-int launch_band_detect(beatamd_ctx *ctx, const double *A, int64_t nd, int64_t M, void *scratch, int64_t *band_host)
+int launch_band_detect(beatamd_ctx *ctx, const double *A, int64_t nd, int64_t M, void *scratch, int64_t *band_host,
+                       double *dropped_rel_host)
 {
-    // scratch: [nd] uint64 + one int
-    unsigned long long *mx = (unsigned long long *)scratch;
-    int *band = reinterpret_cast<int *>(mx + nd);
-    BA_HIP(hipMemsetAsync(scratch, 0, (size_t)nd * 8 + 8, ctx->stream));
-    const unsigned gx = (unsigned)std::min<int64_t>((M * M + 255) / 256, 1024);
-    hipLaunchKernelGGL(k_band_maxabs, dim3(gx, (unsigned)nd), dim3(256), 0, ctx->stream, A, nd, M, mx);
-    hipLaunchKernelGGL(k_band_width, dim3(gx, (unsigned)nd), dim3(256), 0, ctx->stream, A, nd, M, mx, band);
+    // scratch: [nd*M] uint64 row maxima + one uint64 + one int
+    unsigned long long *rmax = (unsigned long long *)scratch;
+    unsigned long long *dropped = rmax + nd * M;
+    int *band = reinterpret_cast<int *>(dropped + 1);
+    BA_HIP(hipMemsetAsync(dropped, 0, 16, ctx->stream));
+    const int64_t nrows = nd * M;
+    const unsigned gx = (unsigned)((nrows + 3) / 4);
+    hipLaunchKernelGGL(k_band_rowmax, dim3(gx), dim3(256), 0, ctx->stream, A, nrows, M, rmax);
+    hipLaunchKernelGGL(k_band_width<0>, dim3(gx), dim3(256), 0, ctx->stream, A, nrows, M, rmax, band, (int64_t)0, dropped);
     BA_HIP(hipGetLastError());
     int b = 0;
     BA_HIP(hipMemcpyAsync(&b, band, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     BA_HIP(hipStreamSynchronize(ctx->stream));
     *band_host = b;
+    *dropped_rel_host = 0.0;
+    if (b <= QF_BAND_LIMIT) {
+        hipLaunchKernelGGL(k_band_width<1>, dim3(gx), dim3(256), 0, ctx->stream, A, nrows, M, rmax, band, (int64_t)b, dropped);
+        BA_HIP(hipGetLastError());
+        unsigned long long u = 0;
+        BA_HIP(hipMemcpyAsync(&u, dropped, sizeof(u), hipMemcpyDeviceToHost, ctx->stream));
+        BA_HIP(hipStreamSynchronize(ctx->stream));
+        memcpy(dropped_rel_host, &u, sizeof(double));
+    }
     return BEATAMD_OK;
 }
 
@@ -502,10 +535,111 @@ __global__ void __launch_bounds__(256) k_quadform_banded(QbArgs a)
     if (tid < nc) a.quad[(c0 + tid) * a.q_stride + d] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
 }
 
+// ---- bidiagonal operators in the CANONICAL summation order (round 6) ----------------------------------------------------
+// The stacking kernels evaluate this misfit inside their epilogues (GF_RESID_BAND1, gfshared.hip): a lane there holds the 64
+// samples of one tile of one chain, so the order every path follows is
+//     quad = 0;  for tile k = 0, 1, ...:   quad += q_k;   if (k is not the last tile) quad = fma(yb_k, yb_k, quad)
+//     q_k  = sum over the tile's samples i but its last, ascending (fma(y_i, y_i, q)), + the trace's very last sample
+//     y_i  = fma(W[i,i+1], r_{i+1}, fma(W[i,i], r_i, 0));  yb_k = y of the tile's last sample (its neighbour = next tile)
+// and a chain's misfit has the same bits whichever kernel stacked it (batch size, rank count, fused or not).  This kernel is
+// the path of everything without the epilogue (the runs / small-group / streaming kernels, beatamd_mvn_chol_logp_batch):
+// workgroup = (dataset, 8 chains); the operator's band rows of a chunk of 64 tiles sit in LDS for all 8 chains, two chains'
+// residual rows at a time beside them (pitch 65: thread <-> (chain, tile) reads its 64 samples conflict-free), one thread
+// per chain adds the tiles up.
+constexpr int QB1_NC = 8, QB1_CT = 64;                 // chains per workgroup, tiles per chunk
+constexpr int QB1_WP = 130, QB1_XP = 65;               // pitches (doubles) of a tile's band rows / residuals in LDS
+constexpr size_t QB1_LDS = ((size_t)QB1_CT * QB1_WP + 2 * ((size_t)QB1_CT * QB1_XP + 1) + 4 * QB1_CT + QB1_NC) * sizeof(double)
+                           + 2 * QB1_CT * sizeof(int);
+
+__global__ void __launch_bounds__(256) k_quadform_band1(QbArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm1[];
+    double *wl = sm1;                                   // [QB1_CT][QB1_WP]: (w0, w1) of sample i of tile k at k * 130 + 2 i
+    double *xl = wl + QB1_CT * QB1_WP;                  // [2][QB1_CT * 65 + 1]
+    double *part = xl + 2 * (QB1_CT * QB1_XP + 1);      // [2][QB1_CT]
+    double *ybv = part + 2 * QB1_CT;                    // [2][QB1_CT]
+    double *sacc = ybv + 2 * QB1_CT;                    // [QB1_NC]
+    int *hasb = reinterpret_cast<int *>(sacc + QB1_NC); // [2][QB1_CT]
+    const int tid = threadIdx.x;
+    const int64_t d = blockIdx.y, c0 = (int64_t)blockIdx.x * QB1_NC;
+    const int nc = (int)min((int64_t)QB1_NC, a.C - c0);
+    const int64_t M = a.M, CH = (int64_t)QB1_CT * 64;
+    const double *wb = a.wb + d * M * 2;
+    if (tid < QB1_NC) sacc[tid] = 0.0;
+    for (int64_t i0 = 0; i0 < M; i0 += CH) {
+        const int64_t nch = min(CH, M - i0);            // samples of the chunk
+        __syncthreads();                                // (the chunk before is done with wl)
+        for (int64_t g = tid; g < 2 * nch; g += 256) wl[(g >> 7) * QB1_WP + (g & 127)] = wb[2 * i0 + g];
+        for (int j0 = 0; j0 < nc; j0 += 2) {
+            __syncthreads();                            // (the pair before is done with xl / part / ybv)
+            for (int jj = 0; jj < 2 && j0 + jj < nc; jj++) {
+                const double *x = a.X + (c0 + j0 + jj) * a.xs_c + d * a.xs_d + i0;
+                double *xr = xl + jj * (QB1_CT * QB1_XP + 1);
+                // (+ the first residual of the next chunk: the neighbour of this chunk's last sample)
+                for (int64_t g = tid; g < nch + (i0 + nch < M ? 1 : 0); g += 256) xr[(g >> 6) * QB1_XP + (g & 63)] = x[g];
+            }
+            __syncthreads();
+            if (tid < 128) {
+                const int jj = tid >> 6, k = tid & 63;
+                const int64_t n0 = i0 + (int64_t)k * 64;
+                const int nvalid = (int)min((int64_t)64, M - n0);
+                if (j0 + jj < nc && nvalid > 0) {
+                    const double *x = xl + jj * (QB1_CT * QB1_XP + 1) + k * QB1_XP;
+                    const double *w = wl + k * QB1_WP;
+                    const bool trace_end = n0 + nvalid == M;
+                    double q = 0.0, ri = x[0];
+                    for (int i = 0; i + 1 < nvalid; i++) {
+                        const double rn = x[i + 1];
+                        double y = fma(w[2 * i], ri, 0.0);
+                        y = fma(w[2 * i + 1], rn, y);
+                        q = fma(y, y, q);
+                        ri = rn;
+                    }
+                    double yb = 0.0;
+                    if (trace_end) {
+                        const double y = fma(w[2 * (nvalid - 1)], ri, 0.0);
+                        q = fma(y, y, q);
+                    } else {
+                        yb = fma(w[126], ri, 0.0);
+                        yb = fma(w[127], x[QB1_XP], yb);     // first residual of the next tile (k = 63: of the next chunk)
+                    }
+                    part[jj * QB1_CT + k] = q;
+                    ybv[jj * QB1_CT + k] = yb;
+                    hasb[jj * QB1_CT + k] = trace_end ? 0 : 1;
+                }
+            }
+            __syncthreads();
+            if (tid < 2 && j0 + tid < nc) {
+                const int ntl = (int)((nch + 63) / 64);
+                double sq = sacc[j0 + tid];
+                for (int k = 0; k < ntl; k++) {
+                    sq += part[tid * QB1_CT + k];
+                    if (hasb[tid * QB1_CT + k]) sq = fma(ybv[tid * QB1_CT + k], ybv[tid * QB1_CT + k], sq);
+                }
+                sacc[j0 + tid] = sq;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < nc) a.quad[(c0 + tid) * a.q_stride + d] = sacc[tid];
+}
+
 int launch_quadform_banded(beatamd_ctx *ctx, const double *wb, int64_t band, int64_t M, int64_t nd, int64_t C, const double *X,
                            int64_t xs_c, int64_t xs_d, double *quad, int64_t q_stride)
 {
     if (C == 0 || nd == 0) return BEATAMD_OK;
+    if (band == 1) {
+        QbArgs b;
+        b.wb = wb; b.M = M; b.nd = nd; b.C = C; b.band = 1;
+        b.X = X; b.xs_c = xs_c; b.xs_d = xs_d; b.quad = quad; b.q_stride = q_stride;
+        BA_CHECK(nd <= 65535, BEATAMD_EINVAL, "quadform_banded: too many datasets");
+        ScopedTimer tm(ctx, "quadform");
+        BA_HIP(hipFuncSetAttribute((const void *)k_quadform_band1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)QB1_LDS));
+        hipLaunchKernelGGL(k_quadform_band1, dim3((unsigned)((C + QB1_NC - 1) / QB1_NC), (unsigned)nd), dim3(256), QB1_LDS,
+                           ctx->stream, b);
+        BA_HIP(hipGetLastError());
+        return BEATAMD_OK;
+    }
     QbArgs a;
     a.wb = wb; a.M = M; a.nd = nd; a.C = C; a.band = band;
     a.X = X; a.xs_c = xs_c; a.xs_d = xs_d; a.quad = quad; a.q_stride = q_stride;
@@ -513,8 +647,7 @@ int launch_quadform_banded(beatamd_ctx *ctx, const double *wb, int64_t band, int
     {
         ScopedTimer tm(ctx, "quadform");
         const dim3 grid((unsigned)((C + QB_NC - 1) / QB_NC), (unsigned)nd);
-        if (band == 1) hipLaunchKernelGGL(k_quadform_banded<1>, grid, dim3(256), 0, ctx->stream, a);
-        else hipLaunchKernelGGL(k_quadform_banded<0>, grid, dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(k_quadform_banded<0>, grid, dim3(256), 0, ctx->stream, a);   // (band 1: k_quadform_band1 above)
     }
     BA_HIP(hipGetLastError());
     return BEATAMD_OK;

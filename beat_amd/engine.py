@@ -235,6 +235,13 @@ class Context(object):
         check(self._lib.beatamd_weights_band(self._h, wset_id, C.byref(b)))
         return b.value
 
+    def weights_band_info(self, wset_id):
+        """-> (half bandwidth or -1, largest entry beyond the band relative to the largest entry of its row): what the banded
+        evaluation of this weight set leaves out (<= 2^-40 by construction)"""
+        b, d = C.c_int64(), C.c_double()
+        check(self._lib.beatamd_weights_band_info(self._h, wset_id, C.byref(b), C.byref(d)))
+        return b.value, d.value
+
     def weights_destroy(self, wset_id):
         check(self._lib.beatamd_weights_destroy(self._h, wset_id))
 

@@ -13,12 +13,15 @@ The reference builds a pytensor graph and compiles it to a one-chain function
 same description is uploaded once to HBM and evaluated for a whole batch of chains per
 call; ``LogpForwFunc`` keeps the one-chain call signature on top of the batched one.
 """
+import logging
 from collections import OrderedDict
 
 import numpy as np
 
 from .. import _lib
 from ..engine import get_context
+
+logger = logging.getLogger("beat_amd.models")
 
 hyper_name_laplacian = "h_laplacian"  # beat/config.py:126
 hypo_vars = ["nucleation_strike", "nucleation_dip", "time"]  # beat/config.py:86
@@ -229,6 +232,7 @@ class FFIProblem(object):
                                    self.n_patch_dip if seismic else [],
                                    self.n_patch_strike if seismic else [],
                                    self.patch_sizes if seismic else [])
+        owned_wm, owned_geo = [], []     # weight sets THIS compiled model creates (released by it alone: ADVICE r5)
         for wm in self.wavemaps:
             libs = []
             for v in self.slip_varnames:
@@ -241,6 +245,8 @@ class FFIProblem(object):
                 wm._wset = ctx.weights_create_scalar(w, wm.slog_pdet, N)
             else:
                 wm._wset = ctx.weights_create_dense(w, wm.slog_pdet)
+                _log_band(ctx, wm._wset, "wavemap %s" % getattr(wm, "name", len(owned_wm)))
+            owned_wm.append(wm._wset)
             hp_off = [lay.offset(n, i) for n, i in wm.hypers]
             shift_off = None
             if wm.time_shifts is not None:
@@ -261,13 +267,14 @@ class FFIProblem(object):
                     g._wsets.append(ctx.weights_create_scalar([float(W)], [sl], n))
                 else:
                     g._wsets.append(ctx.weights_create_dense(np.asarray(W), [sl]))
+            owned_geo = list(g._wsets)
             hp_off = [lay.offset(n, i) for n, i in g.hypers]
             ctx.ffi_model_add_geodetic(mid, libs, g.data, g.odws, g.sizes, g._wsets, hp_off)
         if self.laplacian is not None:
             L, logdet = self.laplacian
             self._lap = ctx.laplacian_create(L, logdet)
             ctx.ffi_model_set_laplacian(mid, self._lap)
-        return LogpForwFunc(ctx, mid, self, return_rvs=return_rvs)
+        return LogpForwFunc(ctx, mid, self, return_rvs=return_rvs, wsets=owned_wm, geo_wsets=owned_geo)
 
 
 class _SharedView(object):
@@ -299,8 +306,12 @@ class LogpForwFunc(object):
     that list; the default returns the deterministics block only (the variables are the input).
     Either way ``f._llk_index`` points at ``like``."""
 
-    def __init__(self, ctx, model_id, problem, return_rvs=False):
+    def __init__(self, ctx, model_id, problem, return_rvs=False, wsets=None, geo_wsets=None):
         self.ctx, self.model_id, self.problem = ctx, model_id, problem
+        # the weight sets of THIS model, per wavemap / geodetic dataset (the ids on the shared wavemap / geodetic objects
+        # are those of the most recent compile: a second model over the same objects must not free or update ours)
+        self._wsets = list(wsets) if wsets is not None else [wm._wset for wm in problem.wavemaps]
+        self._geo_wsets = list(geo_wsets) if geo_wsets is not None else list(getattr(problem.geodetic, "_wsets", []) or [])
         self.nllk = ctx.ffi_model_nllk(model_id)
         self.nparams = problem.layout.size
         self.trust_input = True
@@ -416,17 +427,20 @@ class LogpForwFunc(object):
             return
         self.ctx.ffi_model_destroy(self.model_id)
         self.model_id = None
-        for wm in self.problem.wavemaps:
-            if wm._wset is not None:
-                self.ctx.weights_destroy(wm._wset)
-                wm._wset = None
+        for wm, ws in zip(self.problem.wavemaps, self._wsets):
+            if ws is not None:
+                self.ctx.weights_destroy(ws)
+                if wm._wset == ws:
+                    wm._wset = None
             if getattr(wm, "_whitened_with", None) is not None:
                 wm._whitened_with = None
+        self._wsets = [None] * len(self._wsets)
         g = self.problem.geodetic
-        if g is not None:
-            for ws in getattr(g, "_wsets", []):
-                self.ctx.weights_destroy(ws)
+        for ws in self._geo_wsets:
+            self.ctx.weights_destroy(ws)
+        if g is not None and list(getattr(g, "_wsets", [])) == self._geo_wsets:
             g._wsets = []
+        self._geo_wsets = []
 
     def batch(self, Q, out=None):
         """Q (C, nparams) numpy or torch-cuda -> LL (C, nllk)"""
@@ -482,7 +496,7 @@ class LogpForwFunc(object):
             d = torch.from_numpy(np.ascontiguousarray(wm.data)).to(dev)
             self.ctx.whiten_rows_batch(d.view(T, 1, N), M)
             self.ctx.ffi_model_update_data(self.model_id, wavemap_index, d)
-            self.ctx.weights_update(wm._wset, np.ones(T), sl)
+            self.ctx.weights_update(self._wsets[wavemap_index], np.ones(T), sl)
             self.ctx.synchronize()
             #  M (T x N x N, 8.6 GB at config 3) and the old operator go before the new one is kept: the peak
             # next to the libraries is then two operators (new + M), not three.  The operator stays on the device because
@@ -493,8 +507,21 @@ class LogpForwFunc(object):
             return
         if tuple(w.shape) not in ((T,), (T, N, N)) or tuple(sl.shape) != (T,):
             raise ValueError("weights must be (%d,) or (%d,%d,%d) and slog_pdet (%d,)" % (T, T, N, N, T))
-        self.ctx.weights_update(wm._wset, w, sl)
+        self.ctx.weights_update(self._wsets[wavemap_index], w, sl)
+        if len(tuple(w.shape)) == 3:
+            _log_band(self.ctx, self._wsets[wavemap_index], "wavemap %d (update)" % wavemap_index)
         wm.weights, wm.slog_pdet = w, _host(sl)
+
+
+def _log_band(ctx, wset, what):
+    """once per weights_create / weights_update of a dense set: how the library evaluates it (the
+    banded evaluation is chosen by a device scan -- say so where the user can see it)"""
+    band, dropped = ctx.weights_band_info(wset)
+    if band >= 0:
+        logger.info("%s: whitening operators evaluated on their band (half bandwidth %d; largest entry beyond it %.3g of its "
+                    "row's largest; BEATAMD_QF_BAND=0 keeps the dense kernel)", what, band, dropped)
+    else:
+        logger.info("%s: dense whitening operators (FP64 matrix-core kernel)", what)
 
 
 def _host(a):

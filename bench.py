@@ -932,7 +932,10 @@ def main():
                 "half_bandwidth": band, "chains": B, "steps": Kl, "chain_steps_per_s": B * Kl / legb["dt"],
                 "ms_per_step": legb["dt"] / Kl * 1e3,
                 "kernel_ms_per_step": {k: (v[0] / Kl) for k, v in legb["times"].items() if v[1]},
-                "quadform_kernel": "k_quadform_banded", "quadform_avg_launch_ms": qb_ms / max(qb_n, 1),
+                "kernel": legb["kernel"],
+                "quadform_kernel": "k_quadform_band1 behind the stacking kernel" if qb_n else
+                                   "none: the bidiagonal misfit rides in the stacking kernel's epilogue (mode 3, round 6)",
+                "quadform_avg_launch_ms": qb_ms / max(qb_n, 1),
                 "quadform_bytes_per_launch": 8.0 * B * T * N + 8.0 * T * N * ((band or 1) + 1) * ((B + 7) // 8),
                 "max_rel_dev_of_like_vs_dense": band_dev}
             if B == 512 and T == 64 and N == 4096 and not env_knobs:

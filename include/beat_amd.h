@@ -198,6 +198,12 @@ int beatamd_weights_destroy(beatamd_ctx *ctx, int32_t wset_id);
  * *band = the half bandwidth in use, -1 when the dense kernel is used.  BEATAMD_QF_BAND=0 (environment) keeps the dense
  * kernel for every set. */
 int beatamd_weights_band(beatamd_ctx *ctx, int32_t wset_id, int64_t *band);
+/* the same with what the banded evaluation leaves out: max_dropped_rel = the largest |entry| beyond the band relative to the
+ * largest |entry| of its own row (<= 2^-40 by construction; 0 for an exactly banded operator; rounding residue of
+ * inv + cholesky, ~2e-15, for the reference's "exponential" structure, beat/covariance.py:24-51 through heart.py:201-253).
+ * A caller logs it once per weights_create / weights_update (beat_amd.models.problem does); BEATAMD_VERBOSE=1 prints the
+ * detection to stderr.  band = -1: evaluated by the dense kernel. */
+int beatamd_weights_band_info(beatamd_ctx *ctx, int32_t wset_id, int64_t *band, double *max_dropped_rel);
 /*   residuals [C, nd, M]   hp [C, nd] (hyperparameter already resolved per dataset,
  *   distributions.py:117-126)   ->   logpts [C, nd]                                  */
 int beatamd_mvn_chol_logp_batch(beatamd_ctx *ctx, int32_t wset_id, int64_t C,

@@ -1152,3 +1152,55 @@ def test_banded_whitening_operators(ctx, orc, monkeypatch, M):
     wid = ctx.weights_create_dense(W[:, :20, :20].copy(), slogs)
     assert ctx.weights_band(wid) == -1
     ctx.weights_destroy(wid)
+
+
+@pytest.mark.parametrize("N,C,nvar,shifts", [(64, 300, 1, False), (200, 300, 1, True), (130, 1100, 1, False), (192, 257, 2, True),
+                                             (1030, 64, 1, False)])
+def test_bidiagonal_misfit_inside_the_stacking_kernel(ctx, monkeypatch, N, C, nvar, shifts):
+    """round 6: with the reference's "exponential" noise structure (covariance.py:24-51; bidiagonal
+    W = chol(inv(C)).T) the misfit sum_i (W[i,i] r_i + W[i,i+1] r_{i+1})^2 (distributions.py:119-138) rides in the
+    epilogue of k_gfstack_ws -- no residual store, no second kernel: the inner samples of a 64-sample tile in the kernel,
+    every tile's last sample (its neighbour is the next tile's first residual) in the tile-sum kernel.  Against the
+    unfused path (residual store + k_quadform_banded, BEATAMD_QF_FUSE=0), the dense kernel (BEATAMD_QF_BAND=0) and the
+    oracle's dense product; single tile, ragged last tile (N = 200, 130, 1030), several chain groups, two slip
+    components, station shifts; the same bits on every call"""
+    from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
+    from oracle import problem_oracle
+    names = ("uparr", "uperp")[:nvar]
+    spec = SyntheticSpec((6,), (7,), (1.0,), T=3, N=N, D=3, S=25, covariance="toeplitz", slip_varnames=names,
+                         station_shifts=shifts)
+    prob, host = build_problem(spec)
+    f = prob.compile(ctx)
+    assert ctx.weights_band(f.problem.wavemaps[0]._wset) == 1
+    Q = draw_population(spec, host["layout"], host["lower"], host["upper"], C)
+    monkeypatch.setenv("BEATAMD_GS_CG", "512")      # (a library this small would be stacked in smaller groups)
+    A = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack_ws<1,3,"), ctx.last_kernel()
+    assert np.array_equal(A, f.batch(Q))
+    monkeypatch.setenv("BEATAMD_QF_FUSE", "0")
+    B = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack_ws<1,2,"), ctx.last_kernel()
+    monkeypatch.delenv("BEATAMD_QF_FUSE")
+    # ONE summation order for every path (quadform.hip k_quadform_band1): a chain's misfit has the same bits whichever kernel
+    # stacked it -- batch size, group size and rank count cannot show
+    assert np.array_equal(A, B)
+    monkeypatch.setenv("BEATAMD_QF_BAND", "0")
+    D = f.batch(Q)
+    monkeypatch.delenv("BEATAMD_QF_BAND")
+    np.testing.assert_allclose(A, D, rtol=1e-10)
+    # kernels without the epilogue: the caller still gets the banded misfit (residual store + k_quadform_banded)
+    monkeypatch.setenv("BEATAMD_GS_CG", "128")
+    E = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack_dma<2,1,2,"), ctx.last_kernel()
+    assert np.array_equal(A, E)
+    assert np.array_equal(A[40:90], f.batch(Q[40:90]))      # a sub-batch: another kernel, the same bits
+    monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
+    S_ = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack<"), ctx.last_kernel()
+    if nvar == 1:
+        assert np.array_equal(A, S_)          # (one slip variable: the chain-shared kernels are bitwise the streaming kernel)
+    np.testing.assert_allclose(A, S_, rtol=1e-11)
+    for c in (0, C // 2, C - 1):
+        ref, _ = problem_oracle.forward(host, Q[c])
+        np.testing.assert_allclose(A[c], ref, rtol=1e-9)
+    f.release()
