@@ -106,6 +106,9 @@ _PROTOS = {
     "beatamd_proposal_draw_univariate": [_vp, _i64, _i64, _i32, _vp, C.c_uint64, C.c_uint32, _i64, _vp, _vp],
     "beatamd_gather_rows": [_vp, _i64, _i64, _vp, _i64, _vp, _vp],
     "beatamd_metropolis_tune": [_vp, _i64, _vp, _vp, _i32],
+    "beatamd_like_assemble": [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp],
+    "beatamd_metropolis_propose": [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "beatamd_metropolis_accept": [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _vp],
     "beatamd_whiten_rows": [_vp, _vp, _i64, _i64, _vp],
     "beatamd_whiten_rows_batch": [_vp, _vp, _i64, _i64, _i64, _vp],
     "beatamd_chol_inverse_batch": [_vp, _i64, _i64, _vp, _vp, _vp],

@@ -1421,6 +1421,60 @@ int beatamd_gather_rows(beatamd_ctx *ctx, int64_t nout, int64_t ncols, const dou
     return finish_out(ctx, &rec, 1);
 }
 
+// ------------------------------------------------------------------ a Metropolis step in pieces (target-sharded models)
+int beatamd_like_assemble(beatamd_ctx *ctx, int64_t C, int64_t nllk, int64_t nsrc, const double *gathered,
+                          const int32_t *dst_col, const double *local_ll, int64_t local_ld, int64_t local_col0,
+                          int64_t n_rest, int64_t rest_dst0, int32_t ngroups, const int32_t *group_end, double *LL)
+{
+    ENTER(ctx);
+    BA_CHECK(gathered && dst_col && LL && group_end && C >= 0 && nsrc > 0 && nllk > 1 && ngroups >= 1 && ngroups <= 8 &&
+             n_rest >= 0 && (n_rest == 0 || local_ll), BEATAMD_EINVAL, "like_assemble: bad argument");
+    BA_CHECK(is_device_ptr(gathered) && is_device_ptr(LL) && (!local_ll || is_device_ptr(local_ll)), BEATAMD_EINVAL,
+             "like_assemble: the gathered block, the local vectors and LL live on the device");
+    if (C == 0) return BEATAMD_OK;
+    LikeGroups grp;
+    grp.n = ngroups;
+    for (int g = 0; g < ngroups; g++) {
+        BA_CHECK(group_end[g] > 0 && group_end[g] < nllk && (g == 0 || group_end[g] >= group_end[g - 1]), BEATAMD_EINVAL,
+                 "like_assemble: composite boundaries must ascend inside the vector");
+        grp.end[g] = group_end[g];
+    }
+    for (int64_t r = 0; r < nsrc; r++)
+        BA_CHECK(dst_col[r] >= -1 && dst_col[r] < nllk - 1, BEATAMD_EINVAL, "like_assemble: column %d of row %lld", dst_col[r], (long long)r);
+    BA_CHECK(rest_dst0 >= 0 && rest_dst0 + n_rest <= nllk - 1, BEATAMD_EINVAL, "like_assemble: replicated columns outside the vector");
+    const void *d_dc;
+    BA_TRY(stage_in(ctx, SL_IN0, dst_col, (size_t)nsrc * 4, &d_dc));
+    BA_TRY(launch_like_assemble(ctx, C, nllk, nsrc, gathered, (const int32_t *)d_dc, local_ll, local_ld, local_col0, n_rest,
+                                rest_dst0, grp, LL, nullptr));
+    return BEATAMD_OK;
+}
+
+int beatamd_metropolis_propose(beatamd_ctx *ctx, int64_t C, int64_t nparams, const double *Q0, const double *delta,
+                               const double *scaling, const double *lower, const double *upper, double *Qprop,
+                               int32_t *inbounds)
+{
+    ENTER(ctx);
+    BA_CHECK(Q0 && delta && scaling && lower && upper && Qprop && inbounds && C >= 0 && nparams > 0, BEATAMD_EINVAL,
+             "metropolis_propose: bad argument");
+    BA_CHECK(is_device_ptr(Q0) && is_device_ptr(delta) && is_device_ptr(scaling) && is_device_ptr(lower) && is_device_ptr(upper) &&
+             is_device_ptr(Qprop) && is_device_ptr(inbounds), BEATAMD_EINVAL, "metropolis_propose: device pointers only");
+    return launch_propose(ctx, C, nparams, Q0, delta, scaling, lower, upper, Qprop, inbounds);
+}
+
+int beatamd_metropolis_accept(beatamd_ctx *ctx, int64_t C, int64_t nparams, int64_t nllk, double *Q0, double *L0,
+                              const double *Qprop, double *Lprop, const int32_t *inbounds, const double *log_u, double beta,
+                              const double *betas, int32_t *accepted)
+{
+    ENTER(ctx);
+    BA_CHECK(Q0 && L0 && Qprop && Lprop && inbounds && log_u && accepted && C >= 0 && nparams > 0 && nllk > 0, BEATAMD_EINVAL,
+             "metropolis_accept: bad argument");
+    BA_CHECK(is_device_ptr(Q0) && is_device_ptr(L0) && is_device_ptr(Qprop) && is_device_ptr(Lprop) && is_device_ptr(inbounds) &&
+             is_device_ptr(log_u) && is_device_ptr(accepted) && (!betas || is_device_ptr(betas)), BEATAMD_EINVAL,
+             "metropolis_accept: device pointers only");
+    return launch_accept(ctx, C, nparams, nllk, Q0, L0, Qprop, Lprop, inbounds, log_u, beta, betas, accepted, nullptr, nullptr,
+                         nullptr, nullptr, false);
+}
+
 int beatamd_metropolis_tune(beatamd_ctx *ctx, int64_t C, double *scaling, int32_t *accepted,
                             int32_t tune_interval)
 {

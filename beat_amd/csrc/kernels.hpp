@@ -170,6 +170,10 @@ struct LikeGroups {  // composite boundaries inside the llk vector (exclusive en
 // chain_bad (nullable): chains flagged by the index maps / the sweep get like = NaN
 int launch_like_sum(beatamd_ctx *ctx, int64_t C, int64_t nllk, const LikeGroups &grp, double *LL,
                     const int32_t *chain_bad);
+// likelihood vectors of a target-sharded model from the all-gathered rows of the ranks (k_like_assemble, logp.hip)
+int launch_like_assemble(beatamd_ctx *ctx, int64_t C, int64_t nllk, int64_t nsrc, const double *src, const int32_t *dst_col,
+                         const double *rest, int64_t rest_ld, int64_t rest_col0, int64_t n_rest, int64_t rest_dst0,
+                         const LikeGroups &grp, double *LL, int32_t *chain_bad);
 // gather slips of all variables into a dense [C, nvar, P] buffer
 int launch_gather_slips(beatamd_ctx *ctx, int64_t C, int nvar, int64_t P, const ChainVec *slips,
                         double *out);

@@ -175,6 +175,53 @@ int launch_like_sum(beatamd_ctx *ctx, int64_t C, int64_t nllk, const LikeGroups 
     return BEATAMD_OK;
 }
 
+// Likelihood vectors of a model whose seismic targets are SHARDED over ranks (beat_amd/models/sharded.py; SURVEY 8(e):
+// "each GPU owns T/R targets for all chains ... one small collective"): the all-gathered block `src` [nsrc, C] holds,
+// rank by rank, the rows a rank contributes -- the logpts of its datasets (dst_col[r] = their column in the full vector)
+// and one flag row per rank (dst_col[r] = -1: NaN marks a chain whose times left the library grid on one of THAT rank's
+// targets).  Thread <-> chain: scatter the rows into LL [C, nllk], copy the replicated columns (geodetic, Laplacian) from
+// this rank's local vector, then `like` in k_like_sum's order (per composite, then over composites; problems.py:227-247)
+// -- from the same gathered bits on every rank.
+__global__ void __launch_bounds__(256) k_like_assemble(int64_t C, int64_t nllk, int64_t nsrc, const double *src,
+                                                      const int32_t *dst_col, const double *rest, int64_t rest_ld,
+                                                      int64_t rest_col0, int64_t n_rest, int64_t rest_dst0, LikeGroups grp,
+                                                      double *LL, int32_t *chain_bad)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double *l = LL + c * nllk;
+    bool bad = false;
+    for (int64_t r = 0; r < nsrc; r++) {
+        const double v = src[r * C + c];
+        const int32_t d = dst_col[r];
+        if (d >= 0) l[d] = v;
+        else bad = bad || (v != v);
+    }
+    for (int64_t k = 0; k < n_rest; k++) l[rest_dst0 + k] = rest[c * rest_ld + rest_col0 + k];
+    double total = 0.0;
+    int k = 0;
+    for (int g = 0; g < grp.n; g++) {
+        double s = 0.0;
+        for (; k < grp.end[g]; k++) s += l[k];
+        total += s;
+    }
+    if (bad) total = __builtin_nan("");
+    l[nllk - 1] = total;
+    if (chain_bad) chain_bad[c] = bad ? 1 : 0;
+}
+
+int launch_like_assemble(beatamd_ctx *ctx, int64_t C, int64_t nllk, int64_t nsrc, const double *src, const int32_t *dst_col,
+                         const double *rest, int64_t rest_ld, int64_t rest_col0, int64_t n_rest, int64_t rest_dst0,
+                         const LikeGroups &grp, double *LL, int32_t *chain_bad)
+{
+    if (C == 0) return BEATAMD_OK;
+    ScopedTimer tm(ctx, "finish");
+    hipLaunchKernelGGL(k_like_assemble, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, ctx->stream, C, nllk, nsrc, src,
+                       dst_col, rest, rest_ld, rest_col0, n_rest, rest_dst0, grp, LL, chain_bad);
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
 struct GatherArgs {
     ChainVec slips[4];
 };

@@ -555,6 +555,37 @@ class Context(object):
         check(self._lib.beatamd_metropolis_tune(self._h, int(scaling.shape[0]), ptr(scaling), ptr(accepted),
                                                 int(tune_interval)))
 
+    # -- a Metropolis step in pieces (a collective between forward model and acceptance: target-sharded models)
+    def like_assemble(self, gathered, dst_col, local_ll, local_col0, n_rest, rest_dst0, group_end, LL):
+        """LL [C, nllk] (device) from the all-gathered rows `gathered` [nsrc, C] of all ranks: row r -> column dst_col[r]
+        (-1: a rank's flag row, NaN = chain outside the library grid there), the replicated columns
+        local_ll[:, local_col0 : local_col0 + n_rest] -> columns rest_dst0.., like = the composites' sums (k_like_sum's order)"""
+        self._adopt_stream(gathered, LL)
+        dc = np.ascontiguousarray(dst_col, dtype=np.int32)
+        ge = np.ascontiguousarray(group_end, dtype=np.int32)
+        Cn, nllk = int(LL.shape[0]), int(LL.shape[1])
+        if int(gathered.shape[0]) != dc.size or int(gathered.shape[1]) != Cn or not gathered.is_contiguous() or not LL.is_contiguous():
+            raise ValueError("like_assemble: gathered must be a contiguous (nsrc, C) tensor, LL a contiguous (C, nllk) one")
+        check(self._lib.beatamd_like_assemble(self._h, Cn, nllk, dc.size, ptr(gathered), dc.ctypes.data,
+                                              ptr(local_ll) if n_rest else None, int(local_ll.stride(0)) if n_rest else 0,
+                                              int(local_col0), int(n_rest), int(rest_dst0), ge.size, ge.ctypes.data, ptr(LL)))
+        return LL
+
+    def metropolis_propose(self, Q0, delta, scaling, lower, upper, Qprop, inbounds):
+        """metropolis.py:313-343 for all chains: Qprop = Q0 + delta * scaling inside the prior box, else Q0; inbounds int32 [C]"""
+        self._adopt_stream(Q0, Qprop)
+        check(self._lib.beatamd_metropolis_propose(self._h, int(Q0.shape[0]), int(Q0.shape[1]), ptr(f64(Q0)), ptr(f64(delta)),
+                                                   ptr(f64(scaling)), ptr(f64(lower)), ptr(f64(upper)), ptr(Qprop), ptr(inbounds)))
+
+    def metropolis_accept(self, Q0, L0, Qprop, Lprop, inbounds, log_u, beta, accepted):
+        """metropolis.py:344-385 for all chains, in place on Q0 / L0; beta: float or a device tensor [C]"""
+        self._adopt_stream(Q0, L0)
+        per_chain = hasattr(beta, "data_ptr")
+        check(self._lib.beatamd_metropolis_accept(self._h, int(Q0.shape[0]), int(Q0.shape[1]), int(L0.shape[1]), ptr(Q0), ptr(L0),
+                                                  ptr(Qprop), ptr(Lprop), ptr(inbounds), ptr(f64(log_u)),
+                                                  1.0 if per_chain else float(beta), ptr(f64(beta)) if per_chain else None,
+                                                  ptr(accepted)))
+
     def halfspace_displacements_batch(self, kinds, params, east, north, nu=0.25):
         """params (C, nsrc, 10) -> (C, nsrc, nobs, 3) = (north, east, up) [m]"""
         kinds = np.ascontiguousarray(kinds, dtype=np.int32)

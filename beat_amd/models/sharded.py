@@ -18,8 +18,10 @@ so the likelihood vectors, and with them every accept decision and stage transit
 and to the replicated run.  The geodetic and Laplacian composites are small and stay replicated.
 
 ``TargetShardedLogp`` has the batched interface of ``LogpForwFunc`` that the samplers use (``nparams``, ``nllk``,
-``batch``, ``astep_batch``); the Metropolis step runs in pieces (draws on the device, propose, forward + gather, accept)
-because a collective sits between forward model and acceptance.  ``SMC(..., shard="targets")`` keeps all chains on every
+``batch``, ``astep_batch``, ``update_weights``, ``release``); the Metropolis step runs in pieces -- draws on the device,
+``beatamd_metropolis_propose``, forward model, ONE all-gather, ``beatamd_like_assemble``, ``beatamd_metropolis_accept``:
+the kernels of the fused step (round 6; torch glue before) -- because a collective sits between forward model and
+acceptance.  ``SMC(..., shard="targets")`` keeps all chains on every
 rank.
 """
 import numpy as np
@@ -51,9 +53,15 @@ def shard_wavemap(wm, rank, world):
             part.setup(b - a, P, D, S, N, allocate=False)
             part._gfmatrix = gf._gfmatrix[a:b]
         gfs[v] = part
-    w = np.asarray(wm.weights)
+    w = wm.weights
+    if hasattr(w, "is_cuda"):            # (operators left on the device by update_weights)
+        w = w.detach().cpu().numpy()
+    w = np.asarray(w)
+    if getattr(wm, "is_prewhitened", False) or getattr(wm, "_whitened_with", None) is not None:
+        raise ValueError("target sharding of a PRE-WHITENED wavemap is not supported: shard the problem first, then compile "
+                         "each rank's block with prewhiten=...")
     ts = None if wm.time_shifts is None else (wm.time_shifts[0], np.asarray(wm.time_shifts[1])[a:b])
-    return SeismicWavemap(gfs, wm.data[a:b], w[a:b], wm.slog_pdet[a:b], wm.hypers[a:b], ts, wm.interpolation, wm.name)
+    return SeismicWavemap(gfs, wm.data[a:b], w[a:b], np.asarray(wm.slog_pdet)[a:b], wm.hypers[a:b], ts, wm.interpolation, wm.name)
 
 
 def shard_problem(prob, rank, world):
@@ -105,8 +113,30 @@ class TargetShardedLogp(object):
         return g
 
     # -- evaluation
+    def _plan(self):
+        """static maps of the gathered block (the same on every rank): destination column of every gathered row (-1: a
+        rank's flag row), composite boundaries of the full vector"""
+        if getattr(self, "_dst_col", None) is None:
+            col0 = np.concatenate([[0], np.cumsum(self.n_t)])
+            dst = []
+            for q in range(self.world):
+                for iw in range(len(self.n_t)):
+                    a, b = self.blocks[iw][q]
+                    dst += [int(col0[iw]) + k for k in range(a, b)]
+                dst.append(-1)
+            self._dst_col = np.asarray(dst, dtype=np.int32)
+            ends, e = [], self._seis_total
+            ends.append(e)
+            for gsz in self._rest_groups:
+                e += gsz
+                ends.append(e)
+            self._group_end = np.asarray(ends, dtype=np.int32)
+        return self._dst_col, self._group_end
+
     def batch(self, Q, out=None):
-        """Q [C, nparams] (device tensor or numpy) -> LL [C, nllk] in the layout of the unsharded model"""
+        """Q [C, nparams] (device tensor or numpy) -> LL [C, nllk] in the layout of the unsharded model.  Device side:
+        this rank's rows transposed for the collective (one torch copy), ONE all-gather, ONE kernel (beatamd_like_assemble:
+        scatter + replicated columns + `like` in k_like_sum's order + NaN flags)"""
         t = self.torch
         as_numpy = not t.is_tensor(Q)
         Qd = t.as_tensor(np.ascontiguousarray(Q)).to("cuda:%d" % self.ctx.device) if as_numpy else Q
@@ -115,56 +145,58 @@ class TargetShardedLogp(object):
         ns = sum(self.n_local)
         # this rank's rows: its datasets' logpts (wavemap by wavemap) + its `like` (NaN marks a chain whose times left the
         # library grid on one of ITS targets: the flag has to reach every rank)
-        mine = t.cat([L_loc[:, :ns].t(), L_loc[:, -1:].t()], 0).contiguous()
+        mine = t.empty((ns + 1, C), dtype=t.float64, device=L_loc.device)
+        mine[:ns].copy_(L_loc[:, :ns].t())
+        mine[ns].copy_(L_loc[:, -1])
         allr = parallel.allgather_rows(mine) if self.world > 1 else mine     # (blocks of different length: counts exchanged)
-        LL = t.empty((C, self.nllk), dtype=t.float64, device=L_loc.device)
-        bad = t.zeros(C, dtype=t.bool, device=L_loc.device)
-        col0 = 0
-        rank_rows = [sum(b[q][1] - b[q][0] for b in self.blocks) + 1 for q in range(self.world)]
-        starts = np.concatenate([[0], np.cumsum(rank_rows)])
-        for iw, n in enumerate(self.n_t):
-            for q in range(self.world):
-                a, b = self.blocks[iw][q]
-                before = sum(self.blocks[k][q][1] - self.blocks[k][q][0] for k in range(iw))
-                r0 = int(starts[q]) + before
-                LL[:, col0 + a:col0 + b] = allr[r0:r0 + (b - a)].t()
-            col0 += n
-        for q in range(self.world):
-            bad |= t.isnan(allr[int(starts[q + 1]) - 1])
-        LL[:, col0:col0 + self.n_rest] = L_loc[:, ns:ns + self.n_rest]
-        # like: the sums of k_like_sum (beat_amd/csrc/logp.hip; problems.py:227-247), term by term in column order
-        total = t.zeros(C, dtype=t.float64, device=L_loc.device)
-        k = 0
-        for gsz in [self._seis_total] + self._rest_groups:
-            s = t.zeros(C, dtype=t.float64, device=L_loc.device)
-            for _ in range(gsz):
-                s = s + LL[:, k]
-                k += 1
-            total = total + s
-        LL[:, -1] = t.where(bad, t.full_like(total, float("nan")), total)
-        if out is not None:
+        dst_col, group_end = self._plan()
+        LL = out if (out is not None and t.is_tensor(out) and out.is_contiguous()) else \
+            t.empty((C, self.nllk), dtype=t.float64, device=L_loc.device)
+        self.ctx.like_assemble(allr.contiguous(), dst_col, L_loc, ns, self.n_rest, self._seis_total, group_end, LL)
+        self._last_bad = LL[:, -1]        # (NaN = flagged on SOME rank: the collective error check reads it)
+        if out is not None and out is not LL:
             out.copy_(LL)
             return out
         return LL.cpu().numpy() if as_numpy else LL
 
     def astep_batch(self, Q0, L0, delta, scaling, lower, upper, log_u, beta, accepted=None):
-        """metropolis.py:313-385 for all chains, in place on Q0 / L0 (device tensors): propose, prior box, forward
-        model + gather, tempered acceptance -- the decisions of the fused kernels (out-of-box proposals are parked on
-        the current point and still evaluated; NaN never accepts)"""
+        """metropolis.py:313-385 for all chains, in place on Q0 / L0 (device tensors): propose (k_propose), forward model +
+        gather + assemble, tempered acceptance (k_accept) -- the kernels of the fused step around the collective; out-of-box
+        proposals are parked on the current point and still evaluated; NaN never accepts"""
         t = self.torch
-        q = Q0 + delta * scaling[:, None]
-        inb = ((q >= lower) & (q <= upper)).all(1)
-        qe = t.where(inb[:, None], q, Q0)
-        lp = self.batch(qe)
-        b = beta if t.is_tensor(beta) and beta.ndim else float(beta)
-        mr = b * (lp[:, -1] - L0[:, -1])
-        acc = inb & t.isfinite(mr) & (log_u < mr)
-        Q0.copy_(t.where(acc[:, None], q, Q0))
-        L0.copy_(t.where(acc[:, None], lp, L0))
+        C = Q0.shape[0]
+        if getattr(self, "_qprop", None) is None or self._qprop.shape != Q0.shape:
+            self._qprop = t.empty_like(Q0)
+            self._inb = t.empty(C, dtype=t.int32, device=Q0.device)
+            self._lprop = t.empty((C, self.nllk), dtype=t.float64, device=Q0.device)
         if accepted is None:
-            accepted = t.zeros(Q0.shape[0], dtype=t.int32, device=Q0.device)
-        accepted.copy_(acc.to(t.int32))
+            accepted = t.zeros(C, dtype=t.int32, device=Q0.device)
+        self.ctx.metropolis_propose(Q0, delta, scaling, lower, upper, self._qprop, self._inb)
+        self.batch(self._qprop, out=self._lprop)
+        self.ctx.metropolis_accept(Q0, L0, self._qprop, self._lprop, self._inb, log_u, beta, accepted)
         return accepted
+
+    def check_collectively(self):
+        """the device status word (an index outside the library, ...) is set on the rank that OWNS the offending target
+        only: raised alone it would leave the other ranks waiting in the next collective.  Every rank calls
+        this at the same places (SMC.select_end_points): the ranks' outcomes are all-gathered and every rank raises the
+        same exception class"""
+        from ..sampler.ops import collective_check
+        collective_check(self.ctx, self.world)
+
+    # -- the rest of the LogpForwFunc surface the samplers touch
+    def update_weights(self, wavemap_index, weights, slog_pdet):
+        """new whitening operators / scalar weights of one wavemap (all T targets given): this rank installs its block"""
+        a, b = self.blocks[wavemap_index][self.rank]
+        w = weights[a:b] if hasattr(weights, "__getitem__") else weights
+        self.local.update_weights(wavemap_index, w, slog_pdet[a:b])
+
+    def synthetics(self, Q, wavemap_index=0, residuals=False):
+        raise NotImplementedError("synthetics of a target-sharded model: evaluate the local model (self.local.synthetics) for "
+                                  "this rank's targets %s" % (self.blocks[wavemap_index][self.rank],))
+
+    def release(self):
+        self.local.release()
 
     def __call__(self, q):
         """B1 seam for one point: list of arrays like the compiled function's outputs"""

@@ -172,6 +172,39 @@ class DeviceOps(object):
         self.ctx.synchronize()
 
 
+def collective_check(ctx, world):
+    """ops.check() of models whose ranks can fail alone (target-sharded libraries): every rank synchronises, the outcomes
+    (0 ok, 1 IndexError, 2 ValueError, 3 LinAlgError, 4 anything else) are all-gathered and EVERY rank raises -- its own
+    exception when it has one, else the class the failing rank raised (a rank raising alone leaves the
+    others blocked in the next collective)"""
+    import torch
+
+    from .. import parallel
+    err, code = None, 0
+    try:
+        ctx.synchronize()
+    except IndexError as exc:
+        err, code = exc, 1
+    except np.linalg.LinAlgError as exc:
+        err, code = exc, 3
+    except ValueError as exc:
+        err, code = exc, 2
+    except Exception as exc:       # noqa: BLE001 (re-raised below, on every rank)
+        err, code = exc, 4
+    codes = [code]
+    if world > 1:
+        mine = torch.tensor([[float(code)]], dtype=torch.float64, device="cuda:%d" % ctx.device)
+        codes = [int(x) for x in parallel.allgather_rows(mine)[:, 0].cpu().tolist()]
+    if err is not None:
+        raise err
+    worst = max(codes)
+    if worst:
+        who = [r for r, c_ in enumerate(codes) if c_]
+        msg = "raised on rank(s) %s (this rank's targets are fine)" % who
+        raise {1: IndexError("index out of bounds of the GF library (duration/starttime outside the library grid): " + msg),
+               2: ValueError(msg), 3: np.linalg.LinAlgError(msg)}.get(worst, RuntimeError(msg))
+
+
 class _Base(object):
     """a strided device view handed to the C ABI as (base pointer, stride): quacks like the
     contiguous tensors ``engine.f64`` accepts"""

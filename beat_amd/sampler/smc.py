@@ -101,7 +101,10 @@ class SMC(object):
     def select_end_points(self, Q_local, L_local):
         """smc.py:188-240 -- instead of reading trace files: all-gather the ranks' blocks; the
         gathered arrays stay on the device."""
-        self.ops.check()  # surfaces an out-of-library index of the finished stage (IndexError)
+        if self.shard == "targets" and hasattr(self.target, "check_collectively"):
+            self.target.check_collectively()     # (a rank that owns the offending target must not raise alone: ADVICE r5)
+        else:
+            self.ops.check()  # surfaces an out-of-library index of the finished stage (IndexError)
         if self.shard == "targets":
             self.Q_all, self.L_all = Q_local, L_local      # every rank stepped the whole population
         else:
@@ -190,6 +193,8 @@ def _dump_stage(step, homepath, layout, out_names, backend):
         ac = parallel.allgather_rows(step.stepper.accepted_since_tune[:, None])[:, 0].cpu().numpy()
     _join_stage_writer(step)          # (at most one stage is being written at a time)
     if step.rank != 0:
+        if not getattr(step, "async_stage_files", True):
+            _join_stage_writer(step)  # (in-line writing: rank 0's outcome is broadcast right behind its write, below)
         return
     # everything the files hold is copied to the host HERE; the writing itself (one NumpyChain / TextChain file per
     # chain + the state archive: ~0.5 ms per chain) runs in a thread beside the next stage's sampling, whose host
@@ -219,10 +224,17 @@ def _dump_stage(step, homepath, layout, out_names, backend):
         np.savez(tmp, **state)
         os.replace(tmp, os.path.join(path, "sampler_state.npz"))
 
-    if not getattr(step, "async_stage_files", True):
-        return write()
-    import threading
     box = {}
+    if not getattr(step, "async_stage_files", True):
+        # in line -- but a failure is surfaced where the threaded writer's is: by _join_stage_writer, on EVERY rank (rank 0
+        # raising here alone would leave the others in the next collective)
+        try:
+            write()
+        except BaseException as exc:      # noqa: BLE001
+            box["error"] = exc
+        step._stage_writer = (None, box)
+        return _join_stage_writer(step)
+    import threading
 
     def guarded():
         try:
@@ -243,7 +255,8 @@ def _join_stage_writer(step):
     err = None
     if w is not None:
         step._stage_writer = None
-        w[0].join()
+        if w[0] is not None:
+            w[0].join()
         err = w[1].get("error")
     if getattr(step, "world", 1) > 1 and getattr(step, "_stage_files_on", False):
         failed = parallel.broadcast_array(np.array([1.0 if err is not None else 0.0]), src=0)

@@ -380,7 +380,7 @@ def main():
                     help="skip the labelled legs of the other configurations: multilinear (the reference's "
                          "default interpolation), dense Toeplitz covariance, pre-whitened library, parallel "
                          "tempering, geometry mode")
-    ap.add_argument("--variant-legs", default="multilinear,toeplitz,default_config,stage_update,smc,pt,prewhitened,geometry,fp32,config4,realistic_grid",
+    ap.add_argument("--variant-legs", default="multilinear,toeplitz,default_config,stage_update,smc,pt,prewhitened,geometry,fp32,config4,realistic_grid,sharded",
                     help="which of the labelled configuration legs to run (comma separated)")
     ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "r5_bench_c512_nn_gfstack_ws_summary.json"),
                     help="rocprofv3 PMC summary (tools/run_profile.sh + tools/summarize_rocpd.py) of THIS "
@@ -1150,6 +1150,35 @@ def main():
                 "launches_per_step": 4,
                 "us_per_step_eager": gleg["eager"], "us_per_step_hip_graph": gleg["graph"],
                 "chain_steps_per_s": 1024 / (min(gleg.values()) * 1e-6)}
+        if "sharded" in legs:
+            # libraries sharded by TARGET (SURVEY 8(e) fallback for libraries beyond one GPU): tools/time_sharded.py in
+            # processes of their own -- 1 rank replicated (fused step), then 2 and 8 ranks holding the rows of their targets,
+            # ALL ON THIS ONE GPU (gloo, the all-gather staged through host memory): the step in pieces + one all-gather
+            import subprocess
+            sh = {}
+            tool = os.path.join(ROOT, "tools", "time_sharded.py")
+            env_s = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+            for nr in (1, 2, 8):
+                cmd = [sys.executable, tool] if nr == 1 else \
+                    [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nr), "--master-addr",
+                     "127.0.0.1", "--master-port", str(29650 + nr), tool]
+                try:
+                    r_ = subprocess.run(cmd + ["--targets", "16", "--samples", "2048", "--chains", str(B), "--steps", "10"],
+                                        env=env_s, cwd=ROOT, capture_output=True, text=True, timeout=600)
+                    ln = [x for x in r_.stdout.splitlines() if x.startswith("{")]
+                    sh["%d_rank%s" % (nr, "" if nr == 1 else "s")] = json.loads(ln[-1]) if ln else {"failed": r_.stderr[-300:]}
+                except (subprocess.TimeoutExpired, OSError) as exc:
+                    sh["%d_ranks" % nr] = {"failed": str(exc)[:200]}
+            rep_ = sh.get("1_rank", {})
+            for k_, v_ in sh.items():
+                if k_ != "1_rank" and "ms_per_step" in v_ and "ms_per_step" in rep_:
+                    v_["chain_steps_per_s"] = B / (v_["ms_per_step"] * 1e-3)
+                    v_["overhead_vs_replicated_without_allgather"] = v_["ms_per_step_without_allgather"] / rep_["ms_per_step"] - 1.0
+                    v_["bitwise_equal_to_replicated"] = v_["state_checksum"] == rep_["state_checksum"]
+            if "ms_per_step" in rep_:
+                rep_["chain_steps_per_s"] = B / (rep_["ms_per_step"] * 1e-3)
+            sh["workload"] = ("config 3 with 16 targets x 2048 samples (7.9 GB), %d chains, 10 steps; all ranks on one GPU, gloo" % B)
+            out["sharded_leg"] = sh
         if legs & {"config4", "realistic_grid"}:
             # legs with libraries of their own: the variant models of the main library (dense weight sets of 8.6 GB each,
             # the whitened library copy, update buffers) are not needed any more

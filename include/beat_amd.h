@@ -405,6 +405,27 @@ int beatamd_proposal_draw_univariate(beatamd_ctx *ctx, int64_t C, int64_t nparam
  * at the next synchronisation. */
 int beatamd_gather_rows(beatamd_ctx *ctx, int64_t nout, int64_t ncols, const double *src,
                         int64_t nrows_src, const int32_t *indexes, double *out);
+/* ---- a Metropolis step in pieces, for models with a collective between forward model and acceptance (libraries sharded
+ * by TARGET over ranks; beat_amd/models/sharded.py).  All pointers are device pointers.
+ *
+ * beatamd_like_assemble: the full likelihood vectors LL [C, nllk] (layout of the unsharded model: datasets..., like) from
+ *   the all-gathered block `gathered` [nsrc, C] -- row r goes to column dst_col[r] (host int32 [nsrc]); dst_col[r] = -1
+ *   marks a rank's FLAG row (NaN in it = that rank saw the chain's start times / durations leave the library grid: the
+ *   reference raises IndexError there, beat/ffi/base.py:486-568) -- + the replicated columns (geodetic datasets,
+ *   Laplacian) local_ll[c*local_ld + local_col0 .. +n_rest) -> columns rest_dst0..; then like = the composites' sums in
+ *   order, summed (beat/models/problems.py:227-247; group_end [ngroups] host: exclusive column ends), NaN for flagged chains.
+ * beatamd_metropolis_propose: q = q0 + delta * scaling, prior box test, out-of-box rows parked on q0 (metropolis.py:313-343).
+ * beatamd_metropolis_accept: tempered acceptance iff in bounds, isfinite(mr), log u < mr with mr = beta (like' - like)
+ *   (betas [C] non-NULL: per chain) -- metropolis.py:344-385 + pymc metrop_select; Q0 / L0 updated in place. */
+int beatamd_like_assemble(beatamd_ctx *ctx, int64_t C, int64_t nllk, int64_t nsrc, const double *gathered,
+                          const int32_t *dst_col, const double *local_ll, int64_t local_ld, int64_t local_col0,
+                          int64_t n_rest, int64_t rest_dst0, int32_t ngroups, const int32_t *group_end, double *LL);
+int beatamd_metropolis_propose(beatamd_ctx *ctx, int64_t C, int64_t nparams, const double *Q0, const double *delta,
+                               const double *scaling, const double *lower, const double *upper, double *Qprop,
+                               int32_t *inbounds);
+int beatamd_metropolis_accept(beatamd_ctx *ctx, int64_t C, int64_t nparams, int64_t nllk, double *Q0, double *L0,
+                              const double *Qprop, double *Lprop, const int32_t *inbounds, const double *log_u, double beta,
+                              const double *betas, int32_t *accepted);
 /* replaces: the per-chain step-size tuning of Metropolis.astep   metropolis.py:294-306
  *   scaling [C] *= pymc's tune factor of accepted[c] / tune_interval; accepted [C] reset to 0 */
 int beatamd_metropolis_tune(beatamd_ctx *ctx, int64_t C, double *scaling, int32_t *accepted,

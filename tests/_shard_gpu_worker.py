@@ -51,6 +51,42 @@ def main():
         raise AssertionError("expected the IndexError of the chain outside the library grid")
     except IndexError:
         pass                   # ... and leaves NaN in that chain's `like`
+    if mode == "targets":
+        # a start time that leaves the grid on the targets of ONE rank only -- a station correction of
+        # a station whose channels all live on the last rank (targets 3, 4) -- sets the status word there alone; the
+        # collective check makes EVERY rank raise the IndexError instead of leaving the others in the next all-gather
+        prob2, host2 = build_problem(spec)
+        name, _ = host2["time_shifts"]
+        prob2.wavemaps[0].time_shifts = (name, np.array([0, 0, 0, 1, 1]))
+        f2 = TargetShardedLogp(prob2, ctx)
+        Q2 = torch.from_numpy(draw_population(spec, lay, host["lower"], host["upper"], 64)).to(dev)
+        Q2[11, lay.offset(name, 1)] = -500.0
+        LL2 = f2.batch(Q2)
+        try:
+            f2.check_collectively()
+            raise AssertionError("rank %d: expected the IndexError raised on the rank that owns targets 3, 4" % rank)
+        except IndexError:
+            pass
+        assert bool(torch.isnan(LL2[11, -1])) and int(torch.isnan(LL2[:, -1]).sum()) == 1
+        f2.check_collectively()           # (the status words were cleared: a healthy evaluation passes on every rank)
+        # the step in pieces (propose / forward + gather + assemble / accept kernels) = the same step of the local torch twin
+        L0 = f2.batch(Q2[:32].contiguous()).clone()
+        q0, l0 = Q2[:32].clone(), L0.clone()
+        g = torch.Generator(device=dev)
+        g.manual_seed(5)
+        delta = torch.randn(q0.shape, generator=g, device=dev, dtype=torch.float64) * 1e-3
+        log_u = torch.log(torch.rand(32, generator=g, device=dev, dtype=torch.float64))
+        sc = torch.ones(32, device=dev, dtype=torch.float64)
+        lo_t, up_t = torch.from_numpy(lo).to(dev), torch.from_numpy(up).to(dev)
+        acc = f2.astep_batch(q0, l0, delta, sc, lo_t, up_t, log_u, 0.3)
+        qp = Q2[:32] + delta
+        inb = ((qp >= lo_t) & (qp <= up_t)).all(1)
+        lp = f2.batch(torch.where(inb[:, None], qp, Q2[:32]).contiguous())
+        mr = 0.3 * (lp[:, -1] - L0[:, -1])
+        want = inb & torch.isfinite(mr) & (log_u < mr)
+        assert torch.equal(acc.bool(), want), (int(want.sum()), int(acc.sum()))
+        assert torch.equal(q0, torch.where(want[:, None], qp, Q2[:32])) and torch.equal(l0, torch.where(want[:, None], lp, L0))
+        f2.release()
     step = SMC(f, lo, up, n_chains=256, device=dev, random_seed=11, tune_interval=3,
                shard="targets" if mode == "targets" else "chains")
     pop, lp, betas = smc_sample(4, step, max_stages=3, final_stage=False)

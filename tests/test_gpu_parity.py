@@ -1124,14 +1124,25 @@ def test_banded_whitening_operators(ctx, orc, monkeypatch, M):
     out5 = ctx.mvn_chol_logp_batch(wid, res, hp)
     for c in range(0, C, 9):
         np.testing.assert_allclose(out5[c], orc.multivariate_normal_chol(list(Wb), slogs, hp[c], res[c]), rtol=1e-10)
-    # an entry far from the diagonal, just above / below the threshold (2^-40 of the largest entry)
+    # an entry far from the diagonal, just above / below the threshold: 2^-40 of the largest entry OF ITS ROW (round 6,
+    # a matrix-wide maximum would drop entries that matter in a row of small scale)
     far = Wb.copy()
-    far[1, 0, M - 1] = 2.0 ** -39 * np.abs(Wb[1]).max()
+    far[1, 0, M - 1] = 2.0 ** -39 * np.abs(Wb[1, 0]).max()
     ctx.weights_update(wid, far, slogs)
     assert ctx.weights_band(wid) == (-1 if M > 33 else 5)
-    far[1, 0, M - 1] = 2.0 ** -41 * np.abs(Wb[1]).max()
+    far[1, 0, M - 1] = 2.0 ** -41 * np.abs(Wb[1, 0]).max()
     ctx.weights_update(wid, far, slogs)
     assert ctx.weights_band(wid) == 5
+    band, dropped = ctx.weights_band_info(wid)
+    assert band == 5 and dropped == 2.0 ** -41          # what the banded evaluation leaves out, relative to the row
+    # heterogeneous row scales: a row a million times smaller keeps an entry that is large IN THAT ROW
+    het = Wb.copy()
+    het[1, 3] *= 1e-6
+    het[1, 3, M - 2] = 0.3 * np.abs(het[1, 3]).max()
+    ctx.weights_update(wid, het, slogs)
+    assert ctx.weights_band(wid) == -1
+    np.testing.assert_allclose(ctx.mvn_chol_logp_batch(wid, res, hp)[::9],
+                               [orc.multivariate_normal_chol(list(het), slogs, hp[c], res[c]) for c in range(0, C, 9)], rtol=1e-10)
     # below the diagonal: not triangular -> dense
     low = Wb.copy()
     low[2, 5, 4] = 1e-300
