@@ -150,7 +150,7 @@ struct GfKnobs {
         ws_map = KNOB_UNSET, gs_pair = KNOB_UNSET, gs_nthint = KNOB_UNSET, gs_order = KNOB_UNSET, gs_fit = KNOB_UNSET,
         gs_win = KNOB_UNSET, gf_tinv = KNOB_UNSET, gs_tune = KNOB_UNSET, gf_order = KNOB_UNSET, gf_cgroup = KNOB_UNSET,
         gs_ml = KNOB_UNSET, gc_global = KNOB_UNSET, gc_sort = KNOB_UNSET, gc_keys = KNOB_UNSET, gc_bands = KNOB_UNSET, gr_cap = KNOB_UNSET,
-        gr_pass_alloc = KNOB_UNSET, gr_var = KNOB_UNSET, sweep_v1 = KNOB_UNSET, qf_band = KNOB_UNSET, qf_fuse = KNOB_UNSET;
+        gr_pass_alloc = KNOB_UNSET, gr_var = KNOB_UNSET, sweep_v1 = KNOB_UNSET, qf_band = KNOB_UNSET, qf_fuse = KNOB_UNSET, gf_split = KNOB_UNSET;
     void read_env();
     static int get(int v, int dflt) { return v == KNOB_UNSET ? dflt : v; }
     static bool is(int v, int x) { return v != KNOB_UNSET && v == x; }       // set and equal to x
@@ -250,7 +250,7 @@ enum Slot : int {
     SL_QPROP, SL_LPROP, SL_MISC, SL_GS_UROWS, SL_GS_UCOUNT, SL_GS_SLOT, SL_GS_W, SL_GS_UMAX, SL_GS_USLOT,
     SL_CHAINBAD, SL_Z, SL_ROWSCALE, SL_CUM, SL_STAGE2, SL_WHITEN,
     SL_CHOL_A, SL_CHOL_X, SL_CHOL_D, SL_CHOL_T, SL_CHOL_L,
-    SL_GC_ORDER, SL_GS_ORDER, SL_GC_STREAM, SL_GC_HDR, SL_GC_META, SL_DELTA, SL_LOGU, SL_EDGES, SL_COUNT
+    SL_GC_ORDER, SL_GS_ORDER, SL_GC_STREAM, SL_GC_HDR, SL_GC_META, SL_DELTA, SL_LOGU, SL_EDGES, SL_TSLOT, SL_SPLIT, SL_COUNT
 };
 
 }  // namespace beatamd

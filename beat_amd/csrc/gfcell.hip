@@ -348,6 +348,7 @@ struct GmTabArgs {
     uint32_t *ltab;               // [(g*T+t)][step 0..smax+2][loader][GC_LTABDW]: count, first row of the patch, requests
     uint32_t *dtab;               // [(g*T+t)][consumer][step 0..smax][GR_DLINE] position descriptors (scalar loads)
     uint32_t *ucount;             // [gtp] row segments the loaders move for the patch, all passes (statistics)
+    int64_t R;                    // patch split: slot t covers patches (t % R) * P + p of the real model (slips)
 };
 
 __global__ void __launch_bounds__(256) k_gm_scan(const uint32_t *npass, uint32_t *voff, uint32_t *nv, int64_t P, int64_t vmax,
@@ -648,7 +649,7 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
             }
             if (!slot) continue;
             const uint32_t ring = (uint32_t)((s % 3) * a.cap);
-            const double sl = mine ? a.slips[iv].base[c * a.slips[iv].stride + a.slips[iv].off + p] : 0.0;
+            const double sl = mine ? a.slips[iv].base[c * a.slips[iv].stride + a.slips[iv].off + (t % a.R) * a.P + p] : 0.0;
             const int q = r & 3;
             // weights only: a 256-byte record pair serves eight positions, entry e = {weight e of record 2p, of record 2p + 1}
             char *rec = a.wtab + ((gt * GC_NCONS + w) * (a.smax + 1) + s) * (int64_t)GR_WSTRIDE + (r >> 3) * GR_PAIR + ((r >> 2) & 1) * 8;
@@ -835,6 +836,7 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
     ta.vmax = vmax; ta.smax = smax;
     ta.rowoff = rowoff; ta.fac = fac;
     for (int v = 0; v < k.nvar; v++) ta.slips[v] = k.slips[v];
+    ta.R = k.patch_split;
     ta.order = oa.order;
     BA_TRY(ctx->get_scratch(SL_GC_STREAM, (size_t)GT * GC_NCONS * (smax + 1) * GR_WSTRIDE + 8192, &p));
     ta.wtab = (char *)p;

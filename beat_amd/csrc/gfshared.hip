@@ -1883,6 +1883,7 @@ struct WsTabArgs {
     uint16_t *slot;           // [gt*vmax + v][WS_CG]
     double *w;                // [variable][gt*vmax + v][WS_CG]
     int64_t w_var_stride;
+    int64_t R;                // patch split: slot t covers patches (t % R) * P + p of the real model (slips)
 };
 
 __global__ void __launch_bounds__(256) k_ws_scan(const uint32_t *npass, uint32_t *voff, uint32_t *nv, int64_t P)
@@ -2066,7 +2067,7 @@ __global__ void __launch_bounds__(WS_CG) k_ws_tables(WsTabArgs a)
     const uint16_t myslot = live ? slt[pos] : (uint16_t)0;
     double sl[4] = {0.0, 0.0, 0.0, 0.0};
     for (int iv = 0; iv < a.nvar; iv++)
-        if (live) sl[iv] = a.slips[iv].base[c * a.slips[iv].stride + a.slips[iv].off + p];
+        if (live) sl[iv] = a.slips[iv].base[c * a.slips[iv].stride + a.slips[iv].off + (t % a.R) * a.P + p];
     constexpr int kstr = WS_USTRIDE / WS_LW;
     for (int k = 0; k < npass; k++) {
         const int64_t vs = v0 + k;
@@ -2129,6 +2130,9 @@ int gfstack_shared_candidates(const GfStackCall &k, int *cgs, int *ucaps)
     int n = 0;
     const int cand[4] = {512, 256, 128, 64};
     for (int i = 0; i < 4; i++) {
+        // patch split (small-N libraries): the loader / consumer kernel only (the small-group kernels index their
+        // weight tables by the real patch)
+        if (k.patch_split > 1 && cand[i] != 512) continue;
         // a group size that would leave more than half of its lanes without a chain only pads
         if (cand[i] > 64 && (int64_t)cand[i] / 2 >= k.C) continue;
         // large batches: small groups stage every distinct row many times over and have never been the fastest
@@ -2154,6 +2158,10 @@ bool gfstack_shared_applicable(const GfStackCall &k, int *cg_out, int *ucap_out)
     int cg = pick_group(k.C);
     const int gq = GfKnobs::get(kn.gs_cg, 0);
     if (gq == 64 || gq == 128 || gq == 256 || gq == 512 || gq == 1024) cg = gq;
+    if (k.patch_split > 1) {      // the loader / consumer kernel or none (the streaming kernel then)
+        if (!ws_wanted(k, WS_CG)) return false;
+        cg = WS_CG;
+    }
     const int64_t DS = L.D * L.S;
     int64_t ucap = std::min<int64_t>((int64_t)cg * nrow, DS);
     if (ws_wanted(k, cg)) {
@@ -2205,6 +2213,7 @@ static int launch_gfstack_ws(beatamd_ctx *ctx, const GfStackCall &k, const uint3
     ta.C = k.C; ta.T = Ttab; ta.P = L.P; ta.DS = L.D * L.S; ta.vmax = vmax;
     ta.rowoff = rowoff;
     for (int v = 0; v < k.nvar; v++) ta.slips[v] = k.slips[v];
+    ta.R = k.patch_split;
     // several groups: cut the batch into its groups by bisection along the order keys (the fused model path hands the
     // hypocentre): a compact piece of the fault per group = fewer distinct rows to stage per group and patch.  Scheduling only.
     if (ngroups > 1 && k.order_key[0].base && k.order_key[1].base && GfKnobs::get(kn.gc_global, 1) != 0)

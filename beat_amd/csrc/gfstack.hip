@@ -18,6 +18,7 @@
 //                read exactly once, staging it in LDS would only add latency); LDS is used
 //                for the block reduction of the fused misfit.
 #include <cstdlib>
+#include <cstring>
 
 #include "kernels.hpp"
 
@@ -33,6 +34,7 @@ struct TabArgs {
     uint32_t *rowoff;  // nn: [C,T,P]   ml: [C,T,P,4] (cc, fc, cf, ff)
     double *fac;       // ml: [C,T,P,4]
     int *status;
+    int64_t R;         // patch split: slot t = (real slot t / R, patch range t % R), P = patches per range
 };
 
 // numpy: float64 -> int16 astype (wraps modulo 2^16 for in-range int64 values)
@@ -58,15 +60,17 @@ __global__ void __launch_bounds__(256) k_gf_tables(TabArgs a)
     const int64_t t = ct % a.T;
     const int64_t c = ct / a.T;
 
+    // (patch split: the slot is (real slot ts, range r), the patch is r * P + p of the real model)
+    const int64_t ts = t / a.R, pr = (t % a.R) * a.P + p, Preal = a.P * a.R;
     double st;
     if (a.st.explicit_st) {
-        st = a.st.explicit_st[idx];
+        st = a.st.explicit_st[(c * (a.T / a.R) + ts) * Preal + pr];
     } else {
         // seismic.py:1283-1296: tile(starttimes0, T) - repeat(time_shifts[station_idx], P)
-        st = a.st.starttimes0[c * a.P + p];
-        if (a.st.shift_off) st = st - a.st.Q[c * a.st.nparams + a.st.shift_off[t]];
+        st = a.st.starttimes0[c * Preal + pr];
+        if (a.st.shift_off) st = st - a.st.Q[c * a.st.nparams + a.st.shift_off[ts]];
     }
-    const double du = a.durations.base[c * a.durations.stride + a.durations.off + p];
+    const double du = a.durations.base[c * a.durations.stride + a.durations.off + pr];
     const int D = (int)a.D, S = (int)a.S;
     const int64_t row0 = (t * a.P + p) * a.D;  // row id = (row0 + di) * S + si
     bool ok = true;
@@ -126,6 +130,7 @@ struct GfArgs {
     const int32_t *tslot;            // [T] slot of a target (nullptr: Ttab == 1 ? 0 : t)
     // stand-in launch behind k_gfstack_runs: works only when *guard != 0 (the runs kernel's tables overflowed)
     const int *guard;
+    int64_t R;        // patch split: target t = (real target, range t % R): slips at patch (t % R) * P + p
 };
 
 template <int W> struct VecT;
@@ -195,7 +200,7 @@ __global__ void __launch_bounds__(256) k_gfstack(GfArgs a)
     const double *sl[NVAR];
 #pragma unroll
     for (int iv = 0; iv < NVAR; iv++)
-        sl[iv] = a.slips[iv].base + c * a.slips[iv].stride + a.slips[iv].off;
+        sl[iv] = a.slips[iv].base + c * a.slips[iv].stride + a.slips[iv].off + (t % a.R) * a.P;
 
     V acc[VEC];
 #pragma unroll
@@ -380,8 +385,135 @@ static void launch_nvar(int nvar, int mode, dim3 grid, hipStream_t s, const GfAr
 
 static int launch_gfstack_impl(beatamd_ctx *ctx, const GfStackCall &call);
 
+// ---- patch split of small-N libraries --------------------------------------------------------------------------------
+// A (target, 64-sample tile) walk over P patches is a SERIAL path of P (x slip variables) steps per workgroup; a library
+// of short traces -- the reference's realistic case: 60 s at 2 Hz = 120 samples, SURVEY 8(d) config 4 -- has T * ceil(N / 64)
+// = 70 of them for 256 CUs, each fetching its index tables cold.  Such libraries are stacked in R patch RANGES: the
+// library [T, P, D, S, N] viewed as [T*R, P/R, D, S, N] (the same memory), R times as many and R times shorter walks, the
+// ranges' partial synthetics summed in range order by k_split_combine, which also carries the epilogue.  R depends on the
+// library's shape ONLY (never on the batch): a chain's result cannot depend on the batch it is in; every stacking kernel
+// takes the view unchanged (tables per virtual slot), so the kernels stay bitwise equal to each other.
+// Rule: N <= 256 and at least 32 patches per range: R = the smallest divisor of P that gives >= 512 walks (<= 32).
+static int gf_patch_split(const SeisLib &L, const GfKnobs &kn)
+{
+    const int knob = GfKnobs::get(kn.gf_split, -1);
+    if (knob == 0 || knob == 1) return 1;
+    if (knob > 1) return (L.P % knob == 0) ? knob : 1;
+    if (L.N > 256 || L.P < 64) return 1;
+    const int64_t walks = L.T * ((L.N + 63) / 64);
+    const int64_t want = (512 + walks - 1) / walks;
+    if (want <= 1) return 1;
+    int best = 1;
+    for (int d = 2; d <= 32 && L.P / d >= 32; d++) {
+        if (L.P % d) continue;
+        best = d;
+        if (d >= want) break;
+    }
+    return best;
+}
+
+__global__ void __launch_bounds__(256) k_split_tslot(int64_t Tv, int R, const int32_t *tslot, int32_t *out)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < Tv) out[t] = (tslot ? tslot[t / R] : 0) * R + (int32_t)(t % R);
+}
+
+// syn[c,t,n] = sum over the ranges r ascending of part[c, t*R + r, n], then the epilogue of `mode`:
+//   0 out = syn   2 / 3 out = d - syn (seismic.py:1332)   1 quad[c,t] = sum_n (w_t (d - syn))^2 -- per 64-sample tile
+//   ascending, then the tiles ascending (the order of the lane <-> chain kernels)
+template <int MODE>
+__global__ void __launch_bounds__(256) k_split_combine(const double *part, int64_t C, int64_t T, int64_t N, int R,
+                                                      const double *data, const double *wscalar, double *out, double *quad)
+{
+    __shared__ double sq[256];
+    __shared__ double tsum[4];
+    const int64_t ct = blockIdx.x, t = ct % T, c = ct / T;
+    const int n = threadIdx.x;
+    double v = 0.0;
+    if (n < N) {
+        const double *pp = part + ((c * T + t) * R) * N + n;
+        double syn = pp[0];
+        for (int r = 1; r < R; r++) syn += pp[(int64_t)r * N];
+        if (MODE == GF_STORE_SYN) out[ct * N + n] = syn;
+        else if (MODE == GF_RESID_SCALAR) v = wscalar[t] * (data[t * N + n] - syn);
+        else out[ct * N + n] = data[t * N + n] - syn;
+    }
+    if (MODE != GF_RESID_SCALAR) return;
+    sq[n] = v;
+    __syncthreads();
+    const int ntile = (int)((N + 63) / 64);
+    if (n < ntile) {
+        double q = 0.0;
+        const int hi = (int)min((int64_t)64, N - (int64_t)n * 64);
+        for (int i = 0; i < hi; i++) q = fma(sq[n * 64 + i], sq[n * 64 + i], q);
+        tsum[n] = q;
+    }
+    __syncthreads();
+    if (n == 0) {
+        double s_ = 0.0;
+        for (int k = 0; k < ntile; k++) s_ += tsum[k];
+        quad[ct] = s_;
+    }
+}
+
+static int launch_gfstack_split(beatamd_ctx *ctx, const GfStackCall &call, int R)
+{
+    const SeisLib &L = *call.libs[0];
+    SeisLib views[4];
+    GfStackCall v = call;
+    for (int i = 0; i < call.nvar; i++) {
+        views[i] = *call.libs[i];
+        views[i].T = L.T * R;
+        views[i].P = L.P / R;
+        v.libs[i] = &views[i];
+    }
+    v.patch_split = R;
+    v.mode = GF_STORE_SYN;
+    void *p = nullptr;
+    BA_TRY(ctx->get_scratch(SL_SPLIT, (size_t)call.C * L.T * R * L.N * sizeof(double), &p));
+    double *part = (double *)p;
+    v.out = part;
+    v.quad = nullptr; v.data = nullptr; v.wscalar = nullptr; v.band_w = nullptr;
+    BA_TRY(launch_gfstack_impl(ctx, v));
+    for (int i = 0; i < call.nvar; i++) { views[i].g = nullptr; views[i].g32 = nullptr; }   // (views own nothing)
+    {
+        // (kernel name / plan of the stacking launch stay; the plan says that the library was split)
+        const size_t n0 = strlen(ctx->gf_plan);
+        snprintf(ctx->gf_plan + n0, sizeof(ctx->gf_plan) - n0, "; %lld-sample traces: patches stacked in %d ranges of %lld "
+                 "(%lld walks instead of %lld), partial synthetics summed in range order", (long long)L.N, R, (long long)(L.P / R),
+                 (long long)(L.T * R * ((L.N + 63) / 64)), (long long)(L.T * ((L.N + 63) / 64)));
+    }
+    const dim3 grid((unsigned)(call.C * L.T));
+    BA_CHECK(call.C * L.T < (int64_t)0x7fffffff, BEATAMD_EINVAL, "gfstack: batch too large");
+    ScopedTimer tm(ctx, "gfcombine");
+    switch (call.mode) {
+    case GF_STORE_SYN:
+        hipLaunchKernelGGL(k_split_combine<GF_STORE_SYN>, grid, dim3(256), 0, ctx->stream, part, call.C, L.T, L.N, R, call.data,
+                           call.wscalar, call.out, call.quad);
+        break;
+    case GF_RESID_SCALAR:
+        hipLaunchKernelGGL(k_split_combine<GF_RESID_SCALAR>, grid, dim3(256), 0, ctx->stream, part, call.C, L.T, L.N, R, call.data,
+                           call.wscalar, call.out, call.quad);
+        break;
+    default:
+        hipLaunchKernelGGL(k_split_combine<GF_RESID_STORE>, grid, dim3(256), 0, ctx->stream, part, call.C, L.T, L.N, R, call.data,
+                           call.wscalar, call.out, call.quad);
+    }
+    BA_HIP(hipGetLastError());
+    return BEATAMD_OK;
+}
+
 int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &call)
 {
+    const int R = call.libs[0] ? gf_patch_split(*call.libs[0], gf_knobs(ctx)) : 1;
+    if (R > 1) {
+        BA_TRY(launch_gfstack_split(ctx, call, R));
+        if (call.mode == GF_RESID_BAND1) {
+            const SeisLib &L = *call.libs[0];
+            BA_TRY(launch_quadform_banded(ctx, call.band_w, 1, L.N, L.T, call.C, call.out, L.T * L.N, L.N, call.quad, L.T));
+        }
+        return BEATAMD_OK;
+    }
     if (call.mode != GF_RESID_BAND1) return launch_gfstack_impl(ctx, call);
     // bidiagonal whitening operator: fused into the stacking kernel where that kernel has the epilogue (k_gfstack_ws),
     // else residual store + k_quadform_banded -- the caller gets quad [C,T] either way
@@ -419,20 +551,30 @@ static int launch_gfstack_impl(beatamd_ctx *ctx, const GfStackCall &call)
     // ... and with station corrections only on the station: one table slot per distinct shift variable (the channels of
     // a station share it)
     const bool slots = !k.st.explicit_st && k.st.shift_off && k.st.nslot > 0 && !GfKnobs::is(kn.gf_tinv, 0);
-    const int64_t Ttab = tinv ? 1 : slots ? (int64_t)k.st.nslot : L.T;
+    // patch split (L is the VIEW [T*R, P/R, ...]): every table slot once per patch range -- R slots without station
+    // shifts, nslot * R with them; virtual target t*R + r uses slot (slot of t)*R + r
+    const int64_t R = k.patch_split;
+    const int64_t Ttab = tinv ? R : slots ? (int64_t)k.st.nslot * R : L.T;
     k.tslot = slots ? k.st.tslot : nullptr;
+    void *p = nullptr;
+    if (R > 1 && (tinv || slots)) {
+        BA_TRY(ctx->get_scratch(SL_TSLOT, (size_t)L.T * sizeof(int32_t), &p));
+        hipLaunchKernelGGL(k_split_tslot, dim3((unsigned)((L.T + 255) / 256)), dim3(256), 0, ctx->stream, L.T, (int)R,
+                           slots ? k.st.tslot : nullptr, (int32_t *)p);
+        k.tslot = (const int32_t *)p;
+    }
     const int64_t CTP = k.C * Ttab * L.P;
     const int nrow = k.interp == BEATAMD_MULTILINEAR ? 4 : 1;
 
     TabArgs ta;
     ta.interp = k.interp;
+    ta.R = R;
     ta.C = k.C; ta.T = Ttab; ta.P = L.P; ta.D = L.D; ta.S = L.S;
     ta.st_min = L.st_min; ta.st_dt = L.st_dt; ta.du_min = L.du_min; ta.du_dt = L.du_dt;
     ta.durations = k.durations;
     ta.st = k.st;
     if (slots) ta.st.shift_off = k.st.slot_shift_off;
     ta.status = ctx->d_status;
-    void *p = nullptr;
     BA_TRY(ctx->get_scratch(SL_ROWOFF, (size_t)CTP * nrow * sizeof(uint32_t), &p));
     ta.rowoff = (uint32_t *)p;
     ta.fac = nullptr;
@@ -537,6 +679,7 @@ static int launch_gfstack_impl(beatamd_ctx *ctx, const GfStackCall &call)
     a.Ttab = Ttab; a.rows_per_target = L.P * L.D * L.S;
     a.tslot = k.tslot;
     a.C = k.C;
+    a.R = R;
     {
         a.order = GfKnobs::get(kn.gf_order, 1);
         a.cgroup = GfKnobs::get(kn.gf_cgroup, 128);

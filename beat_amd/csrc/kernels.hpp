@@ -69,6 +69,11 @@ struct GfStackCall {
     // optional scheduling hint: two per-chain sort keys that put chains which rupture alike next to each other
     // (the fused model path: hypocentre strike / dip of the first subfault).  Never changes a result.
     ChainVec order_key[2];
+    // PATCH SPLIT (round 6, small-N libraries): the libraries are VIEWS [T*R, P/R, D, S, N] of the real ones (virtual
+    // target t*R + r = target t, patches [r*P/R, (r+1)*P/R)), the tables are built per virtual slot and the stacking
+    // kernels run unchanged on R times as many, R times shorter (target, tile) walks; slips / start times / durations
+    // are read at the REAL patch r*P/R + p.  Set by launch_gfstack only.
+    int patch_split = 1;
     const GfKnobs *knobs = nullptr;   // set by launch_gfstack (gf_knobs(ctx)): the selection functions read them here
     const int32_t *tslot = nullptr;   // set by launch_gfstack: table slot of a target when targets share tables (device [T])
 };

@@ -70,8 +70,9 @@ def main():
         assert bool(torch.isnan(LL2[11, -1])) and int(torch.isnan(LL2[:, -1]).sum()) == 1
         f2.check_collectively()           # (the status words were cleared: a healthy evaluation passes on every rank)
         # the step in pieces (propose / forward + gather + assemble / accept kernels) = the same step of the local torch twin
-        L0 = f2.batch(Q2[:32].contiguous()).clone()
-        q0, l0 = Q2[:32].clone(), L0.clone()
+        Qs = Q2[32:64].contiguous()        # (chain 11 carries NaN: kept out of the bitwise comparisons below)
+        L0 = f2.batch(Qs).clone()
+        q0, l0 = Qs.clone(), L0.clone()
         g = torch.Generator(device=dev)
         g.manual_seed(5)
         delta = torch.randn(q0.shape, generator=g, device=dev, dtype=torch.float64) * 1e-3
@@ -79,13 +80,13 @@ def main():
         sc = torch.ones(32, device=dev, dtype=torch.float64)
         lo_t, up_t = torch.from_numpy(lo).to(dev), torch.from_numpy(up).to(dev)
         acc = f2.astep_batch(q0, l0, delta, sc, lo_t, up_t, log_u, 0.3)
-        qp = Q2[:32] + delta
+        qp = Qs + delta
         inb = ((qp >= lo_t) & (qp <= up_t)).all(1)
-        lp = f2.batch(torch.where(inb[:, None], qp, Q2[:32]).contiguous())
+        lp = f2.batch(torch.where(inb[:, None], qp, Qs).contiguous())
         mr = 0.3 * (lp[:, -1] - L0[:, -1])
         want = inb & torch.isfinite(mr) & (log_u < mr)
         assert torch.equal(acc.bool(), want), (int(want.sum()), int(acc.sum()))
-        assert torch.equal(q0, torch.where(want[:, None], qp, Q2[:32])) and torch.equal(l0, torch.where(want[:, None], lp, L0))
+        assert torch.equal(q0, torch.where(want[:, None], qp, Qs)) and torch.equal(l0, torch.where(want[:, None], lp, L0))
         f2.release()
     step = SMC(f, lo, up, n_chains=256, device=dev, random_seed=11, tune_interval=3,
                shard="targets" if mode == "targets" else "chains")
