@@ -185,10 +185,24 @@ def population_shapes(layout, out_names):
     return shapes, groups
 
 
-def write_population(homepath, stage, layout, out_names, population, lpoints, backend="bin", n_threads=8):
-    """End points of every chain of a stage as one-draw traces -- what the reference's workers
-    leave on disk (sampler/base.py:310-311) and ``select_end_points`` reads back: variables in
-    layout order, then the likelihood block (seis_like.., geo_like.., laplacian_like, like).
+def thinned_draws(n_steps, thinning):
+    """indices (0-based, within a stage) of the draws the reference's trace buffer keeps: every ``thinning``-th from the
+    first on, and the last one (beat/backend.py:365-404 record_buffer -> utility.thin_buffer(buffer, thinning,
+    ensure_last=True); the buffer holds the whole stage when buffer_size >= n_steps)"""
+    n_steps, thinning = int(n_steps), max(1, int(thinning))
+    keep = list(range(0, n_steps, thinning))
+    if keep and keep[-1] != n_steps - 1:
+        keep.append(n_steps - 1)
+    return keep
+
+
+def write_population(homepath, stage, layout, out_names, population, lpoints, backend="bin", n_threads=8, first_chain=0):
+    """The traces of the chains of a stage: variables in layout order, then the likelihood block (seis_like..,
+    geo_like.., laplacian_like, like) -- what the reference's workers leave on disk (sampler/base.py:310-311,
+    316-395) and ``select_end_points`` reads back.  population (chains, nparams) / lpoints (chains, nllk): the END
+    POINTS as one-draw traces; (draws, chains, nparams) / (draws, chains, nllk): every kept draw of every chain, in
+    order (round 6: ``smc_sample(buffer_thinning=...)``).  ``first_chain``: global index of the first chain (a rank
+    writes the files of ITS block of chains).
 
     "bin" (NumpyChain, beat/backend.py:651-898): the records of ALL chains are packed in one structured array (no
     per-draw Python), the JSON header line is built once, and every chain file is written by one ``open`` / one
@@ -197,33 +211,38 @@ def write_population(homepath, stage, layout, out_names, population, lpoints, ba
     shapes, groups = population_shapes(layout, out_names)
     path = stage_path(homepath, stage)
     population, lpoints = np.asarray(population), np.asarray(lpoints)
-    n_chains = population.shape[0]
+    if population.ndim == 2:
+        population, lpoints = population[None], lpoints[None]
+    n_draws, n_chains = population.shape[0], population.shape[1]
+    first_chain = int(first_chain)
     if backend != "bin":
         for c in range(n_chains):
             ch = backend_catalog[backend](path, shapes)
-            ch.setup(1, c, overwrite=True)
-            pt = layout.rmap(population[c])
-            lp = [pt[k] for k in layout.varsizes]
-            lp += [lpoints[c, idx] if k in ("seis_like", "geo_like") else lpoints[c, idx[0]]
-                   for k, idx in groups.items()]
-            ch.write(lp)
+            ch.setup(n_draws, first_chain + c, overwrite=True)
+            for j in range(n_draws):
+                pt = layout.rmap(population[j, c])
+                lp = [pt[k] for k in layout.varsizes]
+                lp += [lpoints[j, c, idx] if k in ("seis_like", "geo_like") else lpoints[j, c, idx[0]]
+                       for k, idx in groups.items()]
+                ch.write(lp)
         return path
     proto = NumpyChain(path, shapes)
     header = (json.dumps(OrderedDict([
         (proto.flat_names_tag, proto.flat_names),
         (proto.var_shape_tag, OrderedDict((k, list(v)) for k, v in proto.var_shapes.items())),
         (proto.var_dtypes_tag, proto.var_dtypes)])) + "\n").encode()
-    data = np.zeros(n_chains, dtype=proto.data_structure)
+    os.makedirs(path, exist_ok=True)
+    data = np.zeros((n_chains, n_draws), dtype=proto.data_structure)      # a chain's records are consecutive
     for k in layout.varsizes:
         o = layout.offset(k)
-        data[k] = population[:, o:o + layout.varsizes[k]]
+        data[k] = population[:, :, o:o + layout.varsizes[k]].transpose(1, 0, 2)
     for k, idx in groups.items():
-        data[k] = lpoints[:, idx] if k in ("seis_like", "geo_like") else lpoints[:, idx[0]]
-    rec = data.view(np.uint8).reshape(n_chains, data.dtype.itemsize)
+        data[k] = lpoints[:, :, idx].transpose(1, 0, 2) if k in ("seis_like", "geo_like") else lpoints[:, :, idx[0]].T
+    rec = data.view(np.uint8).reshape(n_chains, n_draws * data.dtype.itemsize)
 
     def write_some(first):
         for c in range(first, n_chains, n_threads):
-            with open(os.path.join(path, "chain-{}.bin".format(c)), "wb") as fh:
+            with open(os.path.join(path, "chain-{}.bin".format(first_chain + c)), "wb") as fh:
                 fh.write(header + rec[c].tobytes())
     if n_threads <= 1 or n_chains < 64:
         n_threads = 1

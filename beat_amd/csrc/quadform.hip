@@ -546,45 +546,51 @@ __global__ void __launch_bounds__(256) k_quadform_banded(QbArgs a)
 // workgroup = (dataset, 8 chains); the operator's band rows of a chunk of 64 tiles sit in LDS for all 8 chains, two chains'
 // residual rows at a time beside them (pitch 65: thread <-> (chain, tile) reads its 64 samples conflict-free), one thread
 // per chain adds the tiles up.
-constexpr int QB1_NC = 8, QB1_CT = 64;                 // chains per workgroup, tiles per chunk
+constexpr int QB1_NC = 8, QB1_CT = 64;                 // chains per workgroup, tiles per chunk (at most)
 constexpr int QB1_WP = 130, QB1_XP = 65;               // pitches (doubles) of a tile's band rows / residuals in LDS
-constexpr size_t QB1_LDS = ((size_t)QB1_CT * QB1_WP + 2 * ((size_t)QB1_CT * QB1_XP + 1) + 4 * QB1_CT + QB1_NC) * sizeof(double)
-                           + 2 * QB1_CT * sizeof(int);
+// ct tiles per chunk (min(64, tiles of a row)), npc chains per pass (2 .. 8: short rows take all eight chains at once --
+// M = 120 is two tiles --, thread <-> (chain, tile) of the pass)
+static size_t qb1_lds(int ct, int npc)
+{
+    return ((size_t)ct * QB1_WP + (size_t)npc * ((size_t)ct * QB1_XP + 1) + 2 * (size_t)npc * ct + QB1_NC) * sizeof(double)
+           + (size_t)npc * ct * sizeof(int);
+}
 
-__global__ void __launch_bounds__(256) k_quadform_band1(QbArgs a)
+__global__ void __launch_bounds__(256) k_quadform_band1(QbArgs a, int ct, int npc)
 {
     extern __shared__ __attribute__((aligned(16))) double sm1[];
-    double *wl = sm1;                                   // [QB1_CT][QB1_WP]: (w0, w1) of sample i of tile k at k * 130 + 2 i
-    double *xl = wl + QB1_CT * QB1_WP;                  // [2][QB1_CT * 65 + 1]
-    double *part = xl + 2 * (QB1_CT * QB1_XP + 1);      // [2][QB1_CT]
-    double *ybv = part + 2 * QB1_CT;                    // [2][QB1_CT]
-    double *sacc = ybv + 2 * QB1_CT;                    // [QB1_NC]
-    int *hasb = reinterpret_cast<int *>(sacc + QB1_NC); // [2][QB1_CT]
+    const int xstride = ct * QB1_XP + 1;
+    double *wl = sm1;                                   // [ct][QB1_WP]: (w0, w1) of sample i of tile k at k * 130 + 2 i
+    double *xl = wl + ct * QB1_WP;                      // [npc][ct * 65 + 1]
+    double *part = xl + npc * xstride;                  // [npc][ct]
+    double *ybv = part + npc * ct;                      // [npc][ct]
+    double *sacc = ybv + npc * ct;                      // [QB1_NC]
+    int *hasb = reinterpret_cast<int *>(sacc + QB1_NC); // [npc][ct]
     const int tid = threadIdx.x;
     const int64_t d = blockIdx.y, c0 = (int64_t)blockIdx.x * QB1_NC;
     const int nc = (int)min((int64_t)QB1_NC, a.C - c0);
-    const int64_t M = a.M, CH = (int64_t)QB1_CT * 64;
+    const int64_t M = a.M, CH = (int64_t)ct * 64;
     const double *wb = a.wb + d * M * 2;
     if (tid < QB1_NC) sacc[tid] = 0.0;
     for (int64_t i0 = 0; i0 < M; i0 += CH) {
         const int64_t nch = min(CH, M - i0);            // samples of the chunk
         __syncthreads();                                // (the chunk before is done with wl)
         for (int64_t g = tid; g < 2 * nch; g += 256) wl[(g >> 7) * QB1_WP + (g & 127)] = wb[2 * i0 + g];
-        for (int j0 = 0; j0 < nc; j0 += 2) {
-            __syncthreads();                            // (the pair before is done with xl / part / ybv)
-            for (int jj = 0; jj < 2 && j0 + jj < nc; jj++) {
+        for (int j0 = 0; j0 < nc; j0 += npc) {
+            __syncthreads();                            // (the pass before is done with xl / part / ybv)
+            for (int jj = 0; jj < npc && j0 + jj < nc; jj++) {
                 const double *x = a.X + (c0 + j0 + jj) * a.xs_c + d * a.xs_d + i0;
-                double *xr = xl + jj * (QB1_CT * QB1_XP + 1);
+                double *xr = xl + jj * xstride;
                 // (+ the first residual of the next chunk: the neighbour of this chunk's last sample)
                 for (int64_t g = tid; g < nch + (i0 + nch < M ? 1 : 0); g += 256) xr[(g >> 6) * QB1_XP + (g & 63)] = x[g];
             }
             __syncthreads();
-            if (tid < 128) {
-                const int jj = tid >> 6, k = tid & 63;
+            if (tid < npc * ct) {
+                const int jj = tid / ct, k = tid - jj * ct;
                 const int64_t n0 = i0 + (int64_t)k * 64;
                 const int nvalid = (int)min((int64_t)64, M - n0);
                 if (j0 + jj < nc && nvalid > 0) {
-                    const double *x = xl + jj * (QB1_CT * QB1_XP + 1) + k * QB1_XP;
+                    const double *x = xl + jj * xstride + k * QB1_XP;
                     const double *w = wl + k * QB1_WP;
                     const bool trace_end = n0 + nvalid == M;
                     double q = 0.0, ri = x[0];
@@ -601,20 +607,20 @@ __global__ void __launch_bounds__(256) k_quadform_band1(QbArgs a)
                         q = fma(y, y, q);
                     } else {
                         yb = fma(w[126], ri, 0.0);
-                        yb = fma(w[127], x[QB1_XP], yb);     // first residual of the next tile (k = 63: of the next chunk)
+                        yb = fma(w[127], x[QB1_XP], yb);     // first residual of the next tile (last tile: of the next chunk)
                     }
-                    part[jj * QB1_CT + k] = q;
-                    ybv[jj * QB1_CT + k] = yb;
-                    hasb[jj * QB1_CT + k] = trace_end ? 0 : 1;
+                    part[jj * ct + k] = q;
+                    ybv[jj * ct + k] = yb;
+                    hasb[jj * ct + k] = trace_end ? 0 : 1;
                 }
             }
             __syncthreads();
-            if (tid < 2 && j0 + tid < nc) {
+            if (tid < npc && j0 + tid < nc) {
                 const int ntl = (int)((nch + 63) / 64);
                 double sq = sacc[j0 + tid];
                 for (int k = 0; k < ntl; k++) {
-                    sq += part[tid * QB1_CT + k];
-                    if (hasb[tid * QB1_CT + k]) sq = fma(ybv[tid * QB1_CT + k], ybv[tid * QB1_CT + k], sq);
+                    sq += part[tid * ct + k];
+                    if (hasb[tid * ct + k]) sq = fma(ybv[tid * ct + k], ybv[tid * ct + k], sq);
                 }
                 sacc[j0 + tid] = sq;
             }
@@ -634,9 +640,12 @@ int launch_quadform_banded(beatamd_ctx *ctx, const double *wb, int64_t band, int
         b.X = X; b.xs_c = xs_c; b.xs_d = xs_d; b.quad = quad; b.q_stride = q_stride;
         BA_CHECK(nd <= 65535, BEATAMD_EINVAL, "quadform_banded: too many datasets");
         ScopedTimer tm(ctx, "quadform");
-        BA_HIP(hipFuncSetAttribute((const void *)k_quadform_band1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)QB1_LDS));
-        hipLaunchKernelGGL(k_quadform_band1, dim3((unsigned)((C + QB1_NC - 1) / QB1_NC), (unsigned)nd), dim3(256), QB1_LDS,
-                           ctx->stream, b);
+        const int ct = (int)std::min<int64_t>(QB1_CT, (M + 63) / 64);
+        const int npc = std::max(2, std::min(QB1_NC, 128 / ct));
+        const size_t lds = qb1_lds(ct, npc);
+        BA_HIP(hipFuncSetAttribute((const void *)k_quadform_band1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qb1_lds(QB1_CT, 2)));
+        hipLaunchKernelGGL(k_quadform_band1, dim3((unsigned)((C + QB1_NC - 1) / QB1_NC), (unsigned)nd), dim3(256), lds,
+                           ctx->stream, b, ct, npc);
         BA_HIP(hipGetLastError());
         return BEATAMD_OK;
     }

@@ -163,12 +163,28 @@ class SMC(object):
         sel = self.idx[a:b].contiguous()
         return self.ops.gather(self.Q_all, sel), self.ops.gather(self.L_all, sel)
 
-    def sample_stage(self, n_steps, on_step=None):
+    def sample_stage(self, n_steps, on_step=None, buffer_thinning=None):
         """iter_parallel_chains for one stage: n_steps Metropolis steps of every local chain at
-        self.beta"""
+        self.beta.  ``buffer_thinning`` (the reference's trace option, beat/backend.py:100-117, 365-404): the states of
+        every chain after the draws ``backend.thinned_draws(n_steps, thinning)`` -- every thinning-th and the last --
+        are kept ON THE DEVICE (self.stage_draws = (Q [draws, chains, nparams], L [draws, chains, nllk]), this rank's
+        chains) for the stage's trace files; None: end points only"""
         Q, L = self.restart_points()
         n_acc = self.torch.zeros((), dtype=self.torch.int64, device=Q.device)
-        if on_step is None:
+        self.stage_draws = None
+        if buffer_thinning is not None and on_step is None:
+            from ..backend import thinned_draws
+            keep = thinned_draws(n_steps, buffer_thinning)
+            DQ = self.torch.empty((len(keep),) + tuple(Q.shape), dtype=Q.dtype, device=Q.device)
+            DL = self.torch.empty((len(keep),) + tuple(L.shape), dtype=L.dtype, device=L.device)
+            prev = -1
+            for j, i in enumerate(keep):
+                self.stepper.run(Q, L, self.beta, i - prev, n_acc, use_graph=self.use_graph)
+                DQ[j].copy_(Q)
+                DL[j].copy_(L)
+                prev = i
+            self.stage_draws = (DQ, DL)
+        elif on_step is None:
             self.stepper.run(Q, L, self.beta, n_steps, n_acc, use_graph=self.use_graph)
         else:
             for i in range(int(n_steps)):
@@ -192,6 +208,18 @@ def _dump_stage(step, homepath, layout, out_names, backend):
         sc = parallel.allgather_rows(step.stepper.scaling[:, None])[:, 0].cpu().numpy()
         ac = parallel.allgather_rows(step.stepper.accepted_since_tune[:, None])[:, 0].cpu().numpy()
     _join_stage_writer(step)          # (at most one stage is being written at a time)
+    draws = getattr(step, "stage_draws", None)
+    if draws is not None and layout is not None and step.stage != 0:
+        # every kept draw of every chain (smc_sample(buffer_thinning=...)): each rank writes the trace files of ITS chains
+        # -- like the reference's workers (sampler/base.py:316-395) --, in line (a stage's draws are (draws x chains x
+        # (nparams + nllk)) doubles: they leave the device once, here)
+        from ..backend import write_population
+        a_ = 0 if getattr(step, "shard", "chains") == "targets" else step.block[0]
+        if getattr(step, "shard", "chains") != "targets" or step.rank == 0:
+            write_population(homepath, step.stage, layout, out_names, draws[0].cpu().numpy(), draws[1].cpu().numpy(), backend,
+                             first_chain=a_)
+        step.stage_draws = None
+        layout = None                 # (rank 0 below: the state archive only)
     if step.rank != 0:
         if not getattr(step, "async_stage_files", True):
             _join_stage_writer(step)  # (in-line writing: rank 0's outcome is broadcast right behind its write, below)
@@ -313,7 +341,7 @@ def update_last_samples(step, Q_local):
 
 def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, homepath=None,
                layout=None, out_names=None, backend="bin", resume_stage=None, update=None, final_stage=True,
-               async_stage_files=True):
+               async_stage_files=True, buffer_thinning=None):
     """smc.py:333-546 stage loop.  Returns the final population (n_chains, nparams), the
     likelihood vectors (host arrays) and the list of betas.  With ``homepath`` every stage leaves
     a ``stage_<k>`` / ``stage_final`` directory of NumpyChain/TextChain traces
@@ -329,6 +357,11 @@ def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, 
     the writer is joined before the next stage's files, before every ``on_stage`` callback (which may read the
     directory) and at the end of the call; ``sampler_state.npz`` appears atomically.  Off: written in line.
 
+    ``buffer_thinning`` (needs ``homepath`` and ``layout``): the stage directories hold every ``buffer_thinning``-th draw
+    of every chain and the last one -- the reference's traces (``buffer_thinning`` of its sampler config,
+    beat/backend.py:100-117, 365-404; ``beat summarize`` reads the whole stage) -- instead of the end points only
+    (= ``buffer_thinning >= n_steps``).  Each rank writes the files of its own chains.
+
     ``final_stage=False`` stops after ``max_stages`` tempering stages WITHOUT the stage at beta = 1 (the state of the
     last stage can be resumed from its directory); by default a run that exhausts ``max_stages`` still ends with the
     final stage like a converged one."""
@@ -338,6 +371,9 @@ def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, 
     if n_steps < 1:
         raise TypeError("Argument `n_steps` should be above 0.")
     step.update_map_point = None
+    thin = buffer_thinning if (buffer_thinning is not None and homepath is not None and layout is not None) else None
+    if buffer_thinning is not None and thin is None:
+        raise ValueError("buffer_thinning writes trace files: give homepath and layout (and out_names)")
     # wall-clock split of the call (every part ends on a host-visible result, so no extra synchronisation):
     # Metropolis steps | stage transitions (weights, beta, proposal factor, resampling, restart gathers) |
     # all-gather of the end points | covariance updates | trace / state files
@@ -378,7 +414,7 @@ def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, 
             break
         step.stage += 1
         logger.info("Beta: %f Stage: %i", step.beta, step.stage)
-        Q, L = timed("sample_s", step.sample_stage, n_steps)
+        Q, L = timed("sample_s", step.sample_stage, n_steps, buffer_thinning=thin)
         tm["steps"] += int(n_steps)
         timed("gather_s", step.select_end_points, Q, L)
         if update is not None:
@@ -396,7 +432,7 @@ def smc_sample(n_steps, step, progressbar=False, on_stage=None, max_stages=200, 
     # final stage at beta = 1 (smc.py:526-543)
     step.stage = -1
     timed("transition_s", synced_transition, final=True)
-    Q, L = timed("sample_s", step.sample_stage, n_steps * sample_factor_final_stage)
+    Q, L = timed("sample_s", step.sample_stage, n_steps * sample_factor_final_stage, buffer_thinning=thin)
     tm["steps"] += int(n_steps * sample_factor_final_stage)
     timed("gather_s", step.select_end_points, Q, L)
     betas.append(1.0)

@@ -87,7 +87,8 @@ def test_fused_model_on_a_fine_grid_nn(ctx, monkeypatch, nvar, cov, shifts):
     monkeypatch.delenv("BEATAMD_GF_KERNEL")
     monkeypatch.setenv("BEATAMD_GS_CG", "512")
     B = f.batch(Q)
-    assert ctx.last_kernel().startswith("k_gfstack_ws<1,%d,3," % (1 if cov == "scalar" else 2)), ctx.last_kernel()
+    # (Toeplitz covariance: bidiagonal operator -> the misfit rides in the kernel's epilogue, mode 3; round 6)
+    assert ctx.last_kernel().startswith("k_gfstack_ws<1,%d,3," % (1 if cov == "scalar" else 3)), ctx.last_kernel()
     assert ctx.gf_plan()["max_passes"] >= 2, ctx.gf_plan()
     assert np.isfinite(B).all()
     # (the streaming kernel sums the misfit over 512-sample tiles, the chain-shared kernels over 64-sample tiles)

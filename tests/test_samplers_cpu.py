@@ -137,6 +137,20 @@ def test_smc_stage_traces_and_resume(tmp_path):
     assert nstage >= 2
     assert betas2 == betas[1:]
     assert np.array_equal(pop2, pop) and np.array_equal(lp2, lp)
+    # buffer_thinning: the stage files hold every 6th draw of every chain and the last (draws 0, 6, 12, 18, 19) -- the
+    # reference's traces (beat/backend.py:365-404) -- and the last record is the chain's end point; the same run otherwise
+    step3 = SMC(HostTarget(f, n), -2 * np.ones(n), 2 * np.ones(n), n_chains=64, tune_interval=10, random_seed=3)
+    home3 = str(tmp_path / "thinned")
+    pop3, lp3, betas3 = smc_sample(20, step3, homepath=home3, layout=lay, out_names=["like"], buffer_thinning=6)
+    assert betas3 == betas and np.array_equal(pop3, pop) and np.array_equal(lp3, lp)
+    ch = NumpyChain.load(os.path.join(stage_path(home3, -1), "chain-5.bin"))
+    assert ch.get_values("x").shape == (5, n)
+    np.testing.assert_array_equal(ch.get_values("x")[-1], pop[5])
+    assert ch.get_values("like")[-1] == lp[5, 0]
+    one = NumpyChain.load(os.path.join(stage_path(home3, 0), "chain-5.bin"))
+    assert one.get_values("x").shape == (1, n)             # (stage 0: one evaluation, no move)
+    with pytest.raises(ValueError, match="buffer_thinning writes trace files"):
+        smc_sample(4, step3, buffer_thinning=2)
 
 
 def test_host_proposal_draws_normal_and_cauchy_statistics():
