@@ -42,7 +42,10 @@ def test_small_n_library_is_stacked_in_patch_ranges(ctx, monkeypatch, interp, co
     monkeypatch.delenv("BEATAMD_GF_SPLIT")
     np.testing.assert_allclose(A, U, rtol=1e-10)
     # a chain's result does not depend on its batch: sub-batches through the same and through other kernels
-    assert np.array_equal(A[40:140], f.batch(Q[40:140]))
+    sub = f.batch(Q[40:140])                                 # (100 chains: the k_gfstack_dma family on the same view)
+    if nvar == 1 or interp == "nearest_neighbor":
+        assert np.array_equal(A[40:140], sub)
+    np.testing.assert_allclose(A[40:140], sub, rtol=1e-11)    # two slip variables: the kernels interleave them differently
     small = f.batch(Q[7:27])                                  # 20 chains: the streaming kernel, on the same view
     assert ctx.last_kernel().startswith("k_gfstack<"), ctx.last_kernel()
     if nvar == 1:
@@ -67,7 +70,10 @@ def test_small_n_library_is_stacked_in_patch_ranges(ctx, monkeypatch, interp, co
     # out-of-library chains are still flagged (NaN like + IndexError at the next synchronisation)
     Qb = Q[:64].copy()
     Qb[5, host["layout"].offset("durations") + 100] = 99.0      # a patch of the LAST range
-    Lb = f.batch(Qb)
+    with pytest.raises(IndexError):
+        f.batch(Qb)                                            # host arrays: checked before the results are handed back
+    import torch
+    Lb = f.batch(torch.from_numpy(Qb).to(torch.device("cuda", 0))).cpu().numpy()
     with pytest.raises(IndexError):
         ctx.synchronize()
     assert np.isnan(Lb[5, -1]) and np.isfinite(np.delete(Lb[:, -1], 5)).all()
