@@ -171,11 +171,14 @@ int ffi_logp_device(beatamd_ctx *ctx, FfiModel &m, int64_t C, const double *Q, d
             // synthetics, line of sight and weighted residual in one kernel
             BA_TRY(launch_geom_los(ctx, m.geom, Q, np, C, nullptr, g.data, g.odws, res));
         } else {
+            // every slip variable's G.T . slips in one launch (geodetic.py:1065-1070 sums them)
+            const GeoLib *gls[4] = {nullptr, nullptr, nullptr, nullptr};
+            BA_CHECK(m.layout.nvar <= 4, BEATAMD_EINVAL, "geodetic composite: more than 4 slip variables");
             for (int v = 0; v < m.layout.nvar; v++) {
-                GeoLib *gl = get_obj(ctx->geolibs, g.libs[v]);
-                BA_CHECK(gl, BEATAMD_EINVAL, "geodetic composite refers to a destroyed GF library");
-                BA_TRY(launch_geo_stack(ctx, *gl, C, slips[v], v > 0, mu));
+                gls[v] = get_obj(ctx->geolibs, g.libs[v]);
+                BA_CHECK(gls[v], BEATAMD_EINVAL, "geodetic composite refers to a destroyed GF library");
             }
+            BA_TRY(launch_geo_stack(ctx, gls, m.layout.nvar, C, slips, 0, mu));
             BA_TRY(launch_geo_residual(ctx, C, g.Nobs, g.data, g.odws, mu, res));
         }
         // small dense datasets (SAR scenes / GNSS of a few hundred points): every dataset's
@@ -488,8 +491,9 @@ int beatamd_geo_stack_all_batch(beatamd_ctx *ctx, int32_t lib_id, int64_t C, con
     Arg rec;
     BA_TRY(stage_in(ctx, SL_IN0, slips, (size_t)C * l->P * 8, &d_sl));
     BA_TRY(stage_out(ctx, SL_OUT0, out, (size_t)C * l->Nobs * 8, &d_o, &rec, accumulate != 0));
-    BA_TRY(launch_geo_stack(ctx, *l, C, ChainVec{(const double *)d_sl, l->P, 0}, accumulate,
-                            (double *)d_o));
+    const GeoLib *one[1] = {l};
+    const ChainVec sv[1] = {ChainVec{(const double *)d_sl, l->P, 0}};
+    BA_TRY(launch_geo_stack(ctx, one, 1, C, sv, accumulate, (double *)d_o));
     return finish_out(ctx, &rec, 1);
 }
 

@@ -225,12 +225,25 @@ __global__ void __launch_bounds__(GC_TB) k_gc_order(GcOrderArgs a)
     __syncthreads();
     const int nlive = (int)min((int64_t)GC_CG, a.C - (int64_t)blockIdx.x * GC_CG);
     // dead slots sort behind the live ones (tid >= nlive for all of them)
+    // extents of the two keys: wavefront reductions, then the nine partial results (round 6: every thread used to scan all
+    // 518 keys for them inside the ranking loop -- four fp64 min / max per comparison)
+    __shared__ double ext[4][GC_TB / 64];
+    {
+        double m0 = live ? f0 : ka[0], M0 = m0, m1 = live ? f1 : kb[0], M1 = m1;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            m0 = fmin(m0, __shfl_xor(m0, off, 64)); M0 = fmax(M0, __shfl_xor(M0, off, 64));
+            m1 = fmin(m1, __shfl_xor(m1, off, 64)); M1 = fmax(M1, __shfl_xor(M1, off, 64));
+        }
+        if ((tid & 63) == 0) { ext[0][tid >> 6] = m0; ext[1][tid >> 6] = M0; ext[2][tid >> 6] = m1; ext[3][tid >> 6] = M1; }
+    }
     int r0 = 0;
-    double mn0 = ka[0], mx0 = ka[0], mn1 = kb[0], mx1 = kb[0];
-    for (int k = 0; k < nlive; k++) {
-        r0 += (ka[k] < f0) || (ka[k] == f0 && k < tid);
-        mn0 = fmin(mn0, ka[k]); mx0 = fmax(mx0, ka[k]);
-        mn1 = fmin(mn1, kb[k]); mx1 = fmax(mx1, kb[k]);
+    for (int k = 0; k < nlive; k++) r0 += (ka[k] < f0) || (ka[k] == f0 && k < tid);
+    __syncthreads();
+    double mn0 = ext[0][0], mx0 = ext[1][0], mn1 = ext[2][0], mx1 = ext[3][0];
+    for (int q = 1; q < GC_TB / 64; q++) {
+        mn0 = fmin(mn0, ext[0][q]); mx0 = fmax(mx0, ext[1][q]);
+        mn1 = fmin(mn1, ext[2][q]); mx1 = fmax(mx1, ext[3][q]);
     }
     const int nw = (nlive + GC_NCHAIN - 1) / GC_NCHAIN;
     // bands of whole wavefronts by the first key, as many as make a wavefront's chains a SQUARE piece of the group's
@@ -349,6 +362,7 @@ struct GmTabArgs {
     uint32_t *dtab;               // [(g*T+t)][consumer][step 0..smax][GR_DLINE] position descriptors (scalar loads)
     uint32_t *ucount;             // [gtp] row segments the loaders move for the patch, all passes (statistics)
     int64_t R;                    // patch split: slot t covers patches (t % R) * P + p of the real model (slips)
+    int pb;                       // consecutive patches of a (group, target) per workgroup (divides P)
 };
 
 __global__ void __launch_bounds__(256) k_gm_scan(const uint32_t *npass, uint32_t *voff, uint32_t *nv, int64_t P, int64_t vmax,
@@ -383,7 +397,7 @@ __global__ void __launch_bounds__(256) k_gm_scan(const uint32_t *npass, uint32_t
 // 256 apart, singles at a line's wrap slot, at jumps and at the end
 __device__ __forceinline__ int gm_req_bound(int n, int nlines, int64_t S) { return S > 255 ? n : n / 2 + 2 * nlines + 1; }
 
-// one workgroup per (group, target, patch); thread <-> chain slot of the group order.
+// one workgroup per (group, target, block of a.pb patches); thread <-> chain slot of the group order.
 // FILL = 0: the passes of the patch (npass, cpass);  FILL = 1: the tables of its steps
 template <int FILL>
 __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
@@ -406,9 +420,14 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
     __shared__ uint32_t rsum[2][GC_TB / 64];
     __shared__ int sh_npass, sh_n;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t gtp = blockIdx.x;
-    const int64_t p = gtp % a.P;
-    const int64_t gt = gtp / a.P;
+    // a workgroup takes a.pb CONSECUTIVE patches of one (group, target), one after the other, the next patch's table
+    // entries in flight while a patch is worked on (round 6: one patch per workgroup = 14 000 workgroups of nine
+    // wavefronts for configs[3], each a chain of dependent round trips to memory with nothing to cover them; a chain's
+    // entries of 8 / 4 consecutive patches share a 128-byte line)
+    const int64_t npb = a.P / a.pb;
+    const int64_t blk = xcd_items8(blockIdx.x, gridDim.x);
+    const int64_t gt = blk / npb;
+    const int64_t p0 = (blk % npb) * a.pb;
     const int64_t t = gt % a.T;
     const int64_t g = gt / a.T;
     if constexpr (FILL) {
@@ -418,29 +437,50 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
     const uint32_t cid = slot ? a.order[g * GC_CG + tid] : GC_DEAD;
     const bool live = cid != GC_DEAD;
     const int64_t c = live ? (int64_t)cid : 0;
-    const int64_t row0 = (t * a.P + p) * a.DS;
     const uint32_t S = (uint32_t)a.S;
+    bool have_passes = false;
+    if constexpr (FILL) have_passes = a.voff != nullptr;
 
+    // the patch in flight: row ids (ceil d, ceil s) / (floor d, ceil s), factors, pass of the chain slot, passes of the patch
+    uint32_t n_v0 = 0, n_v2 = 0, n_np = 1;
+    double n_fr[4] = {0, 0, 0, 0};
+    uint8_t n_cp = 0xff;
+    auto fetch = [&](int64_t p) {
+        if (live) {
+            const int64_t e = ((c * a.T + t) * a.P + p) * 4;
+            const uint4 rv = *reinterpret_cast<const uint4 *>(a.rowoff + e);     // (cc, fc, cf, ff: k_gf_tables)
+            n_v0 = rv.x; n_v2 = rv.z;
+            if constexpr (FILL) {
+                const double2 f01 = *reinterpret_cast<const double2 *>(a.fac + e), f23 = *reinterpret_cast<const double2 *>(a.fac + e + 2);
+                n_fr[0] = f01.x; n_fr[1] = f01.y; n_fr[2] = f23.x; n_fr[3] = f23.y;
+            }
+        }
+        if (FILL && have_passes) {
+            if (slot) n_cp = a.cpass[(gt * a.P + p) * GC_CG + tid];
+            if (tid == 0) n_np = a.npass[gt * a.P + p];
+        }
+    };
+    fetch(p0);
+    for (int u = 0; u < a.pb; u++) {
+    const int64_t p = p0 + u, gtp = gt * a.P + p;
+    const int64_t row0 = (t * a.P + p) * a.DS;
     uint32_t dc = 0, sc = 0, df = 0, sa = 0, sb = 0;
-    double fr[4] = {0, 0, 0, 0};
+    double fr[4] = {n_fr[0], n_fr[1], n_fr[2], n_fr[3]};
+    const uint8_t cp_in = n_cp;
+    const uint32_t np_in = n_np;
     if (live) {
-        const int64_t e = ((c * a.T + t) * a.P + p) * 4;
-        const uint32_t v0 = a.rowoff[e] - (uint32_t)row0;        // (ceil d, ceil s)
-        const uint32_t v2 = a.rowoff[e + 2] - (uint32_t)row0;    // (floor d, ceil s)
+        const uint32_t v0 = n_v0 - (uint32_t)row0, v2 = n_v2 - (uint32_t)row0;
         dc = v0 / S; sc = v0 % S; df = v2 / S;
         sb = dc * (uint32_t)S1 + sc;     // the floor node of ceil node sc is slot sc of the line (sc = 0: the wrap copy)
         sa = df * (uint32_t)S1 + sc;
-        if constexpr (FILL)
-            for (int k = 0; k < 4; k++) fr[k] = a.fac[e + k];
     }
+    if (u + 1 < a.pb) fetch(p + 1);
     const uint32_t key = live ? ((sb << 16) | sa) : 0xffffffffu;
     if (slot) keys[tid] = key;
 
-    bool have_passes = false;
-    if constexpr (FILL) have_passes = a.voff != nullptr;
     if (FILL && have_passes) {
-        if (slot) cps[tid] = a.cpass[gtp * GC_CG + tid];
-        if (tid == 0) sh_npass = (int)a.npass[gtp];
+        if (slot) cps[tid] = cp_in;
+        if (tid == 0) sh_npass = (int)np_in;
         __syncthreads();
     } else if (FILL) {
         if (slot) cps[tid] = live ? 0 : 0xff;
@@ -537,9 +577,10 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
         // (pass ids are bytes: a patch cut into more than 250 passes -- buffers of a few slots in tests -- counts as an
         // overflow of the tables: the streaming kernel stands in)
         if (tid == 0) a.npass[gtp] = sh_npass > 250 ? 0x100000u : (uint32_t)sh_npass;
-        return;
+        __syncthreads();
+        continue;
     }
-    if constexpr (!FILL) return;
+    if constexpr (FILL) {
     // ---------------- fill phase
     const int npass = sh_npass;
     const int64_t v0 = a.voff ? (int64_t)a.voff[gtp] : p;
@@ -672,6 +713,8 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
         h[0] = 0;
         h[1] = 0;
     }
+    }   // FILL
+    }   // patches of the workgroup
 }
 
 // ---------------------------------------------------------------------------- stacking
@@ -837,6 +880,14 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
     ta.rowoff = rowoff; ta.fac = fac;
     for (int v = 0; v < k.nvar; v++) ta.slips[v] = k.slips[v];
     ta.R = k.patch_split;
+    {
+        // patches per workgroup of the table kernels: the largest divisor of P up to 8 (BEATAMD_GM_PB: A/B), one when that
+        // would leave fewer workgroups than two per CU
+        const int want = std::max(1, std::min(8, GfKnobs::get(kn.gm_pb, 8)));
+        ta.pb = 1;
+        for (int d = want; d > 1; d--)
+            if (L.P % d == 0 && GTP / d >= 2 * (int64_t)ctx->num_cu) { ta.pb = d; break; }
+    }
     ta.order = oa.order;
     BA_TRY(ctx->get_scratch(SL_GC_STREAM, (size_t)GT * GC_NCONS * (smax + 1) * GR_WSTRIDE + 8192, &p));
     ta.wtab = (char *)p;
@@ -858,12 +909,12 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
         const size_t lds = (size_t)3 * L.D * W * 4 + 2 * (size_t)((dense + 3) & ~(int64_t)3) + 2 * (size_t)((L.D + 3) & ~(int64_t)3) + 64;
         if (passes) {
             BA_HIP(hipMemsetAsync(ovf, 0, sizeof(int), ctx->stream));
-            hipLaunchKernelGGL(k_gm_tables<0>, dim3((unsigned)GTP), dim3(GC_TB), lds, ctx->stream, ta);
+            hipLaunchKernelGGL(k_gm_tables<0>, dim3((unsigned)(GTP / ta.pb)), dim3(GC_TB), lds, ctx->stream, ta);
             hipLaunchKernelGGL(k_gm_scan, dim3((unsigned)GT), dim3(256), 0, ctx->stream, ta.npass, voff, nv, L.P, vmax, ovf);
             ta.voff = voff;
             ta.ovf = ovf;
         }
-        hipLaunchKernelGGL(k_gm_tables<1>, dim3((unsigned)GTP), dim3(GC_TB), lds, ctx->stream, ta);
+        hipLaunchKernelGGL(k_gm_tables<1>, dim3((unsigned)(GTP / ta.pb)), dim3(GC_TB), lds, ctx->stream, ta);
     }
     BA_HIP(hipGetLastError());
 

@@ -72,7 +72,7 @@ __global__ void k_gf_group_tables(GroupTabArgs a)
     uint32_t *lst = gmask + a.DS;         // [128] windowed: local row index of list entry `pos`
     uint32_t *slt = lst + 128;            // [128] windowed: LDS slot of list entry `pos`
     const int tid = threadIdx.x, CG = a.CG;
-    const int64_t gtp = blockIdx.x;       // (g*T + t)*P + p
+    const int64_t gtp = xcd_items8(blockIdx.x, gridDim.x);       // (g*T + t)*P + p
     const int64_t p = gtp % a.P;
     const int64_t gt = gtp / a.P;
     const int64_t t = gt % a.T;
@@ -1926,7 +1926,7 @@ __global__ void __launch_bounds__(WS_CG) k_ws_tables(WsTabArgs a)
     __shared__ uint32_t wsum[WS_CG / 64 + 1];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    const int64_t gtp = blockIdx.x;       // (g*T + t)*P + p
+    const int64_t gtp = xcd_items8(blockIdx.x, gridDim.x);       // (g*T + t)*P + p
     const int64_t p = gtp % a.P;
     const int64_t gt = gtp / a.P;
     const int64_t t = gt % a.T;

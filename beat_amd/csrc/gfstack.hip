@@ -128,8 +128,11 @@ struct GfArgs {
     int cgroup;       // order 1: chains per group
     int64_t Ttab, rows_per_target;   // tables per (chain, table slot, patch): Ttab slots (T, the station shifts, or 1)
     const int32_t *tslot;            // [T] slot of a target (nullptr: Ttab == 1 ? 0 : t)
-    // stand-in launch behind k_gfstack_runs: works only when *guard != 0 (the runs kernel's tables overflowed)
+    // stand-in launch behind k_gfstack_runs: works only when *guard != 0 (the runs kernel's tables overflowed); a small
+    // grid whose workgroups then loop over the nblocks tiles (round 6: a full grid of workgroups that only read the flag
+    // cost 35-100 us per launch on configs[3] with 120-sample traces)
     const int *guard;
+    int64_t nblocks;
     int64_t R;        // patch split: target t = (real target, range t % R): slips at patch (t % R) * P + p
 };
 
@@ -152,7 +155,7 @@ __device__ __forceinline__ void fma_acc(double &acc, double x, double w) { acc =
 // INTERP 0 nn / 1 ml ; NVAR slip variables ; VEC chunks of 256*W samples per thread ;
 // W doubles per lane per load (2 when N is even -> 16-byte loads) ; MODE GfMode
 template <int INTERP, int NVAR, int VEC, int W, int MODE>
-__global__ void __launch_bounds__(256) k_gfstack(GfArgs a)
+__device__ __forceinline__ void gfstack_tile(const GfArgs &a, const int64_t bid)
 {
     using V = typename VecT<W>::type;
     constexpr int NROW = INTERP ? 4 : 1;
@@ -160,9 +163,8 @@ __global__ void __launch_bounds__(256) k_gfstack(GfArgs a)
     // rows of V in flight per lane ~ 8
     constexpr int U = (8 / (NROW * NVAR * VEC)) > 0 ? (8 / (NROW * NVAR * VEC)) : 1;
 
-    if (a.guard && *a.guard == 0) return;
-    const int tile = blockIdx.x % a.ntile;
-    const int64_t bq = blockIdx.x / a.ntile;
+    const int tile = (int)(bid % a.ntile);
+    const int64_t bq = bid / a.ntile;
     int64_t c, t;
     if (a.order == 0) {
         c = bq / a.T;
@@ -290,6 +292,20 @@ __global__ void __launch_bounds__(256) k_gfstack(GfArgs a)
     }
 }
 
+template <int INTERP, int NVAR, int VEC, int W, int MODE>
+__global__ void __launch_bounds__(256) k_gfstack(GfArgs a)
+{
+    if (a.guard) {
+        if (*a.guard == 0) return;
+        for (int64_t b = blockIdx.x; b < a.nblocks; b += gridDim.x) {
+            gfstack_tile<INTERP, NVAR, VEC, W, MODE>(a, b);
+            __syncthreads();
+        }
+    } else {
+        gfstack_tile<INTERP, NVAR, VEC, W, MODE>(a, blockIdx.x);
+    }
+}
+
 // float-storage copy of a library: g32 = (float)g and g itself rounded to the same values, so that
 // every kernel -- whichever copy it reads -- sees one library
 __global__ void __launch_bounds__(256) k_round_to_f32(double *g, float *g32, int64_t n)
@@ -393,21 +409,25 @@ static int launch_gfstack_impl(beatamd_ctx *ctx, const GfStackCall &call);
 // ranges' partial synthetics summed in range order by k_split_combine, which also carries the epilogue.  R depends on the
 // library's shape ONLY (never on the batch): a chain's result cannot depend on the batch it is in; every stacking kernel
 // takes the view unchanged (tables per virtual slot), so the kernels stay bitwise equal to each other.
-// Rule: N <= 256 and at least 32 patches per range: R = the smallest divisor of P that gives >= 512 walks (<= 32).
-static int gf_patch_split(const SeisLib &L, const GfKnobs &kn)
+// Rule: N <= 256 and at least 32 patches per range; among the divisors R of P (<= 32) the one that minimises
+//   ceil(walks * R / CUs) * (P / R + 5)
+// -- the stacking kernels keep one workgroup per CU, a walk costs its steps plus ~5 steps of prologue / epilogue (measured on
+// configs[3] with 120 samples, 70 walks x 400 patches: R = 4: 1.00, 5: 0.80, 8: 0.82, 10: 0.69, 16: 0.76, 25: 0.72 ms).
+static int gf_patch_split(const SeisLib &L, const GfKnobs &kn, int num_cu)
 {
     const int knob = GfKnobs::get(kn.gf_split, -1);
     if (knob == 0 || knob == 1) return 1;
     if (knob > 1) return (L.P % knob == 0) ? knob : 1;
     if (L.N > 256 || L.P < 64) return 1;
     const int64_t walks = L.T * ((L.N + 63) / 64);
-    const int64_t want = (512 + walks - 1) / walks;
-    if (want <= 1) return 1;
+    const int64_t ncu = std::max(1, num_cu);
+    if (walks >= 2 * ncu) return 1;
     int best = 1;
+    int64_t best_cost = ((walks + ncu - 1) / ncu) * (L.P + 5);
     for (int d = 2; d <= 32 && L.P / d >= 32; d++) {
         if (L.P % d) continue;
-        best = d;
-        if (d >= want) break;
+        const int64_t cost = ((walks * d + ncu - 1) / ncu) * (L.P / d + 5);
+        if (cost < best_cost) { best = d; best_cost = cost; }
     }
     return best;
 }
@@ -505,7 +525,7 @@ static int launch_gfstack_split(beatamd_ctx *ctx, const GfStackCall &call, int R
 
 int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &call)
 {
-    const int R = call.libs[0] ? gf_patch_split(*call.libs[0], gf_knobs(ctx)) : 1;
+    const int R = call.libs[0] ? gf_patch_split(*call.libs[0], gf_knobs(ctx), ctx->num_cu) : 1;
     if (R > 1) {
         BA_TRY(launch_gfstack_split(ctx, call, R));
         if (call.mode == GF_RESID_BAND1) {
@@ -703,7 +723,8 @@ static int launch_gfstack_impl(beatamd_ctx *ctx, const GfStackCall &call)
     const int64_t nblocks = k.C * L.T * a.ntile;
     BA_CHECK(nblocks < (int64_t)0x7fffffff, BEATAMD_EINVAL, "gfstack: batch too large (%lld blocks)",
              (long long)nblocks);
-    dim3 grid((unsigned)nblocks);
+    a.nblocks = nblocks;
+    dim3 grid((unsigned)(standin ? std::min<int64_t>(nblocks, (int64_t)ctx->num_cu * 8) : nblocks));
     if (!standin) {
         snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack<%d,%d,%d,%d,%d>",
                  k.interp == BEATAMD_MULTILINEAR ? 1 : 0, k.nvar, VEC, W, k.mode);

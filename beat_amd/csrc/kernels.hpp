@@ -38,6 +38,19 @@ struct ChainVec {
     int64_t stride = 0, off = 0;
 };
 
+// Workgroup id -> work item for table kernels whose NEIGHBOURING items read the same cache lines (the [C,T,P,*] index
+// tables: the entries of consecutive patches of a chain share a 128-byte line).  The hardware deals consecutive workgroup
+// ids round-robin to the 8 XCDs, each with its own L2 -- eight neighbours would fetch the line eight times.  Inside every
+// aligned block of 64 ids the items are dealt so that an XCD gets 8 CONSECUTIVE items (ids b = x mod 8 -> items 8x .. 8x+7).
+#ifdef __HIPCC__
+__device__ __forceinline__ int64_t xcd_items8(int64_t b, int64_t n)
+{
+    if (b >= (n & ~(int64_t)63)) return b;
+    const int64_t r = b & 63;
+    return (b & ~(int64_t)63) + (r & 7) * 8 + (r >> 3);
+}
+#endif
+
 enum GfMode : int {
     GF_STORE_SYN = 0,     // out[c,t,n] = synthetics                      (stack_all)
     GF_RESID_SCALAR = 1,  // partial[c,t,tile] = sum (w_t (d - syn))^2     (fused logp, W = w I)
@@ -159,8 +172,8 @@ int launch_mvn_finish(beatamd_ctx *ctx, int64_t C, int64_t nd, int64_t M, const 
 int launch_scalar_quad(beatamd_ctx *ctx, int64_t C, int64_t nd, int64_t M, const double *X,
                        int64_t xs_c, int64_t xs_d, const double *w, double *quad);
 // geodetic: mu[c,k] (+)= sum_p slips(c,p) G[p,k]
-int launch_geo_stack(beatamd_ctx *ctx, const GeoLib &lib, int64_t C, ChainVec slips,
-                     int accumulate, double *mu);
+int launch_geo_stack(beatamd_ctx *ctx, const GeoLib *const *libs, int nvar, int64_t C, const ChainVec *slips, int accumulate,
+                     double *mu);
 // res[c,k] = (data[k] - mu[c,k]) * odw[k]
 int launch_geo_residual(beatamd_ctx *ctx, int64_t C, int64_t Nobs, const double *data,
                         const double *odw, const double *mu, double *res);

@@ -68,32 +68,83 @@ int launch_scalar_quad(beatamd_ctx *ctx, int64_t C, int64_t nd, int64_t M, const
     return BEATAMD_OK;
 }
 
-// ffi/base.py:292-305  mu = G.T.dot(slips): block (chain c, 256 observations), slips in LDS
-__global__ void __launch_bounds__(256) k_geo_stack(const double *G, int64_t P, int64_t Nobs,
-                                                  ChainVec slips, int accumulate, double *mu)
+// ffi/base.py:292-305  mu = G.T.dot(slips), summed over the slip variables (geodetic.py:1065-1070): block (CH chains,
+// 128 observation points), the chains' slips in LDS as [variable][p][CH]; an element of G is read once per CH chains and
+// sixteen loads are in flight per lane (round 6: one chain per block read the 1.4 MB of G 512 times per call, one launch
+// per slip variable with mu through memory in between: 2 x 58 us at 512 chains x 428 points x 400 patches).  Per (chain,
+// point) the same fma sequence -- variables ascending, patches ascending -- as the one-chain kernel: bitwise equal.
+struct GeoStackArgs {
+    const double *G[4];
+    ChainVec slips[4];
+    int nvar, accumulate;
+    int64_t P, Nobs, C;
+    double *mu;
+};
+
+template <int CH>
+__global__ void __launch_bounds__(256) k_geo_stack(GeoStackArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double s_slip[];
-    const int64_t c = blockIdx.y;
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const double *sl = slips.base + c * slips.stride + slips.off;
-    for (int64_t p = threadIdx.x; p < P; p += 256) s_slip[p] = sl[p];
+    const int64_t c0 = (int64_t)blockIdx.y * CH;
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t P = a.P, Nobs = a.Nobs;
+    for (int v = 0; v < a.nvar; v++)
+        for (int64_t i = threadIdx.x; i < P * CH; i += blockDim.x) {
+            const int64_t p = i / CH, j = i % CH;
+            s_slip[v * P * CH + i] = c0 + j < a.C ? a.slips[v].base[(c0 + j) * a.slips[v].stride + a.slips[v].off + p] : 0.0;
+        }
     __syncthreads();
     if (k >= Nobs) return;
-    double acc = accumulate ? mu[c * Nobs + k] : 0.0;
-    for (int64_t p = 0; p < P; p++) acc = fma(G[p * Nobs + k], s_slip[p], acc);
-    mu[c * Nobs + k] = acc;
+    double acc[CH];
+#pragma unroll
+    for (int j = 0; j < CH; j++) acc[j] = (a.accumulate && c0 + j < a.C) ? a.mu[(c0 + j) * Nobs + k] : 0.0;
+    for (int v = 0; v < a.nvar; v++) {
+        const double *G = a.G[v] + k;
+        const double *sl = s_slip + v * P * CH;
+        int64_t p = 0;
+        for (; p + 16 <= P; p += 16) {
+            double g[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) g[u] = G[(p + u) * Nobs];
+#pragma unroll
+            for (int u = 0; u < 16; u++)
+#pragma unroll
+                for (int j = 0; j < CH; j++) acc[j] = fma(g[u], sl[(p + u) * CH + j], acc[j]);
+        }
+        for (; p < P; p++) {
+            const double g = G[p * Nobs];
+#pragma unroll
+            for (int j = 0; j < CH; j++) acc[j] = fma(g, sl[p * CH + j], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CH; j++)
+        if (c0 + j < a.C) a.mu[(c0 + j) * Nobs + k] = acc[j];
 }
 
-int launch_geo_stack(beatamd_ctx *ctx, const GeoLib &lib, int64_t C, ChainVec slips,
-                     int accumulate, double *mu)
+int launch_geo_stack(beatamd_ctx *ctx, const GeoLib *const *libs, int nvar, int64_t C, const ChainVec *slips, int accumulate,
+                     double *mu)
 {
-    if (C == 0) return BEATAMD_OK;
-    BA_CHECK(C <= 65535, BEATAMD_EINVAL, "geo_stack: at most 65535 chains per call");
-    BA_CHECK(lib.P * 8 <= 64 * 1024, BEATAMD_EINVAL, "geo_stack: more than 8192 patches");
+    if (C == 0 || nvar == 0) return BEATAMD_OK;
+    BA_CHECK(nvar >= 1 && nvar <= 4, BEATAMD_EINVAL, "geo_stack: 1..4 slip variables");
+    const GeoLib &lib = *libs[0];
+    GeoStackArgs a;
+    for (int v = 0; v < nvar; v++) {
+        BA_CHECK(libs[v]->P == lib.P && libs[v]->Nobs == lib.Nobs, BEATAMD_EINVAL, "geo_stack: the libraries of the slip variables differ in shape");
+        a.G[v] = libs[v]->g;
+        a.slips[v] = slips[v];
+    }
+    a.nvar = nvar; a.accumulate = accumulate;
+    a.P = lib.P; a.Nobs = lib.Nobs; a.C = C;
+    a.mu = mu;
     ScopedTimer tm(ctx, "geostack");
-    hipLaunchKernelGGL(k_geo_stack, dim3((unsigned)((lib.Nobs + 255) / 256), (unsigned)C),
-                       dim3(256), (size_t)lib.P * sizeof(double), ctx->stream, lib.g, lib.P,
-                       lib.Nobs, slips, accumulate, mu);
+    const int CH = (C >= 64 && (size_t)lib.P * nvar * 4 * sizeof(double) <= 64 * 1024) ? 4 : 1;
+    const size_t lds = (size_t)lib.P * nvar * CH * sizeof(double);
+    BA_CHECK(lds <= 64 * 1024, BEATAMD_EINVAL, "geo_stack: more than 8192 patch slips per chain");
+    BA_CHECK((C + CH - 1) / CH <= 65535, BEATAMD_EINVAL, "geo_stack: at most %d chains per call", 65535 * CH);
+    const dim3 grid((unsigned)((lib.Nobs + 127) / 128), (unsigned)((C + CH - 1) / CH));
+    if (CH == 4) hipLaunchKernelGGL(k_geo_stack<4>, grid, dim3(128), lds, ctx->stream, a);
+    else hipLaunchKernelGGL(k_geo_stack<1>, grid, dim3(128), lds, ctx->stream, a);
     BA_HIP(hipGetLastError());
     return BEATAMD_OK;
 }
