@@ -363,6 +363,7 @@ struct GmTabArgs {
     uint32_t *ucount;             // [gtp] row segments the loaders move for the patch, all passes (statistics)
     int64_t R;                    // patch split: slot t covers patches (t % R) * P + p of the real model (slips)
     int pb;                       // consecutive patches of a (group, target) per workgroup (divides P)
+    int64_t ngtp;                 // (group, target, patch) items
 };
 
 __global__ void __launch_bounds__(256) k_gm_scan(const uint32_t *npass, uint32_t *voff, uint32_t *nv, int64_t P, int64_t vmax,
@@ -396,6 +397,82 @@ __global__ void __launch_bounds__(256) k_gm_scan(const uint32_t *npass, uint32_t
 // number of row requests a pass of n slots over nlines duration lines can take at most: pairs of ascending rows less than
 // 256 apart, singles at a line's wrap slot, at jumps and at the end
 __device__ __forceinline__ int gm_req_bound(int n, int nlines, int64_t S) { return S > 255 ? n : n / 2 + 2 * nlines + 1; }
+
+// The row passes of a patch from the bitsets of its chain group (one thread): C / F = slots used on a duration line as ceil
+// / floor line, X = cells by ceil line.  Passes along the duration axis; a line whose cells alone exceed a buffer is cut along
+// the start-time axis (linesplit, mark = pass of cell (d, s)).  -> number of passes; linepass[d] = pass of the cells with
+// ceil line d.  (numpy twin: tools/gfcell_emu.py gm_passes)
+__device__ int gm_count_passes(const uint32_t *bC, const uint32_t *bF, const uint32_t *bX, uint8_t *mark, uint8_t *linepass,
+                               uint8_t *linesplit, const int D, const int W, const uint32_t S, const int64_t S1, const int cap,
+                               const int64_t S64)
+{
+    auto pop = [&](const uint32_t *x, const uint32_t *y) {   // |x u y| (y nullable)
+        int n = 0;
+        for (int k = 0; k < W; k++) n += __popc(x[k] | (y ? y[k] : 0u));
+        return n;
+    };
+    auto any = [&](const uint32_t *x) {
+        for (int k = 0; k < W; k++)
+            if (x[k]) return true;
+        return false;
+    };
+    auto fl = [&](int d) { return d == 0 ? D - 1 : d - 1; };   // floor line of ceil line d (base.py:513-517)
+    int cur = -1, n = 0, nlines = 0, first = -1;
+    bool open = false;
+    for (int d = 0; d < D; d++) {
+        if (!any(bX + d * W)) continue;
+        const int f = fl(d);
+        // slots the cells of ceil line d add: their ceil line (with what it already holds as the floor line of
+        // line d + 1 -- only the wrap: line D-1 under ceil line 0) and their floor line (with what it holds as
+        // a ceil line of the pass)
+        const bool wrap_c = open && d == D - 1 && first == 0 && D > 1;      // line D-1 already holds F[D-1]
+        const bool floor_in = open && f != d && ((f >= first && f < d));   // line f is a ceil line of the pass
+        int add, lines_add;
+        if (f == d) {   // one duration node: both usages on one line
+            add = pop(bC + d * W, bF + d * W);
+            lines_add = 1;
+        } else {
+            add = pop(bC + d * W, wrap_c ? bF + d * W : nullptr) - (wrap_c ? pop(bF + d * W, nullptr) : 0);
+            add += floor_in ? pop(bF + f * W, bC + f * W) - pop(bC + f * W, nullptr) : pop(bF + f * W, nullptr);
+            lines_add = (wrap_c ? 0 : 1) + ((floor_in && any(bC + f * W)) ? 0 : 1);
+        }
+        const int alone = (f == d) ? add : pop(bC + d * W, nullptr) + pop(bF + f * W, nullptr);
+        if (open && (n + add > cap || gm_req_bound(n + add, nlines + lines_add, S64) > GC_NLOAD * GC_LREQ)) open = false;
+        if (!open) {
+            if (alone > cap || gm_req_bound(alone, f == d ? 1 : 2, S64) > GC_NLOAD * GC_LREQ) {
+                // the cells of this line alone do not fit: cut the line along the start-time axis; every cell
+                // {sc, sc + 1} on both lines: 2 slots per distinct node
+                linesplit[d] = 1;
+                int m = 0;
+                cur++;
+                int prev = -2;
+                for (uint32_t s_ = 0; s_ < S; s_++) {
+                    if (!((bX[d * W + (s_ >> 5)] >> (s_ & 31)) & 1u)) continue;
+                    const int addc = ((int)s_ == prev + 1 ? 1 : 2) * (f == d ? 1 : 2);
+                    if (m && (m + addc > cap || gm_req_bound(m + addc, 2, S64) > GC_NLOAD * GC_LREQ)) {
+                        cur++;
+                        m = 0;
+                        prev = -2;
+                    }
+                    m += ((int)s_ == prev + 1 ? 1 : 2) * (f == d ? 1 : 2);
+                    prev = (int)s_;
+                    mark[d * S1 + s_] = (uint8_t)cur;     // (mark: pass of cell (d, s) of a split line)
+                }
+                continue;
+            }
+            cur++;
+            open = true;
+            first = d;
+            n = alone;
+            nlines = f == d ? 1 : 2;
+        } else {
+            n += add;
+            nlines += lines_add;
+        }
+        linepass[d] = (uint8_t)cur;
+    }
+    return cur + 1;
+}
 
 // one workgroup per (group, target, block of a.pb patches); thread <-> chain slot of the group order.
 // FILL = 0: the passes of the patch (npass, cpass);  FILL = 1: the tables of its steps
@@ -499,75 +576,7 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
             atomicOr(&bX[dc * W + (sc >> 5)], 1u << (sc & 31));
         }
         __syncthreads();
-        if (tid == 0) {
-            auto pop = [&](const uint32_t *x, const uint32_t *y) {   // |x u y| (y nullable)
-                int n = 0;
-                for (int k = 0; k < W; k++) n += __popc(x[k] | (y ? y[k] : 0u));
-                return n;
-            };
-            auto any = [&](const uint32_t *x) {
-                for (int k = 0; k < W; k++)
-                    if (x[k]) return true;
-                return false;
-            };
-            const int D = (int)a.D;
-            auto fl = [&](int d) { return d == 0 ? D - 1 : d - 1; };   // floor line of ceil line d (base.py:513-517)
-            int cur = -1, n = 0, nlines = 0, first = -1;
-            bool open = false;
-            for (int d = 0; d < D; d++) {
-                if (!any(bX + d * W)) continue;
-                const int f = fl(d);
-                // slots the cells of ceil line d add: their ceil line (with what it already holds as the floor line of
-                // line d + 1 -- only the wrap: line D-1 under ceil line 0) and their floor line (with what it holds as
-                // a ceil line of the pass)
-                const bool wrap_c = open && d == D - 1 && first == 0 && D > 1;      // line D-1 already holds F[D-1]
-                const bool floor_in = open && f != d && ((f >= first && f < d));   // line f is a ceil line of the pass
-                int add, lines_add;
-                if (f == d) {   // one duration node: both usages on one line
-                    add = pop(bC + d * W, bF + d * W);
-                    lines_add = 1;
-                } else {
-                    add = pop(bC + d * W, wrap_c ? bF + d * W : nullptr) - (wrap_c ? pop(bF + d * W, nullptr) : 0);
-                    add += floor_in ? pop(bF + f * W, bC + f * W) - pop(bC + f * W, nullptr) : pop(bF + f * W, nullptr);
-                    lines_add = (wrap_c ? 0 : 1) + ((floor_in && any(bC + f * W)) ? 0 : 1);
-                }
-                const int alone = (f == d) ? add : pop(bC + d * W, nullptr) + pop(bF + f * W, nullptr);
-                if (open && (n + add > a.cap || gm_req_bound(n + add, nlines + lines_add, a.S) > GC_NLOAD * GC_LREQ)) open = false;
-                if (!open) {
-                    if (alone > a.cap || gm_req_bound(alone, f == d ? 1 : 2, a.S) > GC_NLOAD * GC_LREQ) {
-                        // the cells of this line alone do not fit: cut the line along the start-time axis; every cell
-                        // {sc, sc + 1} on both lines: 2 slots per distinct node
-                        linesplit[d] = 1;
-                        int m = 0;
-                        cur++;
-                        int prev = -2;
-                        for (uint32_t s_ = 0; s_ < S; s_++) {
-                            if (!((bX[d * W + (s_ >> 5)] >> (s_ & 31)) & 1u)) continue;
-                            const int addc = ((int)s_ == prev + 1 ? 1 : 2) * (f == d ? 1 : 2);
-                            if (m && (m + addc > a.cap || gm_req_bound(m + addc, 2, a.S) > GC_NLOAD * GC_LREQ)) {
-                                cur++;
-                                m = 0;
-                                prev = -2;
-                            }
-                            m += ((int)s_ == prev + 1 ? 1 : 2) * (f == d ? 1 : 2);
-                            prev = (int)s_;
-                            mark[d * S1 + s_] = (uint8_t)cur;     // (mark: pass of cell (d, s) of a split line)
-                        }
-                        continue;
-                    }
-                    cur++;
-                    open = true;
-                    first = d;
-                    n = alone;
-                    nlines = f == d ? 1 : 2;
-                } else {
-                    n += add;
-                    nlines += lines_add;
-                }
-                linepass[d] = (uint8_t)cur;
-            }
-            sh_npass = cur + 1;
-        }
+        if (tid == 0) sh_npass = gm_count_passes(bC, bF, bX, mark, linepass, linesplit, (int)a.D, W, S, S1, a.cap, a.S);
         __syncthreads();
         if (slot) {
             uint8_t cp = 0xff;
@@ -715,6 +724,284 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
     }
     }   // FILL
     }   // patches of the workgroup
+}
+
+// ---------------------------------------------------------------------------- tables, one WAVEFRONT per patch (round 6)
+// The same tables, entry for entry, as k_gm_tables -- but a (group, target, patch) is the work of ONE wavefront that visits
+// the 518 chain slots nine per lane, with its own piece of LDS and no workgroup barrier anywhere.  k_gm_tables is a chain of
+// ~10 barriers and ~5 dependent round trips to memory per patch on nine wavefronts that mostly wait for each other: with
+// two such workgroups per CU the 14 000 patches of configs[3] (35 station slots x 400 patches) took 0.43 ms -- a quarter of
+// the step at 120 samples per trace, whatever the block of patches per workgroup (a.pb: 8 patches per workgroup were SLOWER,
+// 0.58 ms: it is the per-patch latency, not the launch).  Here a CU holds 16 patches in flight and a wavefront never waits
+// for another.  Libraries up to GW_DENSE_MAX dense slots per patch (one bitset word per lane); beyond that k_gm_tables.
+constexpr int GW_NW = 8;                       // wavefronts (= patches) per workgroup
+constexpr int64_t GW_DENSE_MAX = 2048;         // D * (S + 1)
+constexpr int GW_KC = 520 * 4;                 // bytes of a [GC_CG] array of words
+constexpr uint32_t GW_PAD = 0x3fffffu;         // 22-bit key of a slot that takes no part (no chain / chain of another pass)
+
+__device__ __forceinline__ void wave_sync()
+{
+    // the lanes of a wavefront run in lockstep: wait for its LDS operations, keep the compiler from moving memory
+    // operations across
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// LDS of a wavefront: kc[GC_CG] (pass of the chain slot << 22 | 22-bit key: (B << 11) | A, GW_PAD: no chain), then
+//   count: the bitsets C / F / X [3 D W], mark [dense], linepass / linesplit [D]
+//   fill : skp[GC_CG] sort words, nmw[32], clist[128] u16, bits[64], wpre[64]       (4960 bytes: 32 wavefronts per CU)
+static size_t gw_wave_bytes(int fill, int64_t D, int64_t S)
+{
+    const int64_t W = (S + 1 + 31) / 32, dense = D * (S + 1);
+    const size_t f = (size_t)GW_KC + 32 + 256 + 256 + 256;
+    const size_t c = (size_t)3 * D * W * 4 + ((dense + 3) & ~(int64_t)3) + 2 * ((D + 3) & ~(int64_t)3);
+    return ((size_t)GW_KC + (fill ? f : c) + 15) & ~(size_t)15;
+}
+
+template <int FILL>
+__global__ void __launch_bounds__(64 * GW_NW) k_gm_tables_w(GmTabArgs a, int wstride)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t gtp = xcd_items8(blockIdx.x, gridDim.x) * GW_NW + wave;
+    if (gtp >= a.ngtp) return;
+    if constexpr (FILL) {
+        if (a.ovf && *a.ovf) return;
+    }
+    char *base = reinterpret_cast<char *>(dyn) + (size_t)wave * wstride;
+    uint32_t *kc = reinterpret_cast<uint32_t *>(base);
+    char *rest = base + GW_KC;
+    const int64_t p = gtp % a.P;
+    const int64_t gt = gtp / a.P;
+    const int64_t t = gt % a.T;
+    const int64_t g = gt / a.T;
+    const int64_t row0 = (t * a.P + p) * a.DS;
+    const uint32_t S = (uint32_t)a.S;
+    const int64_t S1 = a.S + 1;
+    const uint32_t S1u = (uint32_t)S1;
+    const bool have_passes = FILL && a.voff != nullptr;
+
+    for (int i = lane; i < GC_CG; i += 64) {
+        const uint32_t cid = a.order[g * GC_CG + i];
+        uint32_t w = 0xffu << 22 | GW_PAD;
+        if (cid != GC_DEAD) {
+            const int64_t e = (((int64_t)cid * a.T + t) * a.P + p) * 4;
+            const uint4 rv = *reinterpret_cast<const uint4 *>(a.rowoff + e);     // (cc, fc, cf, ff: k_gf_tables)
+            const uint32_t v0 = rv.x - (uint32_t)row0, v2 = rv.z - (uint32_t)row0;
+            const uint32_t dc = v0 / S, sc = v0 % S, df = v2 / S;
+            // the floor node of ceil node sc is slot sc of the line (sc = 0: the wrap copy): B = dc (S+1) + sc, A = df (S+1) + sc
+            w = ((dc * S1u + sc) << 11) | (df * S1u + sc);
+            if constexpr (FILL) w |= (have_passes ? (uint32_t)a.cpass[gtp * GC_CG + i] : 0u) << 22;
+        }
+        kc[i] = w;
+    }
+
+    if constexpr (!FILL) {
+        // ---------------- count phase: passes along the duration axis
+        const int W = (int)((a.S + 1 + 31) / 32);
+        const int64_t dense_n = a.D * S1;
+        uint32_t *bC = reinterpret_cast<uint32_t *>(rest), *bF = bC + a.D * W, *bX = bF + a.D * W;
+        uint8_t *mark = reinterpret_cast<uint8_t *>(bX + a.D * W);
+        uint8_t *linepass = mark + ((dense_n + 3) & ~(int64_t)3);
+        uint8_t *linesplit = linepass + ((a.D + 3) & ~(int64_t)3);
+        for (int i = lane; i < 3 * a.D * W; i += 64) bC[i] = 0;
+        for (int i = lane; i < a.D; i += 64) { linepass[i] = 0; linesplit[i] = 0; }
+        wave_sync();
+        for (int i = lane; i < GC_CG; i += 64) {
+            const uint32_t k22 = kc[i] & GW_PAD;
+            if (k22 == GW_PAD) continue;
+            const uint32_t sb = k22 >> 11, sa = k22 & 0x7ffu;
+            const uint32_t dc = sb / S1u, sc = sb - dc * S1u, df = sa / S1u;
+            atomicOr(&bC[dc * W + (sc >> 5)], 1u << (sc & 31));
+            atomicOr(&bC[dc * W + ((sc + 1) >> 5)], 1u << ((sc + 1) & 31));
+            atomicOr(&bF[df * W + (sc >> 5)], 1u << (sc & 31));
+            atomicOr(&bF[df * W + ((sc + 1) >> 5)], 1u << ((sc + 1) & 31));
+            atomicOr(&bX[dc * W + (sc >> 5)], 1u << (sc & 31));
+        }
+        wave_sync();
+        int np = 0;
+        if (lane == 0) np = gm_count_passes(bC, bF, bX, mark, linepass, linesplit, (int)a.D, W, S, S1, a.cap, a.S);
+        wave_sync();
+        np = __shfl(np, 0, 64);
+        for (int i = lane; i < GC_CG; i += 64) {
+            const uint32_t k22 = kc[i] & GW_PAD;
+            uint8_t cp = 0xff;
+            if (k22 != GW_PAD) {
+                const uint32_t sb = k22 >> 11;
+                const uint32_t dc = sb / S1u, sc = sb - dc * S1u;
+                cp = linesplit[dc] ? mark[dc * S1 + sc] : linepass[dc];
+            }
+            a.cpass[gtp * GC_CG + i] = cp;
+        }
+        // (pass ids are bytes: a patch cut into more than 250 passes counts as an overflow of the tables)
+        if (lane == 0) a.npass[gtp] = np > 250 ? 0x100000u : (uint32_t)np;
+        return;
+    } else {
+        // ---------------- fill phase
+        uint32_t *skp = reinterpret_cast<uint32_t *>(rest);                          // sort word of the chain slot in the pass
+        uint8_t *nmw = reinterpret_cast<uint8_t *>(rest + GW_KC);                    // [GC_NCONS] chains of the consumer in the pass
+        uint16_t *clist = reinterpret_cast<uint16_t *>(rest + GW_KC + 32);           // compact slot -> dense slot
+        uint32_t *bits = reinterpret_cast<uint32_t *>(rest + GW_KC + 32 + 256);      // dense slots of the pass, one word per lane
+        uint32_t *wpre = bits + 64;                                                  // set bits in front of the word
+        const int npass = have_passes ? (int)a.npass[gtp] : 1;
+        const int64_t v0 = a.voff ? (int64_t)a.voff[gtp] : p;
+        uint32_t moved = 0;
+        auto row_of = [&](uint32_t sl) { const uint32_t d = sl / S1u, s1 = sl % S1u; return d * S + (s1 ? s1 - 1 : S - 1); };
+        wave_sync();
+        for (int k = 0; k < npass; k++) {
+            // dense slots of the pass -> compact slots; the sort words of the pass: (key, pads: all ones) << 6 | slot in the
+            // consumer -- unique inside a consumer
+            bits[lane] = 0;
+            wave_sync();
+            for (int i = lane; i < GC_CG; i += 64) {
+                const uint32_t w = kc[i];
+                const bool mine = (w >> 22) == (uint32_t)k;          // (no chain: pass 0xff)
+                skp[i] = (mine ? (w & GW_PAD) : GW_PAD) << 6 | (uint32_t)(i % GC_NCHAIN);
+                if (!mine) continue;
+                const uint32_t sa = w & 0x7ffu, sb = (w >> 11) & 0x7ffu;
+                atomicOr(&bits[sa >> 5], 1u << (sa & 31));
+                atomicOr(&bits[(sa + 1) >> 5], 1u << ((sa + 1) & 31));
+                atomicOr(&bits[sb >> 5], 1u << (sb & 31));
+                atomicOr(&bits[(sb + 1) >> 5], 1u << ((sb + 1) & 31));
+            }
+            wave_sync();
+            const uint32_t word = bits[lane];
+            const int cnt = __popc(word);
+            int incl = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += o;
+            }
+            wpre[lane] = (uint32_t)(incl - cnt);
+            const int n = __shfl(incl, 63, 64);       // <= cap (count phase)
+            moved += (uint32_t)n;
+            {
+                uint32_t wd = word;
+                int q = incl - cnt;
+                while (wd) {
+                    const int b = __ffs((int)wd) - 1;
+                    wd &= wd - 1;
+                    if (q < 128) clist[q] = (uint16_t)(lane * 32 + b);
+                    q++;
+                }
+            }
+            if (lane < GC_NCONS) {
+                int nmem = 0;
+                for (int q = 0; q < GC_NCHAIN; q++) nmem += (skp[lane * GC_NCHAIN + q] >> 6) != GW_PAD;
+                nmw[lane] = (uint8_t)nmem;
+            }
+            wave_sync();
+            auto cidx = [&](uint32_t x) { return wpre[x >> 5] + (uint32_t)__popc(bits[x >> 5] & ((1u << (x & 31)) - 1u)); };
+            // ---- row requests: pairs of compact neighbours whose rows ascend by less than 256, singles otherwise; elements
+            // lane and lane + 64
+            uint32_t req[2] = {0, 0};
+            int rq_idx[2] = {-1, -1};
+            int carry_st = 0;
+            uint32_t nlead = 0;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int i = lane + 64 * h;
+                const bool in = i < n && i < 128;
+                const uint32_t r_i = in ? row_of(clist[i]) : 0u;
+                const uint32_t r_p = (in && i > 0) ? row_of(clist[i - 1]) : 0u;
+                const bool pairable = in && i > 0 && r_i > r_p && r_i - r_p < 256;   // may follow its predecessor in a pair
+                // start of the run of pairable elements the element is in: inclusive max scan of (run start ? i : 0)
+                int st = (in && !pairable) ? i : 0;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int o = __shfl_up(st, off, 64);
+                    if (lane >= off) st = max(st, o);
+                }
+                st = max(st, carry_st);
+                carry_st = __shfl(st, 63, 64);
+                const bool leads = in && (((i - st) & 1) == 0);        // first row of a pair, or a single
+                uint32_t r_n = 0;
+                bool pair = false;
+                if (leads && i + 1 < n) {
+                    r_n = row_of(clist[i + 1]);
+                    pair = r_n > r_i && r_n - r_i < 256;
+                }
+                const uint64_t m = __ballot(leads);
+                if (leads) {
+                    rq_idx[h] = (int)(nlead + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
+                    req[h] = r_i | ((pair ? r_n - r_i : 0u) << 16) | ((uint32_t)i << 24);
+                    if (rq_idx[h] >= GC_NLOAD * GC_LREQ) rq_idx[h] = -1;     // (cannot happen: the count phase bounds the requests)
+                }
+                nlead += (uint32_t)__popcll(m);
+            }
+            const int nreq = min((int)nlead, GC_NLOAD * GC_LREQ);
+            for (int iv = 0; iv < a.nvar; iv++) {
+                const int64_t s = (v0 + k) * a.nvar + iv;
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+                    if (rq_idx[h] >= 0) {
+                        const int ll = rq_idx[h] % GC_NLOAD;
+                        a.ltab[((gt * (a.smax + 3) + s) * GC_NLOAD + ll) * GC_LTABDW + 2 + rq_idx[h] / GC_NLOAD] = req[h];
+                    }
+                if (lane < GC_NLOAD) {
+                    uint32_t *h = a.ltab + ((gt * (a.smax + 3) + s) * GC_NLOAD + lane) * GC_LTABDW;
+                    h[0] = nreq > lane ? (uint32_t)((nreq - lane + GC_NLOAD - 1) / GC_NLOAD) : 0u;
+                    h[1] = (uint32_t)(p * a.DS);
+                }
+            }
+            // ---- the chain slots: walk position in the consumer = its sort words below the slot's -- the chains of the pass
+            // in cell order (ties by slot), the others (pads) behind them in slot order, as k_gm_tables --; "the next chain
+            // opens a new cell" from the smallest word above it; weights and descriptors
+            for (int i = lane; i < GC_CG; i += 64) {
+                const int w = i / GC_NCHAIN, j = i % GC_NCHAIN;
+                const uint32_t mysk = skp[i];
+                const uint32_t *grp = skp + w * GC_NCHAIN;
+                int r = 0;
+                uint32_t succ = 0xffffffffu;
+#pragma unroll
+                for (int q = 0; q < GC_NCHAIN; q++) {
+                    const uint32_t x = grp[q];
+                    r += x < mysk;
+                    succ = x > mysk ? min(succ, x) : succ;
+                }
+                const uint32_t k22 = mysk >> 6;
+                const bool mine = k22 != GW_PAD;
+                // (a successor that is a pad -- all ones above the key -- or none at all: the walk's last chain opens nothing)
+                const bool next_opens = mine && succ != 0xffffffffu && (succ >> 6) != GW_PAD && (succ >> 6) != k22;
+                const uint32_t ca = mine ? cidx(k22 & 0x7ffu) : 0u, cb = mine ? cidx(k22 >> 11) : 0u;
+                double fr[4] = {0, 0, 0, 0};
+                int64_t c = 0;
+                if (mine) {
+                    c = (int64_t)a.order[g * GC_CG + i];
+                    const int64_t e = ((c * a.T + t) * a.P + p) * 4;
+                    const double2 f01 = *reinterpret_cast<const double2 *>(a.fac + e), f23 = *reinterpret_cast<const double2 *>(a.fac + e + 2);
+                    fr[0] = f01.x; fr[1] = f01.y; fr[2] = f23.x; fr[3] = f23.y;
+                }
+                const int nmem_w = nmw[w];
+                for (int iv = 0; iv < a.nvar; iv++) {
+                    const int64_t s = (v0 + k) * a.nvar + iv;
+                    const uint32_t ring = (uint32_t)((s % 3) * a.cap);
+                    const double sl = mine ? a.slips[iv].base[c * a.slips[iv].stride + a.slips[iv].off + (t % a.R) * a.P + p] : 0.0;
+                    const int q = r & 3;
+                    // weights only: a 256-byte record pair serves eight positions, entry e = {weight e of record 2p, of record 2p + 1}
+                    char *rec = a.wtab + ((gt * GC_NCONS + w) * (a.smax + 1) + s) * (int64_t)GR_WSTRIDE + (r >> 3) * GR_PAIR + ((r >> 2) & 1) * 8;
+                    for (int kk = 0; kk < 4; kk++)
+                        *reinterpret_cast<double *>(rec + (4 * q + kk) * 16) = mine ? fr[kk] * sl : 0.0;     // base.py:676-679 x slip, as k_gfstack
+                    uint32_t *dl = a.dtab + ((gt * GC_NCONS + w) * (a.smax + 1) + s) * GR_DLINE + (r < GR_NHALF ? 2 * r : GR_DHALF + 2 * (r - GR_NHALF));
+                    // a pad (a chain of another pass, an empty chain slot): zero weights into the scratch accumulator, no row reads
+                    dl[0] = (uint32_t)GR_D_BASE | (uint32_t)(mine ? j : GC_SCRATCH) | ((next_opens ? 1u : 0u) << 31);
+                    dl[1] = (ring + ca) | ((ring + cb) << 16);
+                    // chains of the consumer in this step: the walk leaves the step at the first checkpoint behind them
+                    if (j == 0) a.dtab[((gt * GC_NCONS + w) * (a.smax + 1) + s) * GR_DLINE + GR_D_NCH] = (uint32_t)nmem_w;
+                }
+            }
+            wave_sync();
+        }
+        if (lane == 0) a.ucount[gtp] = moved;
+        // the request lines behind the last step of the (group, target) stay empty: the loaders read three steps ahead
+        if (p == a.P - 1 && lane < 3 * GC_NLOAD) {
+            const int64_t s = (v0 + npass) * a.nvar + lane / GC_NLOAD;
+            uint32_t *h = a.ltab + ((gt * (a.smax + 3) + s) * GC_NLOAD + lane % GC_NLOAD) * GC_LTABDW;
+            h[0] = 0;
+            h[1] = 0;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------- stacking
@@ -880,10 +1167,11 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
     ta.rowoff = rowoff; ta.fac = fac;
     for (int v = 0; v < k.nvar; v++) ta.slips[v] = k.slips[v];
     ta.R = k.patch_split;
+    ta.ngtp = GTP;
     {
         // patches per workgroup of the table kernels: the largest divisor of P up to 8 (BEATAMD_GM_PB: A/B), one when that
         // would leave fewer workgroups than two per CU
-        const int want = std::max(1, std::min(8, GfKnobs::get(kn.gm_pb, 8)));
+        const int want = std::max(1, std::min(8, GfKnobs::get(kn.gm_pb, 1)));
         ta.pb = 1;
         for (int d = want; d > 1; d--)
             if (L.P % d == 0 && GTP / d >= 2 * (int64_t)ctx->num_cu) { ta.pb = d; break; }
@@ -907,14 +1195,26 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
         ScopedTimer tm(ctx, "grouptables");
         const int W = (int)((L.S + 1 + 31) / 32);
         const size_t lds = (size_t)3 * L.D * W * 4 + 2 * (size_t)((dense + 3) & ~(int64_t)3) + 2 * (size_t)((L.D + 3) & ~(int64_t)3) + 64;
+        // one wavefront per patch (k_gm_tables_w) where a patch's dense slots fit one bitset word per lane; BEATAMD_GM_WAVE=0:
+        // the workgroup-per-patch kernels (A/B, tests)
+        const bool per_wave = dense <= GW_DENSE_MAX && cap <= 128 && L.D <= 255 && GfKnobs::get(kn.gm_wave, 1) != 0;
+        const int ws0 = (int)gw_wave_bytes(0, L.D, L.S), ws1 = (int)gw_wave_bytes(1, L.D, L.S);
+        const unsigned wgrid = (unsigned)((GTP + GW_NW - 1) / GW_NW);
+        if (per_wave) {
+            BA_CHECK((size_t)std::max(ws0, ws1) * GW_NW <= 160 * 1024, BEATAMD_EINVAL, "internal: k_gm_tables_w exceeds LDS");
+            BA_HIP(hipFuncSetAttribute((const void *)k_gm_tables_w<0>, hipFuncAttributeMaxDynamicSharedMemorySize, ws0 * GW_NW));
+            BA_HIP(hipFuncSetAttribute((const void *)k_gm_tables_w<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ws1 * GW_NW));
+        }
         if (passes) {
             BA_HIP(hipMemsetAsync(ovf, 0, sizeof(int), ctx->stream));
-            hipLaunchKernelGGL(k_gm_tables<0>, dim3((unsigned)(GTP / ta.pb)), dim3(GC_TB), lds, ctx->stream, ta);
+            if (per_wave) hipLaunchKernelGGL(k_gm_tables_w<0>, dim3(wgrid), dim3(64 * GW_NW), (size_t)ws0 * GW_NW, ctx->stream, ta, ws0);
+            else hipLaunchKernelGGL(k_gm_tables<0>, dim3((unsigned)(GTP / ta.pb)), dim3(GC_TB), lds, ctx->stream, ta);
             hipLaunchKernelGGL(k_gm_scan, dim3((unsigned)GT), dim3(256), 0, ctx->stream, ta.npass, voff, nv, L.P, vmax, ovf);
             ta.voff = voff;
             ta.ovf = ovf;
         }
-        hipLaunchKernelGGL(k_gm_tables<1>, dim3((unsigned)(GTP / ta.pb)), dim3(GC_TB), lds, ctx->stream, ta);
+        if (per_wave) hipLaunchKernelGGL(k_gm_tables_w<1>, dim3(wgrid), dim3(64 * GW_NW), (size_t)ws1 * GW_NW, ctx->stream, ta, ws1);
+        else hipLaunchKernelGGL(k_gm_tables<1>, dim3((unsigned)(GTP / ta.pb)), dim3(GC_TB), lds, ctx->stream, ta);
     }
     BA_HIP(hipGetLastError());
 
