@@ -25,7 +25,7 @@
 // tools/gen_gfruns_asm.py generates the two wavefront programs (gfruns_asm.inc: the accumulators must be a
 // contiguous physical register range, so they are register-allocated by hand); tools/gfcell_emu.py interprets
 // them on the CPU (tests/test_gfcell_program.py).  Rounds 3 / 4 shipped two more consumer programs in this file
-// (k_gfstack_cell, k_gfstack_ml); both were retired in round 5 (DESIGN.md 3.1d-e keeps what they measured).
+// (k_gfstack_cell, k_gfstack_ml); both were retired in round 5 (docs/design_history.md 3.1d-e keeps what they measured).
 #include "kernels.hpp"
 #include "gfruns_asm.inc"
 

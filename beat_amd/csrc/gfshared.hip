@@ -375,7 +375,7 @@ __device__ __forceinline__ void lds_wait8_b64(double (&x)[8])
 // groups (every distinct row staged once for twice the chains).
 //
 // (Three row buffers with requests two steps ahead, and requests issued inside the gather, were
-// tried in this kernel and measured slower -- profiles/r2_variants.md; the deeper pipeline lives
+// tried in this kernel and measured slower -- profiles/archive/r2_variants.md; the deeper pipeline lives
 // in k_gfstack_ws, where other wavefronts do the issue work.)
 template <int WAVES, int NROW, int MODE, int NT, int B64>
 __global__ void __launch_bounds__(WAVES * 64)
@@ -1669,7 +1669,7 @@ k_gfstack_wsp(GsArgs a)
     static_assert(GS_NT == 64, "the read schedule below is written for 64-sample tiles");
     // The gather of a step is 8 groups of 4 ds_read_b64 (two floats each) + 8 (widen + FMA), two groups
     // in flight: HALF the LDS instructions of the f64 kernel per step -- its consumers are bound by the
-    // LDS instruction rate (1081 of ~1300 cycles per step, profiles/r2_variants.md), not by LDS bytes.
+    // LDS instruction rate (1081 of ~1300 cycles per step, profiles/archive/r2_variants.md), not by LDS bytes.
     // Pipelined across the step boundary like k_gfstack_ws; the FMAs are plain fma() between wait
     // statements that name the landing registers.
     pair_t ya[4], yb[4];

@@ -37,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+PROFILE_ROUND = "r6"   # prefix of the counter summaries under profiles/ (tools/run_gpu.sh profile6: one lease)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 LDS_PEAK_GBS = 256 * 256 * 2.4   # 256 CUs x 256 B/clk (ds_read_b64, MI355X_MICROARCH.md LDS table) x 2.4 GHz
 FP64_VALU_PEAK_TFLOPS = 78.6
@@ -382,7 +383,10 @@ def main():
                          "tempering, geometry mode")
     ap.add_argument("--variant-legs", default="multilinear,toeplitz,default_config,stage_update,smc,pt,prewhitened,geometry,fp32,config4,realistic_grid,sharded",
                     help="which of the labelled configuration legs to run (comma separated)")
-    ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "r5_bench_c512_nn_gfstack_ws_summary.json"),
+    ap.add_argument("--profiles-dir", default=os.path.join(ROOT, "profiles"),
+                    help="where the committed rocprofv3 counter summaries (%s_*_summary.json) of the legs' commands are read from"
+                         % PROFILE_ROUND)
+    ap.add_argument("--pmc-summary", default=None,
                     help="rocprofv3 PMC summary (tools/run_profile.sh + tools/summarize_rocpd.py) of THIS "
                          "command; supplies roofline.traffic when its configuration matches")
     ap.add_argument("--gf-order", type=int, default=None,
@@ -638,7 +642,7 @@ def main():
         tr = pmc["hbm_read_bytes_per_launch_corrected"] + pmc.get("hbm_write_bytes_per_launch", 0.0)
         roof_d["traffic"] = tr
         roof_d["traffic_source"] = os.path.relpath(summary_path, ROOT)
-        roof_d["traffic_measured_in"] = "builder rocprofv3 --pmc passes of the same command (not this run)"
+        roof_d["traffic_measured_in"] = "rocprofv3 --pmc passes of the same command (tools/run_gpu.sh profile6; not this run)"
         roof_d["hbm_counter_frac"] = tr / (roof_d["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         roof_d["achieved"] = tr / (roof_d["avg_launch_ms"] * 1e-3) / 1e9
         roof_d["frac"] = roof_d["hbm_counter_frac"]
@@ -707,7 +711,7 @@ def main():
                        and spec.T == 64 and spec.N == 4096 and args.gf_order is None and args.prior == "survey"
                        and not env_knobs)
         if default_cfg:
-            attach_traffic(roof, args.pmc_summary)
+            attach_traffic(roof, args.pmc_summary or os.path.join(args.profiles_dir, PROFILE_ROUND + "_bench_c512_nn_gfstack_ws_summary.json"))
         roof["note"] = ("`bound` names the largest of the fractions; the float-storage leg (half the bytes, same gather: "
                         "same time; half the LDS gather instructions: -9 %) shows the kernel is limited by its LDS-gather "
                         "and row-request instruction counts under a power envelope -- GRBM_GUI_ACTIVE gives 1.72 GHz sustained on "
@@ -739,8 +743,7 @@ def main():
             "traffic": None,
             "note": "no cross-chain row reuse: algorithmic bytes = HBM bytes (block order chain-major)"}
         if Bs == 128 and spec.T == 64 and spec.N == 4096:
-            attach_traffic(out["roofline_streaming"], os.path.join(ROOT, "profiles",
-                                                                   "r5_bench_c512_nn_gfstack0_summary.json"))
+            attach_traffic(out["roofline_streaming"], os.path.join(args.profiles_dir, PROFILE_ROUND + "_bench_c512_nn_gfstack0_summary.json"))
     # ---- the same population in larger batches: chain groups of one (target, tile) share an XCD,
     # rows common to several groups come from its L2 (labelled leg; `value` stays the 512-chain batch)
     if world == 1 and not args.no_batch_leg and spec.covariance == "scalar" and B < 2048:
@@ -814,7 +817,7 @@ def main():
             leg = run_leg(spec_ml, f_ml, B, Kl, 2, seed_offset=1000)
             roof_ml = stack_roofline(spec_ml, leg, B)
             if B == 512 and T == 64 and N == 4096 and args.prior == "survey" and not env_knobs:
-                attach_traffic(roof_ml, os.path.join(ROOT, "profiles", "r5_bench_c512_ml_gfstack_runs_summary.json"))
+                attach_traffic(roof_ml, os.path.join(args.profiles_dir, PROFILE_ROUND + "_bench_c512_ml_gfstack_runs_summary.json"))
             out["multilinear_leg"] = {
                 "interpolation": "multilinear (4 rows per patch and chain; beat/ffi/base.py:663-704)",
                 "chains": B, "steps": Kl, "chain_steps_per_s": B * Kl / leg["dt"],
@@ -1215,8 +1218,8 @@ def main():
                     leg = min((run_leg(sp_i, f_i, nch, n_steps, 3, seed_offset=1000) for _ in range(2)), key=lambda l_: l_["dt"])
                     roof_l = stack_roofline(sp_i, leg, nch)
                     if traffic_tag and not env_knobs:
-                        attach_traffic(roof_l, os.path.join(ROOT, "profiles", "r5_%s_c%d_%s_gfstack_%s_summary.json" % (
-                            traffic_tag, nch, "nn" if interp == "nearest_neighbor" else "ml",
+                        attach_traffic(roof_l, os.path.join(args.profiles_dir, "%s_%s_c%d_%s_gfstack_%s_summary.json" % (
+                            PROFILE_ROUND, traffic_tag, nch, "nn" if interp == "nearest_neighbor" else "ml",
                             "ws" if interp == "nearest_neighbor" else "runs")))
                     plan = ctx.gf_plan() if hasattr(ctx, "gf_plan") else None
                     wband = [ctx.weights_band(wm._wset) for wm in prob_l.wavemaps if getattr(wm, "_wset", None) is not None]
@@ -1268,7 +1271,8 @@ def main():
                     ws = [whitening(gz["d%d_C" % i]) for i in range(len(sizes4))]
                     prob_l.geodetic = GeodeticData(gd.gfs, d4, o4, sizes4, [w_[0] for w_ in ws], [w_[1] for w_ in ws],
                                                    gd.hypers)
-                r4 = own_library_leg(sp4, (512,), ("multilinear", "nearest_neighbor"), max(Kl // 2, 3), laquila)
+                r4 = own_library_leg(sp4, (512,), ("multilinear", "nearest_neighbor"), max(Kl // 2, 3), laquila,
+                                     traffic_tag="config4_N%d" % N4)
                 r4["workload"] = ("BASELINE configs[3]: joint seismic + geodetic FFI, 2 subfaults x (10 x 20) patches of 2 km, 35 "
                                   "targets x %d samples, slip components uparr + uperp, station time shifts, Toeplitz data "
                                   "covariance (dense W), %s; 512 chains = the per-GPU share of 4096 over 8 GPUs"

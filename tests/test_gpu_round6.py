@@ -1,0 +1,108 @@
+"""Round 6's scheduling changes leave every number where it was: index tables built by one wavefront per patch
+(k_gm_tables_w) against the workgroup-per-patch kernel, the geodetic / Laplacian composites on the side stream against one
+stream, the geodetic stack's blocks of four chains against single chains.  Reference arithmetic: beat/ffi/base.py:292-305,
+607-709; beat/models/geodetic.py:1065-1081; beat/models/problems.py:227-247."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import beat_amd
+    return beat_amd.get_context(0)
+
+
+@pytest.mark.parametrize("D,S,cap", [(2, 60, None), (17, 41, None), (3, 25, "10"), (5, 9, "8")])
+def test_tables_by_wavefront_equal_tables_by_workgroup(ctx, monkeypatch, D, S, cap):
+    """multilinear, two slip variables, station shifts, a population over the whole grid: row passes along the duration axis
+    (122 / 714 dense slots per patch against 104 row slots; buffers of 10 / 8 slots cut duration lines along the start-time
+    axis too) -- the runs kernel on the tables of either builder gives the same bits, and the streaming kernel's values"""
+    from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
+    spec = SyntheticSpec((6,), (8,), (1.5,), T=5, N=200, D=D, S=S, slip_varnames=("uparr", "uperp"), station_shifts=True,
+                         interpolation="multilinear", st_dt=0.5, du_min=0.0 if D > 3 else 0.5, du_dt=0.25 if D > 3 else 0.5,
+                         covariance="toeplitz")
+    prob, host = build_problem(spec)
+    f = prob.compile(ctx)
+    C = 700
+    Q = draw_population(spec, host["layout"], host["lower"], host["upper"], C)
+    if cap:
+        monkeypatch.setenv("BEATAMD_GR_CAP", cap)
+        monkeypatch.setenv("BEATAMD_GR_PASS_ALLOC", "40")
+    monkeypatch.setenv("BEATAMD_GF_SPLIT", "0")                   # (the library as it is: one walk per target and tile)
+    A = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack_runs<"), (ctx.last_kernel(), ctx.gf_plan())
+    plan_w = ctx.gf_plan()
+    monkeypatch.setenv("BEATAMD_GM_WAVE", "0")
+    B = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack_runs<")
+    plan_g = ctx.gf_plan()
+    monkeypatch.delenv("BEATAMD_GM_WAVE")
+    assert np.isfinite(A).all() and np.array_equal(A, B)
+    assert plan_w["mean_passes"] == plan_g["mean_passes"] and plan_w["max_passes"] == plan_g["max_passes"], (plan_w, plan_g)
+    if cap or D * (S + 1) > 104:
+        assert plan_w["max_passes"] >= 2, plan_w
+    monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
+    S_ = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack<1,")
+    np.testing.assert_allclose(A, S_, rtol=1e-11)                   # (two variables: the kernels interleave them differently)
+    f.release()
+
+
+def test_side_stream_is_bitwise_the_single_stream(ctx, monkeypatch):
+    """a joint model (seismic + two geodetic datasets + Laplacian): the composites that depend on q only run next to the
+    seismic one; calls back to back on changing populations -- the buffers of the two branches never meet"""
+    import torch
+    from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
+    spec = SyntheticSpec((5, 5), (8, 8), (2.0, 2.0), T=6, N=120, D=2, S=40, slip_varnames=("uparr", "uperp"),
+                         station_shifts=True, geodetic_nobs=(70, 45), laplacian=True, covariance="toeplitz",
+                         interpolation="multilinear", vel_bounds=(3.0, 4.0), time_bounds=(0.0, 2.0))
+    prob, host = build_problem(spec)
+    f = prob.compile(ctx)
+    dev = torch.device("cuda", 0)
+    pops = [torch.from_numpy(draw_population(spec, host["layout"], host["lower"], host["upper"], C, seed_offset=1000 * s)).to(dev)
+            for s, C in ((1, 300), (2, 300), (3, 64), (4, 300))]
+    monkeypatch.setenv("BEATAMD_SIDE", "0")
+    ref = [f.batch(Q).cpu().numpy() for Q in pops]
+    monkeypatch.delenv("BEATAMD_SIDE")
+    for rep in range(3):
+        got = [f.batch(Q) for Q in pops]                      # queued without a synchronisation in between
+        for r, g in zip(ref, got):
+            assert np.array_equal(r, g.cpu().numpy())
+    # host arrays (staged through scratch slots of the main bank) and the Metropolis step on top
+    assert np.array_equal(ref[2], f.batch(pops[2].cpu().numpy()))
+    assert np.isfinite(ref[0]).all()
+    f.release()
+
+
+@pytest.mark.parametrize("nvar", [1, 2])
+def test_geodetic_stack_in_blocks_of_four_chains(ctx, nvar):
+    """ffi/base.py:292-305 batched: 70 chains go through the 4-chain blocks (one launch for all slip variables), 10-chain
+    slices through the one-chain kernel: the same fma sequence per (chain, point) -- bitwise; numpy at rounding"""
+    from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
+    names = ("uparr", "uperp")[:nvar]
+    spec = SyntheticSpec((3,), (7,), (2.0,), T=2, N=64, D=2, S=12, slip_varnames=names, geodetic_nobs=(130, 33))
+    prob, host = build_problem(spec)
+    f = prob.compile(ctx)
+    C = 70
+    Q = draw_population(spec, host["layout"], host["lower"], host["upper"], C)
+    A = f.batch(Q)
+    for a in range(0, C, 10):
+        sub = f.batch(Q[a:a + 10])
+        assert np.array_equal(A[a:a + 10, 2:4], sub[:, 2:4]), a         # the two geodetic datasets' columns
+        np.testing.assert_allclose(A[a:a + 10], sub, rtol=1e-11)
+    # the library method itself against numpy
+    from beat_amd.ffi import GeodeticGFLibrary, GeodeticGFLibraryConfig
+    rng = np.random.default_rng(5)
+    P, Nobs = 37, 301
+    G = rng.standard_normal((P, Nobs))
+    gl = GeodeticGFLibrary(GeodeticGFLibraryConfig(dimensions=(P, Nobs)))
+    gl.setup(P, Nobs, allocate=False)
+    gl._gfmatrix = G
+    gl.init_optimization(ctx)
+    sl = rng.uniform(-1, 4, (C, P))
+    mu = gl.stack_all_batch(sl)
+    np.testing.assert_allclose(mu, sl @ G, rtol=1e-12, atol=1e-12)
+    assert np.array_equal(mu[:9], gl.stack_all_batch(sl[:9]))
+    f.release()

@@ -42,7 +42,7 @@ step, the loaders' request lines and the consumers' descriptor lines and weight 
 The programs are generated because they are register-allocated by hand (the accumulators must be a contiguous
 physical VGPR range) and unrolled; tools/gfcell_emu.py interprets them on the CPU (tests/test_gfcell_program.py).
 Rounds 3 / 4 shipped two more consumer programs (k_gfstack_cell: batch records; k_gfstack_ml: static accumulators,
-LDS-bound); both were retired in round 5 (DESIGN.md 3.1d-e keep their measurements).
+LDS-bound); both were retired in round 5 (docs/design_history.md 3.1d-e keep their measurements).
 
     python tools/gen_gfruns_asm.py        # rewrites beat_amd/csrc/gfruns_asm.inc
 """
