@@ -82,41 +82,6 @@ struct LikeTail {
     const int32_t *chain_bad = nullptr;
 };
 
-// RAII switch of the context to its side stream and second scratch bank (see ffi_logp_device)
-struct SideBranch {
-    beatamd_ctx *ctx;
-    bool on;
-    hipStream_t main = nullptr;
-    SideBranch(beatamd_ctx *c, bool enable) : ctx(c), on(enable) {}
-    int begin()
-    {
-        if (!on) return BEATAMD_OK;
-        if (!ctx->side_stream) {
-            BA_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-            BA_HIP(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
-            BA_HIP(hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
-        }
-        BA_HIP(hipEventRecord(ctx->side_fork, ctx->stream));
-        BA_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
-        main = ctx->stream;
-        ctx->stream = ctx->side_stream;
-        ctx->scratch_bank = 1;
-        return BEATAMD_OK;
-    }
-    int end()
-    {
-        if (!on || !main) return BEATAMD_OK;
-        BA_HIP(hipEventRecord(ctx->side_join, ctx->stream));
-        restore();
-        return BEATAMD_OK;
-    }
-    void restore()
-    {
-        if (main) { ctx->stream = main; ctx->scratch_bank = 0; main = nullptr; }
-    }
-    ~SideBranch() { restore(); }
-};
-
 // logp_forw_func on device pointers
 int ffi_logp_device(beatamd_ctx *ctx, FfiModel &m, int64_t C, const double *Q, double *LL,
                     LikeTail *tail = nullptr)
@@ -140,99 +105,6 @@ int ffi_logp_device(beatamd_ctx *ctx, FfiModel &m, int64_t C, const double *Q, d
         BA_HIP(hipMemsetAsync(chain_bad, 0, (size_t)C * sizeof(int32_t), ctx->stream));
     }
 
-    // The geodetic and Laplacian composites depend on Q only: they run on a SIDE STREAM next to the seismic composite
-    // (round 6: at 120 samples per trace the seismic chain is a row of small latency-bound kernels -- sweep, chain order,
-    // index tables -- and 0.1 ms of geodetic kernels queued behind them in one stream).  Fork behind everything already
-    // queued on the caller's stream (the staged Q), second bank of scratch slots, join in front of `like`.  The columns
-    // of LL they write are theirs alone.  BEATAMD_SIDE=0: one stream, in order.
-    int64_t col_seis = 0;
-    for (auto &wm : m.wavemaps) col_seis += wm.T;
-    const bool have_side = m.has_geo || m.lap >= 0;
-    const bool forked = have_side && !m.wavemaps.empty() && GfKnobs::get(gf_knobs(ctx).side, 1) != 0;
-    LikeGroups side_grp;     // (group ends of the side composites, appended behind the seismic group below)
-    {
-        SideBranch sb(ctx, forked);
-        BA_TRY(sb.begin());
-        int64_t col = col_seis;
-        LikeGroups &grp = side_grp;
-        if (m.has_geo) {
-            Geodetic &g = m.geo;
-            BA_TRY(ctx->get_scratch(SL_MU, (size_t)C * g.Nobs * 2 * sizeof(double), &p));
-            double *mu = (double *)p, *res = mu + C * g.Nobs;
-            if (m.geo_is_geometry) {
-                // synthetics, line of sight and weighted residual in one kernel
-                BA_TRY(launch_geom_los(ctx, m.geom, Q, np, C, nullptr, g.data, g.odws, res));
-            } else {
-                // every slip variable's G.T . slips in one launch (geodetic.py:1065-1070 sums them)
-                const GeoLib *gls[4] = {nullptr, nullptr, nullptr, nullptr};
-                BA_CHECK(m.layout.nvar <= 4, BEATAMD_EINVAL, "geodetic composite: more than 4 slip variables");
-                for (int v = 0; v < m.layout.nvar; v++) {
-                    gls[v] = get_obj(ctx->geolibs, g.libs[v]);
-                    BA_CHECK(gls[v], BEATAMD_EINVAL, "geodetic composite refers to a destroyed GF library");
-                }
-                BA_TRY(launch_geo_stack(ctx, gls, m.layout.nvar, C, slips, 0, mu));
-                BA_TRY(launch_geo_residual(ctx, C, g.Nobs, g.data, g.odws, mu, res));
-            }
-            // small dense datasets (SAR scenes / GNSS of a few hundred points): every dataset's
-            // quadratic form and MVN epilogue in one launch; otherwise per dataset on the 64-row tiles
-            QuadformSmallCall qs;
-            bool small = g.sizes.size() <= 8;
-            int64_t o = 0;
-            for (size_t d = 0; d < g.sizes.size(); d++) {
-                WeightSet *ws = get_obj(ctx->wsets, g.wsets[d]);
-                BA_CHECK(ws && ws->nd == 1 && ws->M == g.sizes[d], BEATAMD_EINVAL,
-                         "geodetic dataset %zu: weight set missing or of the wrong size", d);
-                small = small && ws->kind != BEATAMD_W_SCALAR;
-                if (small) {
-                    qs.A[d] = ws->w; qs.M[d] = ws->M; qs.xoff[d] = o; qs.upper_tri[d] = ws->upper_tri;
-                    qs.slog[d] = ws->slog; qs.hp_off[d] = g.hp_off + d;
-                }
-                o += g.sizes[d];
-            }
-            small = small && quadform_small_applicable((int)g.sizes.size(), qs.M);
-            if (small) {
-                qs.nd = (int)g.sizes.size();
-                qs.C = C; qs.X = res; qs.xs_c = g.Nobs; qs.Q = Q; qs.nparams = np;
-                qs.LL = LL + col; qs.ld = nllk;
-                BA_TRY(launch_quadform_small(ctx, qs));
-            } else {
-                BA_TRY(ctx->get_scratch(SL_QUAD, (size_t)C * sizeof(double), &p));
-                double *quad = (double *)p;
-                o = 0;
-                for (size_t d = 0; d < g.sizes.size(); d++) {
-                    WeightSet *ws = get_obj(ctx->wsets, g.wsets[d]);
-                    BA_TRY(wset_quad(ctx, *ws, C, res + o, g.Nobs, 0, quad));
-                    BA_TRY(launch_mvn_finish(ctx, C, 1, ws->M, quad, ws->slog,
-                                             HpSrc{Q, np, g.hp_off + d}, LL + col + (int64_t)d, nllk));
-                    o += g.sizes[d];
-                }
-            }
-            col += (int64_t)g.sizes.size();
-            grp.end[grp.n++] = (int32_t)col;
-        }
-        if (m.lap >= 0) {
-            Laplacian *lp = get_obj(ctx->laps, m.lap);
-            BA_CHECK(lp, BEATAMD_EINVAL, "model refers to a destroyed laplacian");
-            const int nvar = m.layout.nvar;
-            BA_TRY(ctx->get_scratch(SL_SLIPS, (size_t)C * nvar * lp->P * sizeof(double), &p));
-            double *sl = (double *)p;
-            BA_TRY(launch_gather_slips(ctx, C, nvar, lp->P, slips, sl));
-            BA_TRY(ctx->get_scratch(SL_QUAD, (size_t)C * nvar * sizeof(double), &p));
-            double *quad = (double *)p;
-            QuadformCall q;
-            q.A = lp->L; q.a_stride = 0; q.M = lp->P; q.nd = nvar; q.C = C;
-            q.X = sl; q.xs_c = nvar * lp->P; q.xs_d = lp->P;
-            q.quad = quad; q.q_stride = nvar;
-            BA_TRY(launch_quadform(ctx, q));
-            BA_TRY(launch_laplacian_finish(ctx, C, nvar, lp->P, lp->logdet, quad,
-                                           HpSrc{Q + m.layout.h_laplacian_off, np, nullptr}, LL + col,
-                                           nllk));
-            col += 1;
-            grp.end[grp.n++] = (int32_t)col;
-        }
-        BA_CHECK(col == nllk - 1, BEATAMD_EINVAL, "internal: llk layout mismatch");
-        BA_TRY(sb.end());
-    }
     if (!m.wavemaps.empty()) {
         BA_TRY(ctx->get_scratch(SL_ST0, (size_t)C * m.P * sizeof(double), &p));
         double *st0 = (double *)p;
@@ -291,9 +163,82 @@ int ffi_logp_device(beatamd_ctx *ctx, FfiModel &m, int64_t C, const double *Q, d
         }
         grp.end[grp.n++] = (int32_t)col;
     }
-    BA_CHECK(col == col_seis, BEATAMD_EINVAL, "internal: llk layout mismatch");
-    for (int i = 0; i < side_grp.n; i++) grp.end[grp.n++] = side_grp.end[i];
-    if (forked) BA_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_join, 0));
+    if (m.has_geo) {
+        Geodetic &g = m.geo;
+        BA_TRY(ctx->get_scratch(SL_MU, (size_t)C * g.Nobs * 2 * sizeof(double), &p));
+        double *mu = (double *)p, *res = mu + C * g.Nobs;
+        if (m.geo_is_geometry) {
+            // synthetics, line of sight and weighted residual in one kernel
+            BA_TRY(launch_geom_los(ctx, m.geom, Q, np, C, nullptr, g.data, g.odws, res));
+        } else {
+            // every slip variable's G.T . slips in one launch (geodetic.py:1065-1070 sums them)
+            const GeoLib *gls[4] = {nullptr, nullptr, nullptr, nullptr};
+            BA_CHECK(m.layout.nvar <= 4, BEATAMD_EINVAL, "geodetic composite: more than 4 slip variables");
+            for (int v = 0; v < m.layout.nvar; v++) {
+                gls[v] = get_obj(ctx->geolibs, g.libs[v]);
+                BA_CHECK(gls[v], BEATAMD_EINVAL, "geodetic composite refers to a destroyed GF library");
+            }
+            BA_TRY(launch_geo_stack(ctx, gls, m.layout.nvar, C, slips, 0, mu));
+            BA_TRY(launch_geo_residual(ctx, C, g.Nobs, g.data, g.odws, mu, res));
+        }
+        // small dense datasets (SAR scenes / GNSS of a few hundred points): every dataset's
+        // quadratic form and MVN epilogue in one launch; otherwise per dataset on the 64-row tiles
+        QuadformSmallCall qs;
+        bool small = g.sizes.size() <= 8;
+        int64_t o = 0;
+        for (size_t d = 0; d < g.sizes.size(); d++) {
+            WeightSet *ws = get_obj(ctx->wsets, g.wsets[d]);
+            BA_CHECK(ws && ws->nd == 1 && ws->M == g.sizes[d], BEATAMD_EINVAL,
+                     "geodetic dataset %zu: weight set missing or of the wrong size", d);
+            small = small && ws->kind != BEATAMD_W_SCALAR;
+            if (small) {
+                qs.A[d] = ws->w; qs.M[d] = ws->M; qs.xoff[d] = o; qs.upper_tri[d] = ws->upper_tri;
+                qs.slog[d] = ws->slog; qs.hp_off[d] = g.hp_off + d;
+            }
+            o += g.sizes[d];
+        }
+        small = small && quadform_small_applicable((int)g.sizes.size(), qs.M);
+        if (small) {
+            qs.nd = (int)g.sizes.size();
+            qs.C = C; qs.X = res; qs.xs_c = g.Nobs; qs.Q = Q; qs.nparams = np;
+            qs.LL = LL + col; qs.ld = nllk;
+            BA_TRY(launch_quadform_small(ctx, qs));
+        } else {
+            BA_TRY(ctx->get_scratch(SL_QUAD, (size_t)C * sizeof(double), &p));
+            double *quad = (double *)p;
+            o = 0;
+            for (size_t d = 0; d < g.sizes.size(); d++) {
+                WeightSet *ws = get_obj(ctx->wsets, g.wsets[d]);
+                BA_TRY(wset_quad(ctx, *ws, C, res + o, g.Nobs, 0, quad));
+                BA_TRY(launch_mvn_finish(ctx, C, 1, ws->M, quad, ws->slog,
+                                         HpSrc{Q, np, g.hp_off + d}, LL + col + (int64_t)d, nllk));
+                o += g.sizes[d];
+            }
+        }
+        col += (int64_t)g.sizes.size();
+        grp.end[grp.n++] = (int32_t)col;
+    }
+    if (m.lap >= 0) {
+        Laplacian *lp = get_obj(ctx->laps, m.lap);
+        BA_CHECK(lp, BEATAMD_EINVAL, "model refers to a destroyed laplacian");
+        const int nvar = m.layout.nvar;
+        BA_TRY(ctx->get_scratch(SL_SLIPS, (size_t)C * nvar * lp->P * sizeof(double), &p));
+        double *sl = (double *)p;
+        BA_TRY(launch_gather_slips(ctx, C, nvar, lp->P, slips, sl));
+        BA_TRY(ctx->get_scratch(SL_QUAD, (size_t)C * nvar * sizeof(double), &p));
+        double *quad = (double *)p;
+        QuadformCall q;
+        q.A = lp->L; q.a_stride = 0; q.M = lp->P; q.nd = nvar; q.C = C;
+        q.X = sl; q.xs_c = nvar * lp->P; q.xs_d = lp->P;
+        q.quad = quad; q.q_stride = nvar;
+        BA_TRY(launch_quadform(ctx, q));
+        BA_TRY(launch_laplacian_finish(ctx, C, nvar, lp->P, lp->logdet, quad,
+                                       HpSrc{Q + m.layout.h_laplacian_off, np, nullptr}, LL + col,
+                                       nllk));
+        col += 1;
+        grp.end[grp.n++] = (int32_t)col;
+    }
+    BA_CHECK(col == nllk - 1, BEATAMD_EINVAL, "internal: llk layout mismatch");
     if (tail) {
         tail->grp = grp;
         tail->chain_bad = chain_bad;

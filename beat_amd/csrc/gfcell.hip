@@ -206,10 +206,18 @@ __global__ void __launch_bounds__(GC_CUT_TB) k_gc_cut(GcOrderArgs a, int n, int6
     for (int i = tid; i < C; i += GC_CUT_TB) a.members[i] = (uint32_t)base + (stag[i] & 0xffffu);
 }
 
-__global__ void __launch_bounds__(GC_TB) k_gc_order(GcOrderArgs a)
+// (round 6: two bitonic sorts of the group's 518 slots in LDS -- by the first key, then by (band, second key) -- instead of
+// two O(518^2) ranking loops per thread: the single workgroup of a 512-chain batch took 103 us, a twentieth of a step on
+// 120-sample traces.  Ties go by slot as before: the order is the same.)
+__global__ void __launch_bounds__(GC_CUT_TB) k_gc_order(GcOrderArgs a)
 {
-    __shared__ double ka[GC_CG], kb[GC_CG];
-    __shared__ int bnd[GC_CG];
+    constexpr int NS = 1024;                       // slots sorted: GC_CG rounded up to a power of two
+    static_assert(GC_CG <= NS && NS <= 2 * GC_CUT_TB, "k_gc_order: one workgroup sorts a group");
+    __shared__ double skey[NS];
+    __shared__ uint32_t stag[NS];
+    __shared__ double kb[GC_CG];
+    __shared__ uint32_t cids[GC_CG];
+    __shared__ double ext[4][GC_CUT_TB / 64];
     const int tid = threadIdx.x;
     const int64_t pos = (int64_t)blockIdx.x * GC_CG + tid;
     const bool slot = tid < GC_CG;
@@ -221,15 +229,17 @@ __global__ void __launch_bounds__(GC_TB) k_gc_order(GcOrderArgs a)
     const int64_t c = (live && a.members) ? (int64_t)a.members[pos] : pos;
     double f0 = 0.0, f1 = 0.0;
     if (live) gc_keys(a, c, f0, f1);
-    if (slot) { ka[tid] = f0; kb[tid] = f1; }
-    __syncthreads();
+    if (slot) { kb[tid] = f1; cids[tid] = live ? (uint32_t)c : GC_DEAD; }
+    // dead slots and the pads of the sort: behind every live slot (range 0xffff)
+    for (int i = tid; i < NS; i += GC_CUT_TB) {
+        skey[i] = (i == tid && live) ? f0 : 0.0;
+        stag[i] = (i == tid && live) ? (uint32_t)tid : (0xffff0000u | (uint32_t)(i & 0xffff));
+    }
     const int nlive = (int)min((int64_t)GC_CG, a.C - (int64_t)blockIdx.x * GC_CG);
-    // dead slots sort behind the live ones (tid >= nlive for all of them)
-    // extents of the two keys: wavefront reductions, then the nine partial results (round 6: every thread used to scan all
-    // 518 keys for them inside the ranking loop -- four fp64 min / max per comparison)
-    __shared__ double ext[4][GC_TB / 64];
+    // extents of the two keys over the live slots: wavefront reductions, then the partial results
     {
-        double m0 = live ? f0 : ka[0], M0 = m0, m1 = live ? f1 : kb[0], M1 = m1;
+        const double s0 = __shfl(f0, 0, 64), s1 = __shfl(f1, 0, 64);      // (a live lane's keys for the dead ones: slot 0 of
+        double m0 = live ? f0 : s0, M0 = m0, m1 = live ? f1 : s1, M1 = m1;  //  wavefront 0 is live; later wavefronts see below)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             m0 = fmin(m0, __shfl_xor(m0, off, 64)); M0 = fmax(M0, __shfl_xor(M0, off, 64));
@@ -237,11 +247,11 @@ __global__ void __launch_bounds__(GC_TB) k_gc_order(GcOrderArgs a)
         }
         if ((tid & 63) == 0) { ext[0][tid >> 6] = m0; ext[1][tid >> 6] = M0; ext[2][tid >> 6] = m1; ext[3][tid >> 6] = M1; }
     }
-    int r0 = 0;
-    for (int k = 0; k < nlive; k++) r0 += (ka[k] < f0) || (ka[k] == f0 && k < tid);
     __syncthreads();
+    gc_bitonic(skey, stag, NS, tid);               // slots in (first key, slot) order: position = rank
+    const int nwl = (nlive + 63) / 64;             // wavefronts that hold a live slot (their lane 0 is live)
     double mn0 = ext[0][0], mx0 = ext[1][0], mn1 = ext[2][0], mx1 = ext[3][0];
-    for (int q = 1; q < GC_TB / 64; q++) {
+    for (int q = 1; q < nwl; q++) {
         mn0 = fmin(mn0, ext[0][q]); mx0 = fmax(mx0, ext[1][q]);
         mn1 = fmin(mn1, ext[2][q]); mx1 = fmax(mx1, ext[3][q]);
     }
@@ -257,17 +267,24 @@ __global__ void __launch_bounds__(GC_TB) k_gc_order(GcOrderArgs a)
         nb = max(1, min(nw, (int)rint(sqrt(r))));
         if (a.nbands > 0) nb = min(nw, a.nbands);
     }
-    if (slot) bnd[tid] = live ? (r0 / GC_NCHAIN) * nb / nw : nb;
-    __syncthreads();
-    if (!slot) return;
-    int r1 = tid;
-    if (live) {
-        const int b = bnd[tid];
-        r1 = 0;
-        for (int k = 0; k < nlive; k++)
-            r1 += (bnd[k] < b) || (bnd[k] == b && ((kb[k] < f1) || (kb[k] == f1 && k < tid)));
+    // second sort: (band of the slot's rank, second key, slot)
+    uint32_t t2[NS / GC_CUT_TB];
+    double k2[NS / GC_CUT_TB];
+    for (int i = tid, u = 0; i < NS; i += GC_CUT_TB, u++) {
+        const uint32_t tg = stag[i];
+        const bool lv = (tg >> 16) == 0;           // (live slots sorted to positions 0 .. nlive-1)
+        const uint32_t sl = tg & 0xffffu;
+        t2[u] = lv ? ((uint32_t)((i / GC_NCHAIN) * nb / nw) << 16 | sl) : tg;
+        k2[u] = lv ? kb[sl] : 0.0;
     }
-    a.order[(int64_t)blockIdx.x * GC_CG + r1] = live ? (uint32_t)c : GC_DEAD;
+    __syncthreads();
+    for (int i = tid, u = 0; i < NS; i += GC_CUT_TB, u++) { stag[i] = t2[u]; skey[i] = k2[u]; }
+    __syncthreads();
+    gc_bitonic(skey, stag, NS, tid);
+    if (slot) {
+        const uint32_t tg = stag[tid];
+        a.order[(int64_t)blockIdx.x * GC_CG + tid] = (tg >> 16) == 0xffffu ? GC_DEAD : cids[tg & 0xffffu];
+    }
 }
 
 __global__ void __launch_bounds__(256) k_members_pad(uint32_t *members, int64_t C, int64_t padded)
@@ -335,7 +352,7 @@ static int launch_gc_order(beatamd_ctx *ctx, GcOrderArgs &oa, int64_t ngroups, c
         void *q = reinterpret_cast<void *>(((uintptr_t)(oa.order + norder) + 7) & ~(uintptr_t)7);
         BA_TRY(launch_gc_cut(ctx, oa, q, GC_CG, ngroups, oa.C));
     }
-    hipLaunchKernelGGL(k_gc_order, dim3((unsigned)ngroups), dim3(GC_TB), 0, ctx->stream, oa);
+    hipLaunchKernelGGL(k_gc_order, dim3((unsigned)ngroups), dim3(GC_CUT_TB), 0, ctx->stream, oa);
     return BEATAMD_OK;
 }
 

@@ -6,7 +6,7 @@
 #   profile <tag>                   the round's rocprofv3 evidence: kernel stats of the default bench command and, with
 #                                   separate FETCH_SIZE / WRITE_SIZE passes, of the nn / multilinear / Toeplitz runs and the
 #                                   geometry stage -> gpurun_out/prof_<tag>/out/<tag>_* (tools/summarize_rocpd2.py)
-#   profile6 <tag>                  round 6's evidence from one lease (see the mode)
+#   profile6 <tag> a|b|c|d          round 6's evidence in four parts (see the mode)
 #   stats <tag> <command...>        rocprofv3 --kernel-trace --stats of any command, head of the kernel table
 #   pmc <tag> <kernel-like> <command> <counter set> [<counter set> ...]
 #                                   one rocprofv3 --pmc pass per counter set (kernel trace only: gpurun refuses --pmc
@@ -115,46 +115,62 @@ profile5)
   du -sh $O
   ;;
 profile6)
-  # round 6: everything the record needs from ONE lease -- kernel stats + separate FETCH_SIZE / WRITE_SIZE passes of the
-  # headline run, the multilinear run, the tutorial-grid runs and configs[3] at 120 and 4096 samples (tools/time_config4.py =
-  # the bench leg's problem), kernel stats of the default command, then the default bench.py line itself with the
-  # counter summaries of THIS lease (--profiles-dir) -> gpurun_out/prof_<tag>/out
-  tag=$1; O=$R/gpurun_out/prof_$tag
-  rm -rf $O; mkdir -p $O/out; cd /tmp
+  # round 6: kernel stats + separate FETCH_SIZE / WRITE_SIZE passes, in PARTS that each fit a gpurun call (the whole set once
+  # overran the call's hour and nothing came back): profile6 <tag> a|b|c|d
+  #   a  headline run, multilinear run, configs[3] at 120 samples (tools/time_config4.py = the bench leg's problem)
+  #   b  the tutorial-grid runs (512 and 2048 chains, nn and multilinear)
+  #   c  configs[3] at 4096 samples
+  #   d  kernel stats of the default command, then the default bench.py line itself (reads the summaries of a-c from
+  #      profiles/: copy them there first)
+  # -> gpurun_out/prof_<tag>/out
+  tag=$1; part=$2; O=$R/gpurun_out/prof_$tag
+  mkdir -p $O/out; cd /tmp
   B="python $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-variant-legs --no-narrow-leg --no-batch-leg"
   G="--samples 512 --ndurations 17 --nstarttimes 41 --duration-min 0 --duration-sampling 0.25 --no-streaming-leg"
-  prof() { t=$1; shift; mkdir -p $O/$t
-    timeout 900 rocprofv3 --kernel-trace --stats -d $O/$t/stats -o bench -- "$@" > $O/$t/stats_run.log 2>&1
-    timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/$t/fetch -o bench -- "$@" > $O/$t/fetch_run.log 2>&1
-    timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/$t/write -o bench -- "$@" > $O/$t/write_run.log 2>&1
+  prof() { t=$1; shift; rm -rf $O/$t; mkdir -p $O/$t
+    timeout 600 rocprofv3 --kernel-trace --stats -d $O/$t/stats -o bench -- "$@" > $O/$t/stats_run.log 2>&1
+    timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/$t/fetch -o bench -- "$@" > $O/$t/fetch_run.log 2>&1
+    timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/$t/write -o bench -- "$@" > $O/$t/write_run.log 2>&1
   }
   S="python $R/tools/summarize_rocpd2.py"
-  prof c512_nn $B
-  $S $O/c512_nn $O/out ${tag}_bench_c512_nn k_gfstack_ws "k_gfstack<0" k_ws_tables k_fast_sweep > $O/sum_c512_nn.log 2>&1
-  prof c512_ml $B --interp multilinear --no-streaming-leg
-  $S $O/c512_ml $O/out ${tag}_bench_c512_ml k_gfstack_runs k_gm_tables_w k_gc_order > $O/sum_c512_ml.log 2>&1
-  prof grid_nn $B $G
-  $S $O/grid_nn $O/out ${tag}_grid_c512_nn k_gfstack_ws k_ws_tables > $O/sum_grid_nn.log 2>&1
-  prof grid_ml $B $G --interp multilinear
-  $S $O/grid_ml $O/out ${tag}_grid_c512_ml k_gfstack_runs k_gm_tables_w > $O/sum_grid_ml.log 2>&1
-  prof grid_nn_c2048 $B $G --chains 2048
-  $S $O/grid_nn_c2048 $O/out ${tag}_grid_c2048_nn k_gfstack_ws > $O/sum_grid_nn2048.log 2>&1
-  prof grid_ml_c2048 $B $G --chains 2048 --interp multilinear
-  $S $O/grid_ml_c2048 $O/out ${tag}_grid_c2048_ml k_gfstack_runs > $O/sum_grid_ml2048.log 2>&1
-  for N in 120 4096; do
+  c4() { N=$1
     prof c4_${N}_ml python $R/tools/time_config4.py $N multilinear
     $S $O/c4_${N}_ml $O/out ${tag}_config4_N${N}_c512_ml k_gfstack_runs k_gm_tables_w k_gc_order k_geo_stack > $O/sum_c4_${N}_ml.log 2>&1
     prof c4_${N}_nn python $R/tools/time_config4.py $N nearest_neighbor
     $S $O/c4_${N}_nn $O/out ${tag}_config4_N${N}_c512_nn k_gfstack_ws k_ws_tables k_geo_stack > $O/sum_c4_${N}_nn.log 2>&1
-  done
-  mkdir -p $O/default
-  timeout 900 rocprofv3 --kernel-trace --stats -d $O/default/stats -o bench -- python $R/bench.py --no-cpu-baseline --profiles-dir $O/out > $O/default/stats_run.log 2>&1
-  $S $O/default $O/out ${tag}_bench_default "k_quadform<128>" k_gfstack_runs "k_gemm_f64<0>" k_gfstack_ws > $O/sum_default.log 2>&1
-  grep -h "^{\"metric" $O/*/stats_run.log > $O/out/${tag}_bench_lines_under_profiler.jsonl
-  cd $R
-  timeout 1200 python bench.py --profiles-dir $O/out --full-json $O/out/${tag}_bench_default_full.json > $O/out/${tag}_bench_default.json 2> $O/bench_default.err || tail -5 $O/bench_default.err
-  tail -c 600 $O/out/${tag}_bench_default.json
-  cat $O/sum_*.log | grep -E "kernel\"|avg_us\"|corrected|write_bytes|no dispatch" | cut -c1-160
+  }
+  case $part in
+  a)
+    prof c512_nn $B
+    $S $O/c512_nn $O/out ${tag}_bench_c512_nn k_gfstack_ws "k_gfstack<0" k_ws_tables k_fast_sweep > $O/sum_c512_nn.log 2>&1
+    prof c512_ml $B --interp multilinear --no-streaming-leg
+    $S $O/c512_ml $O/out ${tag}_bench_c512_ml k_gfstack_runs k_gm_tables_w k_gc_order > $O/sum_c512_ml.log 2>&1
+    c4 120
+    ;;
+  b)
+    prof grid_nn $B $G
+    $S $O/grid_nn $O/out ${tag}_grid_c512_nn k_gfstack_ws k_ws_tables > $O/sum_grid_nn.log 2>&1
+    prof grid_ml $B $G --interp multilinear
+    $S $O/grid_ml $O/out ${tag}_grid_c512_ml k_gfstack_runs k_gm_tables_w > $O/sum_grid_ml.log 2>&1
+    prof grid_nn_c2048 $B $G --chains 2048
+    $S $O/grid_nn_c2048 $O/out ${tag}_grid_c2048_nn k_gfstack_ws > $O/sum_grid_nn2048.log 2>&1
+    prof grid_ml_c2048 $B $G --chains 2048 --interp multilinear
+    $S $O/grid_ml_c2048 $O/out ${tag}_grid_c2048_ml k_gfstack_runs > $O/sum_grid_ml2048.log 2>&1
+    ;;
+  c)
+    c4 4096
+    ;;
+  d)
+    mkdir -p $O/default
+    timeout 900 rocprofv3 --kernel-trace --stats -d $O/default/stats -o bench -- python $R/bench.py --no-cpu-baseline > $O/default/stats_run.log 2>&1
+    $S $O/default $O/out ${tag}_bench_default "k_quadform<128>" k_gfstack_runs "k_gemm_f64<0>" k_gfstack_ws > $O/sum_default.log 2>&1
+    cd $R
+    timeout 1200 python bench.py --full-json $O/out/${tag}_bench_default_full.json > $O/out/${tag}_bench_default.json 2> $O/bench_default.err || tail -5 $O/bench_default.err
+    tail -c 600 $O/out/${tag}_bench_default.json
+    ;;
+  esac
+  grep -h "^{\"metric" $O/*/stats_run.log > $O/out/${tag}_bench_lines_under_profiler_$part.jsonl 2>/dev/null
+  cat $O/sum_*.log 2>/dev/null | grep -E "kernel\"|avg_us\"|corrected|write_bytes|no dispatch" | cut -c1-160
   find $O -name "*.db" -size +2M -delete; find $O -name "*.csv" -size +2M -delete
   du -sh $O
   ;;
