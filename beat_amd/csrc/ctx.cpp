@@ -206,7 +206,7 @@ void GfKnobs::read_env()
     gs_order = rd("BEATAMD_GS_ORDER"); gs_fit = rd("BEATAMD_GS_FIT"); gs_win = rd("BEATAMD_GS_WIN"); gf_tinv = rd("BEATAMD_GF_TINV");
     gs_tune = rd("BEATAMD_GS_TUNE"); gf_order = rd("BEATAMD_GF_ORDER"); gf_cgroup = rd("BEATAMD_GF_CGROUP"); gs_ml = rd("BEATAMD_GS_ML");
     gc_global = rd("BEATAMD_GC_GLOBAL"); gc_sort = rd("BEATAMD_GC_SORT"); gc_keys = rd("BEATAMD_GC_KEYS"); gc_bands = rd("BEATAMD_GC_BANDS"); gr_cap = rd("BEATAMD_GR_CAP");
-    gr_pass_alloc = rd("BEATAMD_GR_PASS_ALLOC"); gr_var = rd("BEATAMD_GR_VAR"); sweep_v1 = rd("BEATAMD_SWEEP_V1"); qf_band = rd("BEATAMD_QF_BAND"); qf_fuse = rd("BEATAMD_QF_FUSE"); gf_split = rd("BEATAMD_GF_SPLIT"); gm_pb = rd("BEATAMD_GM_PB"); gm_wave = rd("BEATAMD_GM_WAVE");
+    gr_pass_alloc = rd("BEATAMD_GR_PASS_ALLOC"); gr_var = rd("BEATAMD_GR_VAR"); sweep_v1 = rd("BEATAMD_SWEEP_V1"); qf_band = rd("BEATAMD_QF_BAND"); qf_fuse = rd("BEATAMD_QF_FUSE"); gf_split = rd("BEATAMD_GF_SPLIT"); gm_wave = rd("BEATAMD_GM_WAVE");
 }
 
 const GfKnobs &gf_knobs(beatamd_ctx *ctx)

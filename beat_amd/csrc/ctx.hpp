@@ -150,7 +150,7 @@ struct GfKnobs {
         ws_map = KNOB_UNSET, gs_pair = KNOB_UNSET, gs_nthint = KNOB_UNSET, gs_order = KNOB_UNSET, gs_fit = KNOB_UNSET,
         gs_win = KNOB_UNSET, gf_tinv = KNOB_UNSET, gs_tune = KNOB_UNSET, gf_order = KNOB_UNSET, gf_cgroup = KNOB_UNSET,
         gs_ml = KNOB_UNSET, gc_global = KNOB_UNSET, gc_sort = KNOB_UNSET, gc_keys = KNOB_UNSET, gc_bands = KNOB_UNSET, gr_cap = KNOB_UNSET,
-        gr_pass_alloc = KNOB_UNSET, gr_var = KNOB_UNSET, sweep_v1 = KNOB_UNSET, qf_band = KNOB_UNSET, qf_fuse = KNOB_UNSET, gf_split = KNOB_UNSET, gm_pb = KNOB_UNSET, gm_wave = KNOB_UNSET;
+        gr_pass_alloc = KNOB_UNSET, gr_var = KNOB_UNSET, sweep_v1 = KNOB_UNSET, qf_band = KNOB_UNSET, qf_fuse = KNOB_UNSET, gf_split = KNOB_UNSET, gm_wave = KNOB_UNSET;
     void read_env();
     static int get(int v, int dflt) { return v == KNOB_UNSET ? dflt : v; }
     static bool is(int v, int x) { return v != KNOB_UNSET && v == x; }       // set and equal to x

@@ -379,7 +379,6 @@ struct GmTabArgs {
     uint32_t *dtab;               // [(g*T+t)][consumer][step 0..smax][GR_DLINE] position descriptors (scalar loads)
     uint32_t *ucount;             // [gtp] row segments the loaders move for the patch, all passes (statistics)
     int64_t R;                    // patch split: slot t covers patches (t % R) * P + p of the real model (slips)
-    int pb;                       // consecutive patches of a (group, target) per workgroup (divides P)
     int64_t ngtp;                 // (group, target, patch) items
 };
 
@@ -491,7 +490,7 @@ __device__ int gm_count_passes(const uint32_t *bC, const uint32_t *bF, const uin
     return cur + 1;
 }
 
-// one workgroup per (group, target, block of a.pb patches); thread <-> chain slot of the group order.
+// one workgroup per (group, target, patch); thread <-> chain slot of the group order.
 // FILL = 0: the passes of the patch (npass, cpass);  FILL = 1: the tables of its steps
 template <int FILL>
 __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
@@ -514,14 +513,9 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
     __shared__ uint32_t rsum[2][GC_TB / 64];
     __shared__ int sh_npass, sh_n;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // a workgroup takes a.pb CONSECUTIVE patches of one (group, target), one after the other, the next patch's table
-    // entries in flight while a patch is worked on (round 6: one patch per workgroup = 14 000 workgroups of nine
-    // wavefronts for configs[3], each a chain of dependent round trips to memory with nothing to cover them; a chain's
-    // entries of 8 / 4 consecutive patches share a 128-byte line)
-    const int64_t npb = a.P / a.pb;
-    const int64_t blk = xcd_items8(blockIdx.x, gridDim.x);
-    const int64_t gt = blk / npb;
-    const int64_t p0 = (blk % npb) * a.pb;
+    const int64_t gtp = xcd_items8(blockIdx.x, gridDim.x);
+    const int64_t p = gtp % a.P;
+    const int64_t gt = gtp / a.P;
     const int64_t t = gt % a.T;
     const int64_t g = gt / a.T;
     if constexpr (FILL) {
@@ -531,50 +525,32 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
     const uint32_t cid = slot ? a.order[g * GC_CG + tid] : GC_DEAD;
     const bool live = cid != GC_DEAD;
     const int64_t c = live ? (int64_t)cid : 0;
-    const uint32_t S = (uint32_t)a.S;
-    bool have_passes = false;
-    if constexpr (FILL) have_passes = a.voff != nullptr;
-
-    // the patch in flight: row ids (ceil d, ceil s) / (floor d, ceil s), factors, pass of the chain slot, passes of the patch
-    uint32_t n_v0 = 0, n_v2 = 0, n_np = 1;
-    double n_fr[4] = {0, 0, 0, 0};
-    uint8_t n_cp = 0xff;
-    auto fetch = [&](int64_t p) {
-        if (live) {
-            const int64_t e = ((c * a.T + t) * a.P + p) * 4;
-            const uint4 rv = *reinterpret_cast<const uint4 *>(a.rowoff + e);     // (cc, fc, cf, ff: k_gf_tables)
-            n_v0 = rv.x; n_v2 = rv.z;
-            if constexpr (FILL) {
-                const double2 f01 = *reinterpret_cast<const double2 *>(a.fac + e), f23 = *reinterpret_cast<const double2 *>(a.fac + e + 2);
-                n_fr[0] = f01.x; n_fr[1] = f01.y; n_fr[2] = f23.x; n_fr[3] = f23.y;
-            }
-        }
-        if (FILL && have_passes) {
-            if (slot) n_cp = a.cpass[(gt * a.P + p) * GC_CG + tid];
-            if (tid == 0) n_np = a.npass[gt * a.P + p];
-        }
-    };
-    fetch(p0);
-    for (int u = 0; u < a.pb; u++) {
-    const int64_t p = p0 + u, gtp = gt * a.P + p;
     const int64_t row0 = (t * a.P + p) * a.DS;
+    const uint32_t S = (uint32_t)a.S;
+    // (blocks of several consecutive patches per workgroup with the next patch's entries prefetched were measured in round
+    // 6: 8 patches 0.58 ms against 0.42 for configs[3] -- the per-patch latency is the cost, not the launch; k_gm_tables_w
+    // below is the answer to it)
+
     uint32_t dc = 0, sc = 0, df = 0, sa = 0, sb = 0;
-    double fr[4] = {n_fr[0], n_fr[1], n_fr[2], n_fr[3]};
-    const uint8_t cp_in = n_cp;
-    const uint32_t np_in = n_np;
+    double fr[4] = {0, 0, 0, 0};
     if (live) {
-        const uint32_t v0 = n_v0 - (uint32_t)row0, v2 = n_v2 - (uint32_t)row0;
+        const int64_t e = ((c * a.T + t) * a.P + p) * 4;
+        const uint32_t v0 = a.rowoff[e] - (uint32_t)row0;        // (ceil d, ceil s)
+        const uint32_t v2 = a.rowoff[e + 2] - (uint32_t)row0;    // (floor d, ceil s)
         dc = v0 / S; sc = v0 % S; df = v2 / S;
         sb = dc * (uint32_t)S1 + sc;     // the floor node of ceil node sc is slot sc of the line (sc = 0: the wrap copy)
         sa = df * (uint32_t)S1 + sc;
+        if constexpr (FILL)
+            for (int k = 0; k < 4; k++) fr[k] = a.fac[e + k];
     }
-    if (u + 1 < a.pb) fetch(p + 1);
     const uint32_t key = live ? ((sb << 16) | sa) : 0xffffffffu;
     if (slot) keys[tid] = key;
 
+    bool have_passes = false;
+    if constexpr (FILL) have_passes = a.voff != nullptr;
     if (FILL && have_passes) {
-        if (slot) cps[tid] = cp_in;
-        if (tid == 0) sh_npass = (int)np_in;
+        if (slot) cps[tid] = a.cpass[gtp * GC_CG + tid];
+        if (tid == 0) sh_npass = (int)a.npass[gtp];
         __syncthreads();
     } else if (FILL) {
         if (slot) cps[tid] = live ? 0 : 0xff;
@@ -603,8 +579,7 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
         // (pass ids are bytes: a patch cut into more than 250 passes -- buffers of a few slots in tests -- counts as an
         // overflow of the tables: the streaming kernel stands in)
         if (tid == 0) a.npass[gtp] = sh_npass > 250 ? 0x100000u : (uint32_t)sh_npass;
-        __syncthreads();
-        continue;
+        return;
     }
     if constexpr (FILL) {
     // ---------------- fill phase
@@ -740,7 +715,6 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
         h[1] = 0;
     }
     }   // FILL
-    }   // patches of the workgroup
 }
 
 // ---------------------------------------------------------------------------- tables, one WAVEFRONT per patch (round 6)
@@ -748,7 +722,7 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
 // the 518 chain slots nine per lane, with its own piece of LDS and no workgroup barrier anywhere.  k_gm_tables is a chain of
 // ~10 barriers and ~5 dependent round trips to memory per patch on nine wavefronts that mostly wait for each other: with
 // two such workgroups per CU the 14 000 patches of configs[3] (35 station slots x 400 patches) took 0.43 ms -- a quarter of
-// the step at 120 samples per trace, whatever the block of patches per workgroup (a.pb: 8 patches per workgroup were SLOWER,
+// the step at 120 samples per trace, whatever the block of patches per workgroup (8 consecutive patches per workgroup, prefetched, were SLOWER:
 // 0.58 ms: it is the per-patch latency, not the launch).  Here a CU holds 16 patches in flight and a wavefront never waits
 // for another.  Libraries up to GW_DENSE_MAX dense slots per patch (one bitset word per lane); beyond that k_gm_tables.
 constexpr int GW_NW = 8;                       // wavefronts (= patches) per workgroup
@@ -1185,14 +1159,6 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
     for (int v = 0; v < k.nvar; v++) ta.slips[v] = k.slips[v];
     ta.R = k.patch_split;
     ta.ngtp = GTP;
-    {
-        // patches per workgroup of the table kernels: the largest divisor of P up to 8 (BEATAMD_GM_PB: A/B), one when that
-        // would leave fewer workgroups than two per CU
-        const int want = std::max(1, std::min(8, GfKnobs::get(kn.gm_pb, 1)));
-        ta.pb = 1;
-        for (int d = want; d > 1; d--)
-            if (L.P % d == 0 && GTP / d >= 2 * (int64_t)ctx->num_cu) { ta.pb = d; break; }
-    }
     ta.order = oa.order;
     BA_TRY(ctx->get_scratch(SL_GC_STREAM, (size_t)GT * GC_NCONS * (smax + 1) * GR_WSTRIDE + 8192, &p));
     ta.wtab = (char *)p;
@@ -1212,9 +1178,14 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
         ScopedTimer tm(ctx, "grouptables");
         const int W = (int)((L.S + 1 + 31) / 32);
         const size_t lds = (size_t)3 * L.D * W * 4 + 2 * (size_t)((dense + 3) & ~(int64_t)3) + 2 * (size_t)((L.D + 3) & ~(int64_t)3) + 64;
-        // one wavefront per patch (k_gm_tables_w) where a patch's dense slots fit one bitset word per lane; BEATAMD_GM_WAVE=0:
-        // the workgroup-per-patch kernels (A/B, tests)
-        const bool per_wave = dense <= GW_DENSE_MAX && cap <= 128 && L.D <= 255 && GfKnobs::get(kn.gm_wave, 1) != 0;
+        // one wavefront per patch (k_gm_tables_w) where a patch's dense slots fit one bitset word per lane (BEATAMD_GM_WAVE=0:
+        // the workgroup-per-patch kernels: A/B, tests)
+        // -- and where there are enough patches to fill the machine with wavefronts (a patch is nine serial rounds
+        // there; 400 patches without station shifts: 45 against 30 us, the tutorial grid 112 against 76 us); BEATAMD_GM_WAVE=1
+        // forces it
+        const int wave_knob = GfKnobs::get(kn.gm_wave, -1);
+        const bool per_wave = dense <= GW_DENSE_MAX && cap <= 128 && L.D <= 255 &&
+                              (wave_knob == 1 || (wave_knob != 0 && GTP >= 16 * (int64_t)ctx->num_cu));
         const int ws0 = (int)gw_wave_bytes(0, L.D, L.S), ws1 = (int)gw_wave_bytes(1, L.D, L.S);
         const unsigned wgrid = (unsigned)((GTP + GW_NW - 1) / GW_NW);
         if (per_wave) {
@@ -1225,13 +1196,13 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
         if (passes) {
             BA_HIP(hipMemsetAsync(ovf, 0, sizeof(int), ctx->stream));
             if (per_wave) hipLaunchKernelGGL(k_gm_tables_w<0>, dim3(wgrid), dim3(64 * GW_NW), (size_t)ws0 * GW_NW, ctx->stream, ta, ws0);
-            else hipLaunchKernelGGL(k_gm_tables<0>, dim3((unsigned)(GTP / ta.pb)), dim3(GC_TB), lds, ctx->stream, ta);
+            else hipLaunchKernelGGL(k_gm_tables<0>, dim3((unsigned)GTP), dim3(GC_TB), lds, ctx->stream, ta);
             hipLaunchKernelGGL(k_gm_scan, dim3((unsigned)GT), dim3(256), 0, ctx->stream, ta.npass, voff, nv, L.P, vmax, ovf);
             ta.voff = voff;
             ta.ovf = ovf;
         }
         if (per_wave) hipLaunchKernelGGL(k_gm_tables_w<1>, dim3(wgrid), dim3(64 * GW_NW), (size_t)ws1 * GW_NW, ctx->stream, ta, ws1);
-        else hipLaunchKernelGGL(k_gm_tables<1>, dim3((unsigned)(GTP / ta.pb)), dim3(GC_TB), lds, ctx->stream, ta);
+        else hipLaunchKernelGGL(k_gm_tables<1>, dim3((unsigned)GTP), dim3(GC_TB), lds, ctx->stream, ta);
     }
     BA_HIP(hipGetLastError());
 

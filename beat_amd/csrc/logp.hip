@@ -101,15 +101,36 @@ __global__ void __launch_bounds__(256) k_geo_stack(GeoStackArgs a)
     for (int v = 0; v < a.nvar; v++) {
         const double *G = a.G[v] + k;
         const double *sl = s_slip + v * P * CH;
+        // two groups of sixteen loads of G in flight per lane: the next group is requested before the group in hand is
+        // used (a block is two wavefronts; the loop is a row of round trips to L2, nothing else covers them)
         int64_t p = 0;
-        for (; p + 16 <= P; p += 16) {
-            double g[16];
+        double ga[16], gb[16];
+        const int64_t nfull = P / 16;
+        if (nfull > 0) {
 #pragma unroll
-            for (int u = 0; u < 16; u++) g[u] = G[(p + u) * Nobs];
+            for (int u = 0; u < 16; u++) ga[u] = G[u * Nobs];
+        }
+        for (int64_t ch = 0; ch < nfull; ch += 2) {
+            if (ch + 1 < nfull) {
+#pragma unroll
+                for (int u = 0; u < 16; u++) gb[u] = G[(p + 16 + u) * Nobs];
+            }
 #pragma unroll
             for (int u = 0; u < 16; u++)
 #pragma unroll
-                for (int j = 0; j < CH; j++) acc[j] = fma(g[u], sl[(p + u) * CH + j], acc[j]);
+                for (int j = 0; j < CH; j++) acc[j] = fma(ga[u], sl[(p + u) * CH + j], acc[j]);
+            p += 16;
+            if (ch + 1 < nfull) {
+                if (ch + 2 < nfull) {
+#pragma unroll
+                    for (int u = 0; u < 16; u++) ga[u] = G[(p + 16 + u) * Nobs];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; u++)
+#pragma unroll
+                    for (int j = 0; j < CH; j++) acc[j] = fma(gb[u], sl[(p + u) * CH + j], acc[j]);
+                p += 16;
+            }
         }
         for (; p < P; p++) {
             const double g = G[p * Nobs];

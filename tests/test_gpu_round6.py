@@ -30,6 +30,7 @@ def test_tables_by_wavefront_equal_tables_by_workgroup(ctx, monkeypatch, D, S, c
         monkeypatch.setenv("BEATAMD_GR_CAP", cap)
         monkeypatch.setenv("BEATAMD_GR_PASS_ALLOC", "40")
     monkeypatch.setenv("BEATAMD_GF_SPLIT", "0")                   # (the library as it is: one walk per target and tile)
+    monkeypatch.setenv("BEATAMD_GM_WAVE", "1")                    # (by default only from 16 patches per CU on)
     A = f.batch(Q)
     assert ctx.last_kernel().startswith("k_gfstack_runs<"), (ctx.last_kernel(), ctx.gf_plan())
     plan_w = ctx.gf_plan()

@@ -161,12 +161,15 @@ profile6)
     c4 4096
     ;;
   d)
-    mkdir -p $O/default
-    timeout 900 rocprofv3 --kernel-trace --stats -d $O/default/stats -o bench -- python $R/bench.py --no-cpu-baseline > $O/default/stats_run.log 2>&1
-    $S $O/default $O/out ${tag}_bench_default "k_quadform<128>" k_gfstack_runs "k_gemm_f64<0>" k_gfstack_ws > $O/sum_default.log 2>&1
+    # the line first (the artefact), then the kernel statistics of the command with 10 steps, one timed region and without the sampler / sharded
+    # legs (the full command under rocprofv3 did not end within 15 minutes and the profiler then waits for its child beyond
+    # any timeout -- this part was lost twice)
     cd $R
-    timeout 1200 python bench.py --full-json $O/out/${tag}_bench_default_full.json > $O/out/${tag}_bench_default.json 2> $O/bench_default.err || tail -5 $O/bench_default.err
+    timeout -k 10 1000 python bench.py --full-json $O/out/${tag}_bench_default_full.json > $O/out/${tag}_bench_default.json 2> $O/bench_default.err || tail -5 $O/bench_default.err
     tail -c 600 $O/out/${tag}_bench_default.json
+    mkdir -p $O/default; cd /tmp
+    timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $O/default/stats -o bench -- python $R/bench.py --no-cpu-baseline --steps 10 --repeats 1 --variant-legs multilinear,toeplitz,default_config,prewhitened,geometry,fp32,config4,realistic_grid --full-json /tmp/bench_full_prof.json > $O/default/stats_run.log 2>&1
+    $S $O/default $O/out ${tag}_bench_default "k_quadform<128>" k_gfstack_runs "k_gemm_f64<0>" k_gfstack_ws > $O/sum_default.log 2>&1
     ;;
   esac
   grep -h "^{\"metric" $O/*/stats_run.log > $O/out/${tag}_bench_lines_under_profiler_$part.jsonl 2>/dev/null
