@@ -772,17 +772,40 @@ __global__ void __launch_bounds__(64 * GW_NW) k_gm_tables_w(GmTabArgs a, int wst
     const uint32_t S1u = (uint32_t)S1;
     const bool have_passes = FILL && a.voff != nullptr;
 
-    for (int i = lane; i < GC_CG; i += 64) {
-        const uint32_t cid = a.order[g * GC_CG + i];
+    // the lane's nine chain slots: the chain ids first, then every slot's table entry -- independent loads, one round trip
+    // each (round 6: as a loop of dependent loads this was 9 x 2 round trips per wavefront)
+    constexpr int NIT = (GC_CG + 63) / 64;
+    uint32_t cids[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+        const int i = lane + 64 * k;
+        cids[k] = i < GC_CG ? a.order[g * GC_CG + i] : GC_DEAD;
+    }
+    uint4 rvs[NIT];
+    uint32_t cps_in[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+        const int i = lane + 64 * k;
+        rvs[k] = make_uint4(0, 0, 0, 0);
+        cps_in[k] = 0;
+        if (cids[k] != GC_DEAD) {
+            const int64_t e = (((int64_t)cids[k] * a.T + t) * a.P + p) * 4;
+            rvs[k] = *reinterpret_cast<const uint4 *>(a.rowoff + e);     // (cc, fc, cf, ff: k_gf_tables)
+            if constexpr (FILL)
+                if (have_passes) cps_in[k] = a.cpass[gtp * GC_CG + i];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+        const int i = lane + 64 * k;
+        if (i >= GC_CG) continue;
         uint32_t w = 0xffu << 22 | GW_PAD;
-        if (cid != GC_DEAD) {
-            const int64_t e = (((int64_t)cid * a.T + t) * a.P + p) * 4;
-            const uint4 rv = *reinterpret_cast<const uint4 *>(a.rowoff + e);     // (cc, fc, cf, ff: k_gf_tables)
-            const uint32_t v0 = rv.x - (uint32_t)row0, v2 = rv.z - (uint32_t)row0;
+        if (cids[k] != GC_DEAD) {
+            const uint32_t v0 = rvs[k].x - (uint32_t)row0, v2 = rvs[k].z - (uint32_t)row0;
             const uint32_t dc = v0 / S, sc = v0 % S, df = v2 / S;
             // the floor node of ceil node sc is slot sc of the line (sc = 0: the wrap copy): B = dc (S+1) + sc, A = df (S+1) + sc
             w = ((dc * S1u + sc) << 11) | (df * S1u + sc);
-            if constexpr (FILL) w |= (have_passes ? (uint32_t)a.cpass[gtp * GC_CG + i] : 0u) << 22;
+            if constexpr (FILL) w |= cps_in[k] << 22;
         }
         kc[i] = w;
     }

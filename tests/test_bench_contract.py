@@ -3,6 +3,8 @@ cpu_baseline leg (oracle timed on a bounded sample)."""
 import os
 import sys
 
+import pytest
+
 from conftest import ROOT
 
 sys.path.insert(0, ROOT)
@@ -81,3 +83,25 @@ def test_bench_line_stays_below_the_cap_whatever_the_legs():
     out = _stub_result()
     out["multilinear_leg"]["chain_steps_per_s"] = float("nan")
     json.loads(bench.compact_line(out), parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
+
+
+def test_committed_round6_line_is_what_the_driver_needs():
+    """the line of the round's own `python bench.py` run on the GPU box (profiles/r6_bench_default.json): strict JSON below
+    the driver's 8 KB tail, counter-based roofline of the headline kernel, cpu_baseline, the short-trace legs with counter
+    fractions"""
+    import json
+    path = os.path.join(ROOT, "profiles", "r6_bench_default.json")
+    if not os.path.exists(path):
+        pytest.skip("no committed round-6 line")
+    txt = open(path).read().strip().splitlines()[-1]
+    assert len(txt.encode()) < 8192
+    d = json.loads(txt, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
+    assert d["metric"].startswith("SMC chain-steps/s") and d["unit"] == "chain-steps/s" and d["n_gpus"] == 1
+    assert abs(d["value"] - 512 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["kernel"].startswith("k_gfstack_ws<") and r["traffic"] and 0.5 < r["frac"] < 1.0
+    assert abs(r["frac"] - r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9 / r["peak"]) < 1e-3
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    legs = d["legs"]
+    for name in ("config4.N120.multilinear_512_chains", "config4.N120.nn_512_chains"):
+        assert legs[name].get("pmc") == 1 and legs[name]["frac"] > 0.3, (name, legs[name])
