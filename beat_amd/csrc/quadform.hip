@@ -543,20 +543,23 @@ __global__ void __launch_bounds__(256) k_quadform_banded(QbArgs a)
 //     y_i  = fma(W[i,i+1], r_{i+1}, fma(W[i,i], r_i, 0));  yb_k = y of the tile's last sample (its neighbour = next tile)
 // and a chain's misfit has the same bits whichever kernel stacked it (batch size, rank count, fused or not).  This kernel is
 // the path of everything without the epilogue (the runs / small-group / streaming kernels, beatamd_mvn_chol_logp_batch):
-// workgroup = (dataset, 8 chains); the operator's band rows of a chunk of 64 tiles sit in LDS for all 8 chains, two chains'
-// residual rows at a time beside them (pitch 65: thread <-> (chain, tile) reads its 64 samples conflict-free), one thread
-// per chain adds the tiles up.
-constexpr int QB1_NC = 8, QB1_CT = 64;                 // chains per workgroup, tiles per chunk (at most)
+// workgroup = (dataset, 16 chains) of 128 threads; the operator's band rows of a chunk of 8 tiles sit in LDS beside the 16
+// chains' residual rows of the chunk (pitch 65: thread <-> (chain, tile) reads its 64 samples conflict-free; every thread
+// has a tile; 76 KB: two workgroups per CU), one thread per chain adds the tiles up.  The rows come in as one index space
+// of 16-byte loads, eight in flight per thread.  (The first version -- chunks of 64 tiles, two chains at a time, each a
+// handful of loads and a wait -- took 1.6 ms for 512 chains x 64 traces of 4096 samples, six times the kernel it replaced:
+// 0.47 ms now; the order of the sums is what it was.)
+constexpr int QB1_NC = 16, QB1_CT = 8, QB1_NT = 128;   // chains per workgroup, tiles per chunk (at most), threads
 constexpr int QB1_WP = 130, QB1_XP = 65;               // pitches (doubles) of a tile's band rows / residuals in LDS
-// ct tiles per chunk (min(64, tiles of a row)), npc chains per pass (2 .. 8: short rows take all eight chains at once --
-// M = 120 is two tiles --, thread <-> (chain, tile) of the pass)
+// ct tiles per chunk (min(8, tiles of a row)), npc chains per pass (128 / ct, at most all sixteen; thread <-> (chain, tile)
+// of the pass)
 static size_t qb1_lds(int ct, int npc)
 {
     return ((size_t)ct * QB1_WP + (size_t)npc * ((size_t)ct * QB1_XP + 1) + 2 * (size_t)npc * ct + QB1_NC) * sizeof(double)
            + (size_t)npc * ct * sizeof(int);
 }
 
-__global__ void __launch_bounds__(256) k_quadform_band1(QbArgs a, int ct, int npc)
+__global__ void __launch_bounds__(QB1_NT) k_quadform_band1(QbArgs a, int ct, int npc)
 {
     extern __shared__ __attribute__((aligned(16))) double sm1[];
     const int xstride = ct * QB1_XP + 1;
@@ -566,7 +569,7 @@ __global__ void __launch_bounds__(256) k_quadform_band1(QbArgs a, int ct, int np
     double *ybv = part + npc * ct;                      // [npc][ct]
     double *sacc = ybv + npc * ct;                      // [QB1_NC]
     int *hasb = reinterpret_cast<int *>(sacc + QB1_NC); // [npc][ct]
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, NT = blockDim.x;
     const int64_t d = blockIdx.y, c0 = (int64_t)blockIdx.x * QB1_NC;
     const int nc = (int)min((int64_t)QB1_NC, a.C - c0);
     const int64_t M = a.M, CH = (int64_t)ct * 64;
@@ -575,14 +578,56 @@ __global__ void __launch_bounds__(256) k_quadform_band1(QbArgs a, int ct, int np
     for (int64_t i0 = 0; i0 < M; i0 += CH) {
         const int64_t nch = min(CH, M - i0);            // samples of the chunk
         __syncthreads();                                // (the chunk before is done with wl)
-        for (int64_t g = tid; g < 2 * nch; g += 256) wl[(g >> 7) * QB1_WP + (g & 127)] = wb[2 * i0 + g];
+        for (int64_t g = tid; g < 2 * nch; g += NT) wl[(g >> 7) * QB1_WP + (g & 127)] = wb[2 * i0 + g];
         for (int j0 = 0; j0 < nc; j0 += npc) {
             __syncthreads();                            // (the pass before is done with xl / part / ybv)
-            for (int jj = 0; jj < npc && j0 + jj < nc; jj++) {
-                const double *x = a.X + (c0 + j0 + jj) * a.xs_c + d * a.xs_d + i0;
-                double *xr = xl + jj * xstride;
-                // (+ the first residual of the next chunk: the neighbour of this chunk's last sample)
-                for (int64_t g = tid; g < nch + (i0 + nch < M ? 1 : 0); g += 256) xr[(g >> 6) * QB1_XP + (g & 63)] = x[g];
+            {
+                // the residuals of the pass's chains (+ the first residual of the next chunk: the neighbour of this chunk's
+                // last sample) as ONE index space, eight independent loads per thread in flight (chain after chain, each
+                // a handful of loads and a wait, was 16 round trips per chunk: most of the kernel's time)
+                const int nchn = min(npc, nc - j0);
+                const double *xb = a.X + (c0 + j0) * a.xs_c + d * a.xs_d + i0;
+                const bool vec = (nch % 2 == 0) && (a.xs_c % 2 == 0) && (((uintptr_t)xb) % 16 == 0);
+                if (vec) {
+                    const int per2 = (int)(nch / 2), tot2 = nchn * per2;
+                    for (int e0 = 0; e0 < tot2; e0 += NT * 8) {
+                        double2 v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            const int e = e0 + u * NT + tid;
+                            const int jj = e / per2, g = 2 * (e - jj * per2);
+                            v[u] = e < tot2 ? *reinterpret_cast<const double2 *>(xb + (int64_t)jj * a.xs_c + g) : make_double2(0.0, 0.0);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            const int e = e0 + u * NT + tid;
+                            const int jj = e / per2, g = 2 * (e - jj * per2);
+                            if (e < tot2) {
+                                double *xr = xl + jj * xstride + (g >> 6) * QB1_XP + (g & 63);
+                                xr[0] = v[u].x; xr[1] = v[u].y;
+                            }
+                        }
+                    }
+                    if (i0 + nch < M && tid < nchn) xl[tid * xstride + (int)(nch >> 6) * QB1_XP + (int)(nch & 63)] = xb[(int64_t)tid * a.xs_c + nch];
+                } else {
+                    const int per = (int)nch + (i0 + nch < M ? 1 : 0);
+                    const int tot = nchn * per;
+                    for (int e0 = 0; e0 < tot; e0 += NT * 8) {
+                        double v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            const int e = e0 + u * NT + tid;
+                            const int jj = e / per, g = e - jj * per;
+                            v[u] = e < tot ? xb[(int64_t)jj * a.xs_c + g] : 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            const int e = e0 + u * NT + tid;
+                            const int jj = e / per, g = e - jj * per;
+                            if (e < tot) xl[jj * xstride + (g >> 6) * QB1_XP + (g & 63)] = v[u];
+                        }
+                    }
+                }
             }
             __syncthreads();
             if (tid < npc * ct) {
@@ -594,12 +639,23 @@ __global__ void __launch_bounds__(256) k_quadform_band1(QbArgs a, int ct, int np
                     const double *w = wl + k * QB1_WP;
                     const bool trace_end = n0 + nvalid == M;
                     double q = 0.0, ri = x[0];
-                    for (int i = 0; i + 1 < nvalid; i++) {
-                        const double rn = x[i + 1];
-                        double y = fma(w[2 * i], ri, 0.0);
-                        y = fma(w[2 * i + 1], rn, y);
-                        q = fma(y, y, q);
-                        ri = rn;
+                    if (nvalid == 64) {
+#pragma unroll 9
+                        for (int i = 0; i < 63; i++) {     // (a whole tile: the trip count is known, the LDS reads run ahead)
+                            const double rn = x[i + 1];
+                            double y = fma(w[2 * i], ri, 0.0);
+                            y = fma(w[2 * i + 1], rn, y);
+                            q = fma(y, y, q);
+                            ri = rn;
+                        }
+                    } else {
+                        for (int i = 0; i + 1 < nvalid; i++) {
+                            const double rn = x[i + 1];
+                            double y = fma(w[2 * i], ri, 0.0);
+                            y = fma(w[2 * i + 1], rn, y);
+                            q = fma(y, y, q);
+                            ri = rn;
+                        }
                     }
                     double yb = 0.0;
                     if (trace_end) {
@@ -641,10 +697,10 @@ int launch_quadform_banded(beatamd_ctx *ctx, const double *wb, int64_t band, int
         BA_CHECK(nd <= 65535, BEATAMD_EINVAL, "quadform_banded: too many datasets");
         ScopedTimer tm(ctx, "quadform");
         const int ct = (int)std::min<int64_t>(QB1_CT, (M + 63) / 64);
-        const int npc = std::max(2, std::min(QB1_NC, 128 / ct));
+        const int npc = std::max(2, std::min(QB1_NC, QB1_NT / ct));
         const size_t lds = qb1_lds(ct, npc);
-        BA_HIP(hipFuncSetAttribute((const void *)k_quadform_band1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qb1_lds(QB1_CT, 2)));
-        hipLaunchKernelGGL(k_quadform_band1, dim3((unsigned)((C + QB1_NC - 1) / QB1_NC), (unsigned)nd), dim3(256), lds,
+        BA_HIP(hipFuncSetAttribute((const void *)k_quadform_band1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qb1_lds(QB1_CT, QB1_NC)));
+        hipLaunchKernelGGL(k_quadform_band1, dim3((unsigned)((C + QB1_NC - 1) / QB1_NC), (unsigned)nd), dim3(QB1_NT), lds,
                            ctx->stream, b, ct, npc);
         BA_HIP(hipGetLastError());
         return BEATAMD_OK;
