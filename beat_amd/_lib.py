@@ -18,7 +18,7 @@ W_SCALAR, W_DENSE = 0, 1
 INTERPOLATIONS = {"nearest_neighbor": NEAREST_NEIGHBOR, "multilinear": MULTILINEAR}
 
 OK, EINVAL, EHIP, EINDEX, ENOMEM, ENAN, ENOTPSD, EBADCOV = 0, -1, -2, -3, -4, -5, -6, -7
-ABI_VERSION = 119   # include/beat_amd.h BEATAMD_VERSION this module was written against
+ABI_VERSION = 120   # include/beat_amd.h BEATAMD_VERSION this module was written against
 
 
 class BeatAmdError(RuntimeError):
@@ -96,6 +96,7 @@ _PROTOS = {
     "beatamd_ctx_gf_group_stats": [_vp, _pi64, C.POINTER(_f64), _pi64, _pi64],
     "beatamd_ctx_gf_plan": [_vp, C.c_char_p, _i64, C.POINTER(_f64), _pi64],
     "beatamd_ctx_gf_tune_log": [_vp, C.c_char_p, _i64],
+    "beatamd_gf_patch_ranges": [_i64, _i64, _i64, C.c_int32],
     "beatamd_ctx_reload_knobs": [_vp],
     "beatamd_ctx_gf_chain_groups": [_vp, _i64, _vp, _vp, _i64, _vp],
     "beatamd_smc_calc_beta": [_vp, _i64, _vp, _i64, _f64, _f64, C.POINTER(_f64), _vp],

@@ -1251,6 +1251,12 @@ int beatamd_ctx_gf_tune_log(beatamd_ctx *ctx, char *buf, int64_t buflen)
     return BEATAMD_OK;
 }
 
+int32_t beatamd_gf_patch_ranges(int64_t ntargets, int64_t npatches, int64_t nsamples, int32_t num_cu)
+{
+    if (ntargets <= 0 || npatches <= 0 || nsamples <= 0) return 1;
+    return (int32_t)gf_patch_ranges(ntargets, npatches, nsamples, num_cu > 0 ? num_cu : 256);
+}
+
 int beatamd_ctx_gf_chain_groups(beatamd_ctx *ctx, int64_t C, const double *key0, const double *key1,
                                 int64_t chains_per_group, uint32_t *members)
 {

@@ -413,23 +413,28 @@ static int launch_gfstack_impl(beatamd_ctx *ctx, const GfStackCall &call);
 //   ceil(walks * R / CUs) * (P / R + 5)
 // -- the stacking kernels keep one workgroup per CU, a walk costs its steps plus ~5 steps of prologue / epilogue (measured on
 // configs[3] with 120 samples, 70 walks x 400 patches: R = 4: 1.00, 5: 0.80, 8: 0.82, 10: 0.69, 16: 0.76, 25: 0.72 ms).
+int gf_patch_ranges(int64_t T, int64_t P, int64_t N, int num_cu)
+{
+    if (N > 256 || P < 64) return 1;
+    const int64_t walks = T * ((N + 63) / 64);
+    const int64_t ncu = std::max(1, num_cu);
+    if (walks >= 2 * ncu) return 1;
+    int best = 1;
+    int64_t best_cost = ((walks + ncu - 1) / ncu) * (P + 5);
+    for (int d = 2; d <= 32 && P / d >= 32; d++) {
+        if (P % d) continue;
+        const int64_t cost = ((walks * d + ncu - 1) / ncu) * (P / d + 5);
+        if (cost < best_cost) { best = d; best_cost = cost; }
+    }
+    return best;
+}
+
 static int gf_patch_split(const SeisLib &L, const GfKnobs &kn, int num_cu)
 {
     const int knob = GfKnobs::get(kn.gf_split, -1);
     if (knob == 0 || knob == 1) return 1;
     if (knob > 1) return (L.P % knob == 0) ? knob : 1;
-    if (L.N > 256 || L.P < 64) return 1;
-    const int64_t walks = L.T * ((L.N + 63) / 64);
-    const int64_t ncu = std::max(1, num_cu);
-    if (walks >= 2 * ncu) return 1;
-    int best = 1;
-    int64_t best_cost = ((walks + ncu - 1) / ncu) * (L.P + 5);
-    for (int d = 2; d <= 32 && L.P / d >= 32; d++) {
-        if (L.P % d) continue;
-        const int64_t cost = ((walks * d + ncu - 1) / ncu) * (L.P / d + 5);
-        if (cost < best_cost) { best = d; best_cost = cost; }
-    }
-    return best;
+    return gf_patch_ranges(L.T, L.P, L.N, num_cu);
 }
 
 __global__ void __launch_bounds__(256) k_split_tslot(int64_t Tv, int R, const int32_t *tslot, int32_t *out)

@@ -51,6 +51,9 @@ __device__ __forceinline__ int64_t xcd_items8(int64_t b, int64_t n)
 }
 #endif
 
+// patch ranges a short-trace library is stacked in (gfstack.hip; 1: as it is)
+int gf_patch_ranges(int64_t T, int64_t P, int64_t N, int num_cu);
+
 enum GfMode : int {
     GF_STORE_SYN = 0,     // out[c,t,n] = synthetics                      (stack_all)
     GF_RESID_SCALAR = 1,  // partial[c,t,tile] = sum (w_t (d - syn))^2     (fused logp, W = w I)

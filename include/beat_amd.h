@@ -42,7 +42,7 @@ extern "C" {
 /* ABI revision: bumped whenever an entry point changes its signature or an error code is added
  * (1.1: beatamd_weights_update gained kind/count in round 2; BEATAMD_EBADCOV).  beat_amd/_lib.py
  * refuses a library whose revision differs from the header it was written against. */
-#define BEATAMD_VERSION 119
+#define BEATAMD_VERSION 120
 
 #define BEATAMD_NEAREST_NEIGHBOR 0 /* interpolation="nearest_neighbor" */
 #define BEATAMD_MULTILINEAR 1      /* interpolation="multilinear"      */
@@ -103,6 +103,13 @@ int beatamd_ctx_gf_plan(beatamd_ctx *ctx, char *buf, int64_t buflen, double *mea
  * 512"), empty before the first one.  BEATAMD_VERBOSE=1 prints the same line to stderr when it happens.  No reference
  * counterpart (the reference has no batch; beat/ffi/base.py:607-709 stacks one chain). */
 int beatamd_ctx_gf_tune_log(beatamd_ctx *ctx, char *buf, int64_t buflen);
+/* Libraries of short traces (nsamples <= 256: the usual 60 s at 2 Hz of an FFI set-up) are stacked in R patch
+ * RANGES -- the same memory viewed as [T*R, P/R, D, S, N], the ranges' partial synthetics summed in range order -- so that
+ * T * ceil(N/64) walks of P serial steps become R times as many, R times shorter ones for the device's compute units.
+ * This is the rule (a pure function; num_cu <= 0: 256): R = the divisor of P with >= 32 patches per range that minimises
+ * ceil(walks * R / num_cu) * (P / R + 5); 1 = the library as it is.  What a call did is in beatamd_ctx_gf_plan.  No reference
+ * counterpart (beat/ffi/base.py:607-709 stacks one chain on one core). */
+int32_t beatamd_gf_patch_ranges(int64_t ntargets, int64_t npatches, int64_t nsamples, int32_t num_cu);
 
 /* how a batch of C chains is cut into its chain groups (scheduling only; results never depend on it): recursive
  * bisection of the batch along the key in which a part's chains spread wider -- the fused model path hands the hypocentre

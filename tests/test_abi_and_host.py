@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     # and the python prototype table covers the header
     assert set(declared) == set(_lib.EXPORTS)
     from beat_amd._lib import ABI_VERSION
-    assert lib.beatamd_version() == ABI_VERSION == 119
+    assert lib.beatamd_version() == ABI_VERSION == 120
 
 
 def test_header_cites_reference_interfaces():
@@ -212,3 +212,25 @@ def test_isa_audit_of_hidden_asm_loads(tmp_path):
     if shutil.which("hipcc") is None:
         pytest.skip("hipcc not available")
     assert aud.main() == 0
+
+
+def test_patch_ranges_of_short_trace_libraries():
+    """beatamd_gf_patch_ranges (round 6): how many patch ranges a library of short traces is stacked in -- a
+    pure function of the library's shape and the device's CU count, no GPU needed.  BASELINE configs[3] at 120 samples: 70
+    walks x 400 patches -> 10 ranges (700 walks = 3 rounds of 45 steps on 256 CUs; 8 ranges would be 3 rounds of 55)"""
+    from beat_amd import _lib
+    lib = _lib.load()
+    R = lib.beatamd_gf_patch_ranges
+    assert R(35, 400, 120, 256) == 10
+    assert R(35, 400, 4096, 256) == 1            # long traces: 35 x 64 tiles are walks enough
+    assert R(3, 128, 120, 256) == 4 and R(4, 96, 100, 256) == 3    # (tests/test_gpu_split.py: at least 32 patches per range)
+    assert R(600, 400, 120, 256) == 1            # already two walks per CU and more
+    assert R(35, 50, 120, 256) == 1              # too few patches to cut
+    assert R(35, 400, 120, 0) == R(35, 400, 120, 256)
+    # the rule's own cost model: no divisor with >= 32 patches per range is cheaper than the choice
+    for T, P, N, cu in ((35, 400, 120, 256), (64, 400, 120, 256), (20, 360, 200, 256), (35, 400, 120, 304), (7, 1024, 64, 256)):
+        best = R(T, P, N, cu)
+        walks = T * ((N + 63) // 64)
+        cost = lambda d: -(-walks * d // cu) * (P // d + 5)
+        cands = [d for d in range(1, 33) if P % d == 0 and (d == 1 or P // d >= 32)]
+        assert best in cands and all(cost(best) <= cost(d) for d in cands), (T, P, N, cu, best)
