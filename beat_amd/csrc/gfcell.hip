@@ -1032,6 +1032,8 @@ struct GcArgs {
     const double *data, *wscalar;
     double *out, *partial;
     const uint32_t *dtab;         // position descriptors, [(g*T+t)][consumer][step 0..smax][GR_DLINE]
+    const double *band_w;         // mode 3: [T,N,2] rows (W[i,i], W[i,i+1]) of the bidiagonal whitening operators
+    double *edges;                // mode 3: [C*T, ntile, 2] first / last residual of every tile
 };
 
 // VAR > 0: timing experiments of tools/gen_gfruns_asm.py (GR_ABLATIONS builds only; wrong results)
@@ -1072,12 +1074,21 @@ __global__ void __launch_bounds__(1024) k_gfstack_runs(GcArgs a)
             put64(GC_P_DP, (uint64_t)(uintptr_t)(a.dtab + ((gt * GC_NCONS + wave) * (a.smax + 1)) * (int64_t)GR_DLINE));
             pb[GC_P_RB0] = rb0;
             pb[GC_P_NSTEP] = nsteps;
-            put64(GC_P_OUT, (uint64_t)(uintptr_t)(a.out + t * a.N + n0));
-            pb[GC_P_CTN] = (uint32_t)(a.T * a.N * 8);
             pb[GC_P_MODE] = (uint32_t)a.mode;
             put64(GC_P_DATA, (uint64_t)(uintptr_t)(a.data + t * a.N + n0));
-            const double wt = a.wscalar ? a.wscalar[t] : 0.0;
-            put64(GC_P_W, (uint64_t)__double_as_longlong(wt));
+            if (a.mode == GF_RESID_BAND1) {
+                // (the bidiagonal misfit stores no residual: the words of out / w / ctn carry the tile's edge pair, the band
+                // rows of its first sample and "the tile ends the trace")
+                put64(GC_P_OUT, (uint64_t)(uintptr_t)(a.edges + (t * a.ntile + tile) * 2));
+                pb[GC_P_CTN] = (n0 + 64 >= a.N) ? 1u : 0u;
+                put64(GC_P_W, (uint64_t)(uintptr_t)(a.band_w + (t * a.N + n0) * 2));
+            } else {
+                put64(GC_P_OUT, (uint64_t)(uintptr_t)(a.out + t * a.N + n0));
+                pb[GC_P_CTN] = (uint32_t)(a.T * a.N * 8);
+                const double wt = a.wscalar ? a.wscalar[t] : 0.0;
+                put64(GC_P_W, (uint64_t)__double_as_longlong(wt));
+            }
+            pb[GC_P_WLDS] = rb0 + (uint32_t)(GC_NCONS * 16 * GC_TPITCH + wave * 1024);
             put64(GC_P_CID, (uint64_t)(uintptr_t)(a.order + g * GC_CG + wave * GC_NCHAIN));
             put64(GC_P_PART, (uint64_t)(uintptr_t)(a.partial + t * a.ntile + tile));
             pb[GC_P_PCS] = (uint32_t)(a.T * a.ntile * 8);
@@ -1243,9 +1254,15 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
     a.ovf = passes ? ovf : nullptr;
     a.wtab = ta.wtab; a.ltab = ta.ltab; a.order = oa.order; a.dtab = ta.dtab;
     a.data = k.data; a.wscalar = k.wscalar; a.out = k.out;
-    if (k.mode == GF_RESID_SCALAR) {
+    if (k.mode == GF_RESID_SCALAR || k.mode == GF_RESID_BAND1) {
         BA_TRY(ctx->get_scratch(SL_PARTIAL, (size_t)k.C * L.T * a.ntile * sizeof(double), &p));
         a.partial = (double *)p;
+    }
+    if (k.mode == GF_RESID_BAND1) {
+        BA_CHECK(k.band_w && k.quad && k.data, BEATAMD_EINVAL, "gfstack: mode 3 needs band_w, quad, data");
+        BA_TRY(ctx->get_scratch(SL_EDGES, (size_t)k.C * L.T * a.ntile * 2 * sizeof(double), &p));
+        a.edges = (double *)p;
+        a.band_w = k.band_w;
     }
     int64_t nblocks = ngroups * L.T * a.ntile;
     const int order_knob = GfKnobs::get(kn.gs_order, 1);
@@ -1254,7 +1271,7 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
     BA_CHECK(nblocks < (int64_t)0x7fffffff, BEATAMD_EINVAL, "gfstack: batch too large");
     const int nth_knob = GfKnobs::get(kn.gs_nthint, -1);
     const int nth = nth_knob >= 0 ? (nth_knob != 0) : (ngroups == 1);
-    const size_t ring = std::max<size_t>((size_t)3 * cap * 512, (size_t)GC_NCONS * 16 * GC_TPITCH);
+    const size_t ring = std::max<size_t>((size_t)3 * cap * 512, (size_t)GC_NCONS * 16 * GC_TPITCH + (size_t)GC_NCONS * 1024);
     const size_t lds = GC_PARAM_BYTES + ring;
     BA_CHECK(lds <= 160 * 1024, BEATAMD_EINVAL, "internal: k_gfstack_runs row buffers exceed LDS");
     snprintf(ctx->last_gf_kernel, sizeof(ctx->last_gf_kernel), "k_gfstack_runs<%d,%d>", k.mode, nth);
@@ -1301,6 +1318,8 @@ int launch_gfstack_ml(beatamd_ctx *ctx, const GfStackCall &k, const uint32_t *ro
     }
     BA_HIP(hipGetLastError());
     if (k.mode == GF_RESID_SCALAR) BA_TRY(launch_sum_tiles(ctx, a.partial, k.C * L.T, a.ntile, k.quad, a.ovf, 0));
+    if (k.mode == GF_RESID_BAND1)
+        BA_TRY(launch_sum_tiles_band1(ctx, a.partial, a.edges, k.band_w, k.C, L.T, L.N, a.ntile, 64, k.quad, a.ovf, 0));
     *ovf_out = a.ovf;
     return BEATAMD_OK;
 }

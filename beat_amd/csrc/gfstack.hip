@@ -351,10 +351,12 @@ int launch_sum_tiles(beatamd_ctx *ctx, const double *partial, int64_t n, int nti
 // samples its last one -- y = W[i,i] r_last(tile) + W[i,i+1] r_first(tile + 1), the two products of k_quadform_banded<1> --
 // fixed order: deterministic, the same on every rank
 __global__ void __launch_bounds__(256) k_sum_tiles_band1(const double *partial, const double *edges, const double *band_w,
-                                                        int64_t n, int64_t T, int64_t N, int ntile, int NT, double *quad)
+                                                        int64_t n, int64_t T, int64_t N, int ntile, int NT, double *quad,
+                                                        const int *guard, int want)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    if (guard && (*guard != 0) != (want != 0)) return;
     const int64_t t = i % T;
     double s = 0.0;
     for (int k = 0; k < ntile; k++) {
@@ -371,11 +373,11 @@ __global__ void __launch_bounds__(256) k_sum_tiles_band1(const double *partial, 
 }
 
 int launch_sum_tiles_band1(beatamd_ctx *ctx, const double *partial, const double *edges, const double *band_w, int64_t C,
-                           int64_t T, int64_t N, int ntile, int NT, double *quad)
+                           int64_t T, int64_t N, int ntile, int NT, double *quad, const int *guard, int want)
 {
     const int64_t n = C * T;
     hipLaunchKernelGGL(k_sum_tiles_band1, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, partial, edges, band_w,
-                       n, T, N, ntile, NT, quad);
+                       n, T, N, ntile, NT, quad, guard, want);
     BA_HIP(hipGetLastError());
     return BEATAMD_OK;
 }
@@ -621,13 +623,18 @@ static int launch_gfstack_impl(beatamd_ctx *ctx, const GfStackCall &call)
     // multilinear from 192 chains on: the runs kernel (gfcell.hip).  When its tables can overflow (more row passes than they
     // are sized for) the streaming kernel below is enqueued behind it as a stand-in that works only if they did.
     const int *standin = nullptr;
-    // (mode 3: only launch_gfstack_shared may keep it -- the runs kernel and the streaming kernel store the residuals)
+    // (mode 3: launch_gfstack_shared and the runs kernel have the epilogue -- round 6 --, the streaming kernel stores the
+    // residuals; as the runs kernel's stand-in it is followed by a guarded k_quadform_band1)
     const int mode_in = k.mode;
-    if (mode_in == GF_RESID_BAND1) k.mode = GF_RESID_STORE;
+    // (BEATAMD_QF_FUSE=0: residual store + k_quadform_band1 behind every kernel -- A/B, tests)
+    const bool fuse_runs = mode_in == GF_RESID_BAND1 && GfKnobs::get(kn.qf_fuse, 1) != 0;
+    if (mode_in == GF_RESID_BAND1 && !fuse_runs) k.mode = GF_RESID_STORE;
     if (!f32_all && gfstack_ml_applicable(k)) {
         BA_TRY(launch_gfstack_ml(ctx, k, ta.rowoff, ta.fac, Ttab, &standin));
+        if (fuse_runs) ctx->gf_band_fused = true;
         if (!standin) return BEATAMD_OK;
     }
+    if (mode_in == GF_RESID_BAND1) k.mode = GF_RESID_STORE;
     if (!standin) {
         int cg = 0, ucap = 0;
         if (gfstack_shared_applicable(k, &cg, &ucap)) {
@@ -749,6 +756,9 @@ static int launch_gfstack_impl(beatamd_ctx *ctx, const GfStackCall &call)
     }
     BA_HIP(hipGetLastError());
     if (k.mode == GF_RESID_SCALAR) BA_TRY(launch_sum_tiles(ctx, a.partial, k.C * L.T, a.ntile, k.quad, standin, 1));
+    // stand-in of the runs kernel in mode 3: the misfit of the residuals just stored, only when the tables overflowed
+    if (standin && fuse_runs)
+        BA_TRY(launch_quadform_banded(ctx, call.band_w, 1, L.N, L.T, k.C, k.out, L.T * L.N, L.N, k.quad, L.T, standin, 1));
     return BEATAMD_OK;
 }
 

@@ -99,7 +99,7 @@ int launch_sum_tiles(beatamd_ctx *ctx, const double *partial, int64_t n, int nti
 // mode 3: quad[c,t] = sum over tiles of (partial + the tile's last sample: (w0 r_last + w1 r_first(next tile))^2), fixed order;
 // edges [C*T, ntile, 2] = (first, last residual of the tile), NT samples per tile
 int launch_sum_tiles_band1(beatamd_ctx *ctx, const double *partial, const double *edges, const double *band_w, int64_t C,
-                           int64_t T, int64_t N, int ntile, int NT, double *quad);
+                           int64_t T, int64_t N, int ntile, int NT, double *quad, const int *guard = nullptr, int want = 0);
 // g[i] = (double)(float)g[i]; g32[i] = (float)g[i]  (float-storage copy of a GF library)
 int launch_round_to_f32(beatamd_ctx *ctx, double *g, float *g32, int64_t n);
 // gfshared.hip: chain-shared variant (distinct rows staged once per chain group)
@@ -140,7 +140,7 @@ int launch_band_detect(beatamd_ctx *ctx, const double *A, int64_t nd, int64_t M,
                        double *dropped_rel_host);
 int launch_band_pack(beatamd_ctx *ctx, const double *A, int64_t nd, int64_t M, int64_t band, double *wb);
 int launch_quadform_banded(beatamd_ctx *ctx, const double *wb, int64_t band, int64_t M, int64_t nd, int64_t C, const double *X,
-                           int64_t xs_c, int64_t xs_d, double *quad, int64_t q_stride);
+                           int64_t xs_c, int64_t xs_d, double *quad, int64_t q_stride, const int *guard = nullptr, int want = 0);
 // several small dense datasets (M <= 512 each) of one residual matrix in one launch, MVN epilogue
 // included: LL[c*ld + d] = -0.5 (slog_d + M_d (2 h + log 2pi) + exp(-2h) |W_d x_{c,d}|^2), h = Q[c, hp_off_d]
 struct QuadformSmallCall {

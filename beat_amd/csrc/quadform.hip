@@ -482,6 +482,9 @@ struct QbArgs {
     int64_t xs_c, xs_d;
     double *quad;
     int64_t q_stride;
+    // (nullable) the launch works only when (*guard != 0) == (want != 0): the stand-in behind k_gfstack_runs in mode 3
+    const int *guard;
+    int want;
 };
 
 // BAND1: the bidiagonal case with the loop over the band unrolled (the same two fused multiply-adds per sample)
@@ -570,6 +573,7 @@ __global__ void __launch_bounds__(QB1_NT) k_quadform_band1(QbArgs a, int ct, int
     double *sacc = ybv + npc * ct;                      // [QB1_NC]
     int *hasb = reinterpret_cast<int *>(sacc + QB1_NC); // [npc][ct]
     const int tid = threadIdx.x, NT = blockDim.x;
+    if (a.guard && (*a.guard != 0) != (a.want != 0)) return;
     const int64_t d = blockIdx.y, c0 = (int64_t)blockIdx.x * QB1_NC;
     const int nc = (int)min((int64_t)QB1_NC, a.C - c0);
     const int64_t M = a.M, CH = (int64_t)ct * 64;
@@ -687,13 +691,14 @@ __global__ void __launch_bounds__(QB1_NT) k_quadform_band1(QbArgs a, int ct, int
 }
 
 int launch_quadform_banded(beatamd_ctx *ctx, const double *wb, int64_t band, int64_t M, int64_t nd, int64_t C, const double *X,
-                           int64_t xs_c, int64_t xs_d, double *quad, int64_t q_stride)
+                           int64_t xs_c, int64_t xs_d, double *quad, int64_t q_stride, const int *guard, int want)
 {
     if (C == 0 || nd == 0) return BEATAMD_OK;
     if (band == 1) {
         QbArgs b;
         b.wb = wb; b.M = M; b.nd = nd; b.C = C; b.band = 1;
         b.X = X; b.xs_c = xs_c; b.xs_d = xs_d; b.quad = quad; b.q_stride = q_stride;
+        b.guard = guard; b.want = want;
         BA_CHECK(nd <= 65535, BEATAMD_EINVAL, "quadform_banded: too many datasets");
         ScopedTimer tm(ctx, "quadform");
         const int ct = (int)std::min<int64_t>(QB1_CT, (M + 63) / 64);
@@ -708,6 +713,8 @@ int launch_quadform_banded(beatamd_ctx *ctx, const double *wb, int64_t band, int
     QbArgs a;
     a.wb = wb; a.M = M; a.nd = nd; a.C = C; a.band = band;
     a.X = X; a.xs_c = xs_c; a.xs_d = xs_d; a.quad = quad; a.q_stride = q_stride;
+    a.guard = nullptr; a.want = 0;
+    BA_CHECK(guard == nullptr, BEATAMD_EINVAL, "quadform_banded: a guarded launch exists for the bidiagonal kernel only");
     BA_CHECK(nd <= 65535, BEATAMD_EINVAL, "quadform_banded: too many datasets");
     {
         ScopedTimer tm(ctx, "quadform");

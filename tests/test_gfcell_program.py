@@ -70,6 +70,12 @@ def _run(T, P, D, S, N, C, Ttab_is_one, mode, sort, nth, seed, below_grid=False,
     a["data"] = mem.alloc(data.nbytes, data)
     a["out"] = mem.alloc(C * T * N * 8)
     a["partial"] = mem.alloc(C * T * ntile * 8)
+    if mode == 3:
+        # rows (W[i,i], W[i,i+1]) of a bidiagonal whitening operator per target, 0 behind the end of the trace
+        band = rng.uniform(0.5, 2.0, (T, N, 2))
+        band[:, N - 1, 1] = 0.0
+        a["band_w"] = mem.alloc(band.nbytes, band)
+        a["edges"] = mem.alloc(C * T * ntile * 16)
     ngroups = order.size // emu.CG
     stats = []
     for g in range(ngroups):
@@ -90,6 +96,28 @@ def _run(T, P, D, S, N, C, Ttab_is_one, mode, sort, nth, seed, below_grid=False,
         assert np.array_equal(out, ref)
     elif mode == 2:
         assert np.array_equal(out, data[None] - ref)
+    elif mode == 3:
+        # the canonical order of quadform.hip (k_quadform_band1, the epilogue of k_gfstack_ws): per tile the samples but
+        # its last, ascending, + the trace's very last sample; the first / last residual of every tile for the boundary terms
+        part = mem.array(a["partial"], np.float64, C * T * ntile).reshape(C, T, ntile)
+        edges = mem.array(a["edges"], np.float64, C * T * ntile * 2).reshape(C, T, ntile, 2)
+        resid = data[None] - ref
+        for c in range(C):
+            for t in range(T):
+                for tl in range(ntile):
+                    n0, nv = tl * 64, min(64, N - tl * 64)
+                    q = 0.0
+                    for i in range(n0, n0 + nv - 1):
+                        y = band[t, i, 0] * resid[c, t, i] + 0.0
+                        y = band[t, i, 1] * resid[c, t, i + 1] + y
+                        q = y * y + q
+                    if n0 + nv == N:
+                        y = band[t, N - 1, 0] * resid[c, t, N - 1] + 0.0
+                        q = y * y + q
+                    assert part[c, t, tl] == q, (c, t, tl, part[c, t, tl], q)
+                    assert edges[c, t, tl, 0] == resid[c, t, n0]
+                    if n0 + nv < N:
+                        assert edges[c, t, tl, 1] == resid[c, t, n0 + nv - 1]
     else:
         part = mem.array(a["partial"], np.float64, C * T * ntile).reshape(C, T, ntile)
         exp = np.zeros_like(part)
@@ -105,7 +133,7 @@ def _run(T, P, D, S, N, C, Ttab_is_one, mode, sort, nth, seed, below_grid=False,
     return stats, tabs
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_runs_program_one_group(mode):
     """45 chains (one full consumer wavefront, one partly filled, twelve empty), two tiles (64 + 6 samples), tables per
     target, node-0 wrap, exact-grid durations and start times / durations BELOW the first grid node (the wrapped floor
@@ -138,7 +166,7 @@ def test_programs_with_several_slip_variables(nvar):
     _run(T=2, P=3, D=2, S=5, N=70, C=45, Ttab_is_one=(nvar == 2), mode=nvar % 3, sort=True, nth=0, seed=21 + nvar, nvar=nvar)
 
 
-@pytest.mark.parametrize("mode,nvar,ttab1", [(0, 1, True), (1, 2, False), (2, 1, False)])
+@pytest.mark.parametrize("mode,nvar,ttab1", [(0, 1, True), (1, 2, False), (2, 1, False), (3, 2, True)])
 def test_row_passes(mode, nvar, ttab1):
     """a library with more rows per patch than a row buffer holds (here: buffers of 12 slots, 6 x 9 = 54 rows per patch):
     a patch is staged in several passes, a chain takes part in the pass that holds its cell, the other positions of
@@ -341,6 +369,6 @@ def test_runs_program_random_shapes(seed):
     if cap is not None and (D * (S + 1) <= cap or S + 1 > cap // 2):
         cap = None       # (a buffer holds at least two start-time nodes of a duration line pair)
     _run(T=int(rng.integers(1, 3)), P=int(rng.integers(1, 5)), D=D, S=S, N=[64, 70][int(rng.integers(0, 2))],
-         C=int(rng.integers(1, 121)), Ttab_is_one=bool(rng.integers(0, 2)), mode=int(rng.integers(0, 3)),
+         C=int(rng.integers(1, 121)), Ttab_is_one=bool(rng.integers(0, 2)), mode=int(rng.integers(0, 4)),
          sort=bool(rng.integers(0, 2)), nth=int(rng.integers(0, 2)), seed=seed, below_grid=bool(rng.integers(0, 2)) and D > 1 and S > 1,
          nvar=int(rng.integers(1, 3)), cap=cap)

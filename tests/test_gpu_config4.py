@@ -11,13 +11,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("interp,kernel", [("multilinear", "k_gfstack_runs<2,"), ("nearest_neighbor", "k_gfstack_ws<1,3,3,")])
+@pytest.mark.parametrize("interp,kernel", [("multilinear", "k_gfstack_runs<3,"), ("nearest_neighbor", "k_gfstack_ws<1,3,3,")])
 def test_config4_joint_multifault_512_chains_n4096(interp, kernel):
     """both interpolations (the reference's default for this composite is multilinear, beat/config.py:571-575); the
     kernel that stacks the 512-chain batch is asserted by name: the runs kernel / the loader-consumer kernel, both
-    outside their round-4 envelopes on this (2 durations x 60 start times) library; the nn kernel carries the bidiagonal
-    misfit of the Toeplitz covariance in its epilogue (mode 3, round 6), the 64-chain sub-batch below goes through another
-    kernel + k_quadform_band1 and must give the same bits"""
+    outside their round-4 envelopes on this (2 durations x 60 start times) library; both carry the bidiagonal misfit of the
+    Toeplitz covariance in their epilogues (mode 3, round 6), the 64-chain sub-batch below goes through another kernel +
+    k_quadform_band1 and must give the same bits"""
     import torch
 
     import beat_amd

@@ -320,7 +320,7 @@ def test_fullsize_fused_logp_multilinear(full, monkeypatch, cov):
     Qd = torch.from_numpy(Q).to("cuda:0")
     for name in ("BEATAMD_GF_KERNEL", "BEATAMD_GS_CG", "BEATAMD_GS_ML"):
         monkeypatch.delenv(name, raising=False)
-    mode = 1 if cov == "scalar" else 2
+    mode = 1 if cov == "scalar" else 3     # (the "exponential" Toeplitz structure: bidiagonal operator, misfit in the epilogue)
     LM = f.batch(Qd).cpu().numpy()
     assert ctx.last_kernel().startswith("k_gfstack_runs<%d," % mode), ctx.last_kernel()
     monkeypatch.setenv("BEATAMD_GR_CAP", "24")       # row passes: the same kernel on other tables
@@ -332,7 +332,7 @@ def test_fullsize_fused_logp_multilinear(full, monkeypatch, cov):
     monkeypatch.delenv("BEATAMD_GR_PASS_ALLOC")
     monkeypatch.setenv("BEATAMD_GS_CG", "256")       # the lane <-> chain kernel: same residuals, same epilogue
     LC = f.batch(Qd).cpu().numpy()
-    assert ctx.last_kernel().startswith("k_gfstack_dma<4,4,%d," % mode), ctx.last_kernel()
+    assert ctx.last_kernel().startswith("k_gfstack_dma<4,4,%d," % min(mode, 2)), ctx.last_kernel()   # (stores the residual)
     monkeypatch.delenv("BEATAMD_GS_CG")
     monkeypatch.setenv("BEATAMD_GF_KERNEL", "0")
     LS = f.batch(Qd).cpu().numpy()

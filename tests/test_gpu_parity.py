@@ -485,7 +485,7 @@ def test_multilinear_with_several_slip_variables_through_the_runs_kernel(ctx, mo
     prob, host = build_problem(spec)
     f = prob.compile(ctx)
     Q = draw_population(spec, host["layout"], host["lower"], host["upper"], 530)
-    mode = 1 if cov == "scalar" else 2
+    mode = 1 if cov == "scalar" else 3     # (the "exponential" Toeplitz structure: bidiagonal operator, misfit in the epilogue)
     for name in ("BEATAMD_GF_KERNEL", "BEATAMD_GS_CG", "BEATAMD_GS_ML"):
         monkeypatch.delenv(name, raising=False)
     B = f.batch(Q)

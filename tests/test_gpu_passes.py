@@ -184,7 +184,7 @@ def test_fused_model_on_a_fine_grid_ml(ctx, monkeypatch, nvar, cov, shifts):
     A = f.batch(Q)
     assert ctx.last_kernel().startswith("k_gfstack<1,"), ctx.last_kernel()
     monkeypatch.delenv("BEATAMD_GF_KERNEL")
-    mode = 1 if cov == "scalar" else 2
+    mode = 1 if cov == "scalar" else 3     # (the "exponential" Toeplitz structure: bidiagonal operator, misfit in the epilogue)
     B = f.batch(Q)
     plan = ctx.gf_plan()
     assert ctx.last_kernel().startswith("k_gfstack_runs<%d," % mode) and 2 <= plan["max_passes"] <= 6, (ctx.last_kernel(), plan)

@@ -80,3 +80,60 @@ def test_geodetic_stack_in_blocks_of_four_chains(ctx, nvar):
     np.testing.assert_allclose(mu, sl @ G, rtol=1e-12, atol=1e-12)
     assert np.array_equal(mu[:9], gl.stack_all_batch(sl[:9]))
     f.release()
+
+
+@pytest.mark.parametrize("N,nvar,shifts", [(130, 1, False), (200, 2, True), (64, 1, True)])
+def test_bidiagonal_misfit_inside_the_runs_kernel(ctx, monkeypatch, N, nvar, shifts):
+    """multilinear interpolation with the reference's "exponential" noise structure (bidiagonal W = chol(inv(C)).T,
+    covariance.py:24-51): the misfit of distributions.py:119-138 rides in the epilogue of k_gfstack_runs too (mode 3 of the
+    generated program: the transposed tile of the scalar epilogue, the band rows of the tile in LDS, edges + k_sum_tiles_band1
+    for every tile's last sample) -- in the one canonical order, so the same bits as residual store + k_quadform_band1
+    (BEATAMD_QF_FUSE=0), as the small-batch kernels and, when the tables overflow, as the streaming stand-in with its guarded
+    k_quadform_band1; row passes included"""
+    from beat_amd.synthetic import SyntheticSpec, build_problem, draw_population
+    from oracle import problem_oracle
+    names = ("uparr", "uperp")[:nvar]
+    spec = SyntheticSpec((6,), (7,), (1.0,), T=3, N=N, D=3, S=25, covariance="toeplitz", slip_varnames=names,
+                         station_shifts=shifts, interpolation="multilinear")
+    prob, host = build_problem(spec)
+    f = prob.compile(ctx)
+    assert ctx.weights_band(f.problem.wavemaps[0]._wset) == 1
+    C = 600
+    Q = draw_population(spec, host["layout"], host["lower"], host["upper"], C)
+    monkeypatch.setenv("BEATAMD_GF_SPLIT", "0")
+    A = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack_runs<3,"), (ctx.last_kernel(), ctx.gf_plan())
+    assert np.isfinite(A).all() and np.array_equal(A, f.batch(Q))
+    monkeypatch.setenv("BEATAMD_QF_FUSE", "0")
+    B = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack_runs<2,"), ctx.last_kernel()
+    monkeypatch.delenv("BEATAMD_QF_FUSE")
+    assert np.array_equal(A, B)
+    # row passes (buffers of 10 slots), the same tables through both builders
+    monkeypatch.setenv("BEATAMD_GR_CAP", "10")
+    monkeypatch.setenv("BEATAMD_GR_PASS_ALLOC", "40")
+    P_ = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack_runs<3,") and ctx.gf_plan()["max_passes"] >= 2, ctx.gf_plan()
+    assert np.array_equal(A, P_)
+    # tables sized for one pass per patch overflow: the streaming kernel stands in, its residuals go through the guarded
+    # k_quadform_band1
+    monkeypatch.setenv("BEATAMD_GR_PASS_ALLOC", "1")
+    O = f.batch(Q)
+    assert ctx.last_kernel().startswith("k_gfstack_runs<3,")
+    if nvar == 1:
+        assert np.array_equal(A, O)
+    np.testing.assert_allclose(A, O, rtol=1e-11)
+    monkeypatch.delenv("BEATAMD_GR_CAP")
+    monkeypatch.delenv("BEATAMD_GR_PASS_ALLOC")
+    sub = f.batch(Q[40:140])                                   # 100 chains: the lane <-> chain kernels + k_quadform_band1
+    if nvar == 1:
+        assert np.array_equal(A[40:140], sub)
+    np.testing.assert_allclose(A[40:140], sub, rtol=1e-11)
+    monkeypatch.setenv("BEATAMD_QF_BAND", "0")                 # the dense operator on the matrix cores
+    D_ = f.batch(Q)
+    monkeypatch.delenv("BEATAMD_QF_BAND")
+    np.testing.assert_allclose(A, D_, rtol=1e-10)
+    for c in (0, C // 2, C - 1):
+        ref, _ = problem_oracle.forward(host, Q[c])
+        np.testing.assert_allclose(A[c], ref, rtol=1e-9)
+    f.release()

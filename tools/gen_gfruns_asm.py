@@ -109,6 +109,9 @@ assert D_A + 2 * NHALF <= D_B and D_B + 2 * (NPOS - NHALF) - 1 <= S_LAST
 P_WP, P_RB0, P_NSTEP = 0, 4, 5
 P_DP = 8
 P_OUT, P_CTN, P_MODE, P_DATA, P_W, P_CID, P_PART, P_PCS, P_NVALID, P_TRB = 16, 18, 19, 20, 22, 24, 26, 28, 29, 30
+P_WLDS = 31      # mode 3: LDS address of the wavefront's 1 KB for the tile's band rows (w0, w1)
+# mode 3 (bidiagonal misfit, round 6) re-uses three words: P_OUT = edges + (t * ntile + tile) * 16 (chain stride 2 * PCS),
+# P_W = address of the band rows of the tile's first sample, P_CTN = 1 when the tile ends the trace
 # parameter block of a loader wavefront
 PL_LT, PL_GROW, PL_ROWB, PL_RB0, PL_BUFB, PL_NSTEP, PL_NLANES = 0, 2, 5, 6, 7, 8, 9
 PL_NVAR, PL_G1, PL_G2 = 10, 12, 14   # slip variables (steps cycle through their libraries), bases 2 and 3
@@ -173,11 +176,12 @@ def epilogue(XA, XB, ACC, NCHAIN, idx_mode):
     e("s_waitcnt vmcnt(0)")                            # records requested beyond the last step
     e("s_barrier")                                     # every wavefront is done with the row ring
     S_OUT, S_CTN, S_MODE, S_DATA, S_W, S_CID, S_PART, S_PCS, S_NVAL, S_TRB = 22, 24, 25, 26, 28, 30, 84, 86, 87, 88
+    S_WLDS = 89
     T4, T5 = 20, 21
     for sreg, k in ((S_OUT, P_OUT), (S_OUT + 1, P_OUT + 1), (S_CTN, P_CTN), (S_MODE, P_MODE),
                     (S_DATA, P_DATA), (S_DATA + 1, P_DATA + 1), (S_W, P_W), (S_W + 1, P_W + 1),
                     (S_CID, P_CID), (S_CID + 1, P_CID + 1), (S_PART, P_PART), (S_PART + 1, P_PART + 1),
-                    (S_PCS, P_PCS), (S_NVAL, P_NVALID), (S_TRB, P_TRB)):
+                    (S_PCS, P_PCS), (S_NVAL, P_NVALID), (S_TRB, P_TRB), (S_WLDS, P_WLDS)):
         readlane(sreg, k)
     e("s_nop 4")
     CID = 32   # s[32:79]: chain ids of the accumulators (37 used)
@@ -201,6 +205,8 @@ def epilogue(XA, XB, ACC, NCHAIN, idx_mode):
     e("s_mov_b64 exec, -1")
     e("s_cmp_eq_u32 s%d, 1" % S_MODE)
     br("s_cbranch_scc1", "SCAL")
+    e("s_cmp_eq_u32 s%d, 3" % S_MODE)
+    br("s_cbranch_scc1", "BAND")
 
     def store_loop(tag, resid):
         e("s_mov_b64 exec, vcc")
@@ -263,6 +269,91 @@ def epilogue(XA, XB, ACC, NCHAIN, idx_mode):
         e("v_cmp_ne_u32 %s, -1, v%d" % (sp(T2), V_C))
         e("s_and_b64 exec, exec, %s" % sp(T2))
         e("global_store_dwordx2 %s, %s, off" % (vp(V_T2), vp(Q)))
+        e("s_mov_b64 exec, -1")
+        e("s_waitcnt vmcnt(0)")
+    br("s_branch", "END")
+    # ---- bidiagonal whitening operator (mode 3, round 6; distributions.py:119-138 with W[i,i], W[i,i+1] only): per
+    # (chain, tile) in the CANONICAL order of quadform.hip -- q = sum_{i<63} y_i^2 ascending, y_i = fma(w1_i, r_{i+1},
+    # fma(w0_i, r_i, 0)), + the trace's very last sample --, partial[c,t,tile] = q and edges[c,t,tile] = (first, last
+    # residual): k_sum_tiles_band1 adds the term of a tile's last sample (its neighbour is the next tile's first residual).
+    # The tile's band rows go to LDS once (lane i: (w0_i, w1_i), zeros beyond the trace), then 16 chains at a time through
+    # the transposed tile as above: lane <-> chain, the weights read at a uniform address
+    lab("BAND")
+    V_WU, V_WL16 = 11, V_L16
+    WQ = RREC                          # [WQ+4k : WQ+4k+3] = (w0, w1) of sample i0 + k
+    Y = RREC + 16                      # y_i; [Y : Y+3] stages the lane's band row first
+    RF, RI = V_T1, V_T2                # the tile's first residual, r_i (carried)
+    A1, A2, A3 = XB, XB + 2, XB + 4    # address temporaries behind the sample loop
+    e("v_lshlrev_b32 v%d, 4, v%d" % (V_WL16, V_T0))            # lane * 16 (V_T0: the lane, lane_setup above)
+    for k in range(4):
+        e("v_mov_b32 v%d, 0" % (Y + k))
+    e("s_mov_b64 exec, vcc")
+    e("global_load_dwordx4 v[%d:%d], v%d, %s" % (Y, Y + 3, V_WL16, sp(S_W)))
+    e("s_waitcnt vmcnt(0)")
+    e("s_mov_b64 exec, -1")
+    e("v_add_u32 v%d, s%d, v%d" % (V_WU, S_WLDS, V_WL16))
+    e("ds_write_b128 v%d, v[%d:%d]" % (V_WU, Y, Y + 3))
+    e("v_mov_b32 v%d, s%d" % (V_WU, S_WLDS))
+    e("s_lshl_b32 s%d, s%d, 1" % (T5, S_PCS))                  # chain stride of `edges`
+    e("v_add_u32 v%d, s%d, v%d" % (V_WA, S_TRB, V_RING))
+    e("v_lshrrev_b32 v%d, 3, v%d" % (V_T0, V_RING))
+    e("v_mul_u32_u24 v%d, %d, v%d" % (V_RA, TPITCH, V_T0))
+    e("v_add_u32 v%d, s%d, v%d" % (V_RA, S_TRB, V_RA))
+    e("v_lshlrev_b32 v%d, 2, v%d" % (V_L4, V_T0))
+    e("s_waitcnt lgkmcnt(0)")
+    for r in range((NCHAIN + 15) // 16):
+        n = min(16, NCHAIN - 16 * r)
+        for jj in range(n):
+            j = 16 * r + jj
+            tmp = V_T1 if (jj & 1) == 0 else V_T2
+            e("v_add_f64 %s, %s, -%s" % (vp(tmp), vp(V_D), vp(ACC + 2 * j)))      # seismic.py:1332
+            e("v_cndmask_b32 v%d, 0, v%d, vcc" % (tmp, tmp))                         # samples beyond N: residual 0
+            e("v_cndmask_b32 v%d, 0, v%d, vcc" % (tmp + 1, tmp + 1))
+            e("ds_write_b64 v%d, %s offset:%d" % (V_WA, vp(tmp), jj * TPITCH))
+        e("s_waitcnt lgkmcnt(0)")
+        e("v_mov_b32 v%d, 0" % Q)
+        e("v_mov_b32 v%d, 0" % (Q + 1))
+        e("s_mov_b64 exec, 0x%x" % ((1 << n) - 1))
+        e("global_load_dword v%d, v%d, %s offset:%d" % (V_C, V_L4, sp(S_CID), 64 * r))
+        e("ds_read_b64 %s, v%d" % (vp(RI), V_RA))
+        e("s_waitcnt lgkmcnt(0)")
+        e("v_mov_b32 v%d, v%d" % (RF, RI))
+        e("v_mov_b32 v%d, v%d" % (RF + 1, RI + 1))
+        for i0 in range(0, 64, 4):
+            for k in range(4):
+                e("ds_read_b64 %s, v%d offset:%d" % (vp(WQ + 4 * k), V_WU, (i0 + k) * 16))
+                e("ds_read_b64 %s, v%d offset:%d" % (vp(WQ + 4 * k + 2), V_WU, (i0 + k) * 16 + 8))
+                if i0 + k < 63:
+                    e("ds_read_b64 %s, v%d offset:%d" % (vp(XB + 2 * k), V_RA, (i0 + k + 1) * 8))
+            e("s_waitcnt lgkmcnt(0)")
+            last = RI
+            for k in range(4):
+                if i0 + k == 63:
+                    break
+                e("v_fma_f64 %s, %s, %s, 0" % (vp(Y), vp(WQ + 4 * k), vp(last)))
+                e("v_fma_f64 %s, %s, %s, %s" % (vp(Y), vp(WQ + 4 * k + 2), vp(XB + 2 * k), vp(Y)))
+                e("v_fma_f64 %s, %s, %s, %s" % (vp(Q), vp(Y), vp(Y), vp(Q)))
+                last = XB + 2 * k
+            e("v_mov_b32 v%d, v%d" % (RI, last))
+            e("v_mov_b32 v%d, v%d" % (RI + 1, last + 1))
+        # the trace's very last sample (no neighbour; beyond the trace the staged w0 is 0)
+        e("s_cmp_eq_u32 s%d, 0" % S_CTN)
+        br("s_cbranch_scc1", "BNE%d" % r)
+        e("v_fma_f64 %s, %s, %s, 0" % (vp(Y), vp(WQ + 12), vp(RI)))
+        e("v_fma_f64 %s, %s, %s, %s" % (vp(Q), vp(Y), vp(Y), vp(Q)))
+        lab("BNE%d" % r)
+        e("s_waitcnt vmcnt(0)")
+        e("v_mov_b32 v%d, s%d" % (A1, S_PART))
+        e("v_mov_b32 v%d, s%d" % (A1 + 1, S_PART + 1))
+        e("v_mad_u64_u32 %s, %s, v%d, s%d, %s" % (vp(A2), sp(T2), V_C, S_PCS, vp(A1)))
+        e("v_mov_b32 v%d, s%d" % (A1, S_OUT))
+        e("v_mov_b32 v%d, s%d" % (A1 + 1, S_OUT + 1))
+        e("v_mad_u64_u32 %s, %s, v%d, s%d, %s" % (vp(A3), sp(T2), V_C, T5, vp(A1)))
+        e("v_cmp_ne_u32 %s, -1, v%d" % (sp(T2), V_C))
+        e("s_and_b64 exec, exec, %s" % sp(T2))
+        e("global_store_dwordx2 %s, %s, off" % (vp(A2), vp(Q)))
+        e("global_store_dwordx2 %s, %s, off" % (vp(A3), vp(RF)))
+        e("global_store_dwordx2 %s, %s, off offset:8" % (vp(A3), vp(RI)))
         e("s_mov_b64 exec, -1")
         e("s_waitcnt vmcnt(0)")
     lab("END")
@@ -663,7 +754,7 @@ def main():
             f.write("#define GC_%s %d\n" % (name, val))
         for name, val in (("WP", P_WP), ("RB0", P_RB0), ("NSTEP", P_NSTEP), ("DP", P_DP),
                           ("OUT", P_OUT), ("CTN", P_CTN), ("MODE", P_MODE), ("DATA", P_DATA), ("W", P_W),
-                          ("CID", P_CID), ("PART", P_PART), ("PCS", P_PCS), ("NVALID", P_NVALID), ("TRB", P_TRB)):
+                          ("CID", P_CID), ("PART", P_PART), ("PCS", P_PCS), ("NVALID", P_NVALID), ("TRB", P_TRB), ("WLDS", P_WLDS)):
             f.write("#define GC_P_%s %d\n" % (name, val))
         for name, val in (("LT", PL_LT), ("GROW", PL_GROW), ("ROWB", PL_ROWB), ("RB0", PL_RB0),
                           ("BUFB", PL_BUFB), ("NSTEP", PL_NSTEP), ("NLANES", PL_NLANES), ("NVAR", PL_NVAR),

@@ -834,9 +834,9 @@ class Wave(object):
                 d = self.vreg(ops[1])
                 if ops[2] == "off":
                     a0 = self.vreg(ops[0])
-                    addr = self.v[a0].astype(np.uint64) | (self.v[a0 + 1].astype(np.uint64) << np.uint64(32))
+                    addr = (self.v[a0].astype(np.uint64) | (self.v[a0 + 1].astype(np.uint64) << np.uint64(32))) + np.uint64(imm_off)
                 else:
-                    addr = np.uint64(self.get_s64(ops[2])) + self.v[self.vreg(ops[0])].astype(np.uint64)
+                    addr = np.uint64(self.get_s64(ops[2])) + self.v[self.vreg(ops[0])].astype(np.uint64) + np.uint64(imm_off)
                 for i in np.nonzero(self.lanes())[0]:
                     mem.write(int(addr[i]), np.array([self.v[d][i], self.v[d + 1][i]], dtype=np.uint32).view(np.uint8))
             else:
@@ -895,11 +895,17 @@ def wave_params(w, g, t, tile, a):
         P[gen.P_RB0] = PARAM_BYTES
         P[gen.P_NSTEP] = nsteps
         put64(gen.P_DP, a["dtab"] + ((gt * NCONS + w) * (smax + 1)) * gen.DLINE * 4)
-        put64(gen.P_OUT, a["out"] + (t * N + n0) * 8)
-        P[gen.P_CTN] = T * N * 8
         P[gen.P_MODE] = a["mode"]
         put64(gen.P_DATA, a["data"] + (t * N + n0) * 8)
-        put64(gen.P_W, int(np.float64(a["wscalar"][t]).view(np.uint64)))
+        if a["mode"] == 3:       # bidiagonal misfit: edges, band rows, "the tile ends the trace" in the words of out / w / ctn
+            put64(gen.P_OUT, a["edges"] + (t * a["ntile"] + tile) * 16)
+            P[gen.P_CTN] = 1 if n0 + min(64, N - n0) == N else 0
+            put64(gen.P_W, a["band_w"] + (t * N + n0) * 16)
+        else:
+            put64(gen.P_OUT, a["out"] + (t * N + n0) * 8)
+            P[gen.P_CTN] = T * N * 8
+            put64(gen.P_W, int(np.float64(a["wscalar"][t]).view(np.uint64)))
+        P[gen.P_WLDS] = PARAM_BYTES + NCONS * 16 * TPITCH + w * 1024
         put64(gen.P_CID, a["order"] + (g * CG + w * NCH) * 4)
         put64(gen.P_PART, a["partial"] + (t * a["ntile"] + tile) * 8)
         P[gen.P_PCS] = T * a["ntile"] * 8
@@ -921,4 +927,4 @@ def wave_params(w, g, t, tile, a):
 
 
 def lds_bytes(cap):
-    return PARAM_BYTES + max(3 * cap * 512, NCONS * 16 * TPITCH)
+    return PARAM_BYTES + max(3 * cap * 512, NCONS * 16 * TPITCH + NCONS * 1024)
