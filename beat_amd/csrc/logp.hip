@@ -149,6 +149,12 @@ int launch_geo_stack(beatamd_ctx *ctx, const GeoLib *const *libs, int nvar, int6
     if (C == 0 || nvar == 0) return BEATAMD_OK;
     BA_CHECK(nvar >= 1 && nvar <= 4, BEATAMD_EINVAL, "geo_stack: 1..4 slip variables");
     const GeoLib &lib = *libs[0];
+    if (nvar > 1 && (size_t)lib.P * nvar * sizeof(double) > 64 * 1024) {
+        // (faults of more than 8192 / nvar patches: the variables' slips do not fit the block's LDS together -- one launch per
+        // variable, mu through memory; the same fma sequence)
+        for (int v = 0; v < nvar; v++) BA_TRY(launch_geo_stack(ctx, libs + v, 1, C, slips + v, (v > 0 || accumulate) ? 1 : 0, mu));
+        return BEATAMD_OK;
+    }
     GeoStackArgs a;
     for (int v = 0; v < nvar; v++) {
         BA_CHECK(libs[v]->P == lib.P && libs[v]->Nobs == lib.Nobs, BEATAMD_EINVAL, "geo_stack: the libraries of the slip variables differ in shape");
