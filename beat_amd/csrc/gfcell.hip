@@ -721,7 +721,7 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
 // The same tables, entry for entry, as k_gm_tables -- but a (group, target, patch) is the work of ONE wavefront that visits
 // the 518 chain slots nine per lane, with its own piece of LDS and no workgroup barrier anywhere.  k_gm_tables is a chain of
 // ~10 barriers and ~5 dependent round trips to memory per patch on nine wavefronts that mostly wait for each other: with
-// two such workgroups per CU the 14 000 patches of configs[3] (35 station slots x 400 patches) took 0.43 ms -- a quarter of
+// two such workgroups per CU the 6 800 (slot, patch) pairs of configs[3] (17 station slots x 400 patches) took 0.43 ms -- a quarter of
 // the step at 120 samples per trace, whatever the block of patches per workgroup (8 consecutive patches per workgroup, prefetched, were SLOWER:
 // 0.58 ms: it is the per-patch latency, not the launch).  Here a CU holds 16 patches in flight and a wavefront never waits
 // for another.  Libraries up to GW_DENSE_MAX dense slots per patch (one bitset word per lane); beyond that k_gm_tables.
