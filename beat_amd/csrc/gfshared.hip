@@ -1935,6 +1935,12 @@ __global__ void __launch_bounds__(WS_CG) k_ws_tables(WsTabArgs a)
     const bool live = pos_in_batch < a.C;
     const int64_t c = live ? (a.order ? (int64_t)a.order[pos_in_batch] : pos_in_batch) : 0;
     const uint32_t v = live ? a.rowoff[(c * a.T + t) * a.P + p] : 0xffffffffu;
+    // (the chain's slips are requested here, next to its row id: behind the barriers below they were one more exposed round
+    // trip per patch)
+    double sl[4] = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (FILL)
+        for (int iv = 0; iv < a.nvar; iv++)
+            if (live) sl[iv] = a.slips[iv].base[c * a.slips[iv].stride + a.slips[iv].off + (t % a.R) * a.P + p];
     gm[tid] = 0;
     uint32_t pos = 0, U = 0;
     bool first = false;
@@ -2065,9 +2071,6 @@ __global__ void __launch_bounds__(WS_CG) k_ws_tables(WsTabArgs a)
     __syncthreads();
     const int64_t v0 = gt * a.vmax + (a.voff ? (int64_t)a.voff[gtp] : p);
     const uint16_t myslot = live ? slt[pos] : (uint16_t)0;
-    double sl[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int iv = 0; iv < a.nvar; iv++)
-        if (live) sl[iv] = a.slips[iv].base[c * a.slips[iv].stride + a.slips[iv].off + (t % a.R) * a.P + p];
     constexpr int kstr = WS_USTRIDE / WS_LW;
     for (int k = 0; k < npass; k++) {
         const int64_t vs = v0 + k;
