@@ -450,9 +450,10 @@ __global__ void __launch_bounds__(256) k_split_tslot(int64_t Tv, int R, const in
 //   ascending, then the tiles ascending (the order of the lane <-> chain kernels)
 template <int MODE>
 __global__ void __launch_bounds__(256) k_split_combine(const double *part, int64_t C, int64_t T, int64_t N, int R,
-                                                      const double *data, const double *wscalar, double *out, double *quad)
+                                                      const double *data, const double *wscalar, double *out, double *quad,
+                                                      const double *band_w)
 {
-    __shared__ double sq[256];
+    __shared__ double sq[256 + 1];
     __shared__ double tsum[4];
     const int64_t ct = blockIdx.x, t = ct % T, c = ct / T;
     const int n = threadIdx.x;
@@ -463,12 +464,57 @@ __global__ void __launch_bounds__(256) k_split_combine(const double *part, int64
         for (int r = 1; r < R; r++) syn += pp[(int64_t)r * N];
         if (MODE == GF_STORE_SYN) out[ct * N + n] = syn;
         else if (MODE == GF_RESID_SCALAR) v = wscalar[t] * (data[t * N + n] - syn);
+        else if (MODE == GF_RESID_BAND1) v = data[t * N + n] - syn;              // seismic.py:1332
         else out[ct * N + n] = data[t * N + n] - syn;
     }
-    if (MODE != GF_RESID_SCALAR) return;
+    if (MODE != GF_RESID_SCALAR && MODE != GF_RESID_BAND1) return;
     sq[n] = v;
     __syncthreads();
     const int ntile = (int)((N + 63) / 64);
+    if (MODE == GF_RESID_BAND1) {
+        // the bidiagonal misfit in the canonical order of quadform.hip (k_quadform_band1): per 64-sample tile the samples
+        // but its last, ascending, + the trace's very last sample; then the tiles ascending with every tile's boundary term
+        // (round 6: no residual store, no second kernel behind the patch ranges either)
+        // (the band rows of the target through LDS: read from memory inside the serial loops they were a round trip per
+        // sample)
+        __shared__ double w[2 * 256];
+        if (n < N) {
+            w[2 * n] = band_w[(t * N + n) * 2];
+            w[2 * n + 1] = band_w[(t * N + n) * 2 + 1];
+        }
+        __syncthreads();
+        if (n < ntile) {
+            const int n0 = n * 64, nv = (int)min((int64_t)64, N - (int64_t)n0);
+            double q = 0.0, ri = sq[n0];
+            for (int i = 0; i + 1 < nv; i++) {
+                const double rn = sq[n0 + i + 1];
+                double y = fma(w[2 * (n0 + i)], ri, 0.0);
+                y = fma(w[2 * (n0 + i) + 1], rn, y);
+                q = fma(y, y, q);
+                ri = rn;
+            }
+            if (n0 + nv == N) {
+                const double y = fma(w[2 * (N - 1)], ri, 0.0);
+                q = fma(y, y, q);
+            }
+            tsum[n] = q;
+        }
+        __syncthreads();
+        if (n == 0) {
+            double s_ = 0.0;
+            for (int k = 0; k < ntile; k++) {
+                s_ += tsum[k];
+                if (k + 1 < ntile) {
+                    const int last = k * 64 + 63;
+                    double y = fma(w[2 * last], sq[last], 0.0);
+                    y = fma(w[2 * last + 1], sq[last + 1], y);
+                    s_ = fma(y, y, s_);
+                }
+            }
+            quad[ct] = s_;
+        }
+        return;
+    }
     if (n < ntile) {
         double q = 0.0;
         const int hi = (int)min((int64_t)64, N - (int64_t)n * 64);
@@ -516,15 +562,23 @@ static int launch_gfstack_split(beatamd_ctx *ctx, const GfStackCall &call, int R
     switch (call.mode) {
     case GF_STORE_SYN:
         hipLaunchKernelGGL(k_split_combine<GF_STORE_SYN>, grid, dim3(256), 0, ctx->stream, part, call.C, L.T, L.N, R, call.data,
-                           call.wscalar, call.out, call.quad);
+                           call.wscalar, call.out, call.quad, (const double *)nullptr);
         break;
     case GF_RESID_SCALAR:
         hipLaunchKernelGGL(k_split_combine<GF_RESID_SCALAR>, grid, dim3(256), 0, ctx->stream, part, call.C, L.T, L.N, R, call.data,
-                           call.wscalar, call.out, call.quad);
+                           call.wscalar, call.out, call.quad, (const double *)nullptr);
         break;
+    case GF_RESID_BAND1:
+        if (GfKnobs::get(gf_knobs(ctx).qf_fuse, 1) != 0) {
+            hipLaunchKernelGGL(k_split_combine<GF_RESID_BAND1>, grid, dim3(256), 0, ctx->stream, part, call.C, L.T, L.N, R, call.data,
+                               call.wscalar, call.out, call.quad, call.band_w);
+            ctx->gf_band_fused = true;
+            break;
+        }
+        [[fallthrough]];
     default:
         hipLaunchKernelGGL(k_split_combine<GF_RESID_STORE>, grid, dim3(256), 0, ctx->stream, part, call.C, L.T, L.N, R, call.data,
-                           call.wscalar, call.out, call.quad);
+                           call.wscalar, call.out, call.quad, (const double *)nullptr);
     }
     BA_HIP(hipGetLastError());
     return BEATAMD_OK;
@@ -534,8 +588,9 @@ int launch_gfstack(beatamd_ctx *ctx, const GfStackCall &call)
 {
     const int R = call.libs[0] ? gf_patch_split(*call.libs[0], gf_knobs(ctx), ctx->num_cu) : 1;
     if (R > 1) {
+        ctx->gf_band_fused = false;
         BA_TRY(launch_gfstack_split(ctx, call, R));
-        if (call.mode == GF_RESID_BAND1) {
+        if (call.mode == GF_RESID_BAND1 && !ctx->gf_band_fused) {
             const SeisLib &L = *call.libs[0];
             BA_TRY(launch_quadform_banded(ctx, call.band_w, 1, L.N, L.T, call.C, call.out, L.T * L.N, L.N, call.quad, L.T));
         }
