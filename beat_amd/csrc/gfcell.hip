@@ -723,9 +723,9 @@ __global__ void __launch_bounds__(GC_TB) k_gm_tables(GmTabArgs a)
 // ~10 barriers and ~5 dependent round trips to memory per patch on nine wavefronts that mostly wait for each other: with
 // two such workgroups per CU the 6 800 (slot, patch) pairs of configs[3] (17 station slots x 400 patches) took 0.43 ms -- a quarter of
 // the step at 120 samples per trace, whatever the block of patches per workgroup (8 consecutive patches per workgroup, prefetched, were SLOWER:
-// 0.58 ms: it is the per-patch latency, not the launch).  Here a CU holds 16 patches in flight and a wavefront never waits
+// 0.58 ms: it is the per-patch latency, not the launch).  Here a CU holds 20 patches in flight and a wavefront never waits
 // for another.  Libraries up to GW_DENSE_MAX dense slots per patch (one bitset word per lane); beyond that k_gm_tables.
-constexpr int GW_NW = 8;                       // wavefronts (= patches) per workgroup
+constexpr int GW_NW = 4;                       // wavefronts (= patches) per workgroup
 constexpr int64_t GW_DENSE_MAX = 2048;         // D * (S + 1)
 constexpr int GW_KC = 520 * 4;                 // bytes of a [GC_CG] array of words
 constexpr uint32_t GW_PAD = 0x3fffffu;         // 22-bit key of a slot that takes no part (no chain / chain of another pass)
@@ -740,11 +740,12 @@ __device__ __forceinline__ void wave_sync()
 
 // LDS of a wavefront: kc[GC_CG] (pass of the chain slot << 22 | 22-bit key: (B << 11) | A, GW_PAD: no chain), then
 //   count: the bitsets C / F / X [3 D W], mark [dense], linepass / linesplit [D]
-//   fill : skp[GC_CG] sort words, nmw[32], clist[128] u16, bits[64], wpre[64]       (4960 bytes: 32 wavefronts per CU)
+//   fill : skp[GC_CG] sort words, nmw[32], clist[128] u16, bits[64], wpre[64], the image of a consumer's weight record
+//          (1280 bytes) and descriptor line (320)                                     (6560 bytes: 24 wavefronts per CU)
 static size_t gw_wave_bytes(int fill, int64_t D, int64_t S)
 {
     const int64_t W = (S + 1 + 31) / 32, dense = D * (S + 1);
-    const size_t f = (size_t)GW_KC + 32 + 256 + 256 + 256;
+    const size_t f = (size_t)GW_KC + 32 + 256 + 256 + 256 + GR_WSTRIDE + GR_DLINE * 4 + 256;
     const size_t c = (size_t)3 * D * W * 4 + ((dense + 3) & ~(int64_t)3) + 2 * ((D + 3) & ~(int64_t)3);
     return ((size_t)GW_KC + (fill ? f : c) + 15) & ~(size_t)15;
 }
@@ -857,6 +858,11 @@ __global__ void __launch_bounds__(64 * GW_NW) k_gm_tables_w(GmTabArgs a, int wst
         uint16_t *clist = reinterpret_cast<uint16_t *>(rest + GW_KC + 32);           // compact slot -> dense slot
         uint32_t *bits = reinterpret_cast<uint32_t *>(rest + GW_KC + 32 + 256);      // dense slots of the pass, one word per lane
         uint32_t *wpre = bits + 64;                                                  // set bits in front of the word
+        double *wimg = reinterpret_cast<double *>(wpre + 64);                        // [GR_WSTRIDE / 8] a consumer's weight record of the step
+        uint32_t *dimg = reinterpret_cast<uint32_t *>(wimg + GR_WSTRIDE / 8);         // [GR_DLINE] its descriptor line
+        uint32_t *srt = dimg + GR_DLINE;                                             // [64] the consumer's sort words by walk position
+        for (int e = lane; e < GR_WSTRIDE / 8; e += 64) wimg[e] = 0.0;               // (the entries of positions 37..39: never used)
+        for (int e = lane; e < GR_DLINE; e += 64) dimg[e] = 0;
         const int npass = have_passes ? (int)a.npass[gtp] : 1;
         const int64_t v0 = a.voff ? (int64_t)a.voff[gtp] : p;
         uint32_t moved = 0;
@@ -959,50 +965,68 @@ __global__ void __launch_bounds__(64 * GW_NW) k_gm_tables_w(GmTabArgs a, int wst
                     h[1] = (uint32_t)(p * a.DS);
                 }
             }
-            // ---- the chain slots: walk position in the consumer = its sort words below the slot's -- the chains of the pass
-            // in cell order (ties by slot), the others (pads) behind them in slot order, as k_gm_tables --; "the next chain
-            // opens a new cell" from the smallest word above it; weights and descriptors
-            for (int i = lane; i < GC_CG; i += 64) {
-                const int w = i / GC_NCHAIN, j = i % GC_NCHAIN;
-                const uint32_t mysk = skp[i];
+            // ---- a consumer at a time, lane <-> chain slot of the consumer: walk position = its sort words below the slot's --
+            // the chains of the pass in cell order (ties by slot), the others (pads) behind them in slot order, as
+            // k_gm_tables --; "the next chain opens a new cell" from the smallest word above it.  The consumer's weight record
+            // and descriptor line are put together in LDS and leave in 16-byte lanes (the records are position-major: written
+            // straight from the lanes, every store instruction scattered 8-byte pieces over dozens of lines -- 90 of the
+            // kernel's 236 us on configs[3])
+            uint32_t cid_n = lane < GC_NCHAIN ? a.order[g * GC_CG + lane] : GC_DEAD;
+            for (int w = 0; w < GC_NCONS; w++) {
+                const int j = lane;
+                const bool act = lane < GC_NCHAIN;
+                const uint32_t cid = cid_n;
+                if (w + 1 < GC_NCONS) cid_n = act ? a.order[g * GC_CG + (w + 1) * GC_NCHAIN + lane] : GC_DEAD;
                 const uint32_t *grp = skp + w * GC_NCHAIN;
-                int r = 0;
-                uint32_t succ = 0xffffffffu;
-#pragma unroll
-                for (int q = 0; q < GC_NCHAIN; q++) {
-                    const uint32_t x = grp[q];
-                    r += x < mysk;
-                    succ = x > mysk ? min(succ, x) : succ;
-                }
+                const uint32_t mysk = act ? grp[j] : 0xffffffffu;
                 const uint32_t k22 = mysk >> 6;
-                const bool mine = k22 != GW_PAD;
-                // (a successor that is a pad -- all ones above the key -- or none at all: the walk's last chain opens nothing)
-                const bool next_opens = mine && succ != 0xffffffffu && (succ >> 6) != GW_PAD && (succ >> 6) != k22;
-                const uint32_t ca = mine ? cidx(k22 & 0x7ffu) : 0u, cb = mine ? cidx(k22 >> 11) : 0u;
-                double fr[4] = {0, 0, 0, 0};
-                int64_t c = 0;
+                const bool mine = act && k22 != GW_PAD;
+                // the chain's factors and slips first: the ranking below covers their round trip
+                double fr[4] = {0, 0, 0, 0}, slv[4] = {0, 0, 0, 0};
                 if (mine) {
-                    c = (int64_t)a.order[g * GC_CG + i];
+                    const int64_t c = (int64_t)cid;
                     const int64_t e = ((c * a.T + t) * a.P + p) * 4;
                     const double2 f01 = *reinterpret_cast<const double2 *>(a.fac + e), f23 = *reinterpret_cast<const double2 *>(a.fac + e + 2);
                     fr[0] = f01.x; fr[1] = f01.y; fr[2] = f23.x; fr[3] = f23.y;
+                    for (int iv = 0; iv < a.nvar; iv++)
+                        slv[iv] = a.slips[iv].base[c * a.slips[iv].stride + a.slips[iv].off + (t % a.R) * a.P + p];
                 }
+                int r = 0;
+#pragma unroll
+                for (int q = 0; q < GC_NCHAIN; q++) r += grp[q] < mysk;
+                // the word behind the slot's in the walk: the words by position, one LDS round trip (a running minimum of
+                // the larger words inside the loop above cost three more instructions per comparison)
+                if (act) srt[r] = mysk;
+                wave_sync();
+                const uint32_t succ = (act && r + 1 < GC_NCHAIN) ? srt[r + 1] : 0xffffffffu;
+                // (a successor that is a pad -- all ones above the key -- or none at all: the walk's last chain opens nothing)
+                const bool next_opens = mine && succ != 0xffffffffu && (succ >> 6) != GW_PAD && (succ >> 6) != k22;
+                const uint32_t ca = mine ? cidx(k22 & 0x7ffu) : 0u, cb = mine ? cidx(k22 >> 11) : 0u;
                 const int nmem_w = nmw[w];
                 for (int iv = 0; iv < a.nvar; iv++) {
                     const int64_t s = (v0 + k) * a.nvar + iv;
                     const uint32_t ring = (uint32_t)((s % 3) * a.cap);
-                    const double sl = mine ? a.slips[iv].base[c * a.slips[iv].stride + a.slips[iv].off + (t % a.R) * a.P + p] : 0.0;
-                    const int q = r & 3;
-                    // weights only: a 256-byte record pair serves eight positions, entry e = {weight e of record 2p, of record 2p + 1}
-                    char *rec = a.wtab + ((gt * GC_NCONS + w) * (a.smax + 1) + s) * (int64_t)GR_WSTRIDE + (r >> 3) * GR_PAIR + ((r >> 2) & 1) * 8;
-                    for (int kk = 0; kk < 4; kk++)
-                        *reinterpret_cast<double *>(rec + (4 * q + kk) * 16) = mine ? fr[kk] * sl : 0.0;     // base.py:676-679 x slip, as k_gfstack
-                    uint32_t *dl = a.dtab + ((gt * GC_NCONS + w) * (a.smax + 1) + s) * GR_DLINE + (r < GR_NHALF ? 2 * r : GR_DHALF + 2 * (r - GR_NHALF));
-                    // a pad (a chain of another pass, an empty chain slot): zero weights into the scratch accumulator, no row reads
-                    dl[0] = (uint32_t)GR_D_BASE | (uint32_t)(mine ? j : GC_SCRATCH) | ((next_opens ? 1u : 0u) << 31);
-                    dl[1] = (ring + ca) | ((ring + cb) << 16);
-                    // chains of the consumer in this step: the walk leaves the step at the first checkpoint behind them
-                    if (j == 0) a.dtab[((gt * GC_NCONS + w) * (a.smax + 1) + s) * GR_DLINE + GR_D_NCH] = (uint32_t)nmem_w;
+                    if (act) {
+                        // weights only: a 256-byte record pair serves eight positions, entry e = {weight e of record 2p, of
+                        // record 2p + 1}; a pad (a chain of another pass, an empty chain slot): zero weights into the scratch
+                        // accumulator, no row reads
+                        const double sl = mine ? slv[iv] : 0.0;
+                        double *rec = wimg + (r >> 3) * (GR_PAIR / 8) + ((r >> 2) & 1);
+                        for (int kk = 0; kk < 4; kk++) rec[(4 * (r & 3) + kk) * 2] = mine ? fr[kk] * sl : 0.0;     // base.py:676-679 x slip
+                        uint32_t *dl = dimg + (r < GR_NHALF ? 2 * r : GR_DHALF + 2 * (r - GR_NHALF));
+                        dl[0] = (uint32_t)GR_D_BASE | (uint32_t)(mine ? j : GC_SCRATCH) | ((next_opens ? 1u : 0u) << 31);
+                        dl[1] = (ring + ca) | ((ring + cb) << 16);
+                        // chains of the consumer in this step: the walk leaves the step at the first checkpoint behind them
+                        if (j == 0) dimg[GR_D_NCH] = (uint32_t)nmem_w;
+                    }
+                    wave_sync();
+                    char *wdst = a.wtab + ((gt * GC_NCONS + w) * (a.smax + 1) + s) * (int64_t)GR_WSTRIDE;
+                    for (int e = lane; e < GR_WSTRIDE / 16; e += 64)
+                        *reinterpret_cast<double2 *>(wdst + e * 16) = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(wimg) + e * 16);
+                    uint32_t *ddst = a.dtab + ((gt * GC_NCONS + w) * (a.smax + 1) + s) * GR_DLINE;
+                    if (lane < GR_DLINE / 4)
+                        *reinterpret_cast<uint4 *>(ddst + lane * 4) = *reinterpret_cast<const uint4 *>(dimg + lane * 4);
+                    wave_sync();
                 }
             }
             wave_sync();
